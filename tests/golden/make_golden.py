@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures of tests/golden/ by running the REFERENCE's own code.
+
+Runs only in the build container (needs /root/reference; the GPU box does not have it).  The
+reference package is imported unmodified from /root/reference/build/lib on top of `oracle/pyro_shim`
+(pyro-ppl is not installable here).  What is written is DATA only: inputs, seeds, the
+eps stream, and the reference's outputs (losses, gradients, fitted parameters, posterior summaries).
+
+  basis.npz                 utils.torch_fourier_basis / pack_direction / unpack_direction outputs
+  ref_step_<case>.npz       one Trace_ELBO.loss_and_grads of model_fn/guide_fn (loss + every gradient)
+  ref_fit_<case>.npz        N steps of {Phase,Velocity}FitModel.fit (losses, final params, attributes)
+
+While generating, every case is also evaluated with the oracle restatement (oracle/velocycle_oracle.py)
+and the script ABORTS if the two disagree -- this is what pins the oracle.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from oracle.ref_loader import load_reference          # noqa: E402
+vc = load_reference()
+import pyro                                           # noqa: E402  (the shim)
+from oracle import velocycle_oracle as orc            # noqa: E402
+from velocycle_amd.simulate import simulate_counts    # noqa: E402
+from velocycle_amd.anndata_lite import AnnDataLite    # noqa: E402
+
+CANON = {  # reference param name -> canonical shape builder
+    "ν_locs": lambda p: (p.Ng, p.Nh), "ν_scales": lambda p: (p.Ng, p.Nh),
+    "Δν_locs": lambda p: (p.Nb, p.Ng), "ϕxy_locs": lambda p: (p.Nc, 2),
+    "logγg_locs": lambda p: (p.Ng,), "logγg_scales": lambda p: (p.Ng,),
+    "logβg_locs": lambda p: (p.Ng,), "logβg_scales": lambda p: (p.Ng,),
+    "νω_locs": lambda p: (p.Nx, p.Nhw), "νω_scales": lambda p: (p.Nx, p.Nhw),
+    "shape_inv_locs": lambda p: (p.Ng,), "loc": lambda p: (p.Ng + p.Nx * p.Nhw,),
+    "cov_factor": lambda p: (p.Ng + p.Nx * p.Nhw, p.rho_rank), "cov_diag": lambda p: (p.Ng + p.Nx * p.Nhw,),
+    "rho_real_loc": lambda p: (p.Ng,),
+}
+
+
+def build_inputs(Nc, Ng, H, n_batches, seed):
+    """Synthetic data + priors built with the reference's own containers (tutorial cells 16-21)."""
+    d = simulate_counts(Nc, Ng, omegas=(0.4, 0.3)[:n_batches], seed=seed)
+    ad = AnnDataLite(d["S"].numpy(), d["U"].numpy())
+    ad.obs["batch"] = [f"b{int(b)}" for b in d["batch"]]
+    genes = list(ad.var.index)
+    S = d["S"].numpy()
+    cyc = vc.cycle.Cycle.trivial_prior(gene_names=genes, harmonics=H)
+    nu0 = np.log(S.mean(0) + 0.05)
+    nu0std = np.std(np.log(S + 1), axis=0) / 2 + 0.05
+    rs = np.random.RandomState(seed)
+    means = np.vstack([nu0] + [0.1 * rs.randn(len(genes)) for _ in range(2 * H)])
+    stds = np.vstack([nu0std] + [0.5 * nu0std for _ in range(2 * H)])
+    cyc.set_means(means)
+    cyc.set_stds(stds)
+    phi0 = d["phis"].numpy() + 0.3 * rs.randn(ad.n_obs)
+    ph = vc.phases.Phases.from_array(np.stack([2.0 * np.cos(phi0), 2.0 * np.sin(phi0)]),
+                                     cell_names=list(ad.obs.index))
+    Db = vc.preprocessing.make_design_matrix(ad, ids="batch")
+    return d, ad, cyc, ph, Db
+
+
+def ref_params_canonical(p):
+    store = pyro.get_param_store()
+    vals, grads = {}, {}
+    for name in store.keys():
+        u = store.unconstrained(name)
+        shp = CANON[name](p)
+        vals[name] = u.detach().reshape(shp).clone()
+        grads[name] = (torch.zeros_like(u) if u.grad is None else u.grad).detach().reshape(shp).clone()
+    return vals, grads
+
+
+def problem_arrays(p, prefix="in_"):
+    out = {}
+    for k, v in p.__dict__.items():
+        if isinstance(v, torch.Tensor):
+            out[prefix + k] = v.numpy()
+        elif isinstance(v, (int, float, bool, str)):
+            out[prefix + k] = np.array(v)
+    for k, v in p.condition_on.items():
+        out["cond_" + k] = v.numpy()
+    return out
+
+
+def check(a, b, what, rtol=2e-4, atol=2e-4):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    fin = np.isfinite(a) & np.isfinite(b)
+    if not np.array_equal(np.isfinite(a), np.isfinite(b)) or not np.allclose(a[fin], b[fin], rtol=rtol, atol=atol):
+        err = np.abs(a[fin] - b[fin]).max() if fin.any() else float("nan")
+        raise SystemExit(f"ORACLE != REFERENCE for {what}: max abs err {err}")
+
+
+# ------------------------------------------------------------------------------------------------
+CASES = {
+    # name: dict(kind, Nc, Ng, H, Hw, nb, noise, model_type, with_delta_nu, cond (list of sites), sdnu_tensor)
+    "phase_nb":        dict(kind="phase", Nc=37, Ng=11, H=1, nb=1, noise="NegativeBinomial", wdn=False),
+    "phase_nb_dnu2":   dict(kind="phase", Nc=23, Ng=9, H=2, nb=2, noise="NegativeBinomial", wdn=True, sdnu_tensor=True),
+    "phase_poisson":   dict(kind="phase", Nc=29, Ng=7, H=1, nb=1, noise="Poisson", wdn=True),
+    "phase_lognormal": dict(kind="phase", Nc=29, Ng=7, H=1, nb=1, noise="Lognormal", wdn=False),
+    "vel_mf_joint":    dict(kind="velocity", Nc=37, Ng=11, H=1, Hw=1, nb=1, noise="NegativeBinomial",
+                            model_type="normal", wdn=False),
+    "vel_mf_joint_dnu2": dict(kind="velocity", Nc=23, Ng=9, H=2, Hw=1, nb=2, noise="NegativeBinomial",
+                              model_type="normal", wdn=True),
+    "vel_mf_cond":     dict(kind="velocity", Nc=37, Ng=11, H=1, Hw=0, nb=1, noise="NegativeBinomial",
+                            model_type="normal", wdn=False, cond=["ϕxy", "ν", "shape_inv"]),
+    "vel_lrmn_cond":   dict(kind="velocity", Nc=37, Ng=11, H=1, Hw=1, nb=1, noise="NegativeBinomial",
+                            model_type="lrmn", wdn=False, cond=["ϕxy", "ν", "shape_inv"]),
+    "vel_lrmn_cond_dnu2": dict(kind="velocity", Nc=23, Ng=9, H=1, Hw=0, nb=2, noise="NegativeBinomial",
+                               model_type="lrmn", wdn=True, cond=["ϕxy", "ν", "Δν", "shape_inv"]),
+    "vel_lrmn_joint":  dict(kind="velocity", Nc=29, Ng=7, H=1, Hw=1, nb=1, noise="NegativeBinomial",
+                            model_type="lrmn", wdn=False),
+    "vel_mf_poisson":  dict(kind="velocity", Nc=29, Ng=7, H=1, Hw=1, nb=1, noise="Poisson",
+                            model_type="normal", wdn=False),
+    "vel_mf_lognormal": dict(kind="velocity", Nc=29, Ng=7, H=1, Hw=1, nb=1, noise="Lognormal",
+                             model_type="normal", wdn=False),
+}
+FIT_CASES = {"phase_nb": 25, "vel_mf_joint": 25, "vel_lrmn_cond": 25, "vel_mf_cond": 15}
+
+
+def make_case(name, c, seed=11):
+    d, ad, cyc, ph, Db = build_inputs(c["Nc"], c["Ng"], c["H"], c["nb"], seed)
+    Nc = ad.n_obs
+    rs = np.random.RandomState(seed + 1)
+    cond = {}
+    if c["kind"] == "phase":
+        kw = {}
+        if c.get("sdnu_tensor"):
+            s = torch.ones((c["nb"], c["Ng"], 1))
+            s[0] = 0.001
+            s[1:] = 0.1
+            kw["σΔν"] = s
+        mp = vc.preprocessing.preprocess_for_phase_estimation(
+            ad, cyc, ph, Db, n_harmonics=c["H"], noisemodel=c["noise"], with_delta_nu=c["wdn"], **kw)
+        FitCls = vc.phase_inference_model.PhaseFitModel
+    else:
+        spd = vc.angularspeed.AngularSpeed.trivial_prior(
+            condition_names=[f"b{i}" for i in range(c["nb"])], harmonics=c["Hw"])
+        if c["Hw"] == 1:
+            spd.stds.loc["nu1_cos"] = [0.05] * c["nb"]
+            spd.stds.loc["nu1_sin"] = [0.05] * c["nb"]
+        cf = torch.tensor(np.log(ad.layers["spliced"].sum(1) / ad.layers["spliced"].sum(1).mean())).float()[None, None, :]
+        for site in c.get("cond", []):
+            if site == "ϕxy":
+                cond[site] = ph.phi_xy_tensor.T + torch.tensor(0.05 * rs.randn(Nc, 2)).float()
+            elif site == "ν":
+                cond[site] = cyc.means_tensor.T.unsqueeze(-2) + torch.tensor(0.05 * rs.randn(c["Ng"], 1, 2 * c["H"] + 1)).float()
+            elif site == "Δν":
+                cond[site] = torch.tensor(0.01 * rs.randn(c["nb"], 1, 1, c["Ng"], 1)).float()
+            elif site == "shape_inv":
+                cond[site] = torch.tensor(rs.uniform(0.2, 1.0, (c["Ng"], 1))).float()
+        mp = vc.preprocessing.preprocess_for_velocity_estimation(
+            ad, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=c["H"], ω_n_harmonics=c["Hw"],
+            count_factor=cf, noisemodel=c["noise"], with_delta_nu=c["wdn"], condition_on=cond,
+            model_type=c.get("model_type", "lrmn"))
+        FitCls = vc.velocity_inference_model.VelocityFitModel
+
+    p64 = orc.problem_from_metaparams(mp, c["kind"], cond, dtype=torch.float64)
+    p32 = p64.to(torch.float32)
+
+    # ---- one step through the reference's model_fn / guide_fn --------------------------------
+    fitm = FitCls(mp, condition_on=cond, num_samples=4, n_per_bin=2)
+    pyro.clear_param_store()
+    torch.manual_seed(seed)
+    elbo = pyro.infer.Trace_ELBO(num_particles=1)
+    ref_loss, _ = elbo.loss_and_grads(fitm.model, fitm.guide, mp)
+    ref_par, ref_grad = ref_params_canonical(p32)
+
+    gen = torch.Generator().manual_seed(seed)
+    warm = orc.draw_eps(p32, gen)           # the _guess_max_plate_nesting pass
+    eps = orc.draw_eps(p32, gen)
+    par32 = orc.init_params(p32, warm.get("_cov_factor_draw"))
+    for k in ref_par:                        # initial parameter values agree
+        check(par32[k], ref_par[k], f"{name}: init {k}", 1e-6, 1e-6)
+    o_loss, o_grad, o_val, o_det = orc.loss_and_grads(p32, par32, eps)
+    check(o_loss, ref_loss, f"{name}: loss", 1e-5, 1e-3)
+    for k in ref_grad:
+        check(o_grad[k], ref_grad[k], f"{name}: grad {k}", 2e-3, 2e-3)
+    # float64 oracle values = what the HIP path is compared with
+    par64 = {k: v.double() for k, v in par32.items()}
+    eps64 = {k: v.double() for k, v in eps.items()}
+    l64, g64, v64, d64 = orc.loss_and_grads(p64, par64, eps64)
+    out = problem_arrays(p32)
+    out.update({"par_" + k: v.numpy() for k, v in par32.items()})
+    out.update({"eps_" + k: v.numpy() for k, v in eps.items() if not k.startswith("_")})
+    out.update({"refgrad_" + k: v.numpy() for k, v in ref_grad.items()})
+    out.update({"grad64_" + k: v.numpy() for k, v in g64.items()})
+    out.update({"val64_" + k: v.numpy() for k, v in v64.items()})
+    out["ref_loss"] = np.array(ref_loss)
+    out["loss64"] = np.array(l64)
+    out["seed"] = np.array(seed)
+    np.savez_compressed(os.path.join(OUT, f"ref_step_{name}.npz"), **out)
+    print(f"[step] {name}: ref loss {ref_loss:.4f}  oracle32 {o_loss:.4f}  oracle64 {l64:.4f}")
+
+    # ---- N steps of the reference's own fit() ---------------------------------------------------
+    if name in FIT_CASES:
+        n = FIT_CASES[name]
+        opt_args = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1 / n), "betas": (0.80, 0.99)}
+        fitm = FitCls(mp, condition_on=cond, num_samples=4, n_per_bin=2)
+        pyro.clear_param_store()
+        torch.manual_seed(seed)
+        fitm.fit(pyro.optim.ClippedAdam(dict(opt_args)), loss=pyro.infer.Trace_ELBO(num_particles=1),
+                 num_steps=n, verbose=False)
+        ref_par, _ = ref_params_canonical(p32)
+        o_losses, o_par = orc.fit(p32, opt_args, n, seed=seed)
+        check(o_losses, fitm.losses, f"{name}: fit losses", 1e-4, 1e-2)
+        for k in ref_par:
+            check(o_par[k], ref_par[k], f"{name}: fitted {k}", 2e-3, 2e-3)
+        l64s, par64f = orc.fit(p64, opt_args, n, seed=seed)
+        fo = problem_arrays(p32)
+        fo.update({"reffit_" + k: v.numpy() for k, v in ref_par.items()})
+        fo.update({"fit64_" + k: v.numpy() for k, v in par64f.items()})
+        fo["ref_losses"] = np.array(fitm.losses)
+        fo["losses64"] = np.array(l64s)
+        fo["num_steps"] = np.array(n)
+        fo["seed"] = np.array(seed)
+        for k, v in opt_args.items():
+            fo["opt_" + k] = np.array(v)
+        for attr in ("phis_pyro", "fourier_coef", "fourier_coef_sd", "disp_pyro", "delta_nus",
+                     "log_gammas", "log_betas", "velocity_coef", "velocity_coef_sd"):
+            if hasattr(fitm, attr):
+                fo["attr_" + attr] = np.asarray(getattr(fitm, attr))
+        np.savez_compressed(os.path.join(OUT, f"ref_fit_{name}.npz"), **fo)
+        print(f"[fit ] {name}: {n} steps, ref final loss {fitm.losses[-1]:.4f}, oracle {o_losses[-1]:.4f}")
+
+
+def make_basis():
+    U = vc.utils
+    phi = torch.tensor(np.linspace(-3.5, 7.0, 41), dtype=torch.float32)
+    out = {"phi": phi.numpy()}
+    for H in (0, 1, 2, 3):
+        for der in (0, 1):
+            ref = U.torch_fourier_basis(phi, num_harmonics=H, der=der)
+            mine = orc.fourier_basis(phi, H, der)
+            check(mine, ref, f"basis H={H} der={der}", 1e-6, 1e-6)
+            out[f"basis_H{H}_der{der}"] = ref.numpy()
+    xy = torch.tensor(np.random.RandomState(0).randn(50, 2), dtype=torch.float32)
+    ref = U.pack_direction(xy)
+    check(orc.pack_direction(xy), ref, "pack_direction", 0, 0)
+    out["xy"] = xy.numpy()
+    out["pack_direction"] = ref.numpy()
+    out["unpack_direction"] = U.unpack_direction(ref, 1.0).numpy()
+    np.savez_compressed(os.path.join(OUT, "basis.npz"), **out)
+    print("[basis] ok")
+
+
+if __name__ == "__main__":
+    make_basis()
+    only = sys.argv[1:]
+    for nm, c in CASES.items():
+        if only and nm not in only:
+            continue
+        make_case(nm, c)
+    print("all golden fixtures written; oracle == reference on every case")

@@ -1,0 +1,66 @@
+"""A tiny stand-in for the slice of the AnnData interface that the reference's `preprocess_for_*`
+touch (reference velocycle/preprocessing.py:20-63,124-154,241-268): `.layers[...]`, `.obs[...]`,
+`.var.index`, `adata[:, genes].copy()`.  `anndata`/`h5py` are not installed in this image; real
+`anndata.AnnData` objects are accepted everywhere this class is."""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+
+class AnnDataLite:
+    def __init__(self, spliced, unspliced, gene_names=None, cell_names=None, obs=None):
+        spliced = np.asarray(spliced)
+        unspliced = np.asarray(unspliced)
+        assert spliced.shape == unspliced.shape and spliced.ndim == 2
+        nc, ng = spliced.shape
+        if gene_names is None:
+            gene_names = ["G" + str(i).zfill(5) for i in range(ng)]
+        if cell_names is None:
+            cell_names = ["C" + str(i).zfill(6) for i in range(nc)]
+        self.layers = {"spliced": spliced, "unspliced": unspliced}
+        self.var = pd.DataFrame(index=pd.Index(list(gene_names)))
+        self.obs = pd.DataFrame(index=pd.Index(list(cell_names))) if obs is None else obs
+        self.X = spliced
+
+    @property
+    def shape(self):
+        return self.layers["spliced"].shape
+
+    @property
+    def n_obs(self):
+        return self.shape[0]
+
+    @property
+    def n_vars(self):
+        return self.shape[1]
+
+    def copy(self):
+        out = AnnDataLite.__new__(AnnDataLite)
+        out.layers = {k: np.array(v, copy=True) for k, v in self.layers.items()}
+        out.var = self.var.copy()
+        out.obs = self.obs.copy()
+        out.X = out.layers["spliced"]
+        return out
+
+    def __getitem__(self, key):
+        if not (isinstance(key, tuple) and len(key) == 2):
+            raise IndexError("AnnDataLite supports adata[cells, genes] only")
+        rows, cols = key
+        ridx = np.arange(self.n_obs)[rows] if isinstance(rows, slice) else \
+            self.obs.index.get_indexer(list(rows)) if _is_names(rows) else np.asarray(rows)
+        cidx = np.arange(self.n_vars)[cols] if isinstance(cols, slice) else \
+            self.var.index.get_indexer(list(cols)) if _is_names(cols) else np.asarray(cols)
+        if (np.asarray(cidx) < 0).any() or (np.asarray(ridx) < 0).any():
+            raise KeyError("unknown gene / cell name")
+        out = AnnDataLite.__new__(AnnDataLite)
+        out.layers = {k: np.asarray(v)[np.ix_(ridx, cidx)] for k, v in self.layers.items()}
+        out.var = self.var.iloc[cidx].copy()
+        out.obs = self.obs.iloc[ridx].copy()
+        out.X = out.layers["spliced"]
+        return out
+
+
+def _is_names(k):
+    k = np.asarray(k)
+    return k.dtype.kind in "OUS"
