@@ -1,0 +1,203 @@
+/*
+ * velocycle_hip.h -- C ABI of the MI355X (gfx950) engine for VeloCycle's SVI hot path.
+ *
+ * One engine = one fit (one model + guide + data shard) on one GPU.  One process per GPU; the
+ * caller (velocycle_amd/engine.py through ctypes) owns the flat parameter / gradient buffers
+ * (PyTorch-ROCm tensors passed as device pointers) and does the optimiser update and the
+ * all-reduce; the library owns the count matrices (re-laid-out in HBM), per-step workspaces and
+ * all kernels.  No C++ exception crosses this boundary: every call returns 0 (VC_OK) or a negative
+ * code, with a message available from vc_last_error().
+ *
+ * Reference interfaces each entry point replaces (reference = lamanno-epfl/velocycle v0.1.0.5; the
+ * reference has no FFI of its own -- its "interface" for this path is the set of Python objects
+ * that `pyro.infer.SVI.step` drives):
+ *
+ *   vc_create / vc_set_*        the MetaparContainer built by preprocess_for_phase_estimation
+ *                               (velocycle/preprocessing.py:168-205) and
+ *                               preprocess_for_velocity_estimation (preprocessing.py:270-323),
+ *                               plus poutine.condition/block wiring of
+ *                               PhaseFitModel.__init__ (phase_inference_model.py:109-123) and
+ *                               VelocityFitModel.__init__ (velocity_inference_model.py:60-74)
+ *   vc_get_layout               the pyro.param store created by the guides
+ *                               (phase_inference_guide.py:36-45, velocity_inference_guide.py:25-43, 78-102)
+ *   vc_elbo_grad                one Trace_ELBO(num_particles=1).loss_and_grads(model, guide, mp):
+ *                               guide trace + model replay + log-prob sums + backward, i.e. the body
+ *                               of `svi.step` (phase_inference_model.py:169, velocity_inference_model.py:120)
+ *                               for phase_latent_variable_model/guide (phase_inference_model.py:343-395,
+ *                               phase_inference_guide.py:10-56) and velocity_latent_variable_model/guide
+ *                               [_LRMN] (velocity_inference_model.py:304-471, velocity_inference_guide.py:9-141)
+ *   vc_read_site                the sampled / deterministic sites a trace exposes
+ *                               (pyro.deterministic calls at velocity_inference_model.py:327-369)
+ */
+#ifndef VELOCYCLE_HIP_H
+#define VELOCYCLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_ABI_VERSION 1
+
+/* return codes */
+#define VC_OK 0
+#define VC_ERR_ARG (-1)          /* bad argument / shape */
+#define VC_ERR_HIP (-2)          /* a HIP runtime call failed */
+#define VC_ERR_UNSUPPORTED (-3)  /* configuration outside the compiled kernel set */
+#define VC_ERR_STATE (-4)        /* call order violated (e.g. step before finalize) */
+
+/* model / guide / noise selectors */
+#define VC_MODEL_PHASE 0         /* phase_latent_variable_model */
+#define VC_MODEL_VELOCITY 1      /* velocity_latent_variable_model[_LRMN] */
+#define VC_GUIDE_MEANFIELD 0
+#define VC_GUIDE_LRMN 1
+#define VC_NOISE_NB 0            /* "NegativeBinomial" (GammaPoisson) */
+#define VC_NOISE_POISSON 1
+#define VC_NOISE_LOGNORMAL 2
+
+/* sample sites (bit mask for conditioning, id for vc_set_conditioned / vc_read_site) */
+#define VC_SITE_PHIXY 0      /* "ϕxy"       (Nc_local, 2) */
+#define VC_SITE_NU 1         /* "ν"         (Ng, Nh)      */
+#define VC_SITE_DNU 2        /* "Δν"        (Nb, Ng)      */
+#define VC_SITE_SHAPE_INV 3  /* "shape_inv" (Ng)          */
+#define VC_SITE_LOGGAMMA 4   /* "logγg"     (Ng)          */
+#define VC_SITE_LOGBETA 5    /* "logβg"     (Ng)          */
+#define VC_SITE_NUOMEGA 6    /* "νω"        (Nx, Nhw)     */
+#define VC_SITE_RHO_REAL 7   /* "rho_real"  (Ng)          */
+#define VC_SITE_COUNT 8
+/* deterministic sites readable through vc_read_site */
+#define VC_DET_PHI 16        /* "ϕ"     (Nc_local)        */
+#define VC_DET_OMEGA 17      /* "ω"     (Nc_local)        */
+#define VC_DET_EPS 18        /* the eps vector used by the last step (layout: vc_layout.eps_*) */
+
+/* variational parameters (the guide's pyro.param store), all stored UNCONSTRAINED:
+ * positive parameters are stored as their log (Pyro's transform_to(positive) = exp). */
+#define VC_P_NU_LOCS 0          /* "ν_locs"        (Ng, Nh) */
+#define VC_P_NU_USCALES 1       /* "ν_scales"      (Ng, Nh)  log */
+#define VC_P_DNU_LOCS 2         /* "Δν_locs"       (Nb, Ng) */
+#define VC_P_LOGGAMMA_LOCS 3    /* "logγg_locs"    (Ng) */
+#define VC_P_LOGGAMMA_USCALES 4 /* "logγg_scales"  (Ng)      log */
+#define VC_P_LOGBETA_LOCS 5     /* "logβg_locs"    (Ng) */
+#define VC_P_LOGBETA_USCALES 6  /* "logβg_scales"  (Ng)      log */
+#define VC_P_NUOMEGA_LOCS 7     /* "νω_locs"       (Nx, Nhw) */
+#define VC_P_NUOMEGA_USCALES 8  /* "νω_scales"     (Nx, Nhw) log */
+#define VC_P_SHAPE_INV_ULOCS 9  /* "shape_inv_locs"(Ng)      log */
+#define VC_P_LRMN_LOC 10        /* "loc"           (Ng + Nx*Nhw) */
+#define VC_P_LRMN_UCOV_FACTOR 11/* "cov_factor"    (Ng + Nx*Nhw, rank) log */
+#define VC_P_LRMN_UCOV_DIAG 12  /* "cov_diag"      (Ng + Nx*Nhw) log */
+#define VC_P_RHO_REAL_LOC 13    /* "rho_real_loc"  (Ng) */
+#define VC_P_PHIXY_LOCS 14      /* "ϕxy_locs"      (Nc_local, 2)   -- the only rank-local block */
+#define VC_P_COUNT 15
+
+/* standard-normal draws of one guide call */
+#define VC_E_LOGGAMMA 0   /* (Ng)       mean-field only */
+#define VC_E_LOGBETA 1    /* (Ng)       */
+#define VC_E_NU 2         /* (Ng, Nh)   */
+#define VC_E_NUOMEGA 3    /* (Nx, Nhw)  mean-field only */
+#define VC_E_LRMN_W 4     /* (rank)     LRMN only */
+#define VC_E_LRMN_D 5     /* (Ng + Nx*Nhw) LRMN only */
+#define VC_E_PHIXY 6      /* (Nc_local, 2)  -- rank-local block */
+#define VC_E_COUNT 7
+
+/* per-gene / global prior arrays for vc_set_prior (host pointers, float32) */
+#define VC_PRIOR_MU_NU 0      /* μνg (Ng, Nh) */
+#define VC_PRIOR_SD_NU 1      /* σνg (Ng, Nh) */
+#define VC_PRIOR_MU_GAMMA 2   /* μγ (Ng) */
+#define VC_PRIOR_SD_GAMMA 3
+#define VC_PRIOR_MU_BETA 4
+#define VC_PRIOR_SD_BETA 5
+#define VC_PRIOR_MU_NUOMEGA 6 /* μνω (Nx, Nhw) */
+#define VC_PRIOR_SD_NUOMEGA 7
+#define VC_PRIOR_SD_DNU 8     /* σΔν (Nb, Ng) -- phase model; velocity hard-codes 0.01 (velocity_inference_model.py:332) */
+#define VC_PRIOR_COUNT 9
+
+typedef struct vc_engine vc_engine;
+
+typedef struct vc_config {
+  int32_t abi_version;     /* = VC_ABI_VERSION */
+  int32_t model;           /* VC_MODEL_* */
+  int32_t guide;           /* VC_GUIDE_* (phase: MEANFIELD) */
+  int32_t noise;           /* VC_NOISE_* */
+  int32_t with_delta_nu;   /* 0/1 */
+  int32_t n_harmonics;     /* H   (Nh  = 2H+1), 1..3 */
+  int32_t n_harmonics_w;   /* Hw  (Nhw = 2Hw+1), velocity only */
+  int32_t Nb;              /* batches (rows of Db) */
+  int32_t Nx;              /* conditions (rows of D), velocity only */
+  int32_t lrmn_rank;       /* rho_rank (5) */
+  int32_t rank;            /* data-parallel rank; rank 0 adds the replicated (gene-level) prior/entropy terms */
+  int32_t world_size;
+  int64_t Ng;              /* genes */
+  int64_t Nc_local;        /* cells held by this rank */
+  int64_t Nc_global;       /* cells over all ranks */
+  int64_t cell_offset;     /* global index of this rank's first cell (eps stream slicing) */
+  float gamma_alpha, gamma_beta;      /* shape_inv ~ Gamma(alpha, beta) */
+  float sigma_ln_s, sigma_ln_u;       /* Lognormal noise scales (phase 0.5; velocity 0.1, 0.1) */
+  float rho_mean, rho_std, rho_scale; /* LRMN */
+  float reserved0;
+} vc_config;
+
+typedef struct vc_layout {
+  int64_t header;                 /* floats reserved at the front of params/grad (grad[0..1] = loss hi/lo) */
+  int64_t n_global;               /* floats of replicated parameters (after the header) */
+  int64_t n_local;                /* floats of rank-local parameters (ϕxy_locs) */
+  int64_t total;                  /* header + n_global + n_local */
+  int64_t offset[VC_P_COUNT];     /* absolute float offset of each parameter block, -1 if absent */
+  int64_t size[VC_P_COUNT];
+  int64_t eps_n_global, eps_total;
+  int64_t eps_offset[VC_E_COUNT]; /* float offset in the eps vector, -1 if absent */
+  int64_t eps_size[VC_E_COUNT];
+} vc_layout;
+
+typedef struct vc_stats {
+  int64_t algorithmic_bytes;      /* count-matrix bytes one step must read in the reference's fp32 storage */
+  int64_t streamed_bytes;         /* bytes the main kernel actually streams (padded layout) */
+  int64_t main_grid, main_block;  /* launch geometry of the likelihood kernel */
+  int32_t main_kind;              /* 0 phase(S) 1 velocity(S+U) 2 velocity, S-term hoisted (U only) */
+  int32_t reserved;
+  char main_kernel_name[96];
+} vc_stats;
+
+/* lifecycle ------------------------------------------------------------------------------- */
+int vc_abi_version(void);
+int vc_create(const vc_config* cfg, vc_engine** out);
+void vc_destroy(vc_engine* e);
+/* message of the last failing call on `e` (or of the last failing vc_create when e == NULL) */
+const char* vc_last_error(const vc_engine* e);
+
+/* inputs (call before vc_finalize) ---------------------------------------------------------- */
+/* Count matrices, element (g, c) at ptr[g*gene_stride + c*cell_stride] (so both the reference's
+ * `S.T.float()` view -- gene_stride 1, cell_stride Ng -- and a contiguous (Ng,Nc) array work).
+ * U may be NULL for the phase model.  on_device: pointers are device (1) or host (0) memory. */
+int vc_set_counts(vc_engine* e, const float* S, const float* U, int64_t gene_stride,
+                  int64_t cell_stride, int on_device);
+/* count_factor (Nc_local), D (Nx, Nc_local) row-major [NULL for phase], Db (Nb, Nc_local) row-major
+ * [NULL when Nb == 0], phixy_prior (Nc_local, 2).  Host pointers. */
+int vc_set_cell_data(vc_engine* e, const float* count_factor, const float* D, const float* Db,
+                     const float* phixy_prior);
+int vc_set_prior(vc_engine* e, int which, const float* data, int64_t n);      /* host pointer */
+/* poutine.condition: fix a sample site to `values` (host pointer, canonical shape of VC_SITE_*). */
+int vc_set_conditioned(vc_engine* e, int site, const float* values, int64_t n);
+/* Builds the HBM layout, per-gene count histograms, hoisted constants and workspaces. */
+int vc_finalize(vc_engine* e, void* hip_stream);
+
+/* hot path ---------------------------------------------------------------------------------- */
+int vc_get_layout(const vc_engine* e, vc_layout* out);
+/* One ELBO + gradient evaluation.  params/grad: device float[layout.total]; eps: device
+ * float[layout.eps_total] or NULL (then eps = Philox4x32-10(seed, step, index), identical on every
+ * rank for replicated sites and sliced by cell_offset for ϕxy).  step_dev: optional device int64
+ * read instead of `step` (lets the call be replayed from a captured hipGraph).  loss_dev: device
+ * double[1] receiving this rank's loss contribution (also written as float hi/lo to grad[0..1]).
+ * Asynchronous on `hip_stream`; no allocation, no synchronisation. */
+int vc_elbo_grad(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
+                 const int64_t* step_dev, float* grad, double* loss_dev, void* hip_stream);
+
+/* introspection ----------------------------------------------------------------------------- */
+/* Copies the value a site took in the last vc_elbo_grad to host memory (synchronises the stream). */
+int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream);
+int vc_get_stats(const vc_engine* e, vc_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VELOCYCLE_HIP_H */

@@ -1,0 +1,178 @@
+// Shared definitions of the gfx950 engine: dimensions, buffer tables, wave-level helpers.
+// Device code here is written for CDNA4 only (wave64, DPP row ops, SGPR-resident cell records).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/velocycle_hip.h"
+
+#define VC_GBW 256          // genes per gene block = 64 lanes x 4 genes (one dwordx4 load per lane per cell)
+#define VC_WAVES 4          // waves per workgroup of the likelihood kernel
+#define VC_MAXH 3
+#define VC_MAXNB 4
+#define VC_MAX_NW 64        // max Nx*Nhw (angular-speed coefficients)
+#define VC_MAX_RANK 8
+
+#define VC_KIND_PHASE 0     // S likelihood only (phase model)
+#define VC_KIND_VFULL 1     // S and U likelihoods, every gradient
+#define VC_KIND_VU 2        // U likelihood only: phi, nu, dnu, shape_inv conditioned -> S term hoisted to setup
+
+#define VC_LOG_2PI 1.8378770664093453f
+
+struct VcDims {
+  int Ng, Ng_pad, nGB;
+  int Nc;                 // cells on this rank
+  long long cell_offset;  // global index of the first local cell
+  int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
+  int K;                  // Nh + Nb : expression-map coefficients per gene (harmonics, then batch offsets)
+  int ctw;                // floats per cell record: [sin k, cos k]*H, Db[Nb], omega, cf, pad to x4
+  int model, guide, noise, with_dnu;
+  unsigned cond;          // bit i set <=> site i conditioned
+  int kind;               // VC_KIND_*
+  int nq;                 // per-gene accumulator rows the likelihood kernel emits
+  int nco;                // per-cell accumulator rows
+  int n_chunks;           // cell chunks = workgroups per gene block
+  int cw;                 // cells per wave (multiple of 64)
+  int hist_has_S, hist_has_U;
+  int nmat_r;             // matrices whose NB constant r*log r is evaluated per step
+  float root_w;           // 1 on rank 0, 0 elsewhere: weight of replicated prior / entropy terms
+  float gamma_alpha, gamma_beta, sigma_ln_s, sigma_ln_u, rho_mean, rho_std, rho_scale;
+  long long poff[VC_P_COUNT];   // parameter offsets (floats) in the flat buffers, -1 if absent
+  long long eoff[VC_E_COUNT];   // eps offsets
+  long long eps_n_global;
+  int nb_pre_gene, nb_pre_cell, nb_post_gene, nb_post_cell, n_main_wg;
+};
+
+struct VcBufs {
+  // immutable inputs
+  const float *S, *U;                       // blocked counts [nGB][Nc][256]
+  const float *cf, *Dm, *Dbm, *pxy;         // (Nc), (Nx,Nc), (Nb,Nc), (Nc,2)
+  const float *mu_nu, *sd_nu, *mu_g, *sd_g, *mu_b, *sd_b, *mu_w, *sd_w, *sd_dnu;
+  const float *cnd[VC_SITE_COUNT];          // conditioned values per site (or nullptr)
+  const int *h_ptr;                         // histogram CSR: [2*Ng+1], S genes then U genes
+  const float *h_val, *h_cnt;
+  // per-step workspaces
+  float *eps_used;
+  float *GT;                                // gene table [K+3][Ng_pad]
+  float *CT;                                // cell table [Nc][ctw]
+  float *lat[VC_SITE_COUNT];                // site values of the last step
+  float *lat_delta, *lat_sgam;              // LRMN: (M) deviation W eps_W + sqrt(D) eps_D, (Ng) marginal std of log gamma
+  float *lat_phi, *lat_omega, *lat_domega;  // (Nc)
+  float *GO;                                // per-gene partial sums [n_chunks][nq][Ng_pad]
+  float *CO;                                // per-cell partial sums [nGB][nco][Nc]
+  float *LO;                                // likelihood partial per main workgroup
+  double *LP;                               // loss partials of pre (nb_pre_gene + nb_pre_cell) and post_gene blocks
+  float *PW;                                // [nb_post_cell][NW] partial angular-speed gradients
+  double *HL, *HD;                          // per gene: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
+  double const_loss;                        // step-invariant part of the loss
+};
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions with DPP row operations; the total lands in lane 63.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float vc_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xf, true));
+}
+
+__device__ __forceinline__ float vc_wave_sum_lane63(float v) {
+  v += vc_dpp<0x111, 0xf>(v);   // row_shr:1
+  v += vc_dpp<0x112, 0xf>(v);   // row_shr:2
+  v += vc_dpp<0x114, 0xf>(v);   // row_shr:4
+  v += vc_dpp<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds its row sum
+  v += vc_dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+  v += vc_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+  return v;
+}
+
+__device__ __forceinline__ float vc_wave_sum(float v) {   // broadcast as a wave-uniform scalar
+  v = vc_wave_sum_lane63(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ double vc_wave_sum_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block sum in double for <=1024 threads; result valid in thread 0
+__device__ __forceinline__ double vc_block_sum_d(double v, double* sm /* [16] */) {
+  v = vc_wave_sum_d(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) t += sm[i];
+  __syncthreads();
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG + Box-Muller: eps(index) for (seed, step), identical on every rank.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                          uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float vc_philox_normal(uint64_t seed, long long step, long long idx) {
+  uint32_t o[4];
+  const uint64_t blk = (uint64_t)idx >> 1;
+  vc_philox((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)step, (uint32_t)((uint64_t)step >> 32),
+            (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+  const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-2.0f * logf(u1));
+  float s, c;
+  sincosf(6.283185307179586f * u2, &s, &c);
+  return (idx & 1) ? rad * s : rad * c;
+}
+
+// eps value `li` (local index in this rank's eps vector, global index gi for the counter RNG)
+__device__ __forceinline__ float vc_eps(const float* __restrict__ eps_in, float* __restrict__ eps_used,
+                                        uint64_t seed, long long step, long long li, long long gi) {
+  const float e = eps_in ? eps_in[li] : vc_philox_normal(seed, step, gi);
+  eps_used[li] = e;
+  return e;
+}
+
+__device__ __forceinline__ float vc_normal_lp(float x, float mu, float sd) {
+  const float z = (x - mu) / sd;
+  return -0.5f * z * z - logf(sd) - 0.5f * VC_LOG_2PI;
+}
+
+// digamma in double: recurrence to x >= 10, then the asymptotic series
+__device__ __forceinline__ double vc_digamma_d(double x) {
+  double acc = 0.0;
+  while (x < 10.0) { acc -= 1.0 / x; x += 1.0; }
+  const double i = 1.0 / x, i2 = i * i;
+  return acc + log(x) - 0.5 * i -
+         i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0 - i2 * (1.0 / 132.0)))));
+}
+#endif  // __HIPCC__
+
+// launchers implemented in the .hip translation units -----------------------------------------
+typedef void (*vc_main_launch_fn)(const VcDims& d, const VcBufs& b, hipStream_t st);
+vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, const char** name);
+
+void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
+                           int Ng, int Nc, int nGB, int log1p_transform, hipStream_t st);
+void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
+                   uint64_t seed, long long step, const long long* step_dev, int cond_only, hipStream_t st);
+void vc_launch_hist(const VcDims& d, const VcBufs& b, hipStream_t st);
+void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad,
+                    double* loss_dev, hipStream_t st);

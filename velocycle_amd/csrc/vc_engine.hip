@@ -1,0 +1,613 @@
+// Host side of the engine behind the C ABI of include/velocycle_hip.h: configuration, HBM layout,
+// count histograms, workspaces, kernel sequencing.  No exception leaves this file.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "vc_common.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct vc_engine {
+  vc_config cfg{};
+  VcDims d{};
+  VcBufs b{};
+  vc_layout layout{};
+  std::string err;
+  std::vector<void*> allocs;
+  bool finalized = false;
+  bool have_counts = false, have_cells = false;
+  bool prior_set[VC_PRIOR_COUNT] = {};
+  // host copies needed at finalize
+  std::vector<float> hS, hU;            // dense (Ng, Nc) gene-major copies for histogram building
+  std::vector<float> h_prior[VC_PRIOR_COUNT];
+  std::vector<float> h_cond[VC_SITE_COUNT];
+  float* dS_raw = nullptr;              // packed device matrices
+  float* dU_raw = nullptr;
+  vc_main_launch_fn main_fn = nullptr;
+  vc_main_launch_fn phase_fn = nullptr;  // S-only kernel used once to hoist the S term (VU kind)
+  const char* main_name = "";
+  long long gs = 0, cs = 0;          // strides of the host copies hS / hU
+  bool hist_each_step = false;
+  double lgamma_const = 0.0;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  template <class T>
+  int dalloc(T** out, size_t n) {
+    void* p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc(&p, n * sizeof(T));
+    if (e != hipSuccess) return fail(VC_ERR_HIP, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+    allocs.push_back(p);
+    *out = (T*)p;
+    return VC_OK;
+  }
+};
+
+#define HIPCHK(e_, call)                                                                        \
+  do {                                                                                          \
+    hipError_t _st = (call);                                                                    \
+    if (_st != hipSuccess) return (e_)->fail(VC_ERR_HIP, "%s: %s", #call, hipGetErrorString(_st)); \
+  } while (0)
+#define TRY(x)                 \
+  do {                         \
+    int _rc = (x);             \
+    if (_rc != VC_OK) return _rc; \
+  } while (0)
+
+static bool cond(const vc_engine* e, int site) { return (e->d.cond >> site) & 1u; }
+
+static long long site_size(const vc_engine* e, int site) {
+  const VcDims& d = e->d;
+  switch (site) {
+    case VC_SITE_PHIXY: return 2LL * d.Nc;
+    case VC_SITE_NU: return (long long)d.Ng * d.Nh;
+    case VC_SITE_DNU: return (long long)d.Nb * d.Ng;
+    case VC_SITE_NUOMEGA: return d.NW;
+    default: return d.Ng;
+  }
+}
+
+static bool site_exists(const vc_engine* e, int site) {
+  const VcDims& d = e->d;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  switch (site) {
+    case VC_SITE_PHIXY: case VC_SITE_NU: return true;
+    case VC_SITE_DNU: return d.with_dnu != 0;
+    case VC_SITE_SHAPE_INV: return d.noise == VC_NOISE_NB;
+    case VC_SITE_LOGGAMMA: case VC_SITE_LOGBETA: case VC_SITE_NUOMEGA: return vel;
+    case VC_SITE_RHO_REAL: return vel && d.guide == VC_GUIDE_LRMN;
+  }
+  return false;
+}
+
+static void build_layout(vc_engine* e) {
+  VcDims& d = e->d;
+  vc_layout& L = e->layout;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+  for (int i = 0; i < VC_P_COUNT; ++i) { L.offset[i] = -1; L.size[i] = 0; }
+  for (int i = 0; i < VC_E_COUNT; ++i) { L.eps_offset[i] = -1; L.eps_size[i] = 0; }
+  L.header = 4;
+  long long off = L.header;
+  auto add = [&](int id, long long n) { L.offset[id] = off; L.size[id] = n; off += n; };
+  add(VC_P_NU_LOCS, (long long)d.Ng * d.Nh);
+  add(VC_P_NU_USCALES, (long long)d.Ng * d.Nh);
+  if (d.with_dnu) add(VC_P_DNU_LOCS, (long long)d.Nb * d.Ng);
+  if (vel) {
+    add(VC_P_LOGBETA_LOCS, d.Ng);
+    add(VC_P_LOGBETA_USCALES, d.Ng);
+    if (!lrmn) {
+      add(VC_P_LOGGAMMA_LOCS, d.Ng);
+      add(VC_P_LOGGAMMA_USCALES, d.Ng);
+      add(VC_P_NUOMEGA_LOCS, d.NW);
+      add(VC_P_NUOMEGA_USCALES, d.NW);
+    } else {
+      add(VC_P_LRMN_LOC, d.M);
+      add(VC_P_LRMN_UCOV_FACTOR, (long long)d.M * d.R);
+      add(VC_P_LRMN_UCOV_DIAG, d.M);
+      add(VC_P_RHO_REAL_LOC, d.Ng);
+    }
+  }
+  if (d.noise == VC_NOISE_NB) add(VC_P_SHAPE_INV_ULOCS, d.Ng);
+  L.n_global = off - L.header;
+  add(VC_P_PHIXY_LOCS, 2LL * d.Nc);
+  L.n_local = 2LL * d.Nc;
+  L.total = off;
+  long long eo = 0;
+  auto adde = [&](int id, long long n) { L.eps_offset[id] = eo; L.eps_size[id] = n; eo += n; };
+  if (vel && !lrmn) { adde(VC_E_LOGGAMMA, d.Ng); adde(VC_E_LOGBETA, d.Ng); }
+  if (lrmn) { adde(VC_E_LRMN_W, d.R); adde(VC_E_LRMN_D, d.M); }
+  adde(VC_E_NU, (long long)d.Ng * d.Nh);
+  if (lrmn) adde(VC_E_LOGBETA, d.Ng);
+  if (vel && !lrmn) adde(VC_E_NUOMEGA, d.NW);
+  L.eps_n_global = eo;
+  adde(VC_E_PHIXY, 2LL * d.Nc);
+  L.eps_total = eo;
+  for (int i = 0; i < VC_P_COUNT; ++i) d.poff[i] = L.offset[i];
+  for (int i = 0; i < VC_E_COUNT; ++i) d.eoff[i] = L.eps_offset[i];
+  d.eps_n_global = L.eps_n_global;
+}
+
+extern "C" int vc_abi_version(void) { return VC_ABI_VERSION; }
+
+extern "C" const char* vc_last_error(const vc_engine* e) {
+  return e ? e->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int vc_create(const vc_config* c, vc_engine** out) {
+  auto bad = [&](const char* m) { g_create_error = m; return VC_ERR_ARG; };
+  if (!c || !out) return bad("vc_create: null argument");
+  if (c->abi_version != VC_ABI_VERSION) return bad("vc_create: abi_version mismatch");
+  if (c->model != VC_MODEL_PHASE && c->model != VC_MODEL_VELOCITY) return bad("vc_create: bad model");
+  if (c->noise < 0 || c->noise > 2) return bad("vc_create: bad noise model");
+  if (c->Ng <= 0 || c->Nc_local <= 0) return bad("vc_create: Ng and Nc_local must be positive");
+  if (c->Ng > (1 << 24) || c->Nc_local > (1LL << 30)) return bad("vc_create: problem too large");
+  const bool vel = c->model == VC_MODEL_VELOCITY;
+  if (c->n_harmonics < 1 || c->n_harmonics > VC_MAXH) {
+    g_create_error = "n_harmonics outside the compiled kernel set (1..3)";
+    return VC_ERR_UNSUPPORTED;
+  }
+  if (c->with_delta_nu && (c->Nb < 1 || c->Nb > VC_MAXNB)) {
+    g_create_error = "with_delta_nu needs 1 <= Nb <= 4 (compiled kernel set)";
+    return VC_ERR_UNSUPPORTED;
+  }
+  if (vel) {
+    if (c->n_harmonics_w < 0 || c->n_harmonics_w > VC_MAXH) {
+      g_create_error = "omega harmonics outside 0..3";
+      return VC_ERR_UNSUPPORTED;
+    }
+    if (c->Nx < 1 || c->Nx * (2 * c->n_harmonics_w + 1) > VC_MAX_NW) return bad("vc_create: bad Nx");
+    if (c->guide == VC_GUIDE_LRMN && (c->lrmn_rank < 1 || c->lrmn_rank > VC_MAX_RANK))
+      return bad("vc_create: lrmn_rank outside 1..8");
+  }
+  if (c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size) return bad("vc_create: bad rank/world_size");
+  vc_engine* e = new (std::nothrow) vc_engine();
+  if (!e) return bad("vc_create: out of host memory");
+  e->cfg = *c;
+  VcDims& d = e->d;
+  d.Ng = (int)c->Ng;
+  d.nGB = (d.Ng + VC_GBW - 1) / VC_GBW;
+  d.Ng_pad = d.nGB * VC_GBW;
+  d.Nc = (int)c->Nc_local;
+  d.cell_offset = c->cell_offset;
+  d.H = c->n_harmonics; d.Nh = 2 * d.H + 1;
+  d.Hw = vel ? c->n_harmonics_w : 0; d.Nhw = 2 * d.Hw + 1;
+  d.with_dnu = c->with_delta_nu ? 1 : 0;
+  d.Nb = d.with_dnu ? c->Nb : 0;
+  d.Nx = vel ? c->Nx : 0;
+  d.NW = d.Nx * d.Nhw;
+  d.model = c->model;
+  d.guide = vel ? c->guide : VC_GUIDE_MEANFIELD;
+  d.noise = c->noise;
+  d.R = (vel && d.guide == VC_GUIDE_LRMN) ? c->lrmn_rank : 0;
+  d.M = d.Ng + d.NW;
+  d.K = d.Nh + d.Nb;
+  d.ctw = ((2 * d.H + d.Nb + 2) + 3) / 4 * 4;
+  d.cond = 0;
+  d.root_w = c->rank == 0 ? 1.f : 0.f;
+  d.gamma_alpha = c->gamma_alpha; d.gamma_beta = c->gamma_beta;
+  d.sigma_ln_s = c->sigma_ln_s; d.sigma_ln_u = c->sigma_ln_u;
+  d.rho_mean = c->rho_mean; d.rho_std = c->rho_std; d.rho_scale = c->rho_scale;
+  build_layout(e);
+  *out = e;
+  return VC_OK;
+}
+
+extern "C" void vc_destroy(vc_engine* e) {
+  if (!e) return;
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+extern "C" int vc_get_layout(const vc_engine* e, vc_layout* out) {
+  if (!e || !out) return VC_ERR_ARG;
+  *out = e->layout;
+  return VC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int vc_set_counts(vc_engine* e, const float* S, const float* U, int64_t gs, int64_t cs, int on_device) {
+  if (!e) return VC_ERR_ARG;
+  if (e->finalized) return e->fail(VC_ERR_STATE, "vc_set_counts after vc_finalize");
+  VcDims& d = e->d;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  if (!S || (vel && !U)) return e->fail(VC_ERR_ARG, "vc_set_counts: missing matrix");
+  if (gs <= 0 || cs <= 0) return e->fail(VC_ERR_ARG, "vc_set_counts: strides must be positive");
+  const size_t span = (size_t)(d.Ng - 1) * gs + (size_t)(d.Nc - 1) * cs + 1;
+  const size_t blocked = (size_t)d.nGB * d.Nc * VC_GBW;
+  const int log1p_t = d.noise == VC_NOISE_LOGNORMAL;
+  const float* src[2] = {S, vel ? U : nullptr};
+  float** dst[2] = {&e->dS_raw, &e->dU_raw};
+  std::vector<float>* hcopy[2] = {&e->hS, &e->hU};
+  for (int m = 0; m < 2; ++m) {
+    if (!src[m]) continue;
+    TRY(e->dalloc(dst[m], blocked));
+    float* staging = nullptr;
+    const float* dev_src = src[m];
+    if (!on_device) {
+      HIPCHK(e, hipMalloc((void**)&staging, span * sizeof(float)));
+      hipError_t st = hipMemcpy(staging, src[m], span * sizeof(float), hipMemcpyHostToDevice);
+      if (st != hipSuccess) { (void)hipFree(staging); return e->fail(VC_ERR_HIP, "H2D copy of counts: %s", hipGetErrorString(st)); }
+      dev_src = staging;
+    }
+    vc_launch_pack_counts(dev_src, *dst[m], gs, cs, d.Ng, d.Nc, d.nGB, log1p_t, nullptr);
+    hipError_t st = hipDeviceSynchronize();
+    if (staging) (void)hipFree(staging);
+    if (st != hipSuccess) return e->fail(VC_ERR_HIP, "pack_counts: %s", hipGetErrorString(st));
+    // host copy (raw counts, strided as given) for the histograms / lgamma(k+1) constant
+    if (d.noise != VC_NOISE_LOGNORMAL) {
+      std::vector<float> tmp(span);
+      if (on_device) HIPCHK(e, hipMemcpy(tmp.data(), src[m], span * sizeof(float), hipMemcpyDeviceToHost));
+      else memcpy(tmp.data(), src[m], span * sizeof(float));
+      hcopy[m]->swap(tmp);
+    }
+  }
+  e->gs = gs;
+  e->cs = cs;
+  e->have_counts = true;
+  return VC_OK;
+}
+
+extern "C" int vc_set_cell_data(vc_engine* e, const float* count_factor, const float* D, const float* Db,
+                                const float* phixy_prior) {
+  if (!e) return VC_ERR_ARG;
+  if (e->finalized) return e->fail(VC_ERR_STATE, "vc_set_cell_data after vc_finalize");
+  VcDims& d = e->d;
+  if (!count_factor || !phixy_prior) return e->fail(VC_ERR_ARG, "vc_set_cell_data: null count_factor / phixy_prior");
+  if (d.Nx > 0 && !D) return e->fail(VC_ERR_ARG, "vc_set_cell_data: D required for the velocity model");
+  if (d.Nb > 0 && !Db) return e->fail(VC_ERR_ARG, "vc_set_cell_data: Db required when with_delta_nu");
+  float *cf, *dm = nullptr, *dbm = nullptr, *pxy;
+  TRY(e->dalloc(&cf, d.Nc));
+  TRY(e->dalloc(&pxy, 2 * (size_t)d.Nc));
+  HIPCHK(e, hipMemcpy(cf, count_factor, sizeof(float) * d.Nc, hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(pxy, phixy_prior, sizeof(float) * 2 * d.Nc, hipMemcpyHostToDevice));
+  if (d.Nx > 0) {
+    TRY(e->dalloc(&dm, (size_t)d.Nx * d.Nc));
+    HIPCHK(e, hipMemcpy(dm, D, sizeof(float) * d.Nx * d.Nc, hipMemcpyHostToDevice));
+  }
+  if (d.Nb > 0) {
+    TRY(e->dalloc(&dbm, (size_t)d.Nb * d.Nc));
+    HIPCHK(e, hipMemcpy(dbm, Db, sizeof(float) * d.Nb * d.Nc, hipMemcpyHostToDevice));
+  }
+  e->b.cf = cf; e->b.Dm = dm; e->b.Dbm = dbm; e->b.pxy = pxy;
+  e->have_cells = true;
+  return VC_OK;
+}
+
+static long long prior_size(const vc_engine* e, int which) {
+  const VcDims& d = e->d;
+  switch (which) {
+    case VC_PRIOR_MU_NU: case VC_PRIOR_SD_NU: return (long long)d.Ng * d.Nh;
+    case VC_PRIOR_MU_NUOMEGA: case VC_PRIOR_SD_NUOMEGA: return d.NW;
+    case VC_PRIOR_SD_DNU: return (long long)d.Nb * d.Ng;
+    default: return d.Ng;
+  }
+}
+
+extern "C" int vc_set_prior(vc_engine* e, int which, const float* data, int64_t n) {
+  if (!e) return VC_ERR_ARG;
+  if (e->finalized) return e->fail(VC_ERR_STATE, "vc_set_prior after vc_finalize");
+  if (which < 0 || which >= VC_PRIOR_COUNT || !data) return e->fail(VC_ERR_ARG, "vc_set_prior: bad id / null data");
+  if (n != prior_size(e, which))
+    return e->fail(VC_ERR_ARG, "vc_set_prior(%d): expected %lld values, got %lld", which, prior_size(e, which), (long long)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const bool is_sd = which == VC_PRIOR_SD_NU || which == VC_PRIOR_SD_GAMMA || which == VC_PRIOR_SD_BETA ||
+                       which == VC_PRIOR_SD_NUOMEGA || which == VC_PRIOR_SD_DNU;
+    if (!std::isfinite(data[i]) || (is_sd && !(data[i] > 0.f)))
+      return e->fail(VC_ERR_ARG, "vc_set_prior(%d): value %lld is not finite / not positive", which, (long long)i);
+  }
+  e->h_prior[which].assign(data, data + n);
+  e->prior_set[which] = true;
+  return VC_OK;
+}
+
+extern "C" int vc_set_conditioned(vc_engine* e, int site, const float* values, int64_t n) {
+  if (!e) return VC_ERR_ARG;
+  if (e->finalized) return e->fail(VC_ERR_STATE, "vc_set_conditioned after vc_finalize");
+  if (site < 0 || site >= VC_SITE_COUNT || !values) return e->fail(VC_ERR_ARG, "vc_set_conditioned: bad site / null data");
+  if (!site_exists(e, site)) return e->fail(VC_ERR_ARG, "vc_set_conditioned: site %d does not exist in this model", site);
+  if (n != site_size(e, site))
+    return e->fail(VC_ERR_ARG, "vc_set_conditioned(%d): expected %lld values, got %lld", site, site_size(e, site), (long long)n);
+  e->h_cond[site].assign(values, values + n);
+  e->d.cond |= (1u << site);
+  return VC_OK;
+}
+
+// per-gene histograms of the non-zero counts of one matrix; returns sum lgamma(k+1)
+static double build_hist(const std::vector<float>& M, long long gs, long long cs, int Ng, int Nc,
+                         std::vector<int>& ptr_out, std::vector<float>& val, std::vector<float>& cnt) {
+  const int CAP = 2048;
+  std::vector<std::vector<std::pair<float, float>>> per_gene(Ng);
+  std::vector<double> lg(Ng, 0.0);
+  unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  nt = std::min<unsigned>(nt, (unsigned)Ng);
+  auto work = [&](int ga, int gb) {
+    const int n = gb - ga;
+    std::vector<unsigned> dense((size_t)n * CAP, 0u);
+    std::vector<std::map<float, unsigned>> over(n);
+    auto put = [&](int gi, float v) {
+      if (v == 0.f) return;
+      const int iv = (int)v;
+      if (v > 0.f && iv < CAP && (float)iv == v) dense[(size_t)gi * CAP + iv]++;
+      else over[gi][v]++;
+    };
+    if (gs <= cs) {
+      for (int c = 0; c < Nc; ++c) {
+        const float* row = M.data() + (long long)c * cs;
+        for (int g = ga; g < gb; ++g) put(g - ga, row[(long long)g * gs]);
+      }
+    } else {
+      for (int g = ga; g < gb; ++g) {
+        const float* row = M.data() + (long long)g * gs;
+        for (int c = 0; c < Nc; ++c) put(g - ga, row[(long long)c * cs]);
+      }
+    }
+    for (int gi = 0; gi < n; ++gi) {
+      auto& out = per_gene[ga + gi];
+      double s = 0.0;
+      for (int k = 1; k < CAP; ++k) {
+        const unsigned m = dense[(size_t)gi * CAP + k];
+        if (m) { out.emplace_back((float)k, (float)m); s += (double)m * std::lgamma((double)k + 1.0); }
+      }
+      for (auto& kv : over[gi]) {
+        out.emplace_back(kv.first, (float)kv.second);
+        s += (double)kv.second * std::lgamma((double)kv.first + 1.0);
+      }
+      lg[ga + gi] = s;
+    }
+  };
+  std::vector<std::thread> th;
+  const int per = (Ng + (int)nt - 1) / (int)nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const int ga = (int)t * per, gb = std::min(Ng, ga + per);
+    if (ga < gb) th.emplace_back(work, ga, gb);
+  }
+  for (auto& t : th) t.join();
+  double tot = 0.0;
+  for (int g = 0; g < Ng; ++g) {
+    ptr_out.push_back((int)val.size());
+    for (auto& kv : per_gene[g]) { val.push_back(kv.first); cnt.push_back(kv.second); }
+    tot += lg[g];
+  }
+  return tot;
+}
+
+template <class T>
+static int upload(vc_engine* e, const std::vector<T>& h, const T** dev) {
+  T* p = nullptr;
+  TRY(e->dalloc(&p, h.size()));
+  if (!h.empty()) HIPCHK(e, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dev = p;
+  return VC_OK;
+}
+
+extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (e->finalized) return e->fail(VC_ERR_STATE, "vc_finalize called twice");
+  if (!e->have_counts || !e->have_cells) return e->fail(VC_ERR_STATE, "vc_finalize: counts / cell data not set");
+  hipStream_t st = (hipStream_t)hip_stream;
+  VcDims& d = e->d;
+  VcBufs& b = e->b;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+  const bool nb = d.noise == VC_NOISE_NB;
+  // required priors
+  const int need_all[] = {VC_PRIOR_MU_NU, VC_PRIOR_SD_NU};
+  for (int w : need_all)
+    if (!e->prior_set[w]) return e->fail(VC_ERR_STATE, "vc_finalize: prior %d not set", w);
+  if (vel)
+    for (int w = VC_PRIOR_MU_GAMMA; w <= VC_PRIOR_SD_NUOMEGA; ++w)
+      if (!e->prior_set[w]) return e->fail(VC_ERR_STATE, "vc_finalize: prior %d not set", w);
+  if (!vel && d.with_dnu && !e->prior_set[VC_PRIOR_SD_DNU])
+    return e->fail(VC_ERR_STATE, "vc_finalize: sd_dnu prior not set");
+
+  // kernel kind
+  if (!vel) d.kind = VC_KIND_PHASE;
+  else {
+    const bool vu = cond(e, VC_SITE_PHIXY) && cond(e, VC_SITE_NU) && (!d.with_dnu || cond(e, VC_SITE_DNU)) &&
+                    (!nb || cond(e, VC_SITE_SHAPE_INV));
+    d.kind = vu ? VC_KIND_VU : VC_KIND_VFULL;
+  }
+  auto nq_of = [&](int kind) { return kind == VC_KIND_PHASE ? d.K + 1 : (kind == VC_KIND_VFULL ? d.K + 3 : 2); };
+  auto nco_of = [&](int kind) { return kind == VC_KIND_VFULL ? 3 : 1; };
+  d.nq = nq_of(d.kind);
+  d.nco = nco_of(d.kind);
+  e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, &e->main_name);
+  if (!e->main_fn) return e->fail(VC_ERR_UNSUPPORTED, "no likelihood kernel for H=%d Nb=%d kind=%d noise=%d", d.H, d.Nb, d.kind, d.noise);
+  if (d.kind == VC_KIND_VU) {
+    e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, nullptr);
+    if (!e->phase_fn) return e->fail(VC_ERR_UNSUPPORTED, "no S-only kernel for the hoisted term");
+  }
+  // tiling: 4 waves x cw cells per workgroup; aim at <= ~2048 workgroups so that the second-stage
+  // reduction stays a few per cent of the streamed bytes
+  {
+    const long long wg64 = (long long)d.nGB * ((d.Nc + 255) / 256);
+    long long mult = (wg64 + 2047) / 2048;
+    if (mult < 1) mult = 1;
+    d.cw = (int)(64 * mult);
+    const int per_wg = VC_WAVES * d.cw;
+    d.n_chunks = (d.Nc + per_wg - 1) / per_wg;
+    d.n_main_wg = d.nGB * d.n_chunks;
+  }
+  d.nb_pre_gene = d.Ng_pad / 256;
+  d.nb_pre_cell = (d.Nc + 255) / 256;
+  d.nb_post_gene = d.Ng_pad / 64;
+  d.nb_post_cell = (d.Nc + 255) / 256;
+  d.hist_has_S = nb && d.kind != VC_KIND_VU;
+  d.hist_has_U = nb && vel;
+  d.nmat_r = nb ? (d.kind == VC_KIND_VFULL ? 2 : 1) : 0;
+  e->hist_each_step = nb && !cond(e, VC_SITE_SHAPE_INV);
+
+  // uploads
+  b.S = e->dS_raw; b.U = e->dU_raw;
+  TRY(upload(e, e->h_prior[VC_PRIOR_MU_NU], &b.mu_nu));
+  TRY(upload(e, e->h_prior[VC_PRIOR_SD_NU], &b.sd_nu));
+  if (vel) {
+    TRY(upload(e, e->h_prior[VC_PRIOR_MU_GAMMA], &b.mu_g));
+    TRY(upload(e, e->h_prior[VC_PRIOR_SD_GAMMA], &b.sd_g));
+    TRY(upload(e, e->h_prior[VC_PRIOR_MU_BETA], &b.mu_b));
+    TRY(upload(e, e->h_prior[VC_PRIOR_SD_BETA], &b.sd_b));
+    TRY(upload(e, e->h_prior[VC_PRIOR_MU_NUOMEGA], &b.mu_w));
+    TRY(upload(e, e->h_prior[VC_PRIOR_SD_NUOMEGA], &b.sd_w));
+  }
+  if (!vel && d.with_dnu) TRY(upload(e, e->h_prior[VC_PRIOR_SD_DNU], &b.sd_dnu));
+  for (int s = 0; s < VC_SITE_COUNT; ++s) {
+    b.cnd[s] = nullptr;
+    if (cond(e, s)) TRY(upload(e, e->h_cond[s], &b.cnd[s]));
+    b.lat[s] = nullptr;
+    if (site_exists(e, s)) TRY(e->dalloc(&b.lat[s], (size_t)site_size(e, s)));
+  }
+  TRY(e->dalloc(&b.eps_used, (size_t)e->layout.eps_total));
+  HIPCHK(e, hipMemset(b.eps_used, 0, sizeof(float) * e->layout.eps_total));
+  TRY(e->dalloc(&b.GT, (size_t)(d.K + 3) * d.Ng_pad));
+  TRY(e->dalloc(&b.CT, (size_t)d.Nc * d.ctw));
+  HIPCHK(e, hipMemset(b.CT, 0, sizeof(float) * (size_t)d.Nc * d.ctw));
+  TRY(e->dalloc(&b.lat_delta, (size_t)d.M));
+  TRY(e->dalloc(&b.lat_sgam, (size_t)d.Ng));
+  TRY(e->dalloc(&b.lat_phi, (size_t)d.Nc));
+  TRY(e->dalloc(&b.lat_omega, (size_t)d.Nc));
+  TRY(e->dalloc(&b.lat_domega, (size_t)d.Nc));
+  const int nq_max = std::max(d.nq, d.kind == VC_KIND_VU ? nq_of(VC_KIND_PHASE) : 0);
+  TRY(e->dalloc(&b.GO, (size_t)d.n_chunks * nq_max * d.Ng_pad));
+  TRY(e->dalloc(&b.CO, (size_t)d.nGB * 3 * d.Nc));
+  TRY(e->dalloc(&b.LO, (size_t)d.n_main_wg));
+  TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
+  TRY(e->dalloc(&b.PW, (size_t)d.nb_post_cell * std::max(1, d.NW)));
+  TRY(e->dalloc(&b.HL, (size_t)d.Ng));
+  TRY(e->dalloc(&b.HD, (size_t)d.Ng));
+  HIPCHK(e, hipMemset(b.HL, 0, sizeof(double) * d.Ng));
+  HIPCHK(e, hipMemset(b.HD, 0, sizeof(double) * d.Ng));
+
+  // histograms + step-invariant constants -----------------------------------------------------
+  double lg_S = 0.0, lg_U = 0.0;   // sum lgamma(k+1)
+  {
+    std::vector<int> ptr;
+    std::vector<float> val, cnt;
+    if (d.noise != VC_NOISE_LOGNORMAL) {
+      lg_S = build_hist(e->hS, e->gs, e->cs, d.Ng, d.Nc, ptr, val, cnt);
+      if (vel) lg_U = build_hist(e->hU, e->gs, e->cs, d.Ng, d.Nc, ptr, val, cnt);
+      else for (int g = 0; g < d.Ng; ++g) ptr.push_back((int)val.size());
+    } else {
+      ptr.assign(2 * (size_t)d.Ng, 0);
+    }
+    ptr.push_back((int)val.size());
+    TRY(upload(e, ptr, &b.h_ptr));
+    TRY(upload(e, val, &b.h_val));
+    TRY(upload(e, cnt, &b.h_cnt));
+    std::vector<float>().swap(e->hS);
+    std::vector<float>().swap(e->hU);
+  }
+  const double ln_const_s = (double)d.Ng * d.Nc * (std::log((double)d.sigma_ln_s) + 0.5 * std::log(2.0 * M_PI));
+  const double ln_const_u = (double)d.Ng * d.Nc * (std::log((double)d.sigma_ln_u) + 0.5 * std::log(2.0 * M_PI));
+  auto obs_const = [&](bool is_u) {   // constant part of -loglik of one matrix
+    if (d.noise == VC_NOISE_LOGNORMAL) return is_u ? ln_const_u : ln_const_s;
+    return is_u ? lg_U : lg_S;
+  };
+  double cl = 0.0;
+  if (d.kind != VC_KIND_VU) cl += obs_const(false);
+  if (vel) cl += obs_const(true);
+
+  if (d.kind == VC_KIND_VU) {
+    // hoist the S likelihood: with phi, nu, dnu, shape_inv fixed it does not change between steps
+    VcDims d2 = d;
+    d2.kind = VC_KIND_PHASE; d2.nq = nq_of(VC_KIND_PHASE); d2.nco = 1;
+    d2.hist_has_S = nb; d2.hist_has_U = 0;
+    vc_launch_pre(d2, b, nullptr, nullptr, 0, 0, nullptr, 1, st);
+    if (nb) vc_launch_hist(d2, b, st);
+    e->phase_fn(d2, b, st);
+    HIPCHK(e, hipStreamSynchronize(st));
+    HIPCHK(e, hipGetLastError());
+    std::vector<float> lo(d.n_main_wg), rrow(d.Ng);
+    std::vector<double> hl(d.Ng, 0.0);
+    HIPCHK(e, hipMemcpy(lo.data(), b.LO, sizeof(float) * d.n_main_wg, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(rrow.data(), b.GT + (size_t)(d.K + 2) * d.Ng_pad, sizeof(float) * d.Ng, hipMemcpyDeviceToHost));
+    if (nb) HIPCHK(e, hipMemcpy(hl.data(), b.HL, sizeof(double) * d.Ng, hipMemcpyDeviceToHost));
+    double sconst = obs_const(false);
+    for (float v : lo) sconst -= (double)v;
+    if (nb)
+      for (int g = 0; g < d.Ng; ++g) sconst -= (double)d.Nc * rrow[g] * std::log((double)rrow[g]) + hl[g];
+    cl += sconst;
+  }
+  if (nb && !e->hist_each_step) {
+    // shape_inv conditioned: the lgamma / digamma sums never change -> evaluate them once
+    vc_launch_pre(d, b, nullptr, nullptr, 0, 0, nullptr, 1, st);
+    vc_launch_hist(d, b, st);
+    HIPCHK(e, hipStreamSynchronize(st));
+  }
+  b.const_loss = cl;
+  HIPCHK(e, hipStreamSynchronize(st));
+  HIPCHK(e, hipGetLastError());
+  e->finalized = true;
+  return VC_OK;
+}
+
+extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
+                            const int64_t* step_dev, float* grad, double* loss_dev, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_elbo_grad before vc_finalize");
+  if (!params || !grad) return e->fail(VC_ERR_ARG, "vc_elbo_grad: null params / grad");
+  hipStream_t st = (hipStream_t)hip_stream;
+  vc_launch_pre(e->d, e->b, params, eps, seed, (long long)step, (const long long*)step_dev, 0, st);
+  if (e->hist_each_step) vc_launch_hist(e->d, e->b, st);
+  e->main_fn(e->d, e->b, st);
+  vc_launch_post(e->d, e->b, params, grad, loss_dev, st);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
+extern "C" int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream) {
+  if (!e || !host_out) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_read_site before vc_finalize");
+  const float* src = nullptr;
+  long long sz = 0;
+  if (site >= 0 && site < VC_SITE_COUNT) {
+    if (!site_exists(e, site)) return e->fail(VC_ERR_ARG, "vc_read_site: site %d not in this model", site);
+    src = e->b.lat[site]; sz = site_size(e, site);
+  } else if (site == VC_DET_PHI) { src = e->b.lat_phi; sz = e->d.Nc; }
+  else if (site == VC_DET_OMEGA) { src = e->b.lat_omega; sz = e->d.Nc; }
+  else if (site == VC_DET_EPS) { src = e->b.eps_used; sz = e->layout.eps_total; }
+  else return e->fail(VC_ERR_ARG, "vc_read_site: unknown site %d", site);
+  if (n != sz) return e->fail(VC_ERR_ARG, "vc_read_site(%d): expected %lld values, got %lld", site, sz, (long long)n);
+  HIPCHK(e, hipStreamSynchronize((hipStream_t)hip_stream));
+  HIPCHK(e, hipMemcpy(host_out, src, sizeof(float) * sz, hipMemcpyDeviceToHost));
+  return VC_OK;
+}
+
+extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
+  if (!e || !out) return VC_ERR_ARG;
+  memset(out, 0, sizeof *out);
+  const VcDims& d = e->d;
+  const int nmat = d.kind == VC_KIND_VFULL ? 2 : 1;
+  out->algorithmic_bytes = (int64_t)nmat * 4 * d.Ng * (int64_t)d.Nc;
+  out->streamed_bytes = (int64_t)nmat * 4 * d.Ng_pad * (int64_t)d.Nc;
+  out->main_grid = d.n_main_wg;
+  out->main_block = 256;
+  out->main_kind = d.kind;
+  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s>", d.H, d.Nb, e->main_name);
+  return VC_OK;
+}

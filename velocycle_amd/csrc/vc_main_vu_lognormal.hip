@@ -1,0 +1,3 @@
+// Instantiations of the likelihood kernel: kind=vu, noise=lognormal, H in 1..3, NB in 0..4.
+#include "vc_main_kernel.h"
+VC_DEFINE_TABLE(vc_tab_vu_lognormal, VC_KIND_VU, VC_NOISE_LOGNORMAL)

@@ -1,0 +1,556 @@
+// O(Ng + Nc) kernels around the likelihood kernel:
+//   vc_pack_counts   one-time re-layout of a strided (gene, cell) matrix into [gene block][cell][256]
+//   vc_pre           guide sampling (reparameterisation), site values, prior / guide log-probs,
+//                    gene table + cell table for K_main
+//   vc_hist          negative-binomial lgamma / digamma terms from per-gene count histograms (fp64)
+//   vc_post_gene     second-stage reduction of gene-level partials + chain rule to parameter gradients
+//   vc_post_cell     second-stage reduction of cell-level partials, atan2 Jacobian, omega partials
+//   vc_fin           loss assembly in fp64, angular-speed gradients, loss header
+// Reference semantics restated: velocity_inference_guide.py:9-141, phase_inference_guide.py:10-56,
+// priors of velocity_inference_model.py:322-353,383 / phase_inference_model.py:360-366,392.
+#include "vc_common.h"
+
+#define CND(site) ((d.cond >> (site)) & 1u)
+
+// ---------------------------------------------------------------------------------------------
+__global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                      long long gs, long long cs, int Ng, int Nc, int nGB, int log1p_t) {
+  const long long total = (long long)nGB * Nc * VC_GBW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int gl = (int)(i % VC_GBW);
+    const long long t = i / VC_GBW;
+    const int c = (int)(t % Nc);
+    const int gb = (int)(t / Nc);
+    const int g = gb * VC_GBW + gl;
+    float v = 0.f;
+    if (g < Ng) {
+      v = src[(long long)g * gs + (long long)c * cs];
+      if (log1p_t) v = (float)log((double)v + 1.0 + 1e-16);   // preprocessing.py:154 / :267
+    }
+    dst[i] = v;
+  }
+}
+
+void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
+                           int Ng, int Nc, int nGB, int log1p_transform, hipStream_t st) {
+  hipLaunchKernelGGL(vc_pack_counts_kernel, dim3(2048), dim3(256), 0, st, src, dst, gene_stride,
+                     cell_stride, Ng, Nc, nGB, log1p_transform);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_pre
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBufs b,
+                                                     const float* __restrict__ P,
+                                                     const float* __restrict__ eps_in, uint64_t seed,
+                                                     long long step_host,
+                                                     const long long* __restrict__ step_dev,
+                                                     int cond_only) {
+  __shared__ double sm_red[16];
+  __shared__ float s_nuw[VC_MAX_NW];
+  const long long step = step_dev ? *step_dev : step_host;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+  const bool nb = d.noise == VC_NOISE_NB;
+  double loss = 0.0;
+
+  if ((int)blockIdx.x < d.nb_pre_gene) {
+    // ------------------------------- gene part ------------------------------------------------
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < d.Ng_pad) {
+      float* GT = b.GT + g;
+      const size_t NP = d.Ng_pad;
+      if (g >= d.Ng) {   // padded gene: nu~ = 0 (never reaches a per-cell sum), loss masked in K_main
+        for (int k = 0; k < d.K; ++k) GT[k * NP] = 0.f;
+        GT[d.K * NP] = 0.f; GT[(d.K + 1) * NP] = 1.f; GT[(d.K + 2) * NP] = 1.f;
+      } else {
+        float logp = 0.f, logq = 0.f;
+        // ---- nu ----
+        for (int h = 0; h < d.Nh; ++h) {
+          const long long j = (long long)g * d.Nh + h;
+          float x;
+          if (cond_only) {
+            x = CND(VC_SITE_NU) ? b.cnd[VC_SITE_NU][j] : 0.f;
+          } else {
+            const float e = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_NU] + j, d.eoff[VC_E_NU] + j);
+            const float u = P[d.poff[VC_P_NU_USCALES] + j];
+            const float xg = P[d.poff[VC_P_NU_LOCS] + j] + expf(u) * e;
+            if (CND(VC_SITE_NU)) x = b.cnd[VC_SITE_NU][j];
+            else { x = xg; logq += -0.5f * e * e - u - 0.5f * VC_LOG_2PI; }
+            logp += vc_normal_lp(x, b.mu_nu[j], b.sd_nu[j]);
+            b.lat[VC_SITE_NU][j] = x;
+          }
+          GT[h * NP] = x;
+        }
+        // ---- delta nu (Delta guide) ----
+        for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
+          const long long j = (long long)q * d.Ng + g;
+          float x;
+          if (cond_only) x = CND(VC_SITE_DNU) ? b.cnd[VC_SITE_DNU][j] : 0.f;
+          else {
+            x = CND(VC_SITE_DNU) ? b.cnd[VC_SITE_DNU][j] : P[d.poff[VC_P_DNU_LOCS] + j];
+            logp += vc_normal_lp(x, 0.f, vel ? 0.01f : b.sd_dnu[j]);
+            b.lat[VC_SITE_DNU][j] = x;
+          }
+          GT[(d.Nh + q) * NP] = x;
+        }
+        // ---- shape_inv (Delta guide, positive) ----
+        float si = 1.f;
+        if (nb) {
+          if (cond_only) si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : 1.f;
+          else {
+            si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
+            logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) -
+                    d.gamma_beta * si - lgammaf(d.gamma_alpha);
+            b.lat[VC_SITE_SHAPE_INV][g] = si;
+          }
+        }
+        GT[(d.K + 2) * NP] = 1.0f / si;
+        // ---- log gamma, log beta ----
+        float lg = 0.f, lbv = 0.f;
+        if (vel && !cond_only) {
+          float lg_guide, lb_guide;
+          if (!lrmn) {
+            const float eg = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGGAMMA] + g, d.eoff[VC_E_LOGGAMMA] + g);
+            const float eb = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGBETA] + g, d.eoff[VC_E_LOGBETA] + g);
+            const float ug = P[d.poff[VC_P_LOGGAMMA_USCALES] + g], ub = P[d.poff[VC_P_LOGBETA_USCALES] + g];
+            lg_guide = P[d.poff[VC_P_LOGGAMMA_LOCS] + g] + expf(ug) * eg;
+            lb_guide = P[d.poff[VC_P_LOGBETA_LOCS] + g] + expf(ub) * eb;
+            if (!CND(VC_SITE_LOGGAMMA)) logq += -0.5f * eg * eg - ug - 0.5f * VC_LOG_2PI;
+            if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - ub - 0.5f * VC_LOG_2PI;
+          } else {
+            // LowRankMultivariateNormal.rsample: X = loc + W eps_W + sqrt(cov_diag) eps_D
+            float delta = 0.f, w2 = 0.f;
+            for (int k = 0; k < d.R; ++k) {
+              const float w = expf(P[d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k]);
+              const float ew = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_W] + k, d.eoff[VC_E_LRMN_W] + k);
+              delta += w * ew;
+              w2 += w * w;
+            }
+            const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
+            const float ed = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_D] + g, d.eoff[VC_E_LRMN_D] + g);
+            delta += sqrtf(dg) * ed;
+            const float sgam = sqrtf(w2 + dg);
+            lg_guide = P[d.poff[VC_P_LRMN_LOC] + g] + delta;
+            const float rho_real_g = P[d.poff[VC_P_RHO_REAL_LOC] + g];
+            const float rho = sigmoidf_(rho_real_g / d.rho_scale) * 1.998f - 0.999f;
+            const float ub = P[d.poff[VC_P_LOGBETA_USCALES] + g];
+            const float sb = expf(ub);
+            const float eb = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGBETA] + g, d.eoff[VC_E_LOGBETA] + g);
+            const float tt = sb * sqrtf(1.f - rho * rho);
+            lb_guide = P[d.poff[VC_P_LOGBETA_LOCS] + g] + rho * sb * delta / sgam + tt * eb;
+            if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - logf(tt) - 0.5f * VC_LOG_2PI;
+            b.lat_delta[g] = delta;
+            b.lat_sgam[g] = sgam;
+            const float rho_val = CND(VC_SITE_RHO_REAL) ? b.cnd[VC_SITE_RHO_REAL][g] : rho_real_g;
+            logp += vc_normal_lp(rho_val, d.rho_mean, d.rho_std);
+            b.lat[VC_SITE_RHO_REAL][g] = rho_val;
+          }
+          lg = CND(VC_SITE_LOGGAMMA) ? b.cnd[VC_SITE_LOGGAMMA][g] : lg_guide;
+          lbv = CND(VC_SITE_LOGBETA) ? b.cnd[VC_SITE_LOGBETA][g] : lb_guide;
+          logp += vc_normal_lp(lg, b.mu_g[g], b.sd_g[g]) + vc_normal_lp(lbv, b.mu_b[g], b.sd_b[g]);
+          b.lat[VC_SITE_LOGGAMMA][g] = lg;
+          b.lat[VC_SITE_LOGBETA][g] = lbv;
+        }
+        GT[d.K * NP] = lbv;
+        GT[(d.K + 1) * NP] = expf(lg);
+        loss = -(double)d.root_w * ((double)logp - (double)logq);
+      }
+    }
+  } else {
+    // ------------------------------- cell part ------------------------------------------------
+    const int bc = blockIdx.x - d.nb_pre_gene;
+    if (vel && (int)threadIdx.x < d.NW) {
+      const int j = threadIdx.x;
+      float val = 0.f, lq = 0.f;
+      if (!cond_only) {
+        if (!lrmn) {
+          const float e = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_NUOMEGA] + j, d.eoff[VC_E_NUOMEGA] + j);
+          const float u = P[d.poff[VC_P_NUOMEGA_USCALES] + j];
+          val = P[d.poff[VC_P_NUOMEGA_LOCS] + j] + expf(u) * e;
+          lq = -0.5f * e * e - u - 0.5f * VC_LOG_2PI;
+        } else {
+          const long long i = (long long)d.Ng + j;
+          float delta = 0.f;
+          for (int k = 0; k < d.R; ++k) {
+            const float ew = eps_in ? eps_in[d.eoff[VC_E_LRMN_W] + k]
+                                    : vc_philox_normal(seed, step, d.eoff[VC_E_LRMN_W] + k);
+            delta += expf(P[d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + k]) * ew;
+          }
+          const float ed = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_D] + i, d.eoff[VC_E_LRMN_D] + i);
+          delta += sqrtf(expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + i])) * ed;
+          val = P[d.poff[VC_P_LRMN_LOC] + i] + delta;
+          if (bc == 0) b.lat_delta[i] = delta;
+        }
+        const float x = CND(VC_SITE_NUOMEGA) ? b.cnd[VC_SITE_NUOMEGA][j] : val;
+        if (bc == 0) {
+          b.lat[VC_SITE_NUOMEGA][j] = x;
+          const float lp = vc_normal_lp(x, b.mu_w[j], b.sd_w[j]);
+          loss = -(double)d.root_w * ((double)lp - ((CND(VC_SITE_NUOMEGA) || lrmn) ? 0.0 : (double)lq));
+        }
+        val = x;
+      }
+      s_nuw[j] = val;
+    }
+    __syncthreads();
+    const int c = bc * 256 + threadIdx.x;
+    if (c < d.Nc) {
+      float x, y;
+      if (cond_only) {
+        x = CND(VC_SITE_PHIXY) ? b.cnd[VC_SITE_PHIXY][2 * c] : 1.f;
+        y = CND(VC_SITE_PHIXY) ? b.cnd[VC_SITE_PHIXY][2 * c + 1] : 0.f;
+      } else {
+        const long long li = d.eoff[VC_E_PHIXY] + 2LL * c;
+        const long long gi = d.eoff[VC_E_PHIXY] + 2LL * (d.cell_offset + c);
+        const float ex = vc_eps(eps_in, b.eps_used, seed, step, li, gi);
+        const float ey = vc_eps(eps_in, b.eps_used, seed, step, li + 1, gi + 1);
+        const float px = b.pxy[2 * c], py = b.pxy[2 * c + 1];
+        if (CND(VC_SITE_PHIXY)) {
+          x = b.cnd[VC_SITE_PHIXY][2 * c]; y = b.cnd[VC_SITE_PHIXY][2 * c + 1];
+          loss += 0.5 * ((double)(x - px) * (x - px) + (double)(y - py) * (y - py)) + (double)VC_LOG_2PI;
+        } else {
+          x = P[d.poff[VC_P_PHIXY_LOCS] + 2LL * c] + ex;
+          y = P[d.poff[VC_P_PHIXY_LOCS] + 2LL * c + 1] + ey;
+          // -(log p - log q): the -log(2 pi) of prior and guide cancel
+          loss += 0.5 * ((double)(x - px) * (x - px) + (double)(y - py) * (y - py)) -
+                  0.5 * ((double)ex * ex + (double)ey * ey);
+        }
+        b.lat[VC_SITE_PHIXY][2 * c] = x;
+        b.lat[VC_SITE_PHIXY][2 * c + 1] = y;
+      }
+      const float phi = atan2f(y, x);                      // utils.py:505-506
+      float s1, c1;
+      sincosf(phi, &s1, &c1);
+      float sk[VC_MAXH], ck[VC_MAXH];
+      sk[0] = s1; ck[0] = c1;
+      const int hm = d.H > d.Hw ? d.H : d.Hw;
+      for (int k = 1; k < hm && k < VC_MAXH; ++k) {
+        sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
+        ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
+      }
+      float omega = 0.f, domega = 0.f;
+      if (vel && !cond_only) {
+        for (int xq = 0; xq < d.Nx; ++xq) {
+          const float* nw = s_nuw + xq * d.Nhw;
+          float o = nw[0], dd = 0.f;
+          for (int k = 0; k < d.Hw; ++k) {
+            o += nw[2 * k + 1] * sk[k] + nw[2 * k + 2] * ck[k];
+            dd += (float)(k + 1) * (nw[2 * k + 1] * ck[k] - nw[2 * k + 2] * sk[k]);
+          }
+          const float dx = b.Dm[(size_t)xq * d.Nc + c];
+          omega += dx * o;
+          domega += dx * dd;
+        }
+      }
+      float* ct = b.CT + (size_t)c * d.ctw;
+      for (int k = 0; k < d.H; ++k) { ct[2 * k] = sk[k]; ct[2 * k + 1] = ck[k]; }
+      for (int q = 0; q < d.Nb && d.with_dnu; ++q) ct[2 * d.H + q] = b.Dbm[(size_t)q * d.Nc + c];
+      const int nbk = d.with_dnu ? d.Nb : 0;
+      ct[2 * d.H + nbk] = omega;
+      ct[2 * d.H + nbk + 1] = b.cf[c];
+      b.lat_phi[c] = phi;
+      b.lat_omega[c] = omega;
+      b.lat_domega[c] = domega;
+    }
+  }
+  const double tot = vc_block_sum_d(loss, sm_red);
+  if (threadIdx.x == 0) b.LP[blockIdx.x] = cond_only ? 0.0 : tot;
+}
+
+void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
+                   uint64_t seed, long long step, const long long* step_dev, int cond_only, hipStream_t st) {
+  hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell), dim3(256), 0, st, d, b, params,
+                     eps, seed, step, step_dev, cond_only);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_hist: one wave per gene; sum_k cnt_k * (lgamma(r+k) - lgamma(r)) and its r-derivative, in fp64.
+// Exact restatement of the lgamma terms of GammaPoisson.log_prob summed over cells: they depend on
+// (r_g, k) only, so the per-gene histogram of counts is a sufficient statistic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBufs b) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= d.Ng) return;
+  const double r = (double)b.GT[(size_t)(d.K + 2) * d.Ng_pad + g];
+  const double lg_r = lgamma(r), dg_r = vc_digamma_d(r);
+  double hl = 0.0, hd = 0.0;
+  for (int m = 0; m < 2; ++m) {
+    if ((m == 0 && !d.hist_has_S) || (m == 1 && !d.hist_has_U)) continue;
+    const int beg = b.h_ptr[m * d.Ng + g], end = b.h_ptr[m * d.Ng + g + 1];
+    for (int i = beg + lane; i < end; i += 64) {
+      const double k = (double)b.h_val[i], n = (double)b.h_cnt[i];
+      hl += n * (lgamma(r + k) - lg_r);
+      hd += n * (vc_digamma_d(r + k) - dg_r);
+    }
+  }
+  hl = vc_wave_sum_d(hl);
+  hd = vc_wave_sum_d(hd);
+  if (lane == 0) { b.HL[g] = hl; b.HD[g] = hd; }
+}
+
+void vc_launch_hist(const VcDims& d, const VcBufs& b, hipStream_t st) {
+  hipLaunchKernelGGL(vc_hist_kernel, dim3((d.Ng + 3) / 4), dim3(256), 0, st, d, b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_post_gene: 1024 threads = 16 waves; lanes = 64 genes; wave w sums chunks w, w+16, ...
+// ---------------------------------------------------------------------------------------------
+#define VC_PG_WAVES 16
+#define VC_MAXQ (2 * VC_MAXH + 1 + VC_MAXNB + 3)
+
+__global__ __launch_bounds__(1024) void vc_post_gene_kernel(const VcDims d, const VcBufs b,
+                                                            const float* __restrict__ P,
+                                                            float* __restrict__ G) {
+  __shared__ float sm[VC_PG_WAVES][VC_MAXQ][64];
+  __shared__ double sm_red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.x * 64 + lane;
+  float acc[VC_MAXQ];
+#pragma unroll
+  for (int q = 0; q < VC_MAXQ; ++q) acc[q] = 0.f;
+  for (int ch = wave; ch < d.n_chunks; ch += VC_PG_WAVES) {
+    const float* go = b.GO + ((size_t)ch * d.nq) * d.Ng_pad + g;
+#pragma unroll
+    for (int q = 0; q < VC_MAXQ; ++q)
+      if (q < d.nq) acc[q] += go[(size_t)q * d.Ng_pad];
+  }
+#pragma unroll
+  for (int q = 0; q < VC_MAXQ; ++q) sm[wave][q][lane] = acc[q];
+  __syncthreads();
+  double loss = 0.0;
+  if (wave == 0 && g < d.Ng) {
+    float T[VC_MAXQ];
+#pragma unroll
+    for (int q = 0; q < VC_MAXQ; ++q) {
+      float s = 0.f;
+      for (int w = 0; w < VC_PG_WAVES; ++w) s += sm[w][q][lane];
+      T[q] = s;
+    }
+    const bool vel = d.model == VC_MODEL_VELOCITY;
+    const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+    const bool nb = d.noise == VC_NOISE_NB;
+    const int K = d.K, Nh = d.Nh;
+    const float rw = d.root_w;
+    // upstream d loglik / d site
+    float U_lb = 0.f, U_lg = 0.f, U_r = 0.f;
+    const float gam = b.GT[(size_t)(K + 1) * d.Ng_pad + g];
+    const float r = b.GT[(size_t)(K + 2) * d.Ng_pad + g];
+    if (d.kind == VC_KIND_PHASE) U_r = T[K];
+    else if (d.kind == VC_KIND_VFULL) { U_lb = -T[K]; U_lg = T[K + 1] * gam; U_r = T[K + 2]; }
+    else { U_lb = -T[0]; U_lg = T[1] * gam; }
+
+    // ---- nu ----
+    for (int h = 0; h < Nh; ++h) {
+      const long long j = (long long)g * Nh + h;
+      float gl = 0.f, gu = 0.f;
+      if (!CND(VC_SITE_NU)) {
+        const float x = b.lat[VC_SITE_NU][j];
+        const float sd = b.sd_nu[j];
+        const float gx = T[h] - rw * (x - b.mu_nu[j]) / (sd * sd);
+        const float e = b.eps_used[d.eoff[VC_E_NU] + j];
+        gl = -gx;
+        gu = -gx * expf(P[d.poff[VC_P_NU_USCALES] + j]) * e - rw;
+      }
+      G[d.poff[VC_P_NU_LOCS] + j] = gl;
+      G[d.poff[VC_P_NU_USCALES] + j] = gu;
+    }
+    // ---- delta nu ----
+    for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
+      const long long j = (long long)q * d.Ng + g;
+      float gl = 0.f;
+      if (!CND(VC_SITE_DNU)) {
+        const float x = b.lat[VC_SITE_DNU][j];
+        const float sd = vel ? 0.01f : b.sd_dnu[j];
+        gl = -(T[Nh + q] - rw * x / (sd * sd));
+      }
+      G[d.poff[VC_P_DNU_LOCS] + j] = gl;
+    }
+    // ---- shape_inv (negative binomial) ----
+    if (nb) {
+      // r-only terms of sum_c NB(k; r, eta): nmat*Nc*r*log r + sum_hist cnt*(lgamma(r+k)-lgamma(r))
+      const double lr = log((double)r);
+      if (d.nmat_r > 0) {
+        loss -= (double)d.nmat_r * d.Nc * (double)r * lr + b.HL[g];
+      }
+      float gu = 0.f;
+      if (!CND(VC_SITE_SHAPE_INV)) {
+        const float si = b.lat[VC_SITE_SHAPE_INV][g];
+        const double dr = (double)U_r + (double)d.nmat_r * d.Nc * (lr + 1.0) + b.HD[g];
+        const double gsi = -(double)r * (double)r * dr + (double)rw * ((d.gamma_alpha - 1.f) / si - d.gamma_beta);
+        gu = (float)(-gsi * (double)si);
+      }
+      G[d.poff[VC_P_SHAPE_INV_ULOCS] + g] = gu;
+    }
+    // ---- log gamma / log beta ----
+    if (vel) {
+      float g_lg = 0.f, g_lb = 0.f;   // total d log p / d site (0 when the site is conditioned)
+      if (!CND(VC_SITE_LOGGAMMA)) {
+        const float x = b.lat[VC_SITE_LOGGAMMA][g], sd = b.sd_g[g];
+        g_lg = U_lg - rw * (x - b.mu_g[g]) / (sd * sd);
+      }
+      if (!CND(VC_SITE_LOGBETA)) {
+        const float x = b.lat[VC_SITE_LOGBETA][g], sd = b.sd_b[g];
+        g_lb = U_lb - rw * (x - b.mu_b[g]) / (sd * sd);
+      }
+      if (!lrmn) {
+        const float eg = b.eps_used[d.eoff[VC_E_LOGGAMMA] + g], eb = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
+        const bool cg = CND(VC_SITE_LOGGAMMA), cb = CND(VC_SITE_LOGBETA);
+        G[d.poff[VC_P_LOGGAMMA_LOCS] + g] = -g_lg;
+        G[d.poff[VC_P_LOGGAMMA_USCALES] + g] = cg ? 0.f : -g_lg * expf(P[d.poff[VC_P_LOGGAMMA_USCALES] + g]) * eg - rw;
+        G[d.poff[VC_P_LOGBETA_LOCS] + g] = -g_lb;
+        G[d.poff[VC_P_LOGBETA_USCALES] + g] = cb ? 0.f : -g_lb * expf(P[d.poff[VC_P_LOGBETA_USCALES] + g]) * eb - rw;
+      } else {
+        // q(log beta | log gamma) = N(a + rho s_b delta / s_gamma, s_b sqrt(1-rho^2)); log gamma = loc + delta
+        const bool cb = CND(VC_SITE_LOGBETA);
+        const float A = g_lb;
+        const float ent = cb ? 0.f : rw;        // weight of the guide's -log(std) term
+        const float delta = b.lat_delta[g], sgam = b.lat_sgam[g];
+        const float sb = expf(P[d.poff[VC_P_LOGBETA_USCALES] + g]);
+        const float rho_real = P[d.poff[VC_P_RHO_REAL_LOC] + g];
+        const float sg = sigmoidf_(rho_real / d.rho_scale);
+        const float rho = sg * 1.998f - 0.999f;
+        const float om = 1.f - rho * rho, sq = sqrtf(om);
+        const float eb = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
+        G[d.poff[VC_P_LOGBETA_LOCS] + g] = -A;
+        G[d.poff[VC_P_LOGBETA_USCALES] + g] = -A * (rho * delta / sgam + sq * eb) * sb - ent;
+        float g_rho = -A * (sb * delta / sgam - sb * rho * eb / sq) + ent * rho / om;
+        float g_rr = g_rho * 1.998f * sg * (1.f - sg) / d.rho_scale;
+        if (!CND(VC_SITE_RHO_REAL)) g_rr += rw * (rho_real - d.rho_mean) / (d.rho_std * d.rho_std);
+        G[d.poff[VC_P_RHO_REAL_LOC] + g] = g_rr;
+        G[d.poff[VC_P_LRMN_LOC] + g] = -g_lg;
+        const float dl_ddelta = -g_lg - A * rho * sb / sgam;
+        const float dl_dsg = A * rho * sb * delta / (sgam * sgam);
+        for (int k = 0; k < d.R; ++k) {
+          const long long j = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k;
+          const float w = expf(P[j]);
+          const float ew = b.eps_used[d.eoff[VC_E_LRMN_W] + k];
+          G[j] = (w > 0.f) ? (dl_ddelta * ew + dl_dsg * w / sgam) * w : 0.f;
+        }
+        const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
+        const float ed = b.eps_used[d.eoff[VC_E_LRMN_D] + g];
+        G[d.poff[VC_P_LRMN_UCOV_DIAG] + g] = (dl_ddelta * ed / (2.f * sqrtf(dg)) + dl_dsg / (2.f * sgam)) * dg;
+      }
+    }
+  }
+  const double tot = vc_block_sum_d(loss, sm_red);
+  if (threadIdx.x == 0) b.LP[d.nb_pre_gene + d.nb_pre_cell + blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_post_cell
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vc_post_cell_kernel(const VcDims d, const VcBufs b,
+                                                           float* __restrict__ G) {
+  __shared__ float sm_w[VC_WAVES][VC_MAX_NW];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  float A[3] = {0.f, 0.f, 0.f};
+  float phi = 0.f;
+  if (c < d.Nc) {
+    for (int gb = 0; gb < d.nGB; ++gb)
+      for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + c];
+    phi = b.lat_phi[c];
+    if (d.poff[VC_P_PHIXY_LOCS] >= 0) {
+      float gx = 0.f, gy = 0.f;
+      if (!CND(VC_SITE_PHIXY)) {
+        float dphi = A[0];
+        if (d.kind == VC_KIND_VFULL) dphi += b.lat_omega[c] * A[1] + A[2] * b.lat_domega[c];
+        const float x = b.lat[VC_SITE_PHIXY][2 * c], y = b.lat[VC_SITE_PHIXY][2 * c + 1];
+        const float inv = 1.0f / (x * x + y * y);
+        gx = -(dphi * (-y * inv) - (x - b.pxy[2 * c]));
+        gy = -(dphi * (x * inv) - (y - b.pxy[2 * c + 1]));
+      }
+      G[d.poff[VC_P_PHIXY_LOCS] + 2LL * c] = gx;
+      G[d.poff[VC_P_PHIXY_LOCS] + 2LL * c + 1] = gy;
+    }
+  }
+  if (vel) {
+    // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c)
+    const float a3 = (c < d.Nc) ? (d.kind == VC_KIND_VFULL ? A[2] : A[0]) : 0.f;
+    float s1, c1;
+    sincosf(phi, &s1, &c1);
+    float sk[VC_MAXH], ck[VC_MAXH];
+    sk[0] = s1; ck[0] = c1;
+    for (int k = 1; k < d.Hw && k < VC_MAXH; ++k) {
+      sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
+      ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
+    }
+    for (int xq = 0; xq < d.Nx; ++xq) {
+      const float dx = (c < d.Nc) ? b.Dm[(size_t)xq * d.Nc + c] : 0.f;
+      for (int h = 0; h < d.Nhw; ++h) {
+        const float z = (h == 0) ? 1.f : ((h & 1) ? sk[(h - 1) >> 1] : ck[(h - 1) >> 1]);
+        const float t = vc_wave_sum(a3 * dx * z);
+        if (lane == 0) sm_w[wave][xq * d.Nhw + h] = t;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < d.NW) {
+      const int j = threadIdx.x;
+      b.PW[(size_t)blockIdx.x * d.NW + j] = (sm_w[0][j] + sm_w[1][j]) + (sm_w[2][j] + sm_w[3][j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_fin: one block.  Loss in fp64 (deterministic order), angular-speed gradients, header.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBufs b,
+                                                     const float* __restrict__ P, float* __restrict__ G,
+                                                     double* __restrict__ loss_dev) {
+  __shared__ double sm_red[16];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  const int nlp = d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene;
+  for (int i = t; i < nlp; i += 256) s += b.LP[i];
+  for (int i = t; i < d.n_main_wg; i += 256) s -= (double)b.LO[i];   // loss = -loglik
+  const double tot = vc_block_sum_d(s, sm_red);
+  if (t == 0) {
+    const double loss = tot + b.const_loss;
+    if (loss_dev) loss_dev[0] = loss;
+    const float hi = (float)loss;
+    G[0] = hi;
+    G[1] = (float)(loss - (double)hi);
+    G[2] = 0.f;
+    G[3] = 0.f;
+  }
+  if (d.model == VC_MODEL_VELOCITY && t < d.NW) {
+    const int j = t;
+    const bool lrmn = d.guide == VC_GUIDE_LRMN;
+    float up = 0.f;
+    for (int i = 0; i < d.nb_post_cell; ++i) up += b.PW[(size_t)i * d.NW + j];
+    float gx = 0.f;
+    const bool cnd = CND(VC_SITE_NUOMEGA);
+    if (!cnd) {
+      const float x = b.lat[VC_SITE_NUOMEGA][j], sd = b.sd_w[j];
+      gx = up - d.root_w * (x - b.mu_w[j]) / (sd * sd);
+    }
+    if (!lrmn) {
+      const float e = b.eps_used[d.eoff[VC_E_NUOMEGA] + j];
+      G[d.poff[VC_P_NUOMEGA_LOCS] + j] = -gx;
+      G[d.poff[VC_P_NUOMEGA_USCALES] + j] =
+          cnd ? 0.f : -gx * expf(P[d.poff[VC_P_NUOMEGA_USCALES] + j]) * e - d.root_w;
+    } else {
+      const long long i = (long long)d.Ng + j;
+      G[d.poff[VC_P_LRMN_LOC] + i] = -gx;
+      for (int k = 0; k < d.R; ++k) {
+        const long long q = d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + k;
+        const float w = expf(P[q]);
+        G[q] = (w > 0.f) ? -gx * b.eps_used[d.eoff[VC_E_LRMN_W] + k] * w : 0.f;
+      }
+      const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + i]);
+      G[d.poff[VC_P_LRMN_UCOV_DIAG] + i] = -gx * b.eps_used[d.eoff[VC_E_LRMN_D] + i] / (2.f * sqrtf(dg)) * dg;
+    }
+  }
+}
+
+void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad,
+                    double* loss_dev, hipStream_t st) {
+  hipLaunchKernelGGL(vc_post_gene_kernel, dim3(d.nb_post_gene), dim3(1024), 0, st, d, b, params, grad);
+  hipLaunchKernelGGL(vc_post_cell_kernel, dim3(d.nb_post_cell), dim3(256), 0, st, d, b, grad);
+  hipLaunchKernelGGL(vc_fin_kernel, dim3(1), dim3(256), 0, st, d, b, params, grad, loss_dev);
+}

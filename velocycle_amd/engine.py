@@ -1,0 +1,265 @@
+"""`HipEngine`: one ELBO + reparameterised-gradient evaluator on one MI355X, through the C ABI.
+
+It replaces, for one data shard, what `Trace_ELBO(num_particles=1).loss_and_grads(model, guide, mp)`
+does inside `svi.step` of the reference (phase_inference_model.py:169, velocity_inference_model.py:120).
+PyTorch is used for device memory and streams only; every number is produced by the HIP kernels of
+`velocycle_amd/csrc`.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .spec import ModelSpec
+
+
+class HipEngineError(RuntimeError):
+    pass
+
+
+def shard_bounds(Nc: int, rank: int, world_size: int):
+    """Contiguous cell blocks, sizes differing by at most one."""
+    base, rem = divmod(Nc, world_size)
+    c0 = rank * base + min(rank, rem)
+    return c0, c0 + base + (1 if rank < rem else 0)
+
+
+def _f32c(t, device="cpu"):
+    return torch.as_tensor(t).detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipEngine:
+    def __init__(self, spec: ModelSpec, device: Optional[torch.device] = None, rank: int = 0,
+                 world_size: int = 1):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise HipEngineError("velocycle_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        self.spec, self.rank, self.world_size = spec, rank, world_size
+        self.c0, self.c1 = shard_bounds(spec.Nc, rank, world_size)
+        self.Nc_local = self.c1 - self.c0
+        if self.Nc_local <= 0:
+            raise HipEngineError("more ranks than cells")
+        self._h = C.c_void_p()
+        self._keep = []
+        cfg = _lib.vc_config(
+            abi_version=_lib.VC_ABI_VERSION, model=_lib.MODEL[spec.kind], guide=_lib.GUIDE[spec.guide],
+            noise=self._noise_id(spec.noisemodel), with_delta_nu=int(spec.with_delta_nu),
+            n_harmonics=spec.H, n_harmonics_w=spec.Hw, Nb=spec.Nb, Nx=spec.Nx, lrmn_rank=spec.rho_rank,
+            rank=rank, world_size=world_size, Ng=spec.Ng, Nc_local=self.Nc_local, Nc_global=spec.Nc,
+            cell_offset=self.c0, gamma_alpha=spec.gamma_alpha, gamma_beta=spec.gamma_beta,
+            sigma_ln_s=spec.sigma_ln_s, sigma_ln_u=spec.sigma_ln_u, rho_mean=spec.rho_mean,
+            rho_std=spec.rho_std, rho_scale=spec.rho_scale)
+        rc = self.lib.vc_create(C.byref(cfg), C.byref(self._h))
+        if rc != _lib.VC_OK:
+            msg = self.lib.vc_last_error(None).decode()
+            self._h = C.c_void_p()
+            if rc == _lib.VC_ERR_UNSUPPORTED:
+                raise NotImplementedError(msg)
+            raise ValueError(msg)
+        try:
+            self._setup()
+        except Exception:
+            self.close()
+            raise
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _noise_id(name):
+        if name not in _lib.NOISE:
+            raise ValueError(f"{name} not allowed")      # velocity_inference_model.py:388
+        return _lib.NOISE[name]
+
+    def _check(self, rc):
+        if rc != _lib.VC_OK:
+            msg = self.lib.vc_last_error(self._h).decode()
+            if rc == _lib.VC_ERR_UNSUPPORTED:
+                raise NotImplementedError(msg)
+            if rc == _lib.VC_ERR_ARG:
+                raise ValueError(msg)
+            raise HipEngineError(msg)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _setup(self):
+        sp, lib, h = self.spec, self.lib, self._h
+        sl = slice(self.c0, self.c1)
+        # counts: pass the caller's storage as it is (strided view, host or device)
+        S = sp.S[:, sl]
+        U = sp.U[:, sl] if sp.U is not None else None
+        for m in (S, U):
+            if m is not None and m.dtype != torch.float32:
+                raise ValueError("count matrices must be float32 (the reference passes S.T.float())")
+        on_dev = int(S.is_cuda)
+        if U is not None and U.is_cuda != S.is_cuda:
+            raise ValueError("S and U must live on the same device")
+        norm = lambda m: m if (m is None or (m.stride(0) > 0 and m.stride(1) > 0)) else m.contiguous()
+        S, U = norm(S), norm(U)
+        if U is not None and U.stride() != S.stride():
+            S, U = S.contiguous(), U.contiguous()
+        gs, cs = S.stride()
+        self._check(lib.vc_set_counts(h, C.c_void_p(S.data_ptr()),
+                                      C.c_void_p(U.data_ptr()) if U is not None else None, gs, cs, on_dev))
+        cf = _f32c(sp.count_factor.reshape(-1)[sl])
+        D = _f32c(sp.D[:, sl]) if sp.D is not None else None
+        Db = _f32c(sp.Db[:, sl]) if (sp.with_delta_nu and sp.Nb > 0) else None
+        pxy = _f32c(sp.phixy_prior[sl])
+        self._check(lib.vc_set_cell_data(h, C.c_void_p(cf.data_ptr()),
+                                         C.c_void_p(D.data_ptr()) if D is not None else None,
+                                         C.c_void_p(Db.data_ptr()) if Db is not None else None,
+                                         C.c_void_p(pxy.data_ptr())))
+        priors = {"mu_nu": sp.mu_nu, "sd_nu": sp.sd_nu}
+        if sp.kind == "velocity":
+            priors.update(mu_gamma=sp.mu_gamma, sd_gamma=sp.sd_gamma, mu_beta=sp.mu_beta, sd_beta=sp.sd_beta,
+                          mu_nuw=sp.mu_nuw, sd_nuw=sp.sd_nuw)
+        elif sp.with_delta_nu:
+            sd = sp.sd_dnu
+            sd = torch.full((sp.Nb, sp.Ng), float(sd)) if not torch.is_tensor(sd) else sd.reshape(sp.Nb, sp.Ng)
+            priors["sd_dnu"] = sd
+        for name, val in priors.items():
+            t = _f32c(val).reshape(-1)
+            self._check(lib.vc_set_prior(h, _lib.PRIORS.index(name), C.c_void_p(t.data_ptr()), t.numel()))
+        for name, val in sp.condition_on.items():
+            if name not in _lib.SITE_ID:
+                raise ValueError(f"cannot condition on unknown site {name!r}")
+            t = _f32c(val).reshape(sp.site_shape(name))
+            if name == "ϕxy":
+                t = t[sl]
+            t = t.contiguous().reshape(-1)
+            self._check(lib.vc_set_conditioned(h, _lib.SITE_ID[name], C.c_void_p(t.data_ptr()), t.numel()))
+        self._check(lib.vc_finalize(h, self._stream()))
+        self.layout = _lib.vc_layout()
+        self._check(lib.vc_get_layout(h, C.byref(self.layout)))
+        L = self.layout
+        self.header, self.n_global, self.n_local, self.total = L.header, L.n_global, L.n_local, L.total
+        self.param_slices = {n: (L.offset[i], L.size[i]) for i, n in enumerate(_lib.PARAMS) if L.offset[i] >= 0}
+        self.eps_slices = {n: (L.eps_offset[i], L.eps_size[i]) for i, n in enumerate(_lib.EPS) if L.eps_offset[i] >= 0}
+        self.eps_total, self.eps_n_global = L.eps_total, L.eps_n_global
+        self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.device)
+        st = _lib.vc_stats()
+        self._check(lib.vc_get_stats(h, C.byref(st)))
+        self.stats = dict(algorithmic_bytes=st.algorithmic_bytes, streamed_bytes=st.streamed_bytes,
+                          main_grid=st.main_grid, main_block=st.main_block, main_kind=st.main_kind,
+                          main_kernel=st.main_kernel_name.decode())
+
+    # ------------------------------------------------------------------------------------------
+    def param_shape(self, name):
+        sp = self.spec
+        M = sp.Ng + sp.Nx * sp.Nhw
+        return {"ν_locs": (sp.Ng, sp.Nh), "ν_scales": (sp.Ng, sp.Nh), "Δν_locs": (sp.Nb, sp.Ng),
+                "νω_locs": (sp.Nx, sp.Nhw), "νω_scales": (sp.Nx, sp.Nhw), "loc": (M,),
+                "cov_factor": (M, sp.rho_rank), "cov_diag": (M,),
+                "ϕxy_locs": (self.Nc_local, 2)}.get(name, (sp.Ng,))
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        off, n = self.param_slices[name]
+        return flat[off:off + n].view(self.param_shape(name))
+
+    def named(self, flat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        flat = self.params if flat is None else flat
+        return {n: self.view(flat, n) for n in self.param_slices}
+
+    def init_params(self, cov_factor_draw: Optional[torch.Tensor] = None):
+        """Initial `pyro.param` values of the guide, unconstrained (phase_inference_guide.py:36-45,
+        velocity_inference_guide.py:25-43 / 78-102)."""
+        sp = self.spec
+        host = {}
+        host["ν_locs"] = sp.mu_nu
+        host["ν_scales"] = sp.sd_nu.log()
+        if sp.with_delta_nu:
+            host["Δν_locs"] = torch.full((sp.Nb, sp.Ng), float(sp.mu_dnu))
+        if sp.kind == "velocity":
+            host["logβg_locs"] = sp.mu_beta
+            host["logβg_scales"] = sp.sd_beta.log()
+            if sp.guide == "meanfield":
+                host["logγg_locs"] = sp.mu_gamma
+                host["logγg_scales"] = sp.sd_gamma.log()
+                host["νω_locs"] = sp.mu_nuw
+                host["νω_scales"] = sp.sd_nuw.log()
+            else:
+                if cov_factor_draw is None:
+                    raise ValueError("LRMN guide: pass the first guide call's cov_factor draw")
+                host["loc"] = torch.cat([sp.mu_gamma.reshape(-1), sp.mu_nuw.reshape(-1)])
+                host["cov_factor"] = torch.clip(cov_factor_draw.float(), min=0).log()
+                host["cov_diag"] = (torch.cat([sp.sd_gamma.reshape(-1), sp.sd_nuw.reshape(-1)]) ** 2).log()
+                host["rho_real_loc"] = torch.full((sp.Ng,), float(sp.rho_mean))
+        if sp.noisemodel == "NegativeBinomial":
+            host["shape_inv_locs"] = torch.full((sp.Ng,), math.log(sp.gamma_alpha / sp.gamma_beta))
+        host["ϕxy_locs"] = sp.phixy_prior[self.c0:self.c1]
+        self.params.zero_()
+        for n, v in host.items():
+            self.view(self.params, n).copy_(_f32c(v).reshape(self.param_shape(n)))
+        return self.params
+
+    def set_params(self, named: Dict[str, torch.Tensor]):
+        for n, v in named.items():
+            v = _f32c(v)
+            if n == "ϕxy_locs" and v.shape[0] == self.spec.Nc and self.Nc_local != self.spec.Nc:
+                v = v[self.c0:self.c1]
+            self.view(self.params, n).copy_(v.reshape(self.param_shape(n)))
+
+    def pack_eps(self, eps: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Flat eps vector of this rank from the per-site draws of one guide call (global ϕxy is sliced)."""
+        out = torch.zeros(self.eps_total, dtype=torch.float32)
+        for n, (off, size) in self.eps_slices.items():
+            v = torch.as_tensor(eps[n]).float()
+            if n == "ϕxy":
+                v = v.reshape(-1, 2)
+                if v.shape[0] == self.spec.Nc:
+                    v = v[self.c0:self.c1]
+            out[off:off + size] = v.reshape(-1)
+        return out.to(self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def elbo_grad(self, eps: Optional[torch.Tensor] = None, seed: int = 0, step: int = 0,
+                  step_dev: Optional[torch.Tensor] = None, params: Optional[torch.Tensor] = None,
+                  grad: Optional[torch.Tensor] = None):
+        """Launches one ELBO + gradient evaluation on the current stream (asynchronous).
+        Results: self.grad (header = loss hi/lo) and self.loss_dev."""
+        params = self.params if params is None else params
+        grad = self.grad if grad is None else grad
+        self._check(self.lib.vc_elbo_grad(
+            self._h, C.c_void_p(params.data_ptr()),
+            C.c_void_p(eps.data_ptr()) if eps is not None else None, C.c_uint64(seed), C.c_int64(step),
+            C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
+            C.c_void_p(grad.data_ptr()), C.c_void_p(self.loss_dev.data_ptr()), self._stream()))
+
+    def loss(self) -> float:
+        return float(self.loss_dev.item())
+
+    def read_site(self, name: str) -> torch.Tensor:
+        if name in _lib.SITE_ID:
+            sid, shape = _lib.SITE_ID[name], self.spec.site_shape(name)
+            if name == "ϕxy":
+                shape = (self.Nc_local, 2)
+        elif name == "ϕ":
+            sid, shape = _lib.DET_PHI, (self.Nc_local,)
+        elif name == "ω":
+            sid, shape = _lib.DET_OMEGA, (self.Nc_local,)
+        elif name == "eps":
+            sid, shape = _lib.DET_EPS, (self.eps_total,)
+        else:
+            raise KeyError(name)
+        out = torch.empty(shape, dtype=torch.float32)
+        self._check(self.lib.vc_read_site(self._h, sid, C.c_void_p(out.data_ptr()), out.numel(), self._stream()))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.vc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
