@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Benchmark of the SVI hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full SVI step of velocity inference on the BASELINE.json workload (synthetic
+50k cells x 2k genes): guide sampling -> ELBO + reparameterised gradient (HIP) -> [all-reduce over
+cell shards when N > 1] -> ClippedAdam update.  N > 1: launched by torch.distributed.run, one rank per
+GPU, cells sharded contiguously (strong scaling: the problem is fixed, value = steps/s of the job).
+
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries
+  roofline      HIP-event timing of the likelihood kernel against the HBM roof (ALGORITHMIC bytes:
+                fp32 count matrices read once, 8*Ng*Nc for the joint workload),
+  cpu_baseline  the oracle restatement (op-by-op torch fp32 + autograd + ClippedAdam) timed on this
+                host's cores on a bounded sample of the same workload (rank 0, N=1 only),
+  modes         steps/s of the tutorial flow (conditioned, default LRMN guide) next to the headline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cells", type=int, default=50000)
+    ap.add_argument("--genes", type=int, default=2000)
+    ap.add_argument("--mode", default="vjoint", choices=["vjoint", "vcond", "vcond_mf"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-modes", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=5000)
+    return ap.parse_args()
+
+
+def time_steps(run, steps, warmup, dist_on, device):
+    import torch.distributed as dist
+    run.run_perf(warmup, sync=True)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run.run_perf(steps, sync=False)
+    torch.cuda.synchronize(device)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def kernel_roofline(engine, run, steps):
+    """Average duration of the likelihood kernel over `steps` eager SVI steps, from hipEvents recorded
+    by the library on the launch stream around that kernel only."""
+    saved_graph, saved_flag = run._graph, run.use_graph
+    run._graph, run.use_graph = None, False
+    engine.set_timing(True)
+    run.run_perf(steps, sync=True)
+    ms, n = engine.get_timing()
+    engine.set_timing(False)
+    run._graph, run.use_graph = saved_graph, saved_flag
+    avg_s = ms / max(n, 1) * 1e-3
+    st = engine.stats
+    achieved = st["algorithmic_bytes"] / avg_s / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": st["main_kernel"], "kernel_avg_us": round(avg_s * 1e6, 2), "launches": int(n),
+            "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"]),
+            "streamed_bytes_per_launch": int(st["streamed_bytes"]),
+            "method": "hipEvents around the kernel over eager SVI steps run right after the timed region"}
+
+
+def cpu_baseline(args, mode):
+    """Oracle restatement timed on the host: same workload, first `cpu_sample_cells` cells, scaled."""
+    from oracle import velocycle_oracle as orc
+    from tests import helpers as H
+    from velocycle_amd.workloads import make_velocity_spec
+    nsample = min(args.cpu_sample_cells, args.cells)
+    spec = make_velocity_spec(nsample, args.genes, mode, 1, 1, seed=0, device="cpu")
+    kw = {}
+    for k, v in spec.__dict__.items():
+        if k == "truth":
+            continue
+        kw[k] = v.contiguous() if isinstance(v, torch.Tensor) else v
+    p = orc.Problem(**kw)
+    gen = torch.Generator().manual_seed(0)
+    first = orc.draw_eps(p, gen)
+    params = orc.init_params(p, first.get("_cov_factor_draw"))
+    opt = orc.ClippedAdam({"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)})
+
+    def one():
+        nonlocal params
+        eps = orc.draw_eps(p, gen)
+        _, grads, _, _ = orc.loss_and_grads(p, params, eps)
+        params = opt.step(params, grads)
+    one()                                   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 50):
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    sps_sample = n / dt
+    scale = nsample / args.cells
+    return {"value": round(sps_sample * scale, 4), "unit": "SVI steps/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle (op-by-op torch fp32 + autograd + ClippedAdam) on the first {nsample} of "
+                      f"{args.cells} cells x {args.genes} genes, {n} steps in {dt:.1f}s = {sps_sample:.3f} steps/s, "
+                      f"scaled by {scale:.3f} (cost is linear in cells); host cpu_count={os.cpu_count()}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if args.gpus != world and dist_on:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and not dist_on:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    from velocycle_amd.workloads import make_velocity_spec
+
+    optim = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / 10000), "betas": (0.80, 0.99)}
+
+    def build(mode):
+        spec = make_velocity_spec(args.cells, args.genes, mode, 1, 1, seed=0, device=device)
+        eng = HipEngine(spec, device=device, rank=rank, world_size=world)
+        run = SVIRunner(eng, optim, mode="perf", seed=0, use_graph=(False if args.no_graph else None))
+        return spec, eng, run
+
+    spec, eng, run = build(args.mode)
+    dt = time_steps(run, args.steps, args.warmup, dist_on, device)
+    sps = args.steps / dt
+    losses = run.perf_losses()
+    roof = kernel_roofline(eng, run, min(args.steps, 100))
+    if dist_on:
+        roof["note"] = f"per-rank kernel on {eng.Nc_local} of {args.cells} cells"
+    out = {
+        "metric": "SVI steps/sec, velocity_inference 50k cells x 2k genes",
+        "value": round(sps, 2), "unit": "SVI steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.cells} cells x {args.genes} genes velocity_inference, "
+                               + {"vjoint": "mean-field guide, nothing conditioned (every gradient)",
+                                  "vcond": "tutorial flow: LRMN guide conditioned on phixy, nu, shape_inv",
+                                  "vcond_mf": "mean-field guide conditioned on phixy, nu, shape_inv"}[args.mode]
+                               + ", NegativeBinomial noise, H=1, Hw=1",
+                   "cells": args.cells, "genes": args.genes, "mode": args.mode,
+                   "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
+                   "step": "Philox eps -> ELBO+grad (HIP) -> ClippedAdam (torch), hipGraph replay" if run.use_graph
+                           else "Philox eps -> ELBO+grad (HIP) -> all-reduce -> ClippedAdam (torch), eager launches"},
+        "roofline": roof,
+        "loss_first_last": [losses[0], losses[-1]],
+    }
+    extra = {}
+    if not args.no_extra_modes and not dist_on:
+        del run, eng, spec
+        torch.cuda.empty_cache()
+        for m in [x for x in ("vcond", "vjoint") if x != args.mode]:
+            s2, e2, r2 = build(m)
+            dt2 = time_steps(r2, args.steps, args.warmup, False, device)
+            rf = kernel_roofline(e2, r2, min(args.steps, 100))
+            extra[m] = {"steps_per_s": round(args.steps / dt2, 2), "kernel": rf["kernel"],
+                        "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"],
+                        "hbm_frac": rf["frac"]}
+            del s2, e2, r2
+            torch.cuda.empty_cache()
+        out["modes"] = extra
+    if rank == 0 and not dist_on and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, args.mode)
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out, ensure_ascii=False))
+
+
+if __name__ == "__main__":
+    main()

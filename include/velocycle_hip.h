@@ -196,6 +196,12 @@ int vc_elbo_grad(vc_engine* e, const float* params, const float* eps, uint64_t s
 /* Copies the value a site took in the last vc_elbo_grad to host memory (synchronises the stream). */
 int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream);
 int vc_get_stats(const vc_engine* e, vc_stats* out);
+/* Kernel timing for bench.py's roofline: while enabled, every vc_elbo_grad brackets the likelihood
+ * kernel with a pair of hipEvents recorded on the launch stream (not capturable into a hipGraph).
+ * vc_get_timing synchronises the pending events and returns the accumulated duration (ms) and the
+ * number of launches since timing was enabled. */
+int vc_set_timing(vc_engine* e, int enable);
+int vc_get_timing(vc_engine* e, double* main_ms_total, int64_t* n_launches);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,8 @@ EXPORTS = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "vc_read_site": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "vc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(vc_stats)]),
+    "vc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "vc_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

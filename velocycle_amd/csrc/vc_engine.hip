@@ -44,7 +44,24 @@ struct vc_engine {
   const char* main_name = "";
   long long gs = 0, cs = 0;          // strides of the host copies hS / hU
   bool hist_each_step = false;
-  double lgamma_const = 0.0;
+  // optional hipEvent timing of the likelihood kernel (bench.py roofline)
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double main_ms = 0.0;
+  long long main_launches = 0;
+  int drain_events() {
+    for (size_t i = 0; i < ev_used; ++i) {
+      float ms = 0.f;
+      if (hipEventSynchronize(ev_pool[i].second) != hipSuccess ||
+          hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second) != hipSuccess)
+        return fail(VC_ERR_HIP, "hipEventElapsedTime failed");
+      main_ms += ms;
+      main_launches++;
+    }
+    ev_used = 0;
+    return VC_OK;
+  }
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -220,6 +237,7 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
 extern "C" void vc_destroy(vc_engine* e) {
   if (!e) return;
   for (void* p : e->allocs) (void)hipFree(p);
+  for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete e;
 }
 
@@ -573,7 +591,15 @@ extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps,
   hipStream_t st = (hipStream_t)hip_stream;
   vc_launch_pre(e->d, e->b, params, eps, seed, (long long)step, (const long long*)step_dev, 0, st);
   if (e->hist_each_step) vc_launch_hist(e->d, e->b, st);
-  e->main_fn(e->d, e->b, st);
+  if (e->timing) {
+    if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
+    auto& pr = e->ev_pool[e->ev_used++];
+    HIPCHK(e, hipEventRecord(pr.first, st));
+    e->main_fn(e->d, e->b, st);
+    HIPCHK(e, hipEventRecord(pr.second, st));
+  } else {
+    e->main_fn(e->d, e->b, st);
+  }
   vc_launch_post(e->d, e->b, params, grad, loss_dev, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
@@ -609,5 +635,28 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   out->main_block = 256;
   out->main_kind = d.kind;
   snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s>", d.H, d.Nb, e->main_name);
+  return VC_OK;
+}
+
+extern "C" int vc_set_timing(vc_engine* e, int enable) {
+  if (!e) return VC_ERR_ARG;
+  if (enable && e->ev_pool.empty()) {
+    for (int i = 0; i < 512; ++i) {
+      hipEvent_t a, b2;
+      HIPCHK(e, hipEventCreate(&a));
+      HIPCHK(e, hipEventCreate(&b2));
+      e->ev_pool.emplace_back(a, b2);
+    }
+  }
+  if (enable) { e->ev_used = 0; e->main_ms = 0.0; e->main_launches = 0; }
+  e->timing = enable != 0;
+  return VC_OK;
+}
+
+extern "C" int vc_get_timing(vc_engine* e, double* main_ms_total, int64_t* n_launches) {
+  if (!e || !main_ms_total || !n_launches) return VC_ERR_ARG;
+  TRY(e->drain_events());
+  *main_ms_total = e->main_ms;
+  *n_launches = e->main_launches;
   return VC_OK;
 }

@@ -253,6 +253,15 @@ class HipEngine:
         self._check(self.lib.vc_read_site(self._h, sid, C.c_void_p(out.data_ptr()), out.numel(), self._stream()))
         return out
 
+    def set_timing(self, enable: bool):
+        self._check(self.lib.vc_set_timing(self._h, int(enable)))
+
+    def get_timing(self):
+        """(total ms spent in the likelihood kernel, number of launches) since set_timing(True)."""
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.lib.vc_get_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.vc_destroy(self._h)

@@ -1,0 +1,195 @@
+"""SVI driver on top of `HipEngine`: the loop body of `svi.step` (reference
+phase_inference_model.py:169 / velocity_inference_model.py:120), i.e.
+ELBO+gradient (HIP) -> one all-reduce of the replicated-parameter gradients when cells are sharded
+over GPUs (RCCL through torch.distributed) -> ClippedAdam on ONE flat parameter tensor (PyTorch ops).
+
+`ClippedAdam` here restates pyro.optim.ClippedAdam (pyro-ppl 1.8.6, optim/clipped_adam.py) for a flat
+buffer: lr <- lr*lrd before every update, elementwise clamp of the gradient to +-clip_norm,
+m/v moments, step lr*sqrt(1-b2^t)/(1-b1^t), denominator sqrt(v)+eps (eps outside the sqrt, unlike
+torch.optim.Adam's bias-corrected form).  Pyro keeps one optimiser per parameter tensor, all created
+at step 0 with identical hyper-parameters, so a single flat state is equivalent.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from .engine import HipEngine
+from .rng import draw_eps
+
+
+class ClippedAdam:
+    """Drop-in for `pyro.optim.ClippedAdam({...})` as the tutorials build it; only a holder of the
+    argument dict (`pt_optim_args`, same attribute name as PyroOptim)."""
+
+    def __init__(self, optim_args: dict, clip_args=None):
+        self.pt_optim_args = dict(optim_args)
+
+
+def optim_args_of(optimizer) -> dict:
+    if isinstance(optimizer, dict):
+        return dict(optimizer)
+    if hasattr(optimizer, "pt_optim_args"):
+        a = optimizer.pt_optim_args
+        if callable(a):
+            raise TypeError("callable optim args are not supported")
+        return dict(a)
+    raise TypeError("optimizer must be a ClippedAdam-like object exposing `pt_optim_args`, or a dict")
+
+
+class FlatClippedAdam:
+    def __init__(self, n: int, optim_args: dict, device, capturable: bool = False):
+        a = dict(optim_args)
+        self.lr0 = float(a.get("lr", 1e-3))
+        self.b1, self.b2 = (float(x) for x in a.get("betas", (0.9, 0.999)))
+        self.eps = float(a.get("eps", 1e-8))
+        self.clip = float(a.get("clip_norm", 10.0))
+        self.lrd = float(a.get("lrd", 1.0))
+        if float(a.get("weight_decay", 0.0)) != 0.0:
+            raise NotImplementedError("weight_decay != 0")
+        self.m = torch.zeros(n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=device)
+        self.t = 0
+        self.capturable = capturable
+        if capturable:     # step counter and schedule live on the device so the update can be replayed
+            self.t_dev = torch.zeros((), dtype=torch.float64, device=device)
+            self._c = {k: torch.tensor(v, dtype=torch.float64, device=device)
+                       for k, v in dict(lr0=self.lr0, lrd=self.lrd, b1=self.b1, b2=self.b2).items()}
+
+    def step(self, p: torch.Tensor, g: torch.Tensor):
+        g = g.clamp(-self.clip, self.clip)
+        self.m.lerp_(g, 1.0 - self.b1)
+        self.v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+        denom = self.v.sqrt().add_(self.eps)
+        if not self.capturable:
+            self.t += 1
+            lr = self.lr0 * self.lrd ** self.t
+            step_size = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+            p.addcdiv_(self.m, denom, value=-step_size)
+        else:
+            self.t_dev += 1.0
+            c = self._c
+            step_size = c["lr0"] * torch.pow(c["lrd"], self.t_dev) * \
+                torch.sqrt(1.0 - torch.pow(c["b2"], self.t_dev)) / (1.0 - torch.pow(c["b1"], self.t_dev))
+            p.sub_((self.m / denom) * step_size.float())
+
+    def state_dict(self):
+        return dict(m=self.m.clone(), v=self.v.clone(), t=self.t if not self.capturable else int(self.t_dev.item()))
+
+
+class SVIRunner:
+    """mode="parity": eps drawn on the host in the reference's RNG order (seed-for-seed comparable
+    with the reference), loss read back every step.  mode="perf": eps from the in-kernel Philox
+    stream, the whole step captured in a hipGraph (single GPU), losses kept on the device."""
+
+    def __init__(self, engine: HipEngine, optim_args: dict, mode: str = "parity", seed: Optional[int] = None,
+                 process_group=None, use_graph: Optional[bool] = None, warmup_draw: bool = True,
+                 init: bool = True):
+        assert mode in ("parity", "perf")
+        self.e, self.mode = engine, mode
+        self.pg = process_group
+        self.world = engine.world_size
+        self.seed = 0 if seed is None else int(seed)
+        self.use_graph = (mode == "perf" and self.world == 1) if use_graph is None else use_graph
+        self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
+                                   capturable=self.use_graph)
+        self.step_idx = 0
+        self.losses: List[float] = []
+        self._graph = None
+        self.gen = None
+        if mode == "parity":
+            self.gen = torch.Generator().manual_seed(self.seed) if seed is not None else None
+        if init:
+            cov = None
+            if mode == "parity":
+                self._first = draw_eps(engine.spec, self.gen) if warmup_draw else None
+                self._pending = None
+                if engine.spec.kind == "velocity" and engine.spec.guide == "lrmn":
+                    if self._first is None:
+                        self._pending = draw_eps(engine.spec, self.gen)
+                    cov = (self._first or self._pending)["_cov_factor_draw"]
+            elif engine.spec.kind == "velocity" and engine.spec.guide == "lrmn":
+                g = torch.Generator().manual_seed(self.seed)
+                M = engine.spec.Ng + engine.spec.Nx * engine.spec.Nhw
+                cov = torch.normal(torch.zeros((M, engine.spec.rho_rank)),
+                                   torch.ones((M, engine.spec.rho_rank)) * 0.02, generator=g)
+            engine.init_params(cov)
+        else:
+            self._first, self._pending = None, None
+        if mode == "perf":
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=engine.device)
+            self.loss_hist = None
+
+    # ------------------------------------------------------------------------------------------
+    def _reduce(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.e.grad[: self.e.header + self.e.n_global], group=self.pg)
+
+    def _update(self):
+        h = self.e.header
+        self.opt.step(self.e.params[h:], self.e.grad[h:])
+
+    def step(self, eps: Optional[Dict[str, torch.Tensor]] = None) -> float:
+        """One SVI step in parity mode; returns the loss like `svi.step` does."""
+        e = self.e
+        if eps is None:
+            if getattr(self, "_pending", None) is not None:
+                eps, self._pending = self._pending, None
+            else:
+                eps = draw_eps(e.spec, self.gen)
+        e.elbo_grad(eps=e.pack_eps(eps), step=self.step_idx)
+        self._reduce()
+        hdr = e.grad[:2].double().cpu()
+        loss = float(e.loss_dev.item()) if self.world == 1 else float(hdr.sum())
+        self._update()
+        self.step_idx += 1
+        self.losses.append(loss)
+        return loss
+
+    def _perf_body(self):
+        e = self.e
+        e.elbo_grad(eps=None, seed=self.seed, step=0, step_dev=self.step_dev)
+        self._reduce()
+        self.loss_hist.index_copy_(0, self.step_dev % self.loss_hist.shape[0],
+                                   e.grad[:2].double().sum().reshape(1))
+        self._update()
+        self.step_dev += 1
+
+    def run_perf(self, n_steps: int, sync: bool = True) -> None:
+        """n_steps back-to-back SVI steps with no host round trip (losses stay on the device)."""
+        e = self.e
+        if self.loss_hist is None or self.loss_hist.shape[0] < self.step_idx + n_steps:
+            new = torch.zeros(max(2 * (self.step_idx + n_steps), 1024), dtype=torch.float64, device=e.device)
+            if self.loss_hist is not None:
+                new[: self.loss_hist.shape[0]] = self.loss_hist
+            self.loss_hist = new
+            self._graph = None
+        if self.use_graph and self._graph is None:
+            s = torch.cuda.Stream(device=e.device)
+            s.wait_stream(torch.cuda.current_stream(e.device))
+            with torch.cuda.stream(s):
+                self._perf_body()                      # warm-up (allocator, lazy init) outside capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    self._perf_body()
+            torch.cuda.current_stream(e.device).wait_stream(s)
+            # the warm-up pass was one real step (capture only records)
+            self._graph = g
+            self.step_idx += 1
+            n_steps -= 1
+        for _ in range(n_steps):
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._perf_body()
+        self.step_idx += n_steps
+        if sync:
+            torch.cuda.synchronize(e.device)
+
+    def perf_losses(self) -> List[float]:
+        torch.cuda.synchronize(self.e.device)
+        return self.loss_hist[: self.step_idx].cpu().tolist()
