@@ -167,7 +167,8 @@ __device__ __forceinline__ double vc_digamma_d(double x) {
 
 // launchers implemented in the .hip translation units -----------------------------------------
 typedef void (*vc_main_launch_fn)(const VcDims& d, const VcBufs& b, hipStream_t st);
-vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, const char** name);
+vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, const char** name,
+                                      const void** kernel);
 
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
                            int Ng, int Nc, int nGB, int log1p_transform, hipStream_t st);

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -454,21 +455,37 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   auto nco_of = [&](int kind) { return kind == VC_KIND_VFULL ? 3 : 1; };
   d.nq = nq_of(d.kind);
   d.nco = nco_of(d.kind);
-  e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, &e->main_name);
+  const void* main_kernel = nullptr;
+  e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, &e->main_name, &main_kernel);
   if (!e->main_fn) return e->fail(VC_ERR_UNSUPPORTED, "no likelihood kernel for H=%d Nb=%d kind=%d noise=%d", d.H, d.Nb, d.kind, d.noise);
   if (d.kind == VC_KIND_VU) {
-    e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, nullptr);
+    e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, nullptr, nullptr);
     if (!e->phase_fn) return e->fail(VC_ERR_UNSUPPORTED, "no S-only kernel for the hoisted term");
   }
-  // tiling: 4 waves x cw cells per workgroup; aim at <= ~2048 workgroups so that the second-stage
-  // reduction stays a few per cent of the streamed bytes
+  // tiling: one balanced round.  The grid is sized to the workgroups the chip holds at once for
+  // this kernel (occupancy x 256 CUs); each wave gets an equal share of the cells of its gene block,
+  // so no partially filled last round is left over (a 2.04-round grid costs 3 rounds).
   {
-    const long long wg64 = (long long)d.nGB * ((d.Nc + 255) / 256);
-    long long mult = (wg64 + 2047) / 2048;
-    if (mult < 1) mult = 1;
-    d.cw = (int)(64 * mult);
-    const int per_wg = VC_WAVES * d.cw;
-    d.n_chunks = (d.Nc + per_wg - 1) / per_wg;
+    int blocks_per_cu = 0, n_cu = 256;
+    HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, main_kernel, 256, 0));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIPCHK(e, hipGetDevice(&dev));
+    HIPCHK(e, hipGetDeviceProperties(&prop, dev));
+    if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const char* env = getenv("VC_BLOCKS_PER_CU");
+    if (env && atoi(env) > 0) blocks_per_cu = atoi(env);
+    long long slots = (long long)blocks_per_cu * n_cu;
+    long long chunks = slots / d.nGB;
+    if (chunks < 1) chunks = 1;
+    long long cw = (d.Nc + VC_WAVES * chunks - 1) / (VC_WAVES * chunks);
+    if (cw < 16) cw = 16;                               // keep the per-gene prologue/epilogue amortised
+    env = getenv("VC_CELLS_PER_WAVE");
+    if (env && atoi(env) > 0) cw = atoi(env);
+    d.cw = (int)cw;
+    const long long per_wg = (long long)VC_WAVES * d.cw;
+    d.n_chunks = (int)((d.Nc + per_wg - 1) / per_wg);
     d.n_main_wg = d.nGB * d.n_chunks;
   }
   d.nb_pre_gene = d.Ng_pad / 256;

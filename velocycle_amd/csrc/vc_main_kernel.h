@@ -40,30 +40,37 @@ __device__ __forceinline__ VcCellRec<H, NB> vc_load_cell(const float* __restrict
   return r;
 }
 
-// log-likelihood of one count under mean exp(eta): value, d/d eta, d/d r (NB only; r-only constants
-// -- r log r, lgamma terms -- are added per gene in K_post from the count histograms).
+// Observation model of one count k under log-mean eta.  eta2 = eta * log2(e): the hardware
+// transcendentals are base 2 (v_exp_f32 / v_log_f32), so everything logarithmic is carried in log2
+// units and rescaled once per gene after the cell loop.  Inputs of the raw instructions are never
+// denormal here (t = r + mu >= r > 0), so no range fix-up code is needed around them.
+//   a    = d loglik / d eta                       (natural units)
+//   lacc += k * (eta2 - log2 t)   [NB]  | k*eta2 - mu*log2e [Poisson] | -0.5 e^2/s^2 [Lognormal]
+//   tacc += log2 t                [NB]: sum_c log(r + mu) enters both the loss (times r) and d/dr;
+// the remaining NB pieces need no per-element work: sum_c (r+k)/(r+mu) = Nc + (sum_c a)/r, and the
+// r-only terms (r log r, lgamma) come from the per-gene count histograms in K_post.
+#define VC_LOG2E 1.4426950408889634f
+#define VC_LN2 0.6931471805599453f
+
 template <int NOISE>
-__device__ __forceinline__ void vc_obs(float k, float eta, float r, float inv_s2, float& a, float& ll,
-                                       float& dr) {
+__device__ __forceinline__ void vc_obs(float k, float eta, float eta2, float r, float inv_s2, float& a,
+                                       float& lacc, float& tacc) {
   if (NOISE == VC_NOISE_NB) {
-    const float mu = __expf(eta);
+    const float mu = __builtin_amdgcn_exp2f(eta2);
     const float t = r + mu;
-    const float lt = __logf(t);
+    const float lt2 = __builtin_amdgcn_logf(t);
     const float it = __builtin_amdgcn_rcpf(t);
-    const float rk = r + k;
-    a = r * (k - mu) * it;
-    ll = k * eta - rk * lt;
-    dr = -lt - rk * it;
+    a = (r * (k - mu)) * it;
+    lacc = fmaf(k, eta2 - lt2, lacc);
+    tacc += lt2;
   } else if (NOISE == VC_NOISE_POISSON) {
-    const float mu = __expf(eta);
+    const float mu = __builtin_amdgcn_exp2f(eta2);
     a = k - mu;
-    ll = k * eta - mu;
-    dr = 0.f;
-  } else {  // Lognormal: k already holds log(count + 1)
+    lacc = fmaf(k, eta2, lacc) - mu * VC_LOG2E;
+  } else {  // Lognormal: k already holds log(count + 1); lacc in natural units / LN2 to share the rescale
     const float e = k - eta;
     a = e * inv_s2;
-    ll = -0.5f * e * e * inv_s2;
-    dr = 0.f;
+    lacc = fmaf(-0.5f * VC_LOG2E * e, a, lacc);
   }
 }
 
@@ -104,19 +111,24 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
   }
   const float inv_s2_s = 1.0f / (d.sigma_ln_s * d.sigma_ln_s);
   const float inv_s2_u = 1.0f / (d.sigma_ln_u * d.sigma_ln_u);
+  float lb2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lb2[j] = lb[j] * VC_LOG2E;
 
   // ---- accumulators ---------------------------------------------------------------------------
   float gnu[K][4];     // d loglik / d nu~[k]
-  float gau[4], gw[4], gr[4], ll[4];
+  float gau[4], gw[4];   // sum_c aU, sum_c aU * d etaU/dz
+  float ll[4], lt[4];    // log2-unit accumulators: likelihood pieces, sum_c log2(r + mu)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
 #pragma unroll
     for (int k = 0; k < K; ++k) gnu[k][j] = 0.f;
-    gau[j] = gw[j] = gr[j] = ll[j] = 0.f;
+    gau[j] = gw[j] = ll[j] = lt[j] = 0.f;
   }
 
-  const long long cbeg = (long long)chunk * (VC_WAVES * d.cw) + (long long)wave * d.cw;
+  long long cbeg = (long long)chunk * (VC_WAVES * d.cw) + (long long)wave * d.cw;
   long long cend = cbeg + d.cw;
+  if (cbeg > d.Nc) cbeg = d.Nc;
   if (cend > d.Nc) cend = d.Nc;
 
   const size_t blk_base = ((size_t)gb * d.Nc) * VC_GBW + gl;
@@ -164,23 +176,23 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
 #pragma unroll
         for (int q = 0; q < NB; ++q) es += nu[NH + q][j] * rec.db[q];
 
+        const float es2 = es * VC_LOG2E;
         float a = 0.f, w = 0.f;
         if (HAS_S) {
-          float aS, lS, dS;
-          vc_obs<NOISE>(sv[j], es, rr[j], inv_s2_s, aS, lS, dS);
-          a += aS; ll[j] += lS;
-          if (NOISE == VC_NOISE_NB) gr[j] += dS;
+          float aS;
+          vc_obs<NOISE>(sv[j], es, es2, rr[j], inv_s2_s, aS, ll[j], lt[j]);
+          a += aS;
         }
         if (HAS_U) {
           // eta_U = -log beta + log(relu(dd * omega + gamma) + 1e-5) + eta_S
-          const float z = dd * rec.omega + gam[j];
+          const float z = fmaf(dd, rec.omega, gam[j]);
           const float zp = fmaxf(z, 0.f) + 1e-5f;
-          const float q = (z > 0.f) ? __builtin_amdgcn_rcpf(zp) : 0.f;
-          const float eu = es - lb[j] + __logf(zp);
-          float aU, lU, dU;
-          vc_obs<NOISE>(uv[j], eu, rr[j], inv_s2_u, aU, lU, dU);
-          a += aU; ll[j] += lU;
-          if (NOISE == VC_NOISE_NB && FULL) gr[j] += dU;
+          const float q = (z > 0.f) ? __builtin_amdgcn_rcpf(zp) : 0.f;     // torch.relu': 0 at z <= 0
+          const float lz2 = __builtin_amdgcn_logf(zp);
+          const float eu2 = (es2 - lb2[j]) + lz2;
+          float aU;
+          vc_obs<NOISE>(uv[j], eu2 * VC_LN2, eu2, rr[j], inv_s2_u, aU, ll[j], lt[j]);
+          a += aU;
           w = aU * q;
           gau[j] += aU;
           gw[j] += w;
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
           for (int q = 0; q < NB; ++q) gnu[NH + q][j] += a * rec.db[q];
           A1 += a * dd;
         }
-        if (FULL) A2 += w * e2;
+        if (FULL) A2 = fmaf(w, e2, A2);
         if (HAS_U) A3 += w * dd;
       }
       // per-cell sums over the 256 genes of this wave
@@ -235,13 +247,23 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
     } else {
 #pragma unroll
       for (int k = 0; k < K; ++k) put(k, gnu[k]);
+      // d loglik / d r (NB): -sum_c [log(r+mu) + (r+k)/(r+mu)] = -ln2 * sum log2 t - n_obs - (sum_c a)/r
+      float gr[4];
+      const float nobs = (float)(cend - cbeg) * (FULL ? 2.f : 1.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        gr[j] = (NOISE == VC_NOISE_NB) ? -VC_LN2 * lt[j] - nobs - gnu[0][j] * __builtin_amdgcn_rcpf(rr[j]) : 0.f;
       if (KIND == VC_KIND_PHASE) put(K, gr);
       else { put(K, gau); put(K + 1, gw); put(K + 2, gr); }
     }
-    // likelihood partial: padded genes are masked here (their nu~ is 0, so they never reached A1..A3)
+    // likelihood partial in natural units: ln2 * (sum k (eta2 - log2 t) - r sum log2 t) for NB.
+    // Padded genes are masked here (their nu~ is 0, so they never reached A1..A3).
     float l = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) l += (g0 + j < d.Ng) ? ll[j] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const float lj = VC_LN2 * ((NOISE == VC_NOISE_NB) ? ll[j] - rr[j] * lt[j] : ll[j]);
+      l += (g0 + j < d.Ng) ? lj : 0.f;
+    }
     l = vc_wave_sum(l);
     if (lane == 0) sm_ll[wave] = l;
   }
@@ -261,7 +283,7 @@ static void vc_main_launch(const VcDims& d, const VcBufs& b, hipStream_t st) {
   hipLaunchKernelGGL((vc_main_kernel<H, NB, KIND, NOISE>), dim3(d.n_main_wg), dim3(256), 0, st, d, b);
 }
 
-struct VcMainEntry { int H, NB, kind, noise; vc_main_launch_fn fn; };
+struct VcMainEntry { int H, NB, kind, noise; vc_main_launch_fn fn; const void* kernel; };
 
 // Explicit kernel instantiations are needed in both compilation passes; the launcher table is host-only.
 #define VC_INST_K(KIND, NOISE, H, NB) \
@@ -269,7 +291,8 @@ struct VcMainEntry { int H, NB, kind, noise; vc_main_launch_fn fn; };
 #define VC_INST_KROW(KIND, NOISE, H)                                                   \
   VC_INST_K(KIND, NOISE, H, 0) VC_INST_K(KIND, NOISE, H, 1) VC_INST_K(KIND, NOISE, H, 2) \
   VC_INST_K(KIND, NOISE, H, 3) VC_INST_K(KIND, NOISE, H, 4)
-#define VC_ENT(KIND, NOISE, H, NB) {H, NB, KIND, NOISE, &vc_main_launch<H, NB, KIND, NOISE>}
+#define VC_ENT(KIND, NOISE, H, NB) \
+  {H, NB, KIND, NOISE, &vc_main_launch<H, NB, KIND, NOISE>, (const void*)&vc_main_kernel<H, NB, KIND, NOISE>}
 #define VC_ENT_ROW(KIND, NOISE, H)                                                          \
   VC_ENT(KIND, NOISE, H, 0), VC_ENT(KIND, NOISE, H, 1), VC_ENT(KIND, NOISE, H, 2), VC_ENT(KIND, NOISE, H, 3), \
   VC_ENT(KIND, NOISE, H, 4)
