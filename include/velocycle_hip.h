@@ -186,11 +186,20 @@ int vc_get_layout(const vc_engine* e, vc_layout* out);
 /* One ELBO + gradient evaluation.  params/grad: device float[layout.total]; eps: device
  * float[layout.eps_total] or NULL (then eps = Philox4x32-10(seed, step, index), identical on every
  * rank for replicated sites and sliced by cell_offset for ϕxy).  step_dev: optional device int64
- * read instead of `step` (lets the call be replayed from a captured hipGraph).  loss_dev: device
- * double[1] receiving this rank's loss contribution (also written as float hi/lo to grad[0..1]).
+ * read instead of `step` and INCREMENTED by one at the end of the call (lets the call be replayed
+ * from a captured hipGraph).  loss_dev: device double[loss_slots] (loss_slots >= 1); this rank's loss
+ * contribution is written to slot step % loss_slots (and as float hi/lo to grad[0..1]).
  * Asynchronous on `hip_stream`; no allocation, no synchronisation. */
 int vc_elbo_grad(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
-                 const int64_t* step_dev, float* grad, double* loss_dev, void* hip_stream);
+                 int64_t* step_dev, float* grad, double* loss_dev, int64_t loss_slots, void* hip_stream);
+
+/* pyro.optim.ClippedAdam (pyro-ppl 1.8.6 optim/clipped_adam.py; call sites: tutorial cells 27/43/56)
+ * as ONE launch on a flat buffer of n floats: lr_t = lr*lrd^t, g = clamp(g, +-clip_norm),
+ * m/v moments, p -= lr_t*sqrt(1-beta2^t)/(1-beta1^t) * m/(sqrt(v)+eps).  t is the 1-based step, read
+ * from t_dev (device int64) when non-NULL.  An alternative to the PyTorch-op update of svi.py. */
+int vc_clipped_adam(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    double lr, double lrd, double beta1, double beta2, double eps, double clip_norm,
+                    int64_t t, const int64_t* t_dev, void* hip_stream);
 
 /* introspection ----------------------------------------------------------------------------- */
 /* Copies the value a site took in the last vc_elbo_grad to host memory (synchronises the stream). */

@@ -173,7 +173,11 @@ vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, const 
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
                            int Ng, int Nc, int nGB, int log1p_transform, hipStream_t st);
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
-                   uint64_t seed, long long step, const long long* step_dev, int cond_only, hipStream_t st);
-void vc_launch_hist(const VcDims& d, const VcBufs& b, hipStream_t st);
+                   uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
+                   hipStream_t st);
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad,
-                    double* loss_dev, hipStream_t st);
+                    double* loss_dev, long long loss_slots, long long step, long long* step_dev,
+                    hipStream_t st);
+void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
+                    double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
+                    hipStream_t st);

@@ -571,8 +571,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
     VcDims d2 = d;
     d2.kind = VC_KIND_PHASE; d2.nq = nq_of(VC_KIND_PHASE); d2.nco = 1;
     d2.hist_has_S = nb; d2.hist_has_U = 0;
-    vc_launch_pre(d2, b, nullptr, nullptr, 0, 0, nullptr, 1, st);
-    if (nb) vc_launch_hist(d2, b, st);
+    vc_launch_pre(d2, b, nullptr, nullptr, 0, 0, nullptr, 1, nb ? 1 : 0, st);
     e->phase_fn(d2, b, st);
     HIPCHK(e, hipStreamSynchronize(st));
     HIPCHK(e, hipGetLastError());
@@ -589,8 +588,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   }
   if (nb && !e->hist_each_step) {
     // shape_inv conditioned: the lgamma / digamma sums never change -> evaluate them once
-    vc_launch_pre(d, b, nullptr, nullptr, 0, 0, nullptr, 1, st);
-    vc_launch_hist(d, b, st);
+    vc_launch_pre(d, b, nullptr, nullptr, 0, 0, nullptr, 1, 1, st);
     HIPCHK(e, hipStreamSynchronize(st));
   }
   b.const_loss = cl;
@@ -601,13 +599,14 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
 }
 
 extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
-                            const int64_t* step_dev, float* grad, double* loss_dev, void* hip_stream) {
+                            int64_t* step_dev, float* grad, double* loss_dev, int64_t loss_slots,
+                            void* hip_stream) {
   if (!e) return VC_ERR_ARG;
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_elbo_grad before vc_finalize");
   if (!params || !grad) return e->fail(VC_ERR_ARG, "vc_elbo_grad: null params / grad");
   hipStream_t st = (hipStream_t)hip_stream;
-  vc_launch_pre(e->d, e->b, params, eps, seed, (long long)step, (const long long*)step_dev, 0, st);
-  if (e->hist_each_step) vc_launch_hist(e->d, e->b, st);
+  vc_launch_pre(e->d, e->b, params, eps, seed, (long long)step, (const long long*)step_dev, 0,
+                e->hist_each_step ? 1 : 0, st);
   if (e->timing) {
     if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
     auto& pr = e->ev_pool[e->ev_used++];
@@ -617,7 +616,8 @@ extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps,
   } else {
     e->main_fn(e->d, e->b, st);
   }
-  vc_launch_post(e->d, e->b, params, grad, loss_dev, st);
+  vc_launch_post(e->d, e->b, params, grad, loss_dev, (long long)loss_slots, (long long)step,
+                 (long long*)step_dev, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
   return VC_OK;
@@ -676,4 +676,14 @@ extern "C" int vc_get_timing(vc_engine* e, double* main_ms_total, int64_t* n_lau
   *main_ms_total = e->main_ms;
   *n_launches = e->main_launches;
   return VC_OK;
+}
+
+extern "C" int vc_clipped_adam(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               double lr, double lrd, double beta1, double beta2, double eps, double clip_norm,
+                               int64_t t, const int64_t* t_dev, void* hip_stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || n < 0) return VC_ERR_ARG;
+  if (n == 0) return VC_OK;
+  vc_launch_adam(params, grad, exp_avg, exp_avg_sq, (long long)n, lr, lrd, beta1, beta2, (float)eps,
+                 (float)clip_norm, (long long)t, (const long long*)t_dev, (hipStream_t)hip_stream);
+  return hipGetLastError() == hipSuccess ? VC_OK : VC_ERR_HIP;
 }

@@ -57,6 +57,35 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
   const bool nb = d.noise == VC_NOISE_NB;
   double loss = 0.0;
 
+  if ((int)blockIdx.x >= d.nb_pre_gene + d.nb_pre_cell) {
+    // ------------------------------- histogram part (NB): one wave per gene ---------------------
+    // sum_k cnt_k (lgamma(r+k) - lgamma(r)) and its r-derivative in fp64: the lgamma terms of
+    // GammaPoisson.log_prob summed over cells depend on (r_g, k) only, so the per-gene histogram of
+    // the counts is a sufficient statistic -- no lgamma/digamma in the (gene, cell) loop.
+    const int lane = threadIdx.x & 63;
+    const int g = (blockIdx.x - d.nb_pre_gene - d.nb_pre_cell) * 4 + (threadIdx.x >> 6);
+    if (g < d.Ng) {
+      float si;
+      if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
+      else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
+      const double r = (double)(1.0f / si);
+      const double lg_r = lgamma(r), dg_r = vc_digamma_d(r);
+      double hl = 0.0, hd = 0.0;
+      for (int m = 0; m < 2; ++m) {
+        if ((m == 0 && !d.hist_has_S) || (m == 1 && !d.hist_has_U)) continue;
+        const int beg = b.h_ptr[m * d.Ng + g], end = b.h_ptr[m * d.Ng + g + 1];
+        for (int i = beg + lane; i < end; i += 64) {
+          const double k = (double)b.h_val[i], n = (double)b.h_cnt[i];
+          hl += n * (lgamma(r + k) - lg_r);
+          hd += n * (vc_digamma_d(r + k) - dg_r);
+        }
+      }
+      hl = vc_wave_sum_d(hl);
+      hd = vc_wave_sum_d(hd);
+      if (lane == 0) { b.HL[g] = hl; b.HD[g] = hd; }
+    }
+    return;
+  }
   if ((int)blockIdx.x < d.nb_pre_gene) {
     // ------------------------------- gene part ------------------------------------------------
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -261,39 +290,11 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
 }
 
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
-                   uint64_t seed, long long step, const long long* step_dev, int cond_only, hipStream_t st) {
-  hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell), dim3(256), 0, st, d, b, params,
-                     eps, seed, step, step_dev, cond_only);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K_hist: one wave per gene; sum_k cnt_k * (lgamma(r+k) - lgamma(r)) and its r-derivative, in fp64.
-// Exact restatement of the lgamma terms of GammaPoisson.log_prob summed over cells: they depend on
-// (r_g, k) only, so the per-gene histogram of counts is a sufficient statistic.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBufs b) {
-  const int lane = threadIdx.x & 63;
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (g >= d.Ng) return;
-  const double r = (double)b.GT[(size_t)(d.K + 2) * d.Ng_pad + g];
-  const double lg_r = lgamma(r), dg_r = vc_digamma_d(r);
-  double hl = 0.0, hd = 0.0;
-  for (int m = 0; m < 2; ++m) {
-    if ((m == 0 && !d.hist_has_S) || (m == 1 && !d.hist_has_U)) continue;
-    const int beg = b.h_ptr[m * d.Ng + g], end = b.h_ptr[m * d.Ng + g + 1];
-    for (int i = beg + lane; i < end; i += 64) {
-      const double k = (double)b.h_val[i], n = (double)b.h_cnt[i];
-      hl += n * (lgamma(r + k) - lg_r);
-      hd += n * (vc_digamma_d(r + k) - dg_r);
-    }
-  }
-  hl = vc_wave_sum_d(hl);
-  hd = vc_wave_sum_d(hd);
-  if (lane == 0) { b.HL[g] = hl; b.HD[g] = hd; }
-}
-
-void vc_launch_hist(const VcDims& d, const VcBufs& b, hipStream_t st) {
-  hipLaunchKernelGGL(vc_hist_kernel, dim3((d.Ng + 3) / 4), dim3(256), 0, st, d, b);
+                   uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
+                   hipStream_t st) {
+  const int nb_hist = with_hist ? (d.Ng + 3) / 4 : 0;
+  hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), 0, st, d, b,
+                     params, eps, seed, step, step_dev, cond_only);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -312,11 +313,21 @@ __global__ __launch_bounds__(1024) void vc_post_gene_kernel(const VcDims d, cons
   float acc[VC_MAXQ];
 #pragma unroll
   for (int q = 0; q < VC_MAXQ; ++q) acc[q] = 0.f;
-  for (int ch = wave; ch < d.n_chunks; ch += VC_PG_WAVES) {
-    const float* go = b.GO + ((size_t)ch * d.nq) * d.Ng_pad + g;
+  for (int ch0 = wave; ch0 < d.n_chunks; ch0 += 4 * VC_PG_WAVES) {
+    float v[4][VC_MAXQ];
 #pragma unroll
-    for (int q = 0; q < VC_MAXQ; ++q)
-      if (q < d.nq) acc[q] += go[(size_t)q * d.Ng_pad];
+    for (int u = 0; u < 4; ++u) {        // issue the loads of 4 chunks before consuming any
+      const int ch = ch0 + u * VC_PG_WAVES;
+      const float* go = b.GO + ((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq) * d.Ng_pad + g;
+#pragma unroll
+      for (int q = 0; q < VC_MAXQ; ++q) v[u][q] = (q < d.nq) ? go[(size_t)q * d.Ng_pad] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ch0 + u * VC_PG_WAVES < d.n_chunks) {
+#pragma unroll
+        for (int q = 0; q < VC_MAXQ; ++q) acc[q] += v[u][q];
+      }
   }
 #pragma unroll
   for (int q = 0; q < VC_MAXQ; ++q) sm[wave][q][lane] = acc[q];
@@ -501,9 +512,12 @@ __global__ __launch_bounds__(256) void vc_post_cell_kernel(const VcDims d, const
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBufs b,
                                                      const float* __restrict__ P, float* __restrict__ G,
-                                                     double* __restrict__ loss_dev) {
+                                                     double* __restrict__ loss_dev, long long loss_slots,
+                                                     long long step_host, long long* __restrict__ step_dev) {
   __shared__ double sm_red[16];
+  __shared__ float sm_up[VC_MAX_NW];
   const int t = threadIdx.x;
+  const long long step = step_dev ? *step_dev : step_host;
   double s = 0.0;
   const int nlp = d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene;
   for (int i = t; i < nlp; i += 256) s += b.LP[i];
@@ -511,18 +525,26 @@ __global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBuf
   const double tot = vc_block_sum_d(s, sm_red);
   if (t == 0) {
     const double loss = tot + b.const_loss;
-    if (loss_dev) loss_dev[0] = loss;
+    if (loss_dev) loss_dev[loss_slots > 1 ? (step % loss_slots) : 0] = loss;
     const float hi = (float)loss;
     G[0] = hi;
     G[1] = (float)(loss - (double)hi);
     G[2] = 0.f;
     G[3] = 0.f;
   }
+  if (d.model == VC_MODEL_VELOCITY) {
+    for (int j = 0; j < d.NW; ++j) {     // deterministic block reduction of sum_c d loglik/d omega_c * D * zeta_omega
+      double u = 0.0;
+      for (int i = t; i < d.nb_post_cell; i += 256) u += (double)b.PW[(size_t)i * d.NW + j];
+      const double r = vc_block_sum_d(u, sm_red);
+      if (t == 0) sm_up[j] = (float)r;
+    }
+    __syncthreads();
+  }
   if (d.model == VC_MODEL_VELOCITY && t < d.NW) {
     const int j = t;
     const bool lrmn = d.guide == VC_GUIDE_LRMN;
-    float up = 0.f;
-    for (int i = 0; i < d.nb_post_cell; ++i) up += b.PW[(size_t)i * d.NW + j];
+    const float up = sm_up[j];
     float gx = 0.f;
     const bool cnd = CND(VC_SITE_NUOMEGA);
     if (!cnd) {
@@ -546,11 +568,49 @@ __global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBuf
       G[d.poff[VC_P_LRMN_UCOV_DIAG] + i] = -gx * b.eps_used[d.eoff[VC_E_LRMN_D] + i] / (2.f * sqrtf(dg)) * dg;
     }
   }
+  // every reader of this step's counter (K_pre) has finished: advance it for the optimiser / next step
+  if (t == 0 && step_dev) *step_dev = step + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ClippedAdam on the flat parameter buffer (pyro.optim.ClippedAdam restated, one launch):
+//   lr_t = lr0 * lrd^t ; g = clamp(g, +-clip) ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+//   p -= lr_t * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)            (t = 1-based step)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v,
+                                                      long long n, double lr0, double lrd, double b1, double b2,
+                                                      float eps, float clip, long long t_host,
+                                                      const long long* __restrict__ t_dev) {
+  const long long t = t_dev ? *t_dev : t_host;
+  const double td = (double)t;
+  const float step_size = (float)(lr0 * pow(lrd, td) * sqrt(1.0 - pow(b2, td)) / (1.0 - pow(b1, td)));
+  const float fb1 = (float)b1, fb2 = (float)b2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float gi = fminf(fmaxf(g[i], -clip), clip);
+    const float mi = fb1 * m[i] + (1.f - fb1) * gi;
+    const float vi = fb2 * v[i] + (1.f - fb2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) + eps));
+  }
+}
+
+void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
+                    double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
+                    hipStream_t st) {
+  long long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(vc_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr0, lrd, b1, b2, eps,
+                     clip, t_host, t_dev);
 }
 
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad,
-                    double* loss_dev, hipStream_t st) {
+                    double* loss_dev, long long loss_slots, long long step, long long* step_dev,
+                    hipStream_t st) {
   hipLaunchKernelGGL(vc_post_gene_kernel, dim3(d.nb_post_gene), dim3(1024), 0, st, d, b, params, grad);
   hipLaunchKernelGGL(vc_post_cell_kernel, dim3(d.nb_post_cell), dim3(256), 0, st, d, b, grad);
-  hipLaunchKernelGGL(vc_fin_kernel, dim3(1), dim3(256), 0, st, d, b, params, grad, loss_dev);
+  hipLaunchKernelGGL(vc_fin_kernel, dim3(1), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots, step,
+                     step_dev);
 }

@@ -222,16 +222,27 @@ class HipEngine:
     # ------------------------------------------------------------------------------------------
     def elbo_grad(self, eps: Optional[torch.Tensor] = None, seed: int = 0, step: int = 0,
                   step_dev: Optional[torch.Tensor] = None, params: Optional[torch.Tensor] = None,
-                  grad: Optional[torch.Tensor] = None):
+                  grad: Optional[torch.Tensor] = None, loss_buf: Optional[torch.Tensor] = None):
         """Launches one ELBO + gradient evaluation on the current stream (asynchronous).
-        Results: self.grad (header = loss hi/lo) and self.loss_dev."""
+        Results: self.grad (header = loss hi/lo) and self.loss_dev (or slot step % len(loss_buf) of
+        `loss_buf`, a float64 device ring).  `step_dev` (device int64[1]) is read as the step index and
+        incremented by the call."""
         params = self.params if params is None else params
         grad = self.grad if grad is None else grad
+        lb = self.loss_dev if loss_buf is None else loss_buf
         self._check(self.lib.vc_elbo_grad(
             self._h, C.c_void_p(params.data_ptr()),
             C.c_void_p(eps.data_ptr()) if eps is not None else None, C.c_uint64(seed), C.c_int64(step),
             C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
-            C.c_void_p(grad.data_ptr()), C.c_void_p(self.loss_dev.data_ptr()), self._stream()))
+            C.c_void_p(grad.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()), self._stream()))
+
+    def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None):
+        """Fused HIP ClippedAdam on flat float32 buffers (same stream)."""
+        rc = self.lib.vc_clipped_adam(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                      C.c_void_p(v.data_ptr()), p.numel(), lr, lrd, b1, b2, eps, clip, int(t),
+                                      C.c_void_p(t_dev.data_ptr()) if t_dev is not None else None, self._stream())
+        if rc != _lib.VC_OK:
+            raise HipEngineError("vc_clipped_adam failed")
 
     def loss(self) -> float:
         return float(self.loss_dev.item())

@@ -40,7 +40,11 @@ def optim_args_of(optimizer) -> dict:
 
 
 class FlatClippedAdam:
-    def __init__(self, n: int, optim_args: dict, device, capturable: bool = False):
+    """impl="torch": PyTorch ops on the flat tensor; impl="hip": the library's one-launch fused kernel
+    (vc_clipped_adam), step counter read from the engine's device counter.  Same arithmetic."""
+
+    def __init__(self, n: int, optim_args: dict, device, capturable: bool = False, impl: str = "torch",
+                 engine=None):
         a = dict(optim_args)
         self.lr0 = float(a.get("lr", 1e-3))
         self.b1, self.b2 = (float(x) for x in a.get("betas", (0.9, 0.999)))
@@ -53,12 +57,18 @@ class FlatClippedAdam:
         self.v = torch.zeros(n, dtype=torch.float32, device=device)
         self.t = 0
         self.capturable = capturable
-        if capturable:     # step counter and schedule live on the device so the update can be replayed
+        self.impl, self.engine = impl, engine
+        if capturable and impl == "torch":     # step counter and schedule live on the device so the update can be replayed
             self.t_dev = torch.zeros((), dtype=torch.float64, device=device)
             self._c = {k: torch.tensor(v, dtype=torch.float64, device=device)
                        for k, v in dict(lr0=self.lr0, lrd=self.lrd, b1=self.b1, b2=self.b2).items()}
 
-    def step(self, p: torch.Tensor, g: torch.Tensor):
+    def step(self, p: torch.Tensor, g: torch.Tensor, t_dev: Optional[torch.Tensor] = None):
+        if self.impl == "hip":
+            self.t += 1
+            self.engine.clipped_adam(p, g, self.m, self.v, self.lr0, self.lrd, self.b1, self.b2, self.eps,
+                                     self.clip, t=self.t, t_dev=t_dev)
+            return
         g = g.clamp(-self.clip, self.clip)
         self.m.lerp_(g, 1.0 - self.b1)
         self.v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
@@ -86,15 +96,16 @@ class SVIRunner:
 
     def __init__(self, engine: HipEngine, optim_args: dict, mode: str = "parity", seed: Optional[int] = None,
                  process_group=None, use_graph: Optional[bool] = None, warmup_draw: bool = True,
-                 init: bool = True):
+                 init: bool = True, adam_impl: Optional[str] = None):
         assert mode in ("parity", "perf")
         self.e, self.mode = engine, mode
         self.pg = process_group
         self.world = engine.world_size
         self.seed = 0 if seed is None else int(seed)
         self.use_graph = (mode == "perf" and self.world == 1) if use_graph is None else use_graph
+        self.adam_impl = adam_impl or ("hip" if mode == "perf" else "torch")
         self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
-                                   capturable=self.use_graph)
+                                   capturable=self.use_graph, impl=self.adam_impl, engine=engine)
         self.step_idx = 0
         self.losses: List[float] = []
         self._graph = None
@@ -128,9 +139,9 @@ class SVIRunner:
             import torch.distributed as dist
             dist.all_reduce(self.e.grad[: self.e.header + self.e.n_global], group=self.pg)
 
-    def _update(self):
+    def _update(self, t_dev=None):
         h = self.e.header
-        self.opt.step(self.e.params[h:], self.e.grad[h:])
+        self.opt.step(self.e.params[h:], self.e.grad[h:], t_dev=t_dev)
 
     def step(self, eps: Optional[Dict[str, torch.Tensor]] = None) -> float:
         """One SVI step in parity mode; returns the loss like `svi.step` does."""
@@ -151,12 +162,13 @@ class SVIRunner:
 
     def _perf_body(self):
         e = self.e
-        e.elbo_grad(eps=None, seed=self.seed, step=0, step_dev=self.step_dev)
-        self._reduce()
-        self.loss_hist.index_copy_(0, self.step_dev % self.loss_hist.shape[0],
-                                   e.grad[:2].double().sum().reshape(1))
-        self._update()
-        self.step_dev += 1
+        # K_fin writes the loss into slot step % len(loss_hist) and advances step_dev
+        e.elbo_grad(eps=None, seed=self.seed, step=0, step_dev=self.step_dev, loss_buf=self.loss_hist)
+        if self.world > 1:
+            self._reduce()
+            idx = (self.step_dev - 1) % self.loss_hist.shape[0]
+            self.loss_hist.index_copy_(0, idx, e.grad[:2].double().sum().reshape(1))
+        self._update(t_dev=self.step_dev)          # step_dev now holds the 1-based Adam step
 
     def run_perf(self, n_steps: int, sync: bool = True) -> None:
         """n_steps back-to-back SVI steps with no host round trip (losses stay on the device)."""
