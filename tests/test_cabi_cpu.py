@@ -1,0 +1,86 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports every symbol include/velocycle_hip.h
+declares; argument validation that needs no device memory works; the product has no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from velocycle_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib, _lib.load()
+
+
+def test_library_exports_every_declared_symbol():
+    mod, lib = _lib()
+    hdr = open(os.path.join(ROOT, "include", "velocycle_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vc_[a-z_]+)\s*\(", hdr))
+    assert declared, "no prototypes parsed"
+    assert declared == set(mod.EXPORTS), declared ^ set(mod.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.vc_abi_version() == mod.VC_ABI_VERSION
+
+
+def test_struct_sizes_match_header_layout():
+    mod, _ = _lib()
+    assert C.sizeof(mod.vc_config) == 12 * 4 + 4 * 8 + 8 * 4
+    assert C.sizeof(mod.vc_layout) == 8 * (4 + 2 * mod.VC_P_COUNT + 2 + 2 * mod.VC_E_COUNT)
+    assert C.sizeof(mod.vc_stats) == 4 * 8 + 2 * 4 + 96
+
+
+def test_create_validates_and_reports_errors():
+    mod, lib = _lib()
+    h = C.c_void_p()
+    cfg = mod.vc_config(abi_version=mod.VC_ABI_VERSION, model=1, guide=0, noise=0, with_delta_nu=0, n_harmonics=7,
+                        n_harmonics_w=1, Nb=1, Nx=1, lrmn_rank=5, rank=0, world_size=1, Ng=10, Nc_local=10,
+                        Nc_global=10, cell_offset=0, gamma_alpha=1, gamma_beta=2, sigma_ln_s=.1, sigma_ln_u=.1,
+                        rho_mean=4, rho_std=1, rho_scale=1)
+    assert lib.vc_create(C.byref(cfg), C.byref(h)) == mod.VC_ERR_UNSUPPORTED
+    assert b"n_harmonics" in lib.vc_last_error(None)
+    cfg.n_harmonics = 1
+    cfg.abi_version = 99
+    assert lib.vc_create(C.byref(cfg), C.byref(h)) == mod.VC_ERR_ARG
+    cfg.abi_version = mod.VC_ABI_VERSION
+    cfg.Ng = 0
+    assert lib.vc_create(C.byref(cfg), C.byref(h)) == mod.VC_ERR_ARG
+    # a valid config creates an engine and a layout without touching the GPU
+    cfg.Ng = 10
+    assert lib.vc_create(C.byref(cfg), C.byref(h)) == mod.VC_OK
+    lay = mod.vc_layout()
+    assert lib.vc_get_layout(h, C.byref(lay)) == mod.VC_OK
+    assert lay.header == 4 and lay.n_local == 20
+    # mean-field velocity, NB, Nx=1, Hw=1: nu (2*30) + logbeta (2*10) + loggamma (2*10) + nuw (2*3) + shape_inv 10
+    assert lay.n_global == 60 + 20 + 20 + 6 + 10 and lay.total == 4 + lay.n_global + 20
+    assert lay.eps_total == 10 + 10 + 30 + 3 + 20
+    # call-order errors come back as codes + messages, never as crashes
+    assert lib.vc_elbo_grad(h, None, None, 0, 0, None, None, None, 1, None) == mod.VC_ERR_STATE
+    assert b"before vc_finalize" in lib.vc_last_error(h)
+    assert lib.vc_set_prior(h, 0, None, 3) == mod.VC_ERR_ARG
+    lib.vc_destroy(h)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from tests import helpers as H
+    from velocycle_amd.engine import HipEngine, HipEngineError
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_phase_nb.npz")
+    with pytest.raises(HipEngineError, match="no CPU fallback"):
+        HipEngine(H.spec_from_fixture(z))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "velocycle_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
