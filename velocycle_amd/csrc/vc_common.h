@@ -25,7 +25,7 @@ struct VcDims {
   long long cell_offset;  // global index of the first local cell
   int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
   int K;                  // Nh + Nb : expression-map coefficients per gene (harmonics, then batch offsets)
-  int ctw;                // floats per cell record: [sin k, cos k]*H, Db[Nb], omega, cf, pad to x4
+  int ctw;                // floats per cell record: {x,x} pairs of [sin k, cos k]*H, Db[Nb], omega, cf (padded)
   int model, guide, noise, with_dnu;
   unsigned cond;          // bit i set <=> site i conditioned
   int kind;               // VC_KIND_*

@@ -224,7 +224,7 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   d.R = (vel && d.guide == VC_GUIDE_LRMN) ? c->lrmn_rank : 0;
   d.M = d.Ng + d.NW;
   d.K = d.Nh + d.Nb;
-  d.ctw = ((2 * d.H + d.Nb + 2) + 3) / 4 * 4;
+  d.ctw = 2 * (((2 * d.H + d.Nb + 2) + 3) / 4 * 4);   // values duplicated {x,x}, record padded to 32 B
   d.cond = 0;
   d.root_w = c->rank == 0 ? 1.f : 0.f;
   d.gamma_alpha = c->gamma_alpha; d.gamma_beta = c->gamma_beta;

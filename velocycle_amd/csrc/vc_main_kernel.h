@@ -21,57 +21,71 @@
 #pragma once
 #include "vc_common.h"
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Cell record as stored in the cell table: every value duplicated {x, x}, so that a scalar load
+// delivers it as an SGPR pair that v_pk_*_f32 consume directly as a packed operand (no per-cell
+// v_mov splat).  Layout (pairs): sin k, cos k (k = 1..H), Db[0..NB), omega, cf.
 template <int H, int NB>
 struct VcCellRec {
-  float sn[H], cs[H];
-  float db[NB > 0 ? NB : 1];
-  float omega, cf;
+  v2f sn[H], cs[H];
+  v2f db[NB > 0 ? NB : 1];
+  v2f omega, cf;
 };
 
 template <int H, int NB>
 __device__ __forceinline__ VcCellRec<H, NB> vc_load_cell(const float* __restrict__ ct) {
+  const v2f* c2 = reinterpret_cast<const v2f*>(ct);
   VcCellRec<H, NB> r;
 #pragma unroll
-  for (int k = 0; k < H; ++k) { r.sn[k] = ct[2 * k]; r.cs[k] = ct[2 * k + 1]; }
+  for (int k = 0; k < H; ++k) { r.sn[k] = c2[2 * k]; r.cs[k] = c2[2 * k + 1]; }
 #pragma unroll
-  for (int b = 0; b < NB; ++b) r.db[b] = ct[2 * H + b];
-  r.omega = ct[2 * H + NB];
-  r.cf = ct[2 * H + NB + 1];
+  for (int q = 0; q < NB; ++q) r.db[q] = c2[2 * H + q];
+  r.omega = c2[2 * H + NB];
+  r.cf = c2[2 * H + NB + 1];
   return r;
 }
 
-// Observation model of one count k under log-mean eta.  eta2 = eta * log2(e): the hardware
-// transcendentals are base 2 (v_exp_f32 / v_log_f32), so everything logarithmic is carried in log2
-// units and rescaled once per gene after the cell loop.  Inputs of the raw instructions are never
-// denormal here (t = r + mu >= r > 0), so no range fix-up code is needed around them.
-//   a    = d loglik / d eta                       (natural units)
-//   lacc += k * (eta2 - log2 t)   [NB]  | k*eta2 - mu*log2e [Poisson] | -0.5 e^2/s^2 [Lognormal]
-//   tacc += log2 t                [NB]: sum_c log(r + mu) enters both the loss (times r) and d/dr;
-// the remaining NB pieces need no per-element work: sum_c (r+k)/(r+mu) = Nc + (sum_c a)/r, and the
-// r-only terms (r log r, lgamma) come from the per-gene count histograms in K_post.
+// ---------------------------------------------------------------------------------------------
+// Packed-pair arithmetic.  The kernel is VALU-issue bound before it is HBM bound (rocprof: VALU busy
+// ~100 %, 4 cycles per wave64 instruction, 8 per transcendental), and v_pk_{fma,mul,add}_f32 retire two
+// genes per issue slot, so the per-element math is written on float2 pairs (4 genes/lane = 2 pairs).
+// ---------------------------------------------------------------------------------------------
 #define VC_LOG2E 1.4426950408889634f
 #define VC_LN2 0.6931471805599453f
 
+__device__ __forceinline__ v2f v2(float x) { return v2f{x, x}; }
+__device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// hardware base-2 transcendentals; arguments are never denormal here (t = r + mu >= r > 0, zp >= 1e-5)
+__device__ __forceinline__ v2f v2_exp2(v2f x) { return v2f{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ v2f v2_log2(v2f x) { return v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)}; }
+__device__ __forceinline__ v2f v2_rcp(v2f x) { return v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+
+// Observation model of a pair of counts k with mean mu (= exp of the log-mean, eta2 = log-mean*log2 e):
+//   a   = d loglik / d eta (natural units)
+//   ll += k (eta2 - log2 t)   [NB, t = r + mu]  |  k eta2 - mu log2 e  [Poisson]    (log2 units)
+//   lt += log2 t              [NB]: sum_c log(r+mu) enters the loss (times r) and d/dr.
+// Nothing else of the NB needs per-element work: sum_c (r+k)/(r+mu) = n + (sum_c a)/r, and the r-only
+// terms (r log r, lgamma) come from the per-gene count histograms (K_pre / K_post).
 template <int NOISE>
-__device__ __forceinline__ void vc_obs(float k, float eta, float eta2, float r, float inv_s2, float& a,
-                                       float& lacc, float& tacc) {
+__device__ __forceinline__ void vc_obs_counts(v2f k, v2f eta2, v2f mu, v2f r, v2f& a, v2f& ll, v2f& lt) {
   if (NOISE == VC_NOISE_NB) {
-    const float mu = __builtin_amdgcn_exp2f(eta2);
-    const float t = r + mu;
-    const float lt2 = __builtin_amdgcn_logf(t);
-    const float it = __builtin_amdgcn_rcpf(t);
+    const v2f t = r + mu;
+    const v2f lt2 = v2_log2(t);
+    const v2f it = v2_rcp(t);
     a = (r * (k - mu)) * it;
-    lacc = fmaf(k, eta2 - lt2, lacc);
-    tacc += lt2;
-  } else if (NOISE == VC_NOISE_POISSON) {
-    const float mu = __builtin_amdgcn_exp2f(eta2);
+    ll = v2_fma(k, eta2 - lt2, ll);
+    lt += lt2;
+  } else {
     a = k - mu;
-    lacc = fmaf(k, eta2, lacc) - mu * VC_LOG2E;
-  } else {  // Lognormal: k already holds log(count + 1); lacc in natural units / LN2 to share the rescale
-    const float e = k - eta;
-    a = e * inv_s2;
-    lacc = fmaf(-0.5f * VC_LOG2E * e, a, lacc);
+    ll = v2_fma(k, eta2, ll) - mu * VC_LOG2E;
   }
+}
+// Lognormal: y = log(count + 1) ~ Normal(eta, s); ll carried in natural units / ln 2 to share the rescale
+__device__ __forceinline__ void vc_obs_lognormal(v2f y, v2f eta, float inv_s2, v2f& a, v2f& ll) {
+  const v2f e = y - eta;
+  a = e * inv_s2;
+  ll = v2_fma(e * (-0.5f * VC_LOG2E), a, ll);
 }
 
 template <int H, int NB, int KIND, int NOISE>
@@ -81,6 +95,7 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
   constexpr bool HAS_S = (KIND != VC_KIND_VU);
   constexpr bool HAS_U = (KIND != VC_KIND_PHASE);
   constexpr bool FULL = (KIND == VC_KIND_VFULL);
+  constexpr bool LN = (NOISE == VC_NOISE_LOGNORMAL);
   constexpr int NQ = (KIND == VC_KIND_PHASE) ? K + 1 : (KIND == VC_KIND_VFULL ? K + 3 : 2);
   constexpr int NCO = FULL ? 3 : 1;
 
@@ -93,37 +108,35 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
   const int gl = lane * 4;                 // gene offset inside the block
   const int g0 = gb * VC_GBW + gl;
 
-  // ---- per-gene latents into registers ----------------------------------------------------
-  float nu[K][4], lb[4], gam[4], rr[4];
+  // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
+  v2f nu[K][2], lb2[2], ib[2], gam[2], rr[2];
   {
     const float* gt = b.GT + g0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)k * d.Ng_pad);
-      nu[k][0] = v.x; nu[k][1] = v.y; nu[k][2] = v.z; nu[k][3] = v.w;
+      nu[k][0] = v2f{v.x, v.y}; nu[k][1] = v2f{v.z, v.w};
     }
     const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)K * d.Ng_pad);
     const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(K + 1) * d.Ng_pad);
-    const float4 v2 = *reinterpret_cast<const float4*>(gt + (size_t)(K + 2) * d.Ng_pad);
-    lb[0] = v0.x; lb[1] = v0.y; lb[2] = v0.z; lb[3] = v0.w;
-    gam[0] = v1.x; gam[1] = v1.y; gam[2] = v1.z; gam[3] = v1.w;
-    rr[0] = v2.x; rr[1] = v2.y; rr[2] = v2.z; rr[3] = v2.w;
+    const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(K + 2) * d.Ng_pad);
+    lb2[0] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[1] = v2f{v0.z, v0.w} * VC_LOG2E;
+    ib[0] = v2f{__expf(-v0.x), __expf(-v0.y)}; ib[1] = v2f{__expf(-v0.z), __expf(-v0.w)};   // 1/beta
+    gam[0] = v2f{v1.x, v1.y}; gam[1] = v2f{v1.z, v1.w};
+    rr[0] = v2f{v2r.x, v2r.y}; rr[1] = v2f{v2r.z, v2r.w};
   }
   const float inv_s2_s = 1.0f / (d.sigma_ln_s * d.sigma_ln_s);
   const float inv_s2_u = 1.0f / (d.sigma_ln_u * d.sigma_ln_u);
-  float lb2[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) lb2[j] = lb[j] * VC_LOG2E;
 
   // ---- accumulators ---------------------------------------------------------------------------
-  float gnu[K][4];     // d loglik / d nu~[k]
-  float gau[4], gw[4];   // sum_c aU, sum_c aU * d etaU/dz
-  float ll[4], lt[4];    // log2-unit accumulators: likelihood pieces, sum_c log2(r + mu)
+  v2f gnu[K][2];            // d loglik / d nu~[k]
+  v2f gau[2], gw[2];        // sum_c aU, sum_c aU * d etaU/dz
+  v2f ll[2], lt[2];         // log2-unit accumulators: likelihood pieces, sum_c log2(r + mu)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int p = 0; p < 2; ++p) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) gnu[k][j] = 0.f;
-    gau[j] = gw[j] = ll[j] = lt[j] = 0.f;
+    for (int k = 0; k < K; ++k) gnu[k][p] = v2(0.f);
+    gau[p] = gw[p] = ll[p] = lt[p] = v2(0.f);
   }
 
   long long cbeg = (long long)chunk * (VC_WAVES * d.cw) + (long long)wave * d.cw;
@@ -156,72 +169,88 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
         if (HAS_U) u_nx = *reinterpret_cast<const float4*>(Up + (size_t)(c + 1) * VC_GBW);
         rec_nx = vc_load_cell<H, NB>(b.CT + (size_t)(c + 1) * d.ctw);
       }
-      const float sv[4] = {HAS_S ? s4.x : 0.f, HAS_S ? s4.y : 0.f, HAS_S ? s4.z : 0.f, HAS_S ? s4.w : 0.f};
-      const float uv[4] = {HAS_U ? u4.x : 0.f, HAS_U ? u4.y : 0.f, HAS_U ? u4.z : 0.f, HAS_U ? u4.w : 0.f};
+      const v2f sv[2] = {HAS_S ? v2f{s4.x, s4.y} : v2(0.f), HAS_S ? v2f{s4.z, s4.w} : v2(0.f)};
+      const v2f uv[2] = {HAS_U ? v2f{u4.x, u4.y} : v2(0.f), HAS_U ? v2f{u4.z, u4.w} : v2(0.f)};
 
-      float A1 = 0.f, A2 = 0.f, A3 = 0.f;
+      v2f A1 = v2(0.f), A2 = v2(0.f), A3 = v2(0.f);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int p = 0; p < 2; ++p) {
         // eta_S = nu . zeta(phi) + Db . dnu + cf ;  dd = nu . zeta'(phi) ;  e2 = nu . zeta''(phi)
-        float es = nu[0][j] + rec.cf;
-        float dd = 0.f, e2 = 0.f;
+        v2f es = nu[0][p] + rec.cf;
+        v2f dd = v2(0.f), e2 = v2(0.f);
 #pragma unroll
         for (int k = 0; k < H; ++k) {
-          const float ns = nu[2 * k + 1][j], nc = nu[2 * k + 2][j];
-          const float t = ns * rec.sn[k] + nc * rec.cs[k];
+          const v2f ns = nu[2 * k + 1][p], nc = nu[2 * k + 2][p];
+          const v2f t = v2_fma(ns, rec.sn[k], nc * rec.cs[k]);
           es += t;
-          dd += (float)(k + 1) * (ns * rec.cs[k] - nc * rec.sn[k]);
-          e2 -= (float)((k + 1) * (k + 1)) * t;
+          const v2f u = v2_fma(ns, rec.cs[k], -(nc * rec.sn[k]));
+          dd = (k == 0) ? u : v2_fma(u, v2((float)(k + 1)), dd);
+          e2 = (k == 0) ? -t : v2_fma(t, v2(-(float)((k + 1) * (k + 1))), e2);
         }
 #pragma unroll
-        for (int q = 0; q < NB; ++q) es += nu[NH + q][j] * rec.db[q];
+        for (int q = 0; q < NB; ++q) es = v2_fma(nu[NH + q][p], rec.db[q], es);
 
-        const float es2 = es * VC_LOG2E;
-        float a = 0.f, w = 0.f;
+        const v2f es2 = es * VC_LOG2E;
+        v2f a = v2(0.f), w = v2(0.f), muS = v2(0.f);
         if (HAS_S) {
-          float aS;
-          vc_obs<NOISE>(sv[j], es, es2, rr[j], inv_s2_s, aS, ll[j], lt[j]);
+          v2f aS;
+          if (LN) vc_obs_lognormal(sv[p], es, inv_s2_s, aS, ll[p]);
+          else {
+            muS = v2_exp2(es2);
+            vc_obs_counts<NOISE>(sv[p], es2, muS, rr[p], aS, ll[p], lt[p]);
+          }
           a += aS;
         }
         if (HAS_U) {
           // eta_U = -log beta + log(relu(dd * omega + gamma) + 1e-5) + eta_S
-          const float z = fmaf(dd, rec.omega, gam[j]);
-          const float zp = fmaxf(z, 0.f) + 1e-5f;
-          const float q = (z > 0.f) ? __builtin_amdgcn_rcpf(zp) : 0.f;     // torch.relu': 0 at z <= 0
-          const float lz2 = __builtin_amdgcn_logf(zp);
-          const float eu2 = (es2 - lb2[j]) + lz2;
-          float aU;
-          vc_obs<NOISE>(uv[j], eu2 * VC_LN2, eu2, rr[j], inv_s2_u, aU, ll[j], lt[j]);
+          const v2f z = v2_fma(dd, rec.omega, gam[p]);
+          const v2f zp = v2f{fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)} + 1e-5f;
+          const v2f iz = v2_rcp(zp);
+          const v2f q = v2f{z.x > 0.f ? iz.x : 0.f, z.y > 0.f ? iz.y : 0.f};     // torch.relu': 0 at z <= 0
+          const v2f eu2 = (es2 - lb2[p]) + v2_log2(zp);
+          v2f aU;
+          if (LN) vc_obs_lognormal(uv[p], eu2 * VC_LN2, inv_s2_u, aU, ll[p]);
+          else {
+            // exp(eta_U) = exp(eta_S) * zp / beta: no second exponential when exp(eta_S) is at hand
+            const v2f muU = FULL ? muS * (ib[p] * zp) : v2_exp2(eu2);
+            vc_obs_counts<NOISE>(uv[p], eu2, muU, rr[p], aU, ll[p], lt[p]);
+          }
           a += aU;
           w = aU * q;
-          gau[j] += aU;
-          gw[j] += w;
+          gau[p] += aU;
+          gw[p] += w;
         }
         if (KIND != VC_KIND_VU) {
-          const float wo = w * rec.omega;
-          gnu[0][j] += a;
+          const v2f wo = w * rec.omega;
+          gnu[0][p] += a;
 #pragma unroll
           for (int k = 0; k < H; ++k) {
             const float kk = (float)(k + 1);
-            gnu[2 * k + 1][j] += a * rec.sn[k] + (FULL ? wo * kk * rec.cs[k] : 0.f);
-            gnu[2 * k + 2][j] += a * rec.cs[k] - (FULL ? wo * kk * rec.sn[k] : 0.f);
+            if (FULL) {
+              const v2f wk = (k == 0) ? wo : wo * kk;
+              gnu[2 * k + 1][p] = v2_fma(a, rec.sn[k], v2_fma(wk, rec.cs[k], gnu[2 * k + 1][p]));
+              gnu[2 * k + 2][p] = v2_fma(a, rec.cs[k], v2_fma(-wk, rec.sn[k], gnu[2 * k + 2][p]));
+            } else {
+              gnu[2 * k + 1][p] = v2_fma(a, rec.sn[k], gnu[2 * k + 1][p]);
+              gnu[2 * k + 2][p] = v2_fma(a, rec.cs[k], gnu[2 * k + 2][p]);
+            }
           }
 #pragma unroll
-          for (int q = 0; q < NB; ++q) gnu[NH + q][j] += a * rec.db[q];
-          A1 += a * dd;
+          for (int q = 0; q < NB; ++q) gnu[NH + q][p] = v2_fma(a, rec.db[q], gnu[NH + q][p]);
+          A1 = v2_fma(a, dd, A1);
         }
-        if (FULL) A2 = fmaf(w, e2, A2);
-        if (HAS_U) A3 += w * dd;
+        if (FULL) A2 = v2_fma(w, e2, A2);
+        if (HAS_U) A3 = v2_fma(w, dd, A3);
       }
       // per-cell sums over the 256 genes of this wave
       if (KIND == VC_KIND_PHASE) {
-        const float t0 = vc_wave_sum(A1);
+        const float t0 = vc_wave_sum(A1.x + A1.y);
         keep0 = (lane == i) ? t0 : keep0;
       } else if (KIND == VC_KIND_VU) {
-        const float t0 = vc_wave_sum(A3);
+        const float t0 = vc_wave_sum(A3.x + A3.y);
         keep0 = (lane == i) ? t0 : keep0;
       } else {
-        const float t0 = vc_wave_sum(A1), t1 = vc_wave_sum(A2), t2 = vc_wave_sum(A3);
+        const float t0 = vc_wave_sum(A1.x + A1.y), t1 = vc_wave_sum(A2.x + A2.y), t2 = vc_wave_sum(A3.x + A3.y);
         keep0 = (lane == i) ? t0 : keep0;
         keep1 = (lane == i) ? t1 : keep1;
         keep2 = (lane == i) ? t2 : keep2;
@@ -239,8 +268,8 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
   __shared__ float sm_ll[VC_WAVES];
   {
     float* row = &sm[wave][0][gl];
-    auto put = [&](int q, const float* v) {
-      *reinterpret_cast<float4*>(row + (size_t)q * VC_GBW) = make_float4(v[0], v[1], v[2], v[3]);
+    auto put = [&](int q, const v2f* v) {
+      *reinterpret_cast<float4*>(row + (size_t)q * VC_GBW) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
     };
     if (KIND == VC_KIND_VU) {
       put(0, gau); put(1, gw);
@@ -248,11 +277,11 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
 #pragma unroll
       for (int k = 0; k < K; ++k) put(k, gnu[k]);
       // d loglik / d r (NB): -sum_c [log(r+mu) + (r+k)/(r+mu)] = -ln2 * sum log2 t - n_obs - (sum_c a)/r
-      float gr[4];
+      v2f gr[2];
       const float nobs = (float)(cend - cbeg) * (FULL ? 2.f : 1.f);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        gr[j] = (NOISE == VC_NOISE_NB) ? -VC_LN2 * lt[j] - nobs - gnu[0][j] * __builtin_amdgcn_rcpf(rr[j]) : 0.f;
+      for (int p = 0; p < 2; ++p)
+        gr[p] = (NOISE == VC_NOISE_NB) ? lt[p] * (-VC_LN2) - nobs - gnu[0][p] * v2_rcp(rr[p]) : v2(0.f);
       if (KIND == VC_KIND_PHASE) put(K, gr);
       else { put(K, gau); put(K + 1, gw); put(K + 2, gr); }
     }
@@ -260,9 +289,10 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
     // Padded genes are masked here (their nu~ is 0, so they never reached A1..A3).
     float l = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float lj = VC_LN2 * ((NOISE == VC_NOISE_NB) ? ll[j] - rr[j] * lt[j] : ll[j]);
-      l += (g0 + j < d.Ng) ? lj : 0.f;
+    for (int p = 0; p < 2; ++p) {
+      const v2f lj = ((NOISE == VC_NOISE_NB) ? ll[p] - rr[p] * lt[p] : ll[p]) * VC_LN2;
+      l += (g0 + 2 * p < d.Ng) ? lj.x : 0.f;
+      l += (g0 + 2 * p + 1 < d.Ng) ? lj.y : 0.f;
     }
     l = vc_wave_sum(l);
     if (lane == 0) sm_ll[wave] = l;

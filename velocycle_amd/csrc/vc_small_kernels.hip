@@ -274,12 +274,16 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
           domega += dx * dd;
         }
       }
-      float* ct = b.CT + (size_t)c * d.ctw;
-      for (int k = 0; k < d.H; ++k) { ct[2 * k] = sk[k]; ct[2 * k + 1] = ck[k]; }
-      for (int q = 0; q < d.Nb && d.with_dnu; ++q) ct[2 * d.H + q] = b.Dbm[(size_t)q * d.Nc + c];
+      // every value stored twice {x, x}: K_main fetches it as an SGPR pair = packed-math operand
+      float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
+      for (int k = 0; k < d.H; ++k) { ct[2 * k] = make_float2(sk[k], sk[k]); ct[2 * k + 1] = make_float2(ck[k], ck[k]); }
+      for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
+        const float v = b.Dbm[(size_t)q * d.Nc + c];
+        ct[2 * d.H + q] = make_float2(v, v);
+      }
       const int nbk = d.with_dnu ? d.Nb : 0;
-      ct[2 * d.H + nbk] = omega;
-      ct[2 * d.H + nbk + 1] = b.cf[c];
+      ct[2 * d.H + nbk] = make_float2(omega, omega);
+      ct[2 * d.H + nbk + 1] = make_float2(b.cf[c], b.cf[c]);
       b.lat_phi[c] = phi;
       b.lat_omega[c] = omega;
       b.lat_domega[c] = domega;
