@@ -155,13 +155,33 @@ __device__ __forceinline__ float vc_normal_lp(float x, float mu, float sd) {
   return -0.5f * z * z - logf(sd) - 0.5f * VC_LOG_2PI;
 }
 
-// digamma in double: recurrence to x >= 10, then the asymptotic series
-__device__ __forceinline__ double vc_digamma_d(double x) {
-  double acc = 0.0;
-  while (x < 10.0) { acc -= 1.0 / x; x += 1.0; }
-  const double i = 1.0 / x, i2 = i * i;
-  return acc + log(x) - 0.5 * i -
-         i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0 - i2 * (1.0 / 132.0)))));
+// lgamma(x+k) - lgamma(x) and digamma(x+k) - digamma(x) for x > 0, k >= 0, in double, without ever
+// forming the two large values: shift x up to y >= 8 with the recurrence (as a log of a product ratio /
+// a sum of reciprocal differences), then the Stirling series written as a difference:
+//   lgamma(y+k) - lgamma(y) = (y - 1/2) log1p(k/y) + k log(y+k) - k + S(y+k) - S(y)
+//   psi(y+k)    - psi(y)    = log1p(k/y) - (1/(y+k) - 1/y)/2 - (T(y+k) - T(y))
+__device__ __forceinline__ void vc_lgamma_digamma_diff(double x, double k, double& dl, double& dd) {
+  double lp = 0.0, rs = 0.0, y = x;
+  if (x < 8.0) {
+    const int n = (int)ceil(8.0 - x);
+    double num = 1.0, den = 1.0;
+    for (int j = 0; j < n; ++j) {
+      const double a = x + (double)j, bb = a + k;
+      num *= a; den *= bb;
+      rs += k / (a * bb);              // 1/a - 1/(a+k)
+    }
+    lp = log(num / den);
+    y = x + (double)n;
+  }
+  const double z = y + k;
+  const double l1 = log1p(k / y);
+  const double iy = 1.0 / y, iz = 1.0 / z, iy2 = iy * iy, iz2 = iz * iz;
+  const double Sy = iy * (1.0 / 12.0 - iy2 * (1.0 / 360.0 - iy2 * (1.0 / 1260.0 - iy2 * (1.0 / 1680.0))));
+  const double Sz = iz * (1.0 / 12.0 - iz2 * (1.0 / 360.0 - iz2 * (1.0 / 1260.0 - iz2 * (1.0 / 1680.0))));
+  const double Ty = iy2 * (1.0 / 12.0 - iy2 * (1.0 / 120.0 - iy2 * (1.0 / 252.0 - iy2 * (1.0 / 240.0))));
+  const double Tz = iz2 * (1.0 / 12.0 - iz2 * (1.0 / 120.0 - iz2 * (1.0 / 252.0 - iz2 * (1.0 / 240.0))));
+  dl = (y - 0.5) * l1 + k * log(z) - k + (Sz - Sy) + lp;
+  dd = l1 - 0.5 * (iz - iy) - (Tz - Ty) + rs;
 }
 #endif  // __HIPCC__
 
@@ -175,9 +195,10 @@ void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, 
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
                    hipStream_t st);
-void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad,
-                    double* loss_dev, long long loss_slots, long long step, long long* step_dev,
-                    hipStream_t st);
+void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int cond_only, hipStream_t st);
+void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, hipStream_t st);
+void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev,
+                   long long loss_slots, long long step, long long* step_dev, hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
                     double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
                     hipStream_t st);

@@ -491,7 +491,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   d.nb_pre_gene = d.Ng_pad / 256;
   d.nb_pre_cell = (d.Nc + 255) / 256;
   d.nb_post_gene = d.Ng_pad / 64;
-  d.nb_post_cell = (d.Nc + 255) / 256;
+  d.nb_post_cell = (d.Nc + 1023) / 1024;
   d.hist_has_S = nb && d.kind != VC_KIND_VU;
   d.hist_has_U = nb && vel;
   d.nmat_r = nb ? (d.kind == VC_KIND_VFULL ? 2 : 1) : 0;
@@ -588,7 +588,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   }
   if (nb && !e->hist_each_step) {
     // shape_inv conditioned: the lgamma / digamma sums never change -> evaluate them once
-    vc_launch_pre(d, b, nullptr, nullptr, 0, 0, nullptr, 1, 1, st);
+    vc_launch_hist(d, b, nullptr, 1, st);
     HIPCHK(e, hipStreamSynchronize(st));
   }
   b.const_loss = cl;
@@ -616,8 +616,8 @@ extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps,
   } else {
     e->main_fn(e->d, e->b, st);
   }
-  vc_launch_post(e->d, e->b, params, grad, loss_dev, (long long)loss_slots, (long long)step,
-                 (long long*)step_dev, st);
+  vc_launch_post(e->d, e->b, params, grad, st);
+  vc_launch_fin(e->d, e->b, params, grad, loss_dev, (long long)loss_slots, (long long)step, (long long*)step_dev, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
   return VC_OK;

@@ -39,6 +39,42 @@ void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// K_hist (NB): one wave per gene, fp64 -- also runs as extra blocks of K_pre
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, const float* __restrict__ P,
+                                             int cond_only, int g, int lane) {
+  float si;
+  if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
+  else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
+  const double r = (double)(1.0f / si);
+  double hl = 0.0, hd = 0.0;
+  for (int m = 0; m < 2; ++m) {
+    if ((m == 0 && !d.hist_has_S) || (m == 1 && !d.hist_has_U)) continue;
+    const int beg = b.h_ptr[m * d.Ng + g], end = b.h_ptr[m * d.Ng + g + 1];
+    for (int i = beg + lane; i < end; i += 64) {
+      double dl, dd;
+      vc_lgamma_digamma_diff(r, (double)b.h_val[i], dl, dd);
+      const double n = (double)b.h_cnt[i];
+      hl += n * dl;
+      hd += n * dd;
+    }
+  }
+  hl = vc_wave_sum_d(hl);
+  hd = vc_wave_sum_d(hd);
+  if (lane == 0) { b.HL[g] = hl; b.HD[g] = hd; }
+}
+
+__global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBufs b,
+                                                      const float* __restrict__ P, int cond_only) {
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g < d.Ng) vc_hist_wave(d, b, P, cond_only, g, threadIdx.x & 63);
+}
+
+void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int cond_only, hipStream_t st) {
+  hipLaunchKernelGGL(vc_hist_kernel, dim3((d.Ng + 3) / 4), dim3(256), 0, st, d, b, params, cond_only);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K_pre
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -58,32 +94,9 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
   double loss = 0.0;
 
   if ((int)blockIdx.x >= d.nb_pre_gene + d.nb_pre_cell) {
-    // ------------------------------- histogram part (NB): one wave per gene ---------------------
-    // sum_k cnt_k (lgamma(r+k) - lgamma(r)) and its r-derivative in fp64: the lgamma terms of
-    // GammaPoisson.log_prob summed over cells depend on (r_g, k) only, so the per-gene histogram of
-    // the counts is a sufficient statistic -- no lgamma/digamma in the (gene, cell) loop.
-    const int lane = threadIdx.x & 63;
+    // ------------------------------- histogram part (NB): one wave per gene -------------------------
     const int g = (blockIdx.x - d.nb_pre_gene - d.nb_pre_cell) * 4 + (threadIdx.x >> 6);
-    if (g < d.Ng) {
-      float si;
-      if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
-      else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
-      const double r = (double)(1.0f / si);
-      const double lg_r = lgamma(r), dg_r = vc_digamma_d(r);
-      double hl = 0.0, hd = 0.0;
-      for (int m = 0; m < 2; ++m) {
-        if ((m == 0 && !d.hist_has_S) || (m == 1 && !d.hist_has_U)) continue;
-        const int beg = b.h_ptr[m * d.Ng + g], end = b.h_ptr[m * d.Ng + g + 1];
-        for (int i = beg + lane; i < end; i += 64) {
-          const double k = (double)b.h_val[i], n = (double)b.h_cnt[i];
-          hl += n * (lgamma(r + k) - lg_r);
-          hd += n * (vc_digamma_d(r + k) - dg_r);
-        }
-      }
-      hl = vc_wave_sum_d(hl);
-      hd = vc_wave_sum_d(hd);
-      if (lane == 0) { b.HL[g] = hl; b.HD[g] = hd; }
-    }
+    if (g < d.Ng) vc_hist_wave(d, b, P, cond_only, g, threadIdx.x & 63);
     return;
   }
   if ((int)blockIdx.x < d.nb_pre_gene) {
@@ -302,18 +315,25 @@ void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// K_hist (NB): one wave per gene.  sum_k cnt_k (lgamma(r+k) - lgamma(r)) and its r-derivative in fp64.
+// The lgamma terms of GammaPoisson.log_prob summed over cells depend on (r_g, k) only, so the per-gene
+// histogram of the counts is a sufficient statistic -- no lgamma/digamma in the (gene, cell) loop.
+// Depends on the parameters only, so it runs on a side stream concurrently with K_pre / K_main.
+// ---------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------
 // K_post_gene: 1024 threads = 16 waves; lanes = 64 genes; wave w sums chunks w, w+16, ...
 // ---------------------------------------------------------------------------------------------
 #define VC_PG_WAVES 16
 #define VC_MAXQ (2 * VC_MAXH + 1 + VC_MAXNB + 3)
 
-__global__ __launch_bounds__(1024) void vc_post_gene_kernel(const VcDims d, const VcBufs b,
-                                                            const float* __restrict__ P,
-                                                            float* __restrict__ G) {
+__device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs& b,
+                                                   const float* __restrict__ P, float* __restrict__ G,
+                                                   int gblock) {
   __shared__ float sm[VC_PG_WAVES][VC_MAXQ][64];
   __shared__ double sm_red[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = blockIdx.x * 64 + lane;
+  const int g = gblock * 64 + lane;
   float acc[VC_MAXQ];
 #pragma unroll
   for (int q = 0; q < VC_MAXQ; ++q) acc[q] = 0.f;
@@ -452,16 +472,16 @@ __global__ __launch_bounds__(1024) void vc_post_gene_kernel(const VcDims d, cons
     }
   }
   const double tot = vc_block_sum_d(loss, sm_red);
-  if (threadIdx.x == 0) b.LP[d.nb_pre_gene + d.nb_pre_cell + blockIdx.x] = tot;
+  if (threadIdx.x == 0) b.LP[d.nb_pre_gene + d.nb_pre_cell + gblock] = tot;
 }
 
 // ---------------------------------------------------------------------------------------------
 // K_post_cell
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vc_post_cell_kernel(const VcDims d, const VcBufs b,
-                                                           float* __restrict__ G) {
-  __shared__ float sm_w[VC_WAVES][VC_MAX_NW];
-  const int c = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs& b, float* __restrict__ G,
+                                                   int cblock) {
+  __shared__ float sm_w[16][VC_MAX_NW];
+  const int c = cblock * 1024 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool vel = d.model == VC_MODEL_VELOCITY;
   float A[3] = {0.f, 0.f, 0.f};
@@ -506,9 +526,18 @@ __global__ __launch_bounds__(256) void vc_post_cell_kernel(const VcDims d, const
     __syncthreads();
     if ((int)threadIdx.x < d.NW) {
       const int j = threadIdx.x;
-      b.PW[(size_t)blockIdx.x * d.NW + j] = (sm_w[0][j] + sm_w[1][j]) + (sm_w[2][j] + sm_w[3][j]);
+      float t = 0.f;
+      for (int w = 0; w < 16; ++w) t += sm_w[w][j];
+      b.PW[(size_t)cblock * d.NW + j] = t;
     }
   }
+}
+
+// one launch for both second-stage reductions: blocks [0, nb_post_gene) gene level, the rest cell level
+__global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcBufs b, const float* __restrict__ P,
+                                                       float* __restrict__ G) {
+  if ((int)blockIdx.x < d.nb_post_gene) vc_post_gene_block(d, b, P, G, blockIdx.x);
+  else vc_post_cell_block(d, b, G, blockIdx.x - d.nb_post_gene);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -586,9 +615,13 @@ __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, con
                                                       long long n, double lr0, double lrd, double b1, double b2,
                                                       float eps, float clip, long long t_host,
                                                       const long long* __restrict__ t_dev) {
-  const long long t = t_dev ? *t_dev : t_host;
-  const double td = (double)t;
-  const float step_size = (float)(lr0 * pow(lrd, td) * sqrt(1.0 - pow(b2, td)) / (1.0 - pow(b1, td)));
+  __shared__ float s_step;
+  if (threadIdx.x == 0) {      // three fp64 pow() once per block instead of once per thread
+    const double td = (double)(t_dev ? *t_dev : t_host);
+    s_step = (float)(lr0 * pow(lrd, td) * sqrt(1.0 - pow(b2, td)) / (1.0 - pow(b1, td)));
+  }
+  __syncthreads();
+  const float step_size = s_step;
   const float fb1 = (float)b1, fb2 = (float)b2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float gi = fminf(fmaxf(g[i], -clip), clip);
@@ -610,11 +643,11 @@ void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, d
                      clip, t_host, t_dev);
 }
 
-void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad,
-                    double* loss_dev, long long loss_slots, long long step, long long* step_dev,
-                    hipStream_t st) {
-  hipLaunchKernelGGL(vc_post_gene_kernel, dim3(d.nb_post_gene), dim3(1024), 0, st, d, b, params, grad);
-  hipLaunchKernelGGL(vc_post_cell_kernel, dim3(d.nb_post_cell), dim3(256), 0, st, d, b, grad);
+void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, hipStream_t st) {
+  hipLaunchKernelGGL(vc_post_kernel, dim3(d.nb_post_gene + d.nb_post_cell), dim3(1024), 0, st, d, b, params, grad);
+}
+void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev,
+                   long long loss_slots, long long step, long long* step_dev, hipStream_t st) {
   hipLaunchKernelGGL(vc_fin_kernel, dim3(1), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots, step,
                      step_dev);
 }
