@@ -250,8 +250,29 @@ def make_basis():
     print("[basis] ok")
 
 
+def make_preprocess():
+    """The MetaparContainer tensors the reference's preprocess_for_* build from a duck-typed AnnData."""
+    d, ad, cyc, ph, Db = build_inputs(21, 6, 1, 2, seed=3)
+    out = {"S": ad.layers["spliced"], "U": ad.layers["unspliced"], "batch": np.array(ad.obs["batch"]).astype(str),
+           "cyc_means": cyc.means.values, "cyc_stds": cyc.stds.values, "phi_xy": ph.phi_xy.values}
+    mp = vc.preprocessing.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=1)
+    for k in ("Db", "μνg", "σνg", "φxy_prior", "count_factor", "S", "U", "logS", "σΔν", "μΔν"):
+        out["phase_" + k] = getattr(mp, k).numpy()
+    spd = vc.angularspeed.AngularSpeed.trivial_prior(condition_names=["b0", "b1"], harmonics=1)
+    mv = vc.preprocessing.preprocess_for_velocity_estimation(ad, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=1,
+                                                             count_factor=mp.count_factor, ω_n_harmonics=1)
+    for k in ("D", "Db", "ν", "μγ", "σγ", "μβ", "σβ", "μνω", "σνω", "μνg", "σνg", "φxy_prior", "count_factor", "S", "U",
+              "logU", "σsgc"):
+        out["vel_" + k] = getattr(mv, k).numpy()
+    out["vel_model_type"] = np.array(mv.model_type)
+    out["design"] = Db.numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_preprocess.npz"), **out)
+    print("[preprocess] ok")
+
+
 if __name__ == "__main__":
     make_basis()
+    make_preprocess()
     only = sys.argv[1:]
     for nm, c in CASES.items():
         if only and nm not in only:

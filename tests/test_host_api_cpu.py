@@ -1,0 +1,112 @@
+"""CPU: host-side mirror of the reference's Python surface -- containers, design matrix and the
+MetaparContainer built by preprocess_for_* -- against tensors produced by the reference's own
+preprocessing (tests/golden/ref_preprocess.npz), plus the eps stream order and ClippedAdam restatement."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import velocycle_oracle as orc
+from tests import helpers as H
+from velocycle_amd import containers as C
+from velocycle_amd import preprocessing as P
+from velocycle_amd.anndata_lite import AnnDataLite
+
+
+def _inputs():
+    z = H.load_fixture(f"{H.GOLDEN}/ref_preprocess.npz")
+    ad = AnnDataLite(z["S"], z["U"])
+    ad.obs["batch"] = list(z["batch"])
+    genes = list(ad.var.index)
+    cyc = C.Cycle.trivial_prior(genes, harmonics=1)
+    cyc.set_means(z["cyc_means"])
+    cyc.set_stds(z["cyc_stds"])
+    ph = C.Phases.from_array(z["phi_xy"], cell_names=list(ad.obs.index))
+    return z, ad, cyc, ph
+
+
+def test_design_matrix_and_phase_container_match_reference():
+    z, ad, cyc, ph = _inputs()
+    Db = P.make_design_matrix(ad, ids="batch")
+    assert Db.dtype == torch.int64 and np.array_equal(Db.numpy(), z["design"])
+    with pytest.raises(ValueError):
+        P.make_design_matrix(ad, ids="nope")
+    mp = P.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=1)
+    for k in ("Db", "μνg", "σνg", "φxy_prior", "count_factor", "S", "U", "logS", "σΔν", "μΔν"):
+        got = getattr(mp, k).numpy()
+        assert got.shape == z["phase_" + k].shape, k
+        assert np.allclose(got, z["phase_" + k], rtol=1e-6, atol=1e-6), k
+    assert mp.S.stride() == (1, mp.Ng)                       # the reference's transposed view (cell-major)
+    assert mp.model_fn.__name__ == "phase_latent_variable_model" and mp.Nb == 2 and mp.noisemodel == "NegativeBinomial"
+    with pytest.raises(ValueError):
+        P.preprocess_for_phase_estimation(ad, cyc, ph, Db, gene_selection_model="gmm")
+
+
+def test_velocity_container_matches_reference():
+    z, ad, cyc, ph = _inputs()
+    Db = P.make_design_matrix(ad, ids="batch")
+    mp = P.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=1)
+    spd = C.AngularSpeed.trivial_prior(["b0", "b1"], harmonics=1)
+    mv = P.preprocess_for_velocity_estimation(ad, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=1,
+                                              count_factor=mp.count_factor, ω_n_harmonics=1)
+    for k in ("D", "Db", "ν", "μγ", "σγ", "μβ", "σβ", "μνω", "σνω", "μνg", "σνg", "φxy_prior", "count_factor", "S", "U",
+              "logU", "σsgc"):
+        got = getattr(mv, k).numpy()
+        assert got.shape == z["vel_" + k].shape, (k, got.shape, z["vel_" + k].shape)
+        assert np.allclose(got, z["vel_" + k], rtol=1e-6, atol=1e-6), k
+    assert mv.model_type == "lrmn" == str(z["vel_model_type"])
+    assert mv.guide_fn.__name__ == "velocity_latent_variable_guide_LRMN" and mv.Nhω == 3 and mv.Nx == 2
+    from velocycle_amd.spec import spec_from_metaparams
+    sp = spec_from_metaparams(mv, "velocity")
+    assert (sp.guide, sp.Hw, sp.Nx, sp.Nb) == ("lrmn", 1, 2, 2) and sp.mu_nuw.shape == (2, 3)
+
+
+def test_containers_roundtrip_and_label_quirk(tmp_path):
+    cyc = C.Cycle.from_array(np.arange(6.0).reshape(3, 2), np.ones((3, 2)), ["g1", "g2"])
+    assert list(cyc.means.index) == ["nu0", "nu1_cos", "nu1_sin"]        # labels swapped vs arithmetic
+    cyc.save(tmp_path / "c.csv")
+    back = C.Cycle.load(tmp_path / "c.csv")
+    assert np.allclose(back.means.values, cyc.means.values) and np.allclose(back.stds.values, 1.0)
+    assert back.harmonics == 1 and len(back) == 2 and back.genes == ["g1", "g2"]
+    sp = C.AngularSpeed.trivial_prior(["a"], harmonics=0)
+    assert sp.means.shape == (1, 1) and float(sp.stds.values[0, 0]) == 3.0
+    ph = C.Phases.from_array(np.array([[1.0, 0.0], [0.0, -1.0]]), ["c1", "c2"])
+    assert np.allclose(ph.phis.numpy(), [0.0, 1.5 * np.pi])
+    ph.save(tmp_path / "p.csv")
+    assert np.allclose(C.Phases.load(tmp_path / "p.csv").phi_xy.values, ph.phi_xy.values)
+    with pytest.raises(AssertionError):
+        C.Phases.from_array(np.zeros((3, 2)))
+
+
+def test_host_eps_stream_equals_oracle_stream():
+    from velocycle_amd.rng import draw_eps
+    for case in ("phase_nb", "vel_mf_joint", "vel_lrmn_cond"):
+        z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
+        sp, p = H.spec_from_fixture(z), H.problem_from_fixture(z, torch.float32)
+        a = draw_eps(sp, torch.Generator().manual_seed(3))
+        b = orc.draw_eps(p, torch.Generator().manual_seed(3))
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (case, k)
+        # the fixture's eps (second guide call of the reference run with the fixture's seed) is reproduced
+        g = torch.Generator().manual_seed(int(z["seed"]))
+        draw_eps(sp, g)
+        second = draw_eps(sp, g)
+        for k, v in z.items():
+            if k.startswith("eps_"):
+                assert np.array_equal(second[k[4:]].numpy(), v), (case, k)
+
+
+def test_flat_clipped_adam_matches_oracle_restatement():
+    from velocycle_amd.svi import FlatClippedAdam
+    torch.manual_seed(0)
+    args = {"lr": 0.03, "lrd": 0.97, "betas": (0.8, 0.99)}
+    p0 = torch.randn(50)
+    flat = FlatClippedAdam(50, args, "cpu")
+    oa = orc.ClippedAdam(args)
+    p, par = p0.clone(), {"x": p0.clone()}
+    for i in range(7):
+        g = torch.randn(50) * (30.0 if i == 3 else 1.0)      # exercises the +-10 clamp
+        flat.step(p, g)
+        par = oa.step(par, {"x": g})
+    assert torch.allclose(p, par["x"], rtol=1e-6, atol=1e-7)

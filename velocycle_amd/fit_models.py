@@ -1,0 +1,287 @@
+"""`PhaseFitModel` / `VelocityFitModel`: the reference's fit drivers (phase_inference_model.py:81-341,
+velocity_inference_model.py:32-302) on top of the HIP engine.  Same constructor and `fit()` signature,
+same attributes after the fit (`losses`, `phis_pyro`, `fourier_coef`, `fourier_coef_sd`, `disp_pyro`,
+`delta_nus`, `cycle_pyro`, `phase_pyro`, `log_gammas`, `log_betas`, `velocity_coef[_sd]`, `speed_pyro`,
+`posterior`, `metaparams_avg`).  Extra keyword arguments of `fit()` (not in the reference):
+  mode   "perf" (default): eps from the engine's Philox stream (seeded from torch.initial_seed()), whole
+         step replayed from a hipGraph, losses read back at the end;
+         "parity": eps drawn on the host from torch's default generator in Pyro's order, so that
+         `torch.manual_seed(s); fit(...)` reproduces the reference run with the same seed.
+"""
+from __future__ import annotations
+
+import copy
+import logging
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import pyro_compat
+from .containers import AngularSpeed, Cycle, Phases
+from .engine import HipEngine
+from .spec import ModelSpec, spec_from_metaparams
+from .svi import SVIRunner, optim_args_of
+from .utils import torch_basis, torch_fourier_basis
+
+
+class _FitBase:
+    _kind = None
+    # The reference's default `loss=Trace_ELBO(...)` object is created once per class and shared by later
+    # fit() calls, so only the FIRST fit of a process makes Trace_ELBO's extra guide pass (one eps set drawn
+    # and discarded before step 0).  Mirrored per class for mode="parity".
+    _default_elbo_fresh = True
+
+    def __init__(self, metaparams, condition_on={}, early_exit=False, get_posterior=True, num_samples=500,
+                 n_per_bin=50):
+        self.model = metaparams.model_fn
+        self.guide = metaparams.guide_fn
+        self.posterior = None
+        self.condition = condition_on
+        self.condition_on = list(condition_on.keys())
+        self.metaparams = metaparams
+        self.early_exit = early_exit
+        self.get_posterior = get_posterior
+        self.num_samples = num_samples
+        self.n_per_bin = n_per_bin
+        self.engine: Optional[HipEngine] = None
+
+    # ------------------------------------------------------------------------------------------
+    def _make_engine(self, device=None):
+        spec = spec_from_metaparams(self.metaparams, self._kind, self.condition)
+        dev = device if device is not None else getattr(self.metaparams, "device", None)
+        if dev is None or torch.device(dev).type != "cuda":
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self.spec = spec
+        self.engine = HipEngine(spec, device=dev)          # raises without a GPU: no CPU fallback
+        return self.engine
+
+    def _warn_sizes(self):
+        pass
+
+    def fit(self, optimizer, loss=None, num_steps=1000, intermediate_output_step_size=100, store_output=False,
+            verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None):
+        self._warn_sizes()
+        if self.engine is None:
+            self._make_engine(device)
+        eng = self.engine
+        args = optim_args_of(optimizer)
+        exact = mode == "parity" or self.early_exit or store_output
+        if mode == "parity":
+            gen_seed = seed
+            warm = type(self)._default_elbo_fresh if loss is None else bool(getattr(loss, "fresh", True))
+            run = SVIRunner(eng, args, mode="parity", seed=gen_seed, warmup_draw=warm)   # seed None -> torch's global RNG
+            if loss is None:
+                type(self)._default_elbo_fresh = False
+        else:
+            s = int(torch.initial_seed() % (2 ** 63)) if seed is None else int(seed)
+            run = SVIRunner(eng, args, mode="perf", seed=s)
+        self._runner = run
+        losses, intermediate_output = [], []
+        if mode == "perf" and not exact:
+            run.run_perf(num_steps)
+            losses = run.perf_losses()
+        else:
+            early = False
+            for step in range(num_steps):
+                if mode == "parity":
+                    l = run.step()
+                else:
+                    run.run_perf(1)
+                    l = run.perf_losses()[-1]
+                losses.append(l)
+                if store_output and step % intermediate_output_step_size == 0:
+                    logging.info("Elbo loss: {}".format(l))
+                    intermediate_output.append(self.sample_posterior(num_samples=self.n_per_bin))
+                if early:                                    # velocity_inference_model.py:147-151
+                    if np.abs(np.mean(losses[-100:]) - np.mean(losses[-10:])) < 5:
+                        break
+                elif step > 200 and self.early_exit:
+                    early = True
+        self.losses = losses
+        self._extract()
+        if self.get_posterior:
+            self._posterior()
+        if store_output:
+            return intermediate_output
+
+    # ------------------------------------------------------------------------------------------
+    def _constrained(self) -> Dict[str, torch.Tensor]:
+        from ._lib import POSITIVE_PARAMS
+        out = {}
+        for k, v in self.engine.named().items():
+            v = v.detach().cpu().clone()
+            out[k] = v.exp() if k in POSITIVE_PARAMS else v
+        return out
+
+    def _publish(self, par):
+        """Fill the param store with Pyro's names and shapes."""
+        sp = self.spec
+        shp = {"ν_locs": (sp.Ng, 1, sp.Nh), "ν_scales": (sp.Ng, 1, sp.Nh), "ϕxy_locs": (sp.Nc, 2),
+               "shape_inv_locs": (sp.Ng, 1), "logγg_locs": (sp.Ng, 1), "logγg_scales": (sp.Ng, 1),
+               "logβg_locs": (sp.Ng, 1), "logβg_scales": (sp.Ng, 1), "νω_locs": (sp.Nx, sp.Nhw, 1, 1),
+               "νω_scales": (sp.Nx, sp.Nhw, 1, 1),
+               "Δν_locs": (sp.Nb, sp.Ng, 1) if sp.kind == "phase" else (sp.Nb, 1, 1, sp.Ng, 1)}
+        for k, v in par.items():
+            pyro_compat._STORE[k] = v.reshape(shp.get(k, v.shape))
+
+    def _extract(self):
+        sp = self.spec
+        par = self._constrained()
+        self._publish(par)
+        P = pyro_compat._STORE
+        self.phis_pyro = P["ϕxy_locs"].squeeze().numpy().T
+        self.fourier_coef = P["ν_locs"].squeeze().numpy().T
+        self.fourier_coef_sd = P["ν_scales"].squeeze().numpy().T
+        new_cycle = Cycle.from_array(self.fourier_coef, self.fourier_coef_sd, self.metaparams.cycle_prior.genes)
+        new_phase = Phases.from_array(self.phis_pyro, cell_names=self.metaparams.phase_prior.phi_xy.columns)
+        if "shape_inv_locs" in P:
+            self.disp_pyro = P["shape_inv_locs"].squeeze().numpy().T
+        if sp.with_delta_nu:
+            d = P["Δν_locs"]
+            self.delta_nus = (d.unsqueeze(-3).unsqueeze(-4) if sp.kind == "phase" else
+                              d.unsqueeze(-3).unsqueeze(-4)).float().numpy()
+        self.cycle_pyro, self.phase_pyro = new_cycle, new_phase
+        return par
+
+    def sample_posterior(self, num_samples=1, rs=None, mp=None, take_mean=True):
+        """`Predictive(model, guide=guide, num_samples=n, return_sites=rs)`: n guide draws pushed through
+        the model; returns {site: (n, ...) CPU tensor} with Pyro's site shapes."""
+        eng, sp = self.engine, self.spec
+        base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        names = [n for n in ("ν", "Δν", "ϕxy", "shape_inv", "logγg", "logβg", "νω", "rho_real")
+                 if self._site_exists(n)]
+        acc = {n: [] for n in names + ["ϕ"] + (["ω"] if sp.kind == "velocity" else [])}
+        for i in range(num_samples):
+            eng.elbo_grad(eps=None, seed=base, step=i)
+            for n in acc:
+                acc[n].append(eng.read_site(n))
+        out = {n: torch.stack(v) for n, v in acc.items()}
+        n = num_samples
+        res = {"ν": out["ν"].reshape(n, sp.Ng, 1, sp.Nh), "ϕxy": out["ϕxy"].reshape(n, sp.Nc, 2), "ϕ": out["ϕ"]}
+        res["ζ"] = torch.stack([torch_fourier_basis(p, sp.H, der=0) for p in out["ϕ"]])
+        if "shape_inv" in out:
+            res["shape_inv"] = out["shape_inv"].reshape(n, sp.Ng, 1)
+        if "Δν" in out:
+            res["Δν"] = out["Δν"].reshape((n, sp.Nb, sp.Ng, 1) if sp.kind == "phase" else (n, sp.Nb, 1, 1, sp.Ng, 1))
+        if sp.kind == "velocity":
+            res["logγg"] = out["logγg"].reshape(n, sp.Ng, 1)
+            res["γg"] = res["logγg"].exp()
+            res["logβg"] = out["logβg"].reshape(n, sp.Ng, 1)
+            res["νω"] = out["νω"].reshape(n, sp.Nx, sp.Nhw, 1, 1)
+            res["ζ_dϕ"] = torch.stack([torch_fourier_basis(p, sp.H, der=1) for p in out["ϕ"]])
+            res["ζω"] = torch.stack([torch_fourier_basis(p, sp.Hw, der=0).T for p in out["ϕ"]])
+            res["ω"] = out["ω"].reshape(n, 1, sp.Nc)
+            if "rho_real" in out:
+                res["rho_real"] = out["rho_real"].reshape(n, sp.Ng, 1)
+        if rs is not None:
+            res = {k: v for k, v in res.items() if k in rs}
+        return res
+
+    def _site_exists(self, n):
+        sp = self.spec
+        return {"ν": True, "ϕxy": True, "Δν": sp.with_delta_nu, "shape_inv": sp.noisemodel == "NegativeBinomial",
+                "logγg": sp.kind == "velocity", "logβg": sp.kind == "velocity", "νω": sp.kind == "velocity",
+                "rho_real": sp.kind == "velocity" and sp.guide == "lrmn"}[n]
+
+    def _binned_posterior(self):
+        nbins = int(np.ceil(self.num_samples / self.n_per_bin))
+        parts = [self.sample_posterior(num_samples=self.n_per_bin) for _ in range(nbins)]
+        return {k: torch.vstack([p[k] for p in parts]) for k in parts[0]}
+
+    def check_model(self):
+        st = self.engine.stats if self.engine else {}
+        print({"kind": self._kind, "spec": None if self.engine is None else
+               (self.spec.Ng, self.spec.Nc, self.spec.guide, self.spec.noisemodel), **st})
+
+    check_guide = check_model
+
+
+class PhaseFitModel(_FitBase):
+    _kind = "phase"
+
+    def __init__(self, metaparams, condition_on={}, early_exit=False, get_posterior=True, num_samples=500,
+                 n_per_bin=50):
+        super().__init__(metaparams, condition_on, early_exit, True, num_samples, n_per_bin)   # reference forces True
+
+    def _posterior(self):
+        sp, mp = self.spec, self.metaparams
+        post = self._binned_posterior()
+        self.metaparams_avg = mp._replace(count_factor=torch.full_like(mp.count_factor, float(mp.count_factor.mean())))
+        ν = pyro_compat.param("ν_locs")
+        ζ = torch_fourier_basis(self.phase_pyro.phis, num_harmonics=sp.H, der=0)
+        base = torch.einsum("...gch,ch->gc", ν, ζ)
+        if sp.with_delta_nu:
+            base = base + torch.einsum("bgc,bgc->gc", mp.Db.cpu(), pyro_compat.param("Δν_locs"))
+        post["ElogS"] = (base + mp.count_factor.cpu()).squeeze()
+        post["ElogS2"] = (base + self.metaparams_avg.count_factor.cpu()).squeeze()
+        self.posterior = post
+
+
+class VelocityFitModel(_FitBase):
+    _kind = "velocity"
+
+    def _warn_sizes(self):
+        mp = self.metaparams
+        if (mp.Ng < 50) & (mp.Nc < 500):
+            print("USER WARNING: the number of genes is below the recommended number for reliable velocity-learning.")
+        if (mp.Ng < 350) & (mp.Nc < 50):
+            print("USER WARNING: the number of cells is below the recommended number for reliable velocity-learning.")
+
+    def _extract(self):
+        par = super()._extract()
+        sp, P = self.spec, pyro_compat._STORE
+        if sp.guide != "lrmn":
+            self.log_gammas = P["logγg_locs"].squeeze().numpy().T
+            self.cycle_pyro.set_log_gammas(self.log_gammas)
+            self.velocity_coef = P["νω_locs"].unsqueeze(-3).unsqueeze(-4).float().numpy()
+            self.velocity_coef_sd = P["νω_scales"].unsqueeze(-3).unsqueeze(-4).float().numpy()
+            self.speed_pyro = AngularSpeed.from_array(condition_names=self.metaparams.speed_prior.conditions,
+                                                      means_array=self.velocity_coef.squeeze(),
+                                                      stds_array=self.velocity_coef_sd.squeeze(), Nhω=sp.Nhw)
+        self.log_betas = P["logβg_locs"].squeeze().numpy().T
+        self.cycle_pyro.set_log_betas(self.log_betas)
+        self.cycle_pyro.set_disp_pyro(getattr(self, "disp_pyro", None))
+        return par
+
+    def _posterior(self):
+        sp, mp = self.spec, self.metaparams
+        post = self._binned_posterior()
+        self.metaparams_avg = mp._replace(count_factor=torch.full_like(mp.count_factor, float(mp.count_factor.float().mean())))
+        ν = pyro_compat.param("ν_locs")
+        phis = self.phase_pyro.phis
+        ζ = torch_basis(phis, der=0, kind="fourier", num_harmonics=sp.H)
+        base = torch.einsum("...gch,ch->gc", ν, ζ)
+        if sp.with_delta_nu:
+            base = base + torch.einsum("bxhgc,bxhgc->gc", mp.Db.cpu().float(), pyro_compat.param("Δν_locs"))
+        ElogS = base + mp.count_factor.cpu()
+        ElogS2 = base + self.metaparams_avg.count_factor.cpu()
+        ζ_dϕ = torch_basis(phis, der=1, kind="fourier", num_harmonics=sp.H)
+        γg = post["γg"].mean(0).squeeze().unsqueeze(-1)
+        logβg = post["logβg"].mean(0).squeeze().unsqueeze(-1)
+        ζω = torch_basis(phis, der=0, kind="fourier", num_harmonics=sp.Hw).T
+        νω = post["νω"].mean(0)
+        ω = torch.einsum("...xhgc,hc,xhgc->gc", [νω, ζω, mp.D.cpu().float()])
+        core = -logβg + torch.log(torch.relu(torch.einsum("gch,ch->gc", ν, ζ_dϕ) * ω + γg) + 1e-5)
+        post["ElogS"], post["ElogU"] = ElogS.squeeze(), (core + ElogS).squeeze()
+        post["ElogS2"], post["ElogU2"] = ElogS2.squeeze(), (core + ElogS2).squeeze()
+        self.posterior = post
+        if sp.guide == "lrmn":                      # velocity_inference_model.py:264-274
+            self.log_gammas = post["logγg"].mean(0).squeeze().numpy().T
+            self.cycle_pyro.set_log_gammas(self.log_gammas)
+            self.velocity_coef = post["νω"].mean(0).float().numpy()
+            self.speed_pyro = AngularSpeed.from_array(condition_names=mp.speed_prior.conditions,
+                                                      means_array=self.velocity_coef.squeeze(),
+                                                      stds_array=post["νω"].std(0).float().squeeze().numpy(),
+                                                      Nhω=sp.Nhw)
+
+
+def run_svi(metaparams, optimizer, num_steps=1000, condition_on={}, kind=None, **fit_kwargs):
+    """Thin convenience wrapper named in BASELINE.json's north_star (the reference has no `run_svi`;
+    its nearest relative is the notebook-local `fit_SVI`, tutorials/1D_Pancreas_Analysis.ipynb cell 26)."""
+    kind = kind or ("velocity" if hasattr(metaparams, "Nx") else "phase")
+    cls = VelocityFitModel if kind == "velocity" else PhaseFitModel
+    m = cls(metaparams, condition_on=condition_on, get_posterior=fit_kwargs.pop("get_posterior", False))
+    m.fit(optimizer, num_steps=num_steps, verbose=False, **fit_kwargs)
+    return m
