@@ -139,6 +139,7 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=device)
 
     from velocycle_amd.engine import HipEngine
@@ -150,7 +151,10 @@ def main():
     def build(mode):
         spec = make_velocity_spec(args.cells, args.genes, mode, 1, 1, seed=0, device=device)
         eng = HipEngine(spec, device=device, rank=rank, world_size=world)
-        run = SVIRunner(eng, optim, mode="perf", seed=0, use_graph=(False if args.no_graph else None))
+        graph = None
+        if args.no_graph or (dist_on and os.environ.get("VC_BENCH_DIST_GRAPH", "1") == "0"):
+            graph = False
+        run = SVIRunner(eng, optim, mode="perf", seed=0, use_graph=graph)
         return spec, eng, run
 
     spec, eng, run = build(args.mode)
@@ -172,8 +176,8 @@ def main():
                                + ", NegativeBinomial noise, H=1, Hw=1",
                    "cells": args.cells, "genes": args.genes, "mode": args.mode,
                    "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
-                   "step": "Philox eps -> ELBO+grad (HIP) -> ClippedAdam (torch), hipGraph replay" if run.use_graph
-                           else "Philox eps -> ELBO+grad (HIP) -> all-reduce -> ClippedAdam (torch), eager launches"},
+                   "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + ("RCCL all-reduce -> " if dist_on else "")
+                            + f"ClippedAdam ({run.adam_impl}), " + ("hipGraph replay" if run.use_graph else "eager launches"))},
         "roofline": roof,
         "loss_first_last": [losses[0], losses[-1]],
     }

@@ -168,3 +168,30 @@ def test_shard_invariance_two_ranks_on_one_gpu():
     assert torch.equal(shards[1].read_site("eps")[: shards[1].eps_n_global], e_full[: full.eps_n_global])
     for s in shards + [full]:
         s.close()
+
+
+def test_rccl_allreduce_inside_captured_step_single_rank():
+    """The N > 1 step (RCCL all-reduce between the HIP kernels and the optimiser, all inside one hipGraph)
+    exercised with a 1-rank nccl process group: results equal the plain single-GPU path."""
+    import os
+    import torch.distributed as dist
+    from velocycle_amd.svi import SVIRunner
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_vel_mf_joint.npz")
+    spec = H.spec_from_fixture(z)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        outs = []
+        for force in (True, False):
+            e = _mk(spec)
+            r = SVIRunner(e, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=11, use_graph=True,
+                          force_reduce=force)
+            r.run_perf(8)
+            outs.append((e.params.clone().cpu(), r.perf_losses()))
+            e.close()
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert np.allclose(outs[0][1], outs[1][1], rtol=1e-6)      # reduced loss is float hi+lo
+    finally:
+        dist.destroy_process_group()

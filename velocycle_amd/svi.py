@@ -96,13 +96,15 @@ class SVIRunner:
 
     def __init__(self, engine: HipEngine, optim_args: dict, mode: str = "parity", seed: Optional[int] = None,
                  process_group=None, use_graph: Optional[bool] = None, warmup_draw: bool = True,
-                 init: bool = True, adam_impl: Optional[str] = None):
+                 init: bool = True, adam_impl: Optional[str] = None, force_reduce: bool = False):
         assert mode in ("parity", "perf")
         self.e, self.mode = engine, mode
         self.pg = process_group
         self.world = engine.world_size
         self.seed = 0 if seed is None else int(seed)
-        self.use_graph = (mode == "perf" and self.world == 1) if use_graph is None else use_graph
+        # force_reduce: issue the all-reduce even with one rank (exercises the RCCL-in-graph path on one GPU)
+        self.do_reduce = self.world > 1 or force_reduce
+        self.use_graph = (mode == "perf") if use_graph is None else use_graph
         self.adam_impl = adam_impl or ("hip" if mode == "perf" else "torch")
         self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
                                    capturable=self.use_graph, impl=self.adam_impl, engine=engine)
@@ -135,7 +137,7 @@ class SVIRunner:
 
     # ------------------------------------------------------------------------------------------
     def _reduce(self):
-        if self.world > 1:
+        if self.do_reduce:
             import torch.distributed as dist
             dist.all_reduce(self.e.grad[: self.e.header + self.e.n_global], group=self.pg)
 
@@ -164,7 +166,7 @@ class SVIRunner:
         e = self.e
         # K_fin writes the loss into slot step % len(loss_hist) and advances step_dev
         e.elbo_grad(eps=None, seed=self.seed, step=0, step_dev=self.step_dev, loss_buf=self.loss_hist)
-        if self.world > 1:
+        if self.do_reduce:
             self._reduce()
             idx = (self.step_dev - 1) % self.loss_hist.shape[0]
             self.loss_hist.index_copy_(0, idx, e.grad[:2].double().sum().reshape(1))
@@ -185,6 +187,11 @@ class SVIRunner:
             with torch.cuda.stream(s):
                 self._perf_body()                      # warm-up (allocator, lazy init) outside capture
                 torch.cuda.synchronize()
+                if self.do_reduce:
+                    # ProcessGroupNCCL's watchdog polls the events of collectives issued before the capture;
+                    # on ROCm such a query during capture aborts (hipErrorCapturedEvent) -> let it retire them
+                    import time
+                    time.sleep(2.0)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s):
                     self._perf_body()
