@@ -155,33 +155,35 @@ __device__ __forceinline__ float vc_normal_lp(float x, float mu, float sd) {
   return -0.5f * z * z - logf(sd) - 0.5f * VC_LOG_2PI;
 }
 
-// lgamma(x+k) - lgamma(x) and digamma(x+k) - digamma(x) for x > 0, k >= 0, in double, without ever
-// forming the two large values: shift x up to y >= 8 with the recurrence (as a log of a product ratio /
-// a sum of reciprocal differences), then the Stirling series written as a difference:
+// lgamma(x+k) - lgamma(x) and digamma(x+k) - digamma(x) for x > 0, k >= 0, without ever forming the two
+// large values: shift x up to y >= 8 with the recurrence (as logs of ratios / a sum of reciprocal
+// differences), then the Stirling series written as a difference:
 //   lgamma(y+k) - lgamma(y) = (y - 1/2) log1p(k/y) + k log(y+k) - k + S(y+k) - S(y)
 //   psi(y+k)    - psi(y)    = log1p(k/y) - (1/(y+k) - 1/y)/2 - (T(y+k) - T(y))
-__device__ __forceinline__ void vc_lgamma_digamma_diff(double x, double k, double& dl, double& dd) {
-  double lp = 0.0, rs = 0.0, y = x;
-  if (x < 8.0) {
-    const int n = (int)ceil(8.0 - x);
-    double num = 1.0, den = 1.0;
+// Evaluated in fp32 (no cancellation is left in this form: relative error ~1e-6, checked against
+// scipy in tests/test_oracle_golden.py through the Python twin of this routine); the caller
+// accumulates cnt * value over the histogram in fp64.
+__device__ __forceinline__ void vc_lgamma_digamma_diff(float x, float k, float& dl, float& dd) {
+  float lp = 0.f, rs = 0.f, y = x;
+  if (x < 8.f) {
+    const int n = (int)ceilf(8.f - x);
     for (int j = 0; j < n; ++j) {
-      const double a = x + (double)j, bb = a + k;
-      num *= a; den *= bb;
-      rs += k / (a * bb);              // 1/a - 1/(a+k)
+      const float a = x + (float)j, bb = a + k;
+      const float ib = 1.0f / bb;
+      lp += logf(a * ib);              // log((x+j)/(x+j+k))
+      rs += k * ib / a;                // 1/a - 1/(a+k)
     }
-    lp = log(num / den);
-    y = x + (double)n;
+    y = x + (float)n;
   }
-  const double z = y + k;
-  const double l1 = log1p(k / y);
-  const double iy = 1.0 / y, iz = 1.0 / z, iy2 = iy * iy, iz2 = iz * iz;
-  const double Sy = iy * (1.0 / 12.0 - iy2 * (1.0 / 360.0 - iy2 * (1.0 / 1260.0 - iy2 * (1.0 / 1680.0))));
-  const double Sz = iz * (1.0 / 12.0 - iz2 * (1.0 / 360.0 - iz2 * (1.0 / 1260.0 - iz2 * (1.0 / 1680.0))));
-  const double Ty = iy2 * (1.0 / 12.0 - iy2 * (1.0 / 120.0 - iy2 * (1.0 / 252.0 - iy2 * (1.0 / 240.0))));
-  const double Tz = iz2 * (1.0 / 12.0 - iz2 * (1.0 / 120.0 - iz2 * (1.0 / 252.0 - iz2 * (1.0 / 240.0))));
-  dl = (y - 0.5) * l1 + k * log(z) - k + (Sz - Sy) + lp;
-  dd = l1 - 0.5 * (iz - iy) - (Tz - Ty) + rs;
+  const float z = y + k;
+  const float l1 = log1pf(k / y);
+  const float iy = 1.0f / y, iz = 1.0f / z, iy2 = iy * iy, iz2 = iz * iz;
+  const float Sy = iy * (1.f / 12.f - iy2 * (1.f / 360.f - iy2 * (1.f / 1260.f - iy2 * (1.f / 1680.f))));
+  const float Sz = iz * (1.f / 12.f - iz2 * (1.f / 360.f - iz2 * (1.f / 1260.f - iz2 * (1.f / 1680.f))));
+  const float Ty = iy2 * (1.f / 12.f - iy2 * (1.f / 120.f - iy2 * (1.f / 252.f - iy2 * (1.f / 240.f))));
+  const float Tz = iz2 * (1.f / 12.f - iz2 * (1.f / 120.f - iz2 * (1.f / 252.f - iz2 * (1.f / 240.f))));
+  dl = (y - 0.5f) * l1 + k * (logf(z) - 1.0f) + (Sz - Sy) + lp;
+  dd = l1 - 0.5f * (iz - iy) - (Tz - Ty) + rs;
 }
 #endif  // __HIPCC__
 

@@ -495,7 +495,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   d.hist_has_S = nb && d.kind != VC_KIND_VU;
   d.hist_has_U = nb && vel;
   d.nmat_r = nb ? (d.kind == VC_KIND_VFULL ? 2 : 1) : 0;
-  e->hist_each_step = nb && !cond(e, VC_SITE_SHAPE_INV);
+  e->hist_each_step = nb && !cond(e, VC_SITE_SHAPE_INV) && !getenv("VC_DEBUG_SKIP_HIST");
 
   // uploads
   b.S = e->dS_raw; b.U = e->dU_raw;

@@ -46,17 +46,17 @@ __device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, c
   float si;
   if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
   else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
-  const double r = (double)(1.0f / si);
+  const float r = 1.0f / si;
   double hl = 0.0, hd = 0.0;
   for (int m = 0; m < 2; ++m) {
     if ((m == 0 && !d.hist_has_S) || (m == 1 && !d.hist_has_U)) continue;
     const int beg = b.h_ptr[m * d.Ng + g], end = b.h_ptr[m * d.Ng + g + 1];
     for (int i = beg + lane; i < end; i += 64) {
-      double dl, dd;
-      vc_lgamma_digamma_diff(r, (double)b.h_val[i], dl, dd);
+      float dl, dd;
+      vc_lgamma_digamma_diff(r, b.h_val[i], dl, dd);
       const double n = (double)b.h_cnt[i];
-      hl += n * dl;
-      hd += n * dd;
+      hl += n * (double)dl;
+      hd += n * (double)dd;
     }
   }
   hl = vc_wave_sum_d(hl);
