@@ -82,8 +82,12 @@ __device__ __forceinline__ float vc_wave_sum_lane63(float v) {
   v += vc_dpp<0x112, 0xf>(v);   // row_shr:2
   v += vc_dpp<0x114, 0xf>(v);   // row_shr:4
   v += vc_dpp<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds its row sum
-  v += vc_dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
-  v += vc_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+  // row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 as fused adds that leave the other rows
+  // untouched (row_mask), instead of v_mov_dpp into a zeroed temporary + v_add.  hipcc inserts no wait
+  // states inside an asm statement: a VALU write needs 2 of them before a DPP read (s_nop 1).
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\t"
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc"
+               : "+v"(v));
   return v;
 }
 
