@@ -6,7 +6,6 @@
 
 #include "../../include/velocycle_hip.h"
 
-#define VC_GBW 256          // genes per gene block = 64 lanes x 4 genes (one dwordx4 load per lane per cell)
 #define VC_WAVES 4          // waves per workgroup of the likelihood kernel
 #define VC_MAXH 3
 #define VC_MAXNB 4
@@ -21,6 +20,7 @@
 
 struct VcDims {
   int Ng, Ng_pad, nGB;
+  int gpl, gbw;           // genes per lane of the likelihood kernel (4 or 8), genes per gene block = 64*gpl
   int Nc;                 // cells on this rank
   long long cell_offset;  // global index of the first local cell
   int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
@@ -45,7 +45,7 @@ struct VcDims {
 
 struct VcBufs {
   // immutable inputs
-  const float *S, *U;                       // blocked counts [nGB][Nc][256]
+  const float *S, *U;                       // blocked counts [nGB][Nc][gbw]
   const float *cf, *Dm, *Dbm, *pxy;         // (Nc), (Nx,Nc), (Nb,Nc), (Nc,2)
   const float *mu_nu, *sd_nu, *mu_g, *sd_g, *mu_b, *sd_b, *mu_w, *sd_w, *sd_dnu;
   const float *cnd[VC_SITE_COUNT];          // conditioned values per site (or nullptr)
@@ -193,11 +193,11 @@ __device__ __forceinline__ void vc_lgamma_digamma_diff(float x, float k, float& 
 
 // launchers implemented in the .hip translation units -----------------------------------------
 typedef void (*vc_main_launch_fn)(const VcDims& d, const VcBufs& b, hipStream_t st);
-vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, const char** name,
+vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, const char** name,
                                       const void** kernel);
 
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
-                           int Ng, int Nc, int nGB, int log1p_transform, hipStream_t st);
+                           int Ng, int Nc, int nGB, int gbw, int log1p_transform, hipStream_t st);
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
                    hipStream_t st);

@@ -38,8 +38,7 @@ struct vc_engine {
   std::vector<float> hS, hU;            // dense (Ng, Nc) gene-major copies for histogram building
   std::vector<float> h_prior[VC_PRIOR_COUNT];
   std::vector<float> h_cond[VC_SITE_COUNT];
-  float* dS_raw = nullptr;              // packed device matrices
-  float* dU_raw = nullptr;
+  float* raw[2] = {nullptr, nullptr};   // device copies of S / U in the caller's strides (until finalize)
   vc_main_launch_fn main_fn = nullptr;
   vc_main_launch_fn phase_fn = nullptr;  // S-only kernel used once to hoist the S term (VU kind)
   const char* main_name = "";
@@ -208,8 +207,9 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   e->cfg = *c;
   VcDims& d = e->d;
   d.Ng = (int)c->Ng;
-  d.nGB = (d.Ng + VC_GBW - 1) / VC_GBW;
-  d.Ng_pad = d.nGB * VC_GBW;
+  d.gpl = 4; d.gbw = 256;
+  d.nGB = (d.Ng + d.gbw - 1) / d.gbw;
+  d.Ng_pad = d.nGB * d.gbw;       // provisional; fixed by vc_finalize
   d.Nc = (int)c->Nc_local;
   d.cell_offset = c->cell_offset;
   d.H = c->n_harmonics; d.Nh = 2 * d.H + 1;
@@ -238,6 +238,7 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
 extern "C" void vc_destroy(vc_engine* e) {
   if (!e) return;
   for (void* p : e->allocs) (void)hipFree(p);
+  for (float* r : e->raw) if (r) (void)hipFree(r);
   for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete e;
 }
@@ -257,27 +258,16 @@ extern "C" int vc_set_counts(vc_engine* e, const float* S, const float* U, int64
   if (!S || (vel && !U)) return e->fail(VC_ERR_ARG, "vc_set_counts: missing matrix");
   if (gs <= 0 || cs <= 0) return e->fail(VC_ERR_ARG, "vc_set_counts: strides must be positive");
   const size_t span = (size_t)(d.Ng - 1) * gs + (size_t)(d.Nc - 1) * cs + 1;
-  const size_t blocked = (size_t)d.nGB * d.Nc * VC_GBW;
-  const int log1p_t = d.noise == VC_NOISE_LOGNORMAL;
   const float* src[2] = {S, vel ? U : nullptr};
-  float** dst[2] = {&e->dS_raw, &e->dU_raw};
   std::vector<float>* hcopy[2] = {&e->hS, &e->hU};
   for (int m = 0; m < 2; ++m) {
     if (!src[m]) continue;
-    TRY(e->dalloc(dst[m], blocked));
-    float* staging = nullptr;
-    const float* dev_src = src[m];
-    if (!on_device) {
-      HIPCHK(e, hipMalloc((void**)&staging, span * sizeof(float)));
-      hipError_t st = hipMemcpy(staging, src[m], span * sizeof(float), hipMemcpyHostToDevice);
-      if (st != hipSuccess) { (void)hipFree(staging); return e->fail(VC_ERR_HIP, "H2D copy of counts: %s", hipGetErrorString(st)); }
-      dev_src = staging;
-    }
-    vc_launch_pack_counts(dev_src, *dst[m], gs, cs, d.Ng, d.Nc, d.nGB, log1p_t, nullptr);
-    hipError_t st = hipDeviceSynchronize();
-    if (staging) (void)hipFree(staging);
-    if (st != hipSuccess) return e->fail(VC_ERR_HIP, "pack_counts: %s", hipGetErrorString(st));
-    // host copy (raw counts, strided as given) for the histograms / lgamma(k+1) constant
+    // device copy in the caller's strides; re-laid-out by vc_finalize once the kernel (and with it the
+    // gene-block width of the HBM layout) is known
+    if (e->raw[m]) { (void)hipFree(e->raw[m]); e->raw[m] = nullptr; }
+    HIPCHK(e, hipMalloc((void**)&e->raw[m], span * sizeof(float)));
+    HIPCHK(e, hipMemcpy(e->raw[m], src[m], span * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    // host copy (raw counts) for the histograms / lgamma(k+1) constant
     if (d.noise != VC_NOISE_LOGNORMAL) {
       std::vector<float> tmp(span);
       if (on_device) HIPCHK(e, hipMemcpy(tmp.data(), src[m], span * sizeof(float), hipMemcpyDeviceToHost));
@@ -455,12 +445,35 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   auto nco_of = [&](int kind) { return kind == VC_KIND_VFULL ? 3 : 1; };
   d.nq = nq_of(d.kind);
   d.nco = nco_of(d.kind);
+  // genes per lane: 8 wherever the kernel's per-gene state still fits 2 waves per SIMD without scratch
+  // (from -Rpass-analysis=kernel-resource-usage over the instantiations), else 4
+  d.gpl = (d.kind == VC_KIND_VU) ? 8 : (d.kind == VC_KIND_VFULL ? (d.K <= 4 ? 8 : 4) : (d.K <= 9 ? 8 : 4));
+  if (const char* env = getenv("VC_GPL")) { if (atoi(env) == 4 || atoi(env) == 8) d.gpl = atoi(env); }
+  d.gbw = 64 * d.gpl;
+  d.nGB = (d.Ng + d.gbw - 1) / d.gbw;
+  d.Ng_pad = d.nGB * d.gbw;
   const void* main_kernel = nullptr;
-  e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, &e->main_name, &main_kernel);
+  e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, &e->main_name, &main_kernel);
   if (!e->main_fn) return e->fail(VC_ERR_UNSUPPORTED, "no likelihood kernel for H=%d Nb=%d kind=%d noise=%d", d.H, d.Nb, d.kind, d.noise);
   if (d.kind == VC_KIND_VU) {
-    e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, nullptr, nullptr);
+    e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, nullptr, nullptr);
     if (!e->phase_fn) return e->fail(VC_ERR_UNSUPPORTED, "no S-only kernel for the hoisted term");
+  }
+  // HBM layout of the counts: [gene block][cell][gbw], zero padded in genes
+  {
+    const size_t blocked = (size_t)d.nGB * d.Nc * d.gbw;
+    const float** dstp[2] = {&b.S, &b.U};
+    for (int m = 0; m < 2; ++m) {
+      *dstp[m] = nullptr;
+      if (!e->raw[m]) continue;
+      float* packed = nullptr;
+      TRY(e->dalloc(&packed, blocked));
+      vc_launch_pack_counts(e->raw[m], packed, e->gs, e->cs, d.Ng, d.Nc, d.nGB, d.gbw, d.noise == VC_NOISE_LOGNORMAL, st);
+      HIPCHK(e, hipStreamSynchronize(st));
+      (void)hipFree(e->raw[m]);
+      e->raw[m] = nullptr;
+      *dstp[m] = packed;
+    }
   }
   // tiling: one balanced round.  The grid is sized to the workgroups the chip holds at once for
   // this kernel (occupancy x 256 CUs); each wave gets an equal share of the cells of its gene block,
@@ -498,7 +511,6 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   e->hist_each_step = nb && !cond(e, VC_SITE_SHAPE_INV) && !getenv("VC_DEBUG_SKIP_HIST");
 
   // uploads
-  b.S = e->dS_raw; b.U = e->dU_raw;
   TRY(upload(e, e->h_prior[VC_PRIOR_MU_NU], &b.mu_nu));
   TRY(upload(e, e->h_prior[VC_PRIOR_SD_NU], &b.sd_nu));
   if (vel) {
@@ -651,7 +663,7 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   out->main_grid = d.n_main_wg;
   out->main_block = 256;
   out->main_kind = d.kind;
-  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s>", d.H, d.Nb, e->main_name);
+  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d>", d.H, d.Nb, e->main_name, d.gpl);
   return VC_OK;
 }
 

@@ -88,8 +88,12 @@ __device__ __forceinline__ void vc_obs_lognormal(v2f y, v2f eta, float inv_s2, v
   ll = v2_fma(e * (-0.5f * VC_LOG2E), a, ll);
 }
 
-template <int H, int NB, int KIND, int NOISE>
-__global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBufs b) {
+// GPL = genes per lane (4 or 8): 8 amortises the per-cell work (DPP reductions, staging, loop) over twice
+// the genes and is faster whenever its accumulators still fit 2 waves per SIMD (launch bound) -- the host
+// picks GPL per (kind, K); the HBM layout [gene block][cell][64*GPL] follows it.
+template <int H, int NB, int KIND, int NOISE, int GPL>
+__global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const VcDims d, const VcBufs b) {
+  constexpr int GBW = 64 * GPL;
   constexpr int NH = 2 * H + 1;
   constexpr int K = NH + NB;
   constexpr bool HAS_S = (KIND != VC_KIND_VU);
@@ -105,35 +109,40 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gb = blockIdx.x % d.nGB;
   const int chunk = blockIdx.x / d.nGB;
-  const int gl = lane * 4;                 // gene offset inside the block
-  const int g0 = gb * VC_GBW + gl;
+  const int gl = lane * GPL;            // gene offset inside the block
+  const int g0 = gb * GBW + gl;
 
   // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
-  v2f nu[K][2], lb2[2], ib[2], gam[2], rr[2];
+  constexpr int NP = GPL / 2;           // packed pairs per lane
+  constexpr int NV4 = GPL / 4;          // dwordx4 loads per lane per matrix per cell
+  v2f nu[K][NP], lb2[NP], ib[NP], gam[NP], rr[NP];
   {
     const float* gt = b.GT + g0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)k * d.Ng_pad);
-      nu[k][0] = v2f{v.x, v.y}; nu[k][1] = v2f{v.z, v.w};
+    for (int q4 = 0; q4 < NV4; ++q4) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)k * d.Ng_pad + 4 * q4);
+        nu[k][2 * q4] = v2f{v.x, v.y}; nu[k][2 * q4 + 1] = v2f{v.z, v.w};
+      }
+      const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)K * d.Ng_pad + 4 * q4);
+      const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(K + 1) * d.Ng_pad + 4 * q4);
+      const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(K + 2) * d.Ng_pad + 4 * q4);
+      lb2[2 * q4] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[2 * q4 + 1] = v2f{v0.z, v0.w} * VC_LOG2E;
+      ib[2 * q4] = v2f{__expf(-v0.x), __expf(-v0.y)}; ib[2 * q4 + 1] = v2f{__expf(-v0.z), __expf(-v0.w)};   // 1/beta
+      gam[2 * q4] = v2f{v1.x, v1.y}; gam[2 * q4 + 1] = v2f{v1.z, v1.w};
+      rr[2 * q4] = v2f{v2r.x, v2r.y}; rr[2 * q4 + 1] = v2f{v2r.z, v2r.w};
     }
-    const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)K * d.Ng_pad);
-    const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(K + 1) * d.Ng_pad);
-    const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(K + 2) * d.Ng_pad);
-    lb2[0] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[1] = v2f{v0.z, v0.w} * VC_LOG2E;
-    ib[0] = v2f{__expf(-v0.x), __expf(-v0.y)}; ib[1] = v2f{__expf(-v0.z), __expf(-v0.w)};   // 1/beta
-    gam[0] = v2f{v1.x, v1.y}; gam[1] = v2f{v1.z, v1.w};
-    rr[0] = v2f{v2r.x, v2r.y}; rr[1] = v2f{v2r.z, v2r.w};
   }
   const float inv_s2_s = 1.0f / (d.sigma_ln_s * d.sigma_ln_s);
   const float inv_s2_u = 1.0f / (d.sigma_ln_u * d.sigma_ln_u);
 
   // ---- accumulators ---------------------------------------------------------------------------
-  v2f gnu[K][2];            // d loglik / d nu~[k]
-  v2f gau[2], gw[2];        // sum_c aU, sum_c aU * d etaU/dz
-  v2f ll[2], lt[2];         // log2-unit accumulators: likelihood pieces, sum_c log2(r + mu)
+  v2f gnu[K][NP];           // d loglik / d nu~[k]
+  v2f gau[NP], gw[NP];      // sum_c aU, sum_c aU * d etaU/dz
+  v2f ll[NP], lt[NP];       // log2-unit accumulators: likelihood pieces, sum_c log2(r + mu)
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < NP; ++p) {
 #pragma unroll
     for (int k = 0; k < K; ++k) gnu[k][p] = v2(0.f);
     gau[p] = gw[p] = ll[p] = lt[p] = v2(0.f);
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
   if (cbeg > d.Nc) cbeg = d.Nc;
   if (cend > d.Nc) cend = d.Nc;
 
-  const size_t blk_base = ((size_t)gb * d.Nc) * VC_GBW + gl;
+  const size_t blk_base = ((size_t)gb * d.Nc) * GBW + gl;
   const float* Sp = HAS_S ? b.S + blk_base : nullptr;
   const float* Up = HAS_U ? b.U + blk_base : nullptr;
 
@@ -153,28 +162,37 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
     float keep0 = 0.f, keep1 = 0.f, keep2 = 0.f;
 
     // software pipeline: counts and cell record of the next cell are in flight while this one is processed
-    float4 s_nx, u_nx;
-    if (HAS_S) s_nx = *reinterpret_cast<const float4*>(Sp + (size_t)cb * VC_GBW);
-    if (HAS_U) u_nx = *reinterpret_cast<const float4*>(Up + (size_t)cb * VC_GBW);
+    float4 s_nx[NV4], u_nx[NV4];
+#pragma unroll
+    for (int q4 = 0; q4 < NV4; ++q4) {
+      if (HAS_S) s_nx[q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cb * GBW + 4 * q4);
+      if (HAS_U) u_nx[q4] = *reinterpret_cast<const float4*>(Up + (size_t)cb * GBW + 4 * q4);
+    }
     VcCellRec<H, NB> rec_nx = vc_load_cell<H, NB>(b.CT + (size_t)cb * d.ctw);
 
     for (int i = 0; i < n; ++i) {
       const long long c = cb + i;
-      float4 s4, u4;
-      if (HAS_S) s4 = s_nx;
-      if (HAS_U) u4 = u_nx;
+      v2f sv[NP], uv[NP];
+#pragma unroll
+      for (int q4 = 0; q4 < NV4; ++q4) {
+        sv[2 * q4] = HAS_S ? v2f{s_nx[q4].x, s_nx[q4].y} : v2(0.f);
+        sv[2 * q4 + 1] = HAS_S ? v2f{s_nx[q4].z, s_nx[q4].w} : v2(0.f);
+        uv[2 * q4] = HAS_U ? v2f{u_nx[q4].x, u_nx[q4].y} : v2(0.f);
+        uv[2 * q4 + 1] = HAS_U ? v2f{u_nx[q4].z, u_nx[q4].w} : v2(0.f);
+      }
       const VcCellRec<H, NB> rec = rec_nx;
       if (i + 1 < n) {
-        if (HAS_S) s_nx = *reinterpret_cast<const float4*>(Sp + (size_t)(c + 1) * VC_GBW);
-        if (HAS_U) u_nx = *reinterpret_cast<const float4*>(Up + (size_t)(c + 1) * VC_GBW);
+#pragma unroll
+        for (int q4 = 0; q4 < NV4; ++q4) {
+          if (HAS_S) s_nx[q4] = *reinterpret_cast<const float4*>(Sp + (size_t)(c + 1) * GBW + 4 * q4);
+          if (HAS_U) u_nx[q4] = *reinterpret_cast<const float4*>(Up + (size_t)(c + 1) * GBW + 4 * q4);
+        }
         rec_nx = vc_load_cell<H, NB>(b.CT + (size_t)(c + 1) * d.ctw);
       }
-      const v2f sv[2] = {HAS_S ? v2f{s4.x, s4.y} : v2(0.f), HAS_S ? v2f{s4.z, s4.w} : v2(0.f)};
-      const v2f uv[2] = {HAS_U ? v2f{u4.x, u4.y} : v2(0.f), HAS_U ? v2f{u4.z, u4.w} : v2(0.f)};
 
       v2f A1 = v2(0.f), A2 = v2(0.f), A3 = v2(0.f);
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < NP; ++p) {
         // eta_S = nu . zeta(phi) + Db . dnu + cf ;  dd = nu . zeta'(phi) ;  e2 = nu . zeta''(phi)
         v2f es = nu[0][p] + rec.cf;
         v2f dd = v2(0.f), e2 = v2(0.f);
@@ -264,32 +282,23 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
   }
 
   // ---- combine the 4 waves' gene-level partials through LDS, one store per workgroup ----------
-  __shared__ float sm[VC_WAVES][NQ][VC_GBW];
+  // d loglik / d r (NB): -sum_c [log(r+mu) + (r+k)/(r+mu)] = -ln2 * sum log2 t - n_obs - (sum_c a)/r
+  v2f gr[NP];
+  {
+    const float nobs = (float)(cend - cbeg) * (FULL ? 2.f : 1.f);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      gr[p] = (NOISE == VC_NOISE_NB && KIND != VC_KIND_VU) ? lt[p] * (-VC_LN2) - nobs - gnu[0][p] * v2_rcp(rr[p])
+                                                           : v2(0.f);
+  }
+  __shared__ float sm[VC_WAVES][GBW];
   __shared__ float sm_ll[VC_WAVES];
   {
-    float* row = &sm[wave][0][gl];
-    auto put = [&](int q, const v2f* v) {
-      *reinterpret_cast<float4*>(row + (size_t)q * VC_GBW) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
-    };
-    if (KIND == VC_KIND_VU) {
-      put(0, gau); put(1, gw);
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; ++k) put(k, gnu[k]);
-      // d loglik / d r (NB): -sum_c [log(r+mu) + (r+k)/(r+mu)] = -ln2 * sum log2 t - n_obs - (sum_c a)/r
-      v2f gr[2];
-      const float nobs = (float)(cend - cbeg) * (FULL ? 2.f : 1.f);
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        gr[p] = (NOISE == VC_NOISE_NB) ? lt[p] * (-VC_LN2) - nobs - gnu[0][p] * v2_rcp(rr[p]) : v2(0.f);
-      if (KIND == VC_KIND_PHASE) put(K, gr);
-      else { put(K, gau); put(K + 1, gw); put(K + 2, gr); }
-    }
     // likelihood partial in natural units: ln2 * (sum k (eta2 - log2 t) - r sum log2 t) for NB.
     // Padded genes are masked here (their nu~ is 0, so they never reached A1..A3).
     float l = 0.f;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const v2f lj = ((NOISE == VC_NOISE_NB) ? ll[p] - rr[p] * lt[p] : ll[p]) * VC_LN2;
       l += (g0 + 2 * p < d.Ng) ? lj.x : 0.f;
       l += (g0 + 2 * p + 1 < d.Ng) ? lj.y : 0.f;
@@ -297,32 +306,45 @@ __global__ __launch_bounds__(256) void vc_main_kernel(const VcDims d, const VcBu
     l = vc_wave_sum(l);
     if (lane == 0) sm_ll[wave] = l;
   }
-  __syncthreads();
-  {
-    const int t = threadIdx.x;   // gene t of the block
-    float* go = b.GO + ((size_t)chunk * NQ) * d.Ng_pad + gb * VC_GBW + t;
+  float* go = b.GO + ((size_t)chunk * NQ) * d.Ng_pad + gb * GBW;
+  auto row = [&](int q, const v2f* v) {      // one output row: stage the 4 waves' values, sum, store
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      go[(size_t)q * d.Ng_pad] = (sm[0][q][t] + sm[1][q][t]) + (sm[2][q][t] + sm[3][q][t]);
-    if (t == 0) b.LO[blockIdx.x] = (sm_ll[0] + sm_ll[1]) + (sm_ll[2] + sm_ll[3]);
+    for (int q4 = 0; q4 < NV4; ++q4)
+      *reinterpret_cast<float4*>(&sm[wave][gl + 4 * q4]) =
+          make_float4(v[2 * q4].x, v[2 * q4].y, v[2 * q4 + 1].x, v[2 * q4 + 1].y);
+    __syncthreads();
+    for (int t = threadIdx.x; t < GBW; t += 256)
+      go[(size_t)q * d.Ng_pad + t] = (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
+    __syncthreads();
+  };
+  if (KIND == VC_KIND_VU) {
+    row(0, gau); row(1, gw);
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) row(k, gnu[k]);
+    if (KIND == VC_KIND_PHASE) row(K, gr);
+    else { row(K, gau); row(K + 1, gw); row(K + 2, gr); }
   }
+  if (threadIdx.x == 0) b.LO[blockIdx.x] = (sm_ll[0] + sm_ll[1]) + (sm_ll[2] + sm_ll[3]);
 }
 
-template <int H, int NB, int KIND, int NOISE>
+template <int H, int NB, int KIND, int NOISE, int GPL>
 static void vc_main_launch(const VcDims& d, const VcBufs& b, hipStream_t st) {
-  hipLaunchKernelGGL((vc_main_kernel<H, NB, KIND, NOISE>), dim3(d.n_main_wg), dim3(256), 0, st, d, b);
+  hipLaunchKernelGGL((vc_main_kernel<H, NB, KIND, NOISE, GPL>), dim3(d.n_main_wg), dim3(256), 0, st, d, b);
 }
 
-struct VcMainEntry { int H, NB, kind, noise; vc_main_launch_fn fn; const void* kernel; };
+struct VcMainEntry { int H, NB, kind, noise, gpl; vc_main_launch_fn fn; const void* kernel; };
 
 // Explicit kernel instantiations are needed in both compilation passes; the launcher table is host-only.
-#define VC_INST_K(KIND, NOISE, H, NB) \
-  template __global__ void vc_main_kernel<H, NB, KIND, NOISE>(const VcDims, const VcBufs);
+#define VC_INST_K(KIND, NOISE, H, NB)                                                        \
+  template __global__ void vc_main_kernel<H, NB, KIND, NOISE, 4>(const VcDims, const VcBufs); \
+  template __global__ void vc_main_kernel<H, NB, KIND, NOISE, 8>(const VcDims, const VcBufs);
 #define VC_INST_KROW(KIND, NOISE, H)                                                   \
   VC_INST_K(KIND, NOISE, H, 0) VC_INST_K(KIND, NOISE, H, 1) VC_INST_K(KIND, NOISE, H, 2) \
   VC_INST_K(KIND, NOISE, H, 3) VC_INST_K(KIND, NOISE, H, 4)
-#define VC_ENT(KIND, NOISE, H, NB) \
-  {H, NB, KIND, NOISE, &vc_main_launch<H, NB, KIND, NOISE>, (const void*)&vc_main_kernel<H, NB, KIND, NOISE>}
+#define VC_ENT(KIND, NOISE, H, NB)                                                                    \
+  {H, NB, KIND, NOISE, 4, &vc_main_launch<H, NB, KIND, NOISE, 4>, (const void*)&vc_main_kernel<H, NB, KIND, NOISE, 4>}, \
+  {H, NB, KIND, NOISE, 8, &vc_main_launch<H, NB, KIND, NOISE, 8>, (const void*)&vc_main_kernel<H, NB, KIND, NOISE, 8>}
 #define VC_ENT_ROW(KIND, NOISE, H)                                                          \
   VC_ENT(KIND, NOISE, H, 0), VC_ENT(KIND, NOISE, H, 1), VC_ENT(KIND, NOISE, H, 2), VC_ENT(KIND, NOISE, H, 3), \
   VC_ENT(KIND, NOISE, H, 4)
@@ -333,6 +355,6 @@ struct VcMainEntry { int H, NB, kind, noise; vc_main_launch_fn fn; const void* k
 #else
 #define VC_DEFINE_TABLE(NAME, KIND, NOISE)                                                   \
   VC_INST_KROW(KIND, NOISE, 1) VC_INST_KROW(KIND, NOISE, 2) VC_INST_KROW(KIND, NOISE, 3)      \
-  extern const VcMainEntry NAME[15] = {VC_ENT_ROW(KIND, NOISE, 1), VC_ENT_ROW(KIND, NOISE, 2), \
+  extern const VcMainEntry NAME[30] = {VC_ENT_ROW(KIND, NOISE, 1), VC_ENT_ROW(KIND, NOISE, 2), \
                                        VC_ENT_ROW(KIND, NOISE, 3)};
 #endif

@@ -14,15 +14,15 @@
 
 // ---------------------------------------------------------------------------------------------
 __global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                      long long gs, long long cs, int Ng, int Nc, int nGB, int log1p_t) {
-  const long long total = (long long)nGB * Nc * VC_GBW;
+                                      long long gs, long long cs, int Ng, int Nc, int nGB, int gbw, int log1p_t) {
+  const long long total = (long long)nGB * Nc * gbw;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int gl = (int)(i % VC_GBW);
-    const long long t = i / VC_GBW;
+    const int gl = (int)(i % gbw);
+    const long long t = i / gbw;
     const int c = (int)(t % Nc);
     const int gb = (int)(t / Nc);
-    const int g = gb * VC_GBW + gl;
+    const int g = gb * gbw + gl;
     float v = 0.f;
     if (g < Ng) {
       v = src[(long long)g * gs + (long long)c * cs];
@@ -33,9 +33,9 @@ __global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __re
 }
 
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
-                           int Ng, int Nc, int nGB, int log1p_transform, hipStream_t st) {
+                           int Ng, int Nc, int nGB, int gbw, int log1p_transform, hipStream_t st) {
   hipLaunchKernelGGL(vc_pack_counts_kernel, dim3(2048), dim3(256), 0, st, src, dst, gene_stride,
-                     cell_stride, Ng, Nc, nGB, log1p_transform);
+                     cell_stride, Ng, Nc, nGB, gbw, log1p_transform);
 }
 
 // ---------------------------------------------------------------------------------------------
