@@ -201,6 +201,15 @@ int vc_clipped_adam(float* params, const float* grad, float* exp_avg, float* exp
                     double lr, double lrd, double beta1, double beta2, double eps, double clip_norm,
                     int64_t t, const int64_t* t_dev, void* hip_stream);
 
+/* One whole SVI step (single rank): vc_elbo_grad with pyro's ClippedAdam merged into its last kernel -- 4
+ * launches instead of 5.  exp_avg / exp_avg_sq: device float[total - header], zero-initialised by the caller;
+ * the optimiser step is step + 1.  Equivalent to vc_elbo_grad followed by vc_clipped_adam on params[header:].
+ * grad still receives the gradient and the loss header.  Returns VC_ERR_STATE when world_size > 1: with sharded
+ * cells the all-reduce has to sit between the two halves. */
+int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64_t seed, int64_t step, int64_t* step_dev,
+                float* grad, double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
+                double lrd, double beta1, double beta2, double adam_eps, double clip_norm, void* hip_stream);
+
 /* introspection ----------------------------------------------------------------------------- */
 /* Copies the value a site took in the last vc_elbo_grad to host memory (synchronises the stream). */
 int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream);

@@ -85,7 +85,7 @@ def test_hip_adam_equals_torch_ops():
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_vel_mf_joint.npz")
     spec = H.spec_from_fixture(z)
     res = []
-    for impl in ("torch", "hip"):
+    for impl in ("torch", "hip", "fused"):
         e = _mk(spec)
         r = SVIRunner(e, {"lr": 0.03, "lrd": 0.99, "betas": (0.8, 0.99)}, mode="perf", seed=3, use_graph=False,
                       adam_impl=impl)
@@ -94,6 +94,8 @@ def test_hip_adam_equals_torch_ops():
         e.close()
     assert np.allclose(res[0][0].numpy(), res[1][0].numpy(), rtol=2e-5, atol=2e-6)
     assert np.allclose(res[0][1], res[1][1], rtol=1e-6)
+    # optimiser merged into K_fin's launch == separate one-launch optimiser, bit for bit
+    assert torch.equal(res[1][0], res[2][0]) and res[1][1] == res[2][1]
 
 
 @pytest.mark.parametrize("mode", ["vjoint", "vcond", "vcond_mf"])

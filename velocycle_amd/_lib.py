@@ -71,6 +71,9 @@ EXPORTS = {
     "vc_get_layout": (C.c_int, [C.c_void_p, C.POINTER(vc_layout)]),
     "vc_elbo_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vc_svi_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                              C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "vc_clipped_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                   C.c_void_p, C.c_void_p]),

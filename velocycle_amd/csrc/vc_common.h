@@ -140,10 +140,9 @@ __device__ __forceinline__ float vc_philox_normal(uint64_t seed, long long step,
             (uint32_t)seed, (uint32_t)(seed >> 32), o);
   const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
   const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  const float rad = sqrtf(-2.0f * logf(u1));
-  float s, c;
-  sincosf(6.283185307179586f * u2, &s, &c);
-  return (idx & 1) ? rad * s : rad * c;
+  // hardware log2 / sin / cos (v_log_f32, v_sin_f32, v_cos_f32 take revolutions): plenty for a noise draw
+  const float rad = sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(u1));
+  return rad * ((idx & 1) ? __builtin_amdgcn_sinf(u2) : __builtin_amdgcn_cosf(u2));
 }
 
 // eps value `li` (local index in this rank's eps vector, global index gi for the counter RNG)
@@ -202,9 +201,14 @@ void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const 
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
                    hipStream_t st);
 void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int cond_only, hipStream_t st);
-void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, hipStream_t st);
+void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,
+                    hipStream_t st);
 void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev,
-                   long long loss_slots, long long step, long long* step_dev, hipStream_t st);
+                   long long loss_slots, long long step, const long long* step_dev, hipStream_t st);
+void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* grad, double* loss_dev,
+                        long long loss_slots, long long step, long long* step_dev, float* m, float* v, double lr0,
+                        double lrd, double b1, double b2, float eps, float clip, int header, long long total,
+                        hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
                     double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
                     hipStream_t st);

@@ -610,13 +610,8 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   return VC_OK;
 }
 
-extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
-                            int64_t* step_dev, float* grad, double* loss_dev, int64_t loss_slots,
-                            void* hip_stream) {
-  if (!e) return VC_ERR_ARG;
-  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_elbo_grad before vc_finalize");
-  if (!params || !grad) return e->fail(VC_ERR_ARG, "vc_elbo_grad: null params / grad");
-  hipStream_t st = (hipStream_t)hip_stream;
+static int launch_front(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
+                        int64_t* step_dev, float* grad, hipStream_t st) {
   vc_launch_pre(e->d, e->b, params, eps, seed, (long long)step, (const long long*)step_dev, 0,
                 e->hist_each_step ? 1 : 0, st);
   if (e->timing) {
@@ -628,8 +623,39 @@ extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps,
   } else {
     e->main_fn(e->d, e->b, st);
   }
-  vc_launch_post(e->d, e->b, params, grad, st);
-  vc_launch_fin(e->d, e->b, params, grad, loss_dev, (long long)loss_slots, (long long)step, (long long*)step_dev, st);
+  vc_launch_post(e->d, e->b, params, grad, (long long*)step_dev, st);
+  return VC_OK;
+}
+
+extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
+                            int64_t* step_dev, float* grad, double* loss_dev, int64_t loss_slots,
+                            void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_elbo_grad before vc_finalize");
+  if (!params || !grad) return e->fail(VC_ERR_ARG, "vc_elbo_grad: null params / grad");
+  hipStream_t st = (hipStream_t)hip_stream;
+  TRY(launch_front(e, params, eps, seed, step, step_dev, grad, st));
+  vc_launch_fin(e->d, e->b, params, grad, loss_dev, (long long)loss_slots, (long long)step, (const long long*)step_dev, st);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
+extern "C" int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64_t seed, int64_t step,
+                           int64_t* step_dev, float* grad, double* loss_dev, int64_t loss_slots, float* exp_avg,
+                           float* exp_avg_sq, double lr, double lrd, double beta1, double beta2, double adam_eps,
+                           double clip_norm, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_step before vc_finalize");
+  if (e->cfg.world_size != 1)
+    return e->fail(VC_ERR_STATE, "vc_svi_step merges the optimiser with the last gradient kernel: single rank only "
+                                 "(use vc_elbo_grad + all-reduce + vc_clipped_adam when cells are sharded)");
+  if (!params || !grad || !exp_avg || !exp_avg_sq) return e->fail(VC_ERR_ARG, "vc_svi_step: null buffer");
+  hipStream_t st = (hipStream_t)hip_stream;
+  TRY(launch_front(e, params, eps, seed, step, step_dev, grad, st));
+  vc_launch_fin_adam(e->d, e->b, params, grad, loss_dev, (long long)loss_slots, (long long)step, (long long*)step_dev,
+                     exp_avg, exp_avg_sq, lr, lrd, beta1, beta2, (float)adam_eps, (float)clip_norm,
+                     (int)e->layout.header, (long long)e->layout.total, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
   return VC_OK;

@@ -535,7 +535,10 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
 
 // one launch for both second-stage reductions: blocks [0, nb_post_gene) gene level, the rest cell level
 __global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcBufs b, const float* __restrict__ P,
-                                                       float* __restrict__ G) {
+                                                       float* __restrict__ G, long long* __restrict__ step_dev) {
+  // every reader of this step's counter (K_pre) has finished and nothing in this launch reads it:
+  // advance it here, so that K_fin / the optimiser (which only read it) see step + 1 = the 1-based Adam step
+  if (blockIdx.x == 0 && threadIdx.x == 0 && step_dev) *step_dev += 1;
   if ((int)blockIdx.x < d.nb_post_gene) vc_post_gene_block(d, b, P, G, blockIdx.x);
   else vc_post_cell_block(d, b, G, blockIdx.x - d.nb_post_gene);
 }
@@ -543,14 +546,11 @@ __global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcB
 // ---------------------------------------------------------------------------------------------
 // K_fin: one block.  Loss in fp64 (deterministic order), angular-speed gradients, header.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBufs b,
-                                                     const float* __restrict__ P, float* __restrict__ G,
-                                                     double* __restrict__ loss_dev, long long loss_slots,
-                                                     long long step_host, long long* __restrict__ step_dev) {
+__device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, const float* P, float* G,
+                                             double* loss_dev, long long loss_slots, long long step) {
   __shared__ double sm_red[16];
   __shared__ float sm_up[VC_MAX_NW];
   const int t = threadIdx.x;
-  const long long step = step_dev ? *step_dev : step_host;
   double s = 0.0;
   const int nlp = d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene;
   for (int i = t; i < nlp; i += 256) s += b.LP[i];
@@ -601,8 +601,12 @@ __global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBuf
       G[d.poff[VC_P_LRMN_UCOV_DIAG] + i] = -gx * b.eps_used[d.eoff[VC_E_LRMN_D] + i] / (2.f * sqrtf(dg)) * dg;
     }
   }
-  // every reader of this step's counter (K_pre) has finished: advance it for the optimiser / next step
-  if (t == 0 && step_dev) *step_dev = step + 1;
+}
+
+__global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBufs b, const float* P, float* G,
+                                                     double* loss_dev, long long loss_slots, long long step_host,
+                                                     const long long* step_dev) {
+  vc_fin_block(d, b, P, G, loss_dev, loss_slots, step_dev ? *step_dev - 1 : step_host);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -633,6 +637,64 @@ __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, con
   }
 }
 
+// K_fin + ClippedAdam in one launch (single rank).  Block 0 finishes the loss and the angular-speed gradients
+// and then updates exactly those parameters; every block updates the rest, whose gradients K_post completed.
+__global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const VcBufs b, float* P, float* G,
+                                                          double* loss_dev, long long loss_slots, long long step_host,
+                                                          const long long* step_dev, float* __restrict__ m,
+                                                          float* __restrict__ v, double lr0, double lrd, double b1,
+                                                          double b2, float eps, float clip, int header, long long total) {
+  __shared__ float s_step;
+  const long long t1 = step_dev ? *step_dev : step_host + 1;        // 1-based optimiser step
+  if (threadIdx.x == 0) {
+    const double td = (double)t1;
+    s_step = (float)(lr0 * pow(lrd, td) * sqrt(1.0 - pow(b2, td)) / (1.0 - pow(b1, td)));
+  }
+  // parameters whose gradient K_fin produces: nu_omega (mean-field) or the LRMN tail rows
+  long long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  if (d.model == VC_MODEL_VELOCITY) {
+    if (d.guide != VC_GUIDE_LRMN) {
+      lo[0] = d.poff[VC_P_NUOMEGA_LOCS]; hi[0] = lo[0] + d.NW;
+      lo[1] = d.poff[VC_P_NUOMEGA_USCALES]; hi[1] = lo[1] + d.NW;
+    } else {
+      lo[0] = d.poff[VC_P_LRMN_LOC] + d.Ng; hi[0] = d.poff[VC_P_LRMN_LOC] + d.M;
+      lo[1] = d.poff[VC_P_LRMN_UCOV_DIAG] + d.Ng; hi[1] = d.poff[VC_P_LRMN_UCOV_DIAG] + d.M;
+      lo[2] = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)d.Ng * d.R; hi[2] = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)d.M * d.R;
+    }
+  }
+  if (blockIdx.x == 0) vc_fin_block(d, b, P, G, loss_dev, loss_slots, t1 - 1);
+  __syncthreads();
+  const float step_size = s_step;
+  const float fb1 = (float)b1, fb2 = (float)b2;
+  auto upd = [&](long long idx) {
+    const long long j = idx - header;
+    const float gi = fminf(fmaxf(G[idx], -clip), clip);
+    const float mi = fb1 * m[j] + (1.f - fb1) * gi;
+    const float vi = fb2 * v[j] + (1.f - fb2) * gi * gi;
+    m[j] = mi;
+    v[j] = vi;
+    P[idx] = P[idx] - step_size * (mi / (sqrtf(vi) + eps));
+  };
+  for (long long idx = header + (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const bool tail = (idx >= lo[0] && idx < hi[0]) || (idx >= lo[1] && idx < hi[1]) || (idx >= lo[2] && idx < hi[2]);
+    if (!tail) upd(idx);
+  }
+  if (blockIdx.x == 0)
+    for (int q = 0; q < 3; ++q)
+      for (long long idx = lo[q] + threadIdx.x; idx < hi[q]; idx += 256) upd(idx);
+}
+
+void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* grad, double* loss_dev,
+                        long long loss_slots, long long step, long long* step_dev, float* m, float* v, double lr0,
+                        double lrd, double b1, double b2, float eps, float clip, int header, long long total,
+                        hipStream_t st) {
+  long long nb = (total - header + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(vc_fin_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots,
+                     step, step_dev, m, v, lr0, lrd, b1, b2, eps, clip, header, total);
+}
+
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
                     double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
                     hipStream_t st) {
@@ -643,11 +705,13 @@ void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, d
                      clip, t_host, t_dev);
 }
 
-void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, hipStream_t st) {
-  hipLaunchKernelGGL(vc_post_kernel, dim3(d.nb_post_gene + d.nb_post_cell), dim3(1024), 0, st, d, b, params, grad);
+void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(vc_post_kernel, dim3(d.nb_post_gene + d.nb_post_cell), dim3(1024), 0, st, d, b, params, grad,
+                     step_dev);
 }
 void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev,
-                   long long loss_slots, long long step, long long* step_dev, hipStream_t st) {
+                   long long loss_slots, long long step, const long long* step_dev, hipStream_t st) {
   hipLaunchKernelGGL(vc_fin_kernel, dim3(1), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots, step,
                      step_dev);
 }

@@ -236,6 +236,16 @@ class HipEngine:
             C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
             C.c_void_p(grad.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()), self._stream()))
 
+    def svi_step(self, m, v, lr, lrd, b1, b2, adam_eps, clip, eps=None, seed=0, step=0, step_dev=None,
+                 loss_buf=None):
+        """ELBO + gradient + ClippedAdam in four launches (single rank); m, v: float32[total - header]."""
+        lb = self.loss_dev if loss_buf is None else loss_buf
+        self._check(self.lib.vc_svi_step(
+            self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(eps.data_ptr()) if eps is not None else None,
+            C.c_uint64(seed), C.c_int64(step), C.c_void_p(step_dev.data_ptr()) if step_dev is not None else None,
+            C.c_void_p(self.grad.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()),
+            C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, self._stream()))
+
     def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None):
         """Fused HIP ClippedAdam on flat float32 buffers (same stream)."""
         rc = self.lib.vc_clipped_adam(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),

@@ -105,9 +105,13 @@ class SVIRunner:
         # force_reduce: issue the all-reduce even with one rank (exercises the RCCL-in-graph path on one GPU)
         self.do_reduce = self.world > 1 or force_reduce
         self.use_graph = (mode == "perf") if use_graph is None else use_graph
-        self.adam_impl = adam_impl or ("hip" if mode == "perf" else "torch")
+        # "torch": PyTorch ops; "hip": one kernel after the gradient; "fused": merged with the last gradient kernel
+        self.adam_impl = adam_impl or (("hip" if self.do_reduce else "fused") if mode == "perf" else "torch")
+        if self.adam_impl == "fused" and (self.do_reduce or mode != "perf"):
+            raise ValueError("adam_impl='fused' needs mode='perf' on a single rank")
         self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
-                                   capturable=self.use_graph, impl=self.adam_impl, engine=engine)
+                                   capturable=self.use_graph,
+                                   impl=("hip" if self.adam_impl == "fused" else self.adam_impl), engine=engine)
         self.step_idx = 0
         self.losses: List[float] = []
         self._graph = None
@@ -164,7 +168,12 @@ class SVIRunner:
 
     def _perf_body(self):
         e = self.e
-        # K_fin writes the loss into slot step % len(loss_hist) and advances step_dev
+        if self.adam_impl == "fused":          # single rank: optimiser merged into the last gradient kernel
+            o = self.opt
+            e.svi_step(o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, eps=None, seed=self.seed, step=0,
+                       step_dev=self.step_dev, loss_buf=self.loss_hist)
+            return
+        # K_fin writes the loss into slot step % len(loss_hist); K_post has advanced step_dev
         e.elbo_grad(eps=None, seed=self.seed, step=0, step_dev=self.step_dev, loss_buf=self.loss_hist)
         if self.do_reduce:
             self._reduce()
