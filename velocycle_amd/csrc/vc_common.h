@@ -50,6 +50,9 @@ struct VcBufs {
   const float *mu_nu, *sd_nu, *mu_g, *sd_g, *mu_b, *sd_b, *mu_w, *sd_w, *sd_dnu;
   const float *cnd[VC_SITE_COUNT];          // conditioned values per site (or nullptr)
   const int *h_ptr;                         // histogram CSR: [2*Ng+1], S genes then U genes
+  const int *h_task;                        // histogram tasks (<= 64 entries each): {gene, matrix, begin, end} x n_tasks
+  const int *h_tptr;                        // [Ng+1] first task of every gene (tasks are sorted by gene)
+  int n_tasks;
   const float *h_val, *h_cnt;
   // per-step workspaces
   float *eps_used;
@@ -63,7 +66,7 @@ struct VcBufs {
   float *LO;                                // likelihood partial per main workgroup
   double *LP;                               // loss partials of pre (nb_pre_gene + nb_pre_cell) and post_gene blocks
   float *PW;                                // [nb_post_cell][NW] partial angular-speed gradients
-  double *HL, *HD;                          // per gene: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
+  double *HL, *HD;                          // per histogram task: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
   double const_loss;                        // step-invariant part of the loss
 };
 

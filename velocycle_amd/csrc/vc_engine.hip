@@ -544,10 +544,6 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.LO, (size_t)d.n_main_wg));
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
   TRY(e->dalloc(&b.PW, (size_t)d.nb_post_cell * std::max(1, d.NW)));
-  TRY(e->dalloc(&b.HL, (size_t)d.Ng));
-  TRY(e->dalloc(&b.HD, (size_t)d.Ng));
-  HIPCHK(e, hipMemset(b.HL, 0, sizeof(double) * d.Ng));
-  HIPCHK(e, hipMemset(b.HD, 0, sizeof(double) * d.Ng));
 
   // histograms + step-invariant constants -----------------------------------------------------
   double lg_S = 0.0, lg_U = 0.0;   // sum lgamma(k+1)
@@ -562,6 +558,23 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
       ptr.assign(2 * (size_t)d.Ng, 0);
     }
     ptr.push_back((int)val.size());
+    // tasks: runs of <= 64 histogram entries of one gene and matrix, sorted by gene
+    std::vector<int> task, tptr;
+    for (int g = 0; g < d.Ng; ++g) {
+      tptr.push_back((int)task.size() / 4);
+      for (int m = 0; m < 2; ++m)
+        for (int beg = ptr[(size_t)m * d.Ng + g], end = ptr[(size_t)m * d.Ng + g + 1]; beg < end; beg += 64) {
+          task.insert(task.end(), {g, m, beg, std::min(end, beg + 64)});
+        }
+    }
+    tptr.push_back((int)task.size() / 4);
+    b.n_tasks = (int)task.size() / 4;
+    TRY(upload(e, task, &b.h_task));
+    TRY(upload(e, tptr, &b.h_tptr));
+    TRY(e->dalloc(&b.HL, (size_t)std::max(1, b.n_tasks)));
+    TRY(e->dalloc(&b.HD, (size_t)std::max(1, b.n_tasks)));
+    HIPCHK(e, hipMemset(b.HL, 0, sizeof(double) * std::max(1, b.n_tasks)));
+    HIPCHK(e, hipMemset(b.HD, 0, sizeof(double) * std::max(1, b.n_tasks)));
     TRY(upload(e, ptr, &b.h_ptr));
     TRY(upload(e, val, &b.h_val));
     TRY(upload(e, cnt, &b.h_cnt));
@@ -588,14 +601,16 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
     HIPCHK(e, hipStreamSynchronize(st));
     HIPCHK(e, hipGetLastError());
     std::vector<float> lo(d.n_main_wg), rrow(d.Ng);
-    std::vector<double> hl(d.Ng, 0.0);
+    std::vector<double> hl(std::max(1, b.n_tasks), 0.0);
     HIPCHK(e, hipMemcpy(lo.data(), b.LO, sizeof(float) * d.n_main_wg, hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(rrow.data(), b.GT + (size_t)(d.K + 2) * d.Ng_pad, sizeof(float) * d.Ng, hipMemcpyDeviceToHost));
-    if (nb) HIPCHK(e, hipMemcpy(hl.data(), b.HL, sizeof(double) * d.Ng, hipMemcpyDeviceToHost));
+    if (nb) HIPCHK(e, hipMemcpy(hl.data(), b.HL, sizeof(double) * b.n_tasks, hipMemcpyDeviceToHost));
     double sconst = obs_const(false);
     for (float v : lo) sconst -= (double)v;
-    if (nb)
-      for (int g = 0; g < d.Ng; ++g) sconst -= (double)d.Nc * rrow[g] * std::log((double)rrow[g]) + hl[g];
+    if (nb) {
+      for (int g = 0; g < d.Ng; ++g) sconst -= (double)d.Nc * rrow[g] * std::log((double)rrow[g]);
+      for (int t = 0; t < b.n_tasks; ++t) sconst -= hl[t];          // only S tasks are non-zero in this pass
+    }
     cl += sconst;
   }
   if (nb && !e->hist_each_step) {

@@ -41,37 +41,41 @@ void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, 
 // ---------------------------------------------------------------------------------------------
 // K_hist (NB): one wave per gene, fp64 -- also runs as extra blocks of K_pre
 // ---------------------------------------------------------------------------------------------
+// One wave per histogram TASK (<= 64 distinct count values of one gene and matrix, one per lane), so the
+// latency of the kernel is one pass whatever the spread of a gene's counts; K_post adds the few task sums of
+// a gene in fixed order.
 __device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, const float* __restrict__ P,
-                                             int cond_only, int g, int lane) {
-  float si;
-  if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
-  else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
-  const float r = 1.0f / si;
+                                             int cond_only, int task, int lane) {
+  const int g = b.h_task[4 * task], m = b.h_task[4 * task + 1];
+  const int beg = b.h_task[4 * task + 2], end = b.h_task[4 * task + 3];
   double hl = 0.0, hd = 0.0;
-  for (int m = 0; m < 2; ++m) {
-    if ((m == 0 && !d.hist_has_S) || (m == 1 && !d.hist_has_U)) continue;
-    const int beg = b.h_ptr[m * d.Ng + g], end = b.h_ptr[m * d.Ng + g + 1];
-    for (int i = beg + lane; i < end; i += 64) {
+  if ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U)) {
+    float si;
+    if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
+    else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
+    const float r = 1.0f / si;
+    const int i = beg + lane;
+    if (i < end) {
       float dl, dd;
       vc_lgamma_digamma_diff(r, b.h_val[i], dl, dd);
       const double n = (double)b.h_cnt[i];
-      hl += n * (double)dl;
-      hd += n * (double)dd;
+      hl = n * (double)dl;
+      hd = n * (double)dd;
     }
+    hl = vc_wave_sum_d(hl);
+    hd = vc_wave_sum_d(hd);
   }
-  hl = vc_wave_sum_d(hl);
-  hd = vc_wave_sum_d(hd);
-  if (lane == 0) { b.HL[g] = hl; b.HD[g] = hd; }
+  if (lane == 0) { b.HL[task] = hl; b.HD[task] = hd; }
 }
 
 __global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBufs b,
                                                       const float* __restrict__ P, int cond_only) {
-  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (g < d.Ng) vc_hist_wave(d, b, P, cond_only, g, threadIdx.x & 63);
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task < b.n_tasks) vc_hist_wave(d, b, P, cond_only, task, threadIdx.x & 63);
 }
 
 void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int cond_only, hipStream_t st) {
-  hipLaunchKernelGGL(vc_hist_kernel, dim3((d.Ng + 3) / 4), dim3(256), 0, st, d, b, params, cond_only);
+  hipLaunchKernelGGL(vc_hist_kernel, dim3((b.n_tasks + 3) / 4), dim3(256), 0, st, d, b, params, cond_only);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
 
   if ((int)blockIdx.x >= d.nb_pre_gene + d.nb_pre_cell) {
     // ------------------------------- histogram part (NB): one wave per gene -------------------------
-    const int g = (blockIdx.x - d.nb_pre_gene - d.nb_pre_cell) * 4 + (threadIdx.x >> 6);
-    if (g < d.Ng) vc_hist_wave(d, b, P, cond_only, g, threadIdx.x & 63);
+    const int task = (blockIdx.x - d.nb_pre_gene - d.nb_pre_cell) * 4 + (threadIdx.x >> 6);
+    if (task < b.n_tasks) vc_hist_wave(d, b, P, cond_only, task, threadIdx.x & 63);
     return;
   }
   if ((int)blockIdx.x < d.nb_pre_gene) {
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
                    hipStream_t st) {
-  const int nb_hist = with_hist ? (d.Ng + 3) / 4 : 0;
+  const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
   hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), 0, st, d, b,
                      params, eps, seed, step, step_dev, cond_only);
 }
@@ -408,13 +412,15 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
     if (nb) {
       // r-only terms of sum_c NB(k; r, eta): nmat*Nc*r*log r + sum_hist cnt*(lgamma(r+k)-lgamma(r))
       const double lr = log((double)r);
+      double HLg = 0.0, HDg = 0.0;        // histogram task sums of this gene, fixed order
+      for (int t = b.h_tptr[g]; t < b.h_tptr[g + 1]; ++t) { HLg += b.HL[t]; HDg += b.HD[t]; }
       if (d.nmat_r > 0) {
-        loss -= (double)d.nmat_r * d.Nc * (double)r * lr + b.HL[g];
+        loss -= (double)d.nmat_r * d.Nc * (double)r * lr + HLg;
       }
       float gu = 0.f;
       if (!CND(VC_SITE_SHAPE_INV)) {
         const float si = b.lat[VC_SITE_SHAPE_INV][g];
-        const double dr = (double)U_r + (double)d.nmat_r * d.Nc * (lr + 1.0) + b.HD[g];
+        const double dr = (double)U_r + (double)d.nmat_r * d.Nc * (lr + 1.0) + HDg;
         const double gsi = -(double)r * (double)r * dr + (double)rw * ((d.gamma_alpha - 1.f) / si - d.gamma_beta);
         gu = (float)(-gsi * (double)si);
       }
