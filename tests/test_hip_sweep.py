@@ -1,0 +1,142 @@
+"""GPU: sweep over the compiled kernel set (harmonics, batches, conditioning patterns, noise models, guides,
+both genes-per-lane layouts) on small ragged problems, every gradient against the float64 oracle."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import velocycle_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(kind, guide, noise, H, Hw, Nb, Nx, cond_sites, Nc, Ng, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    phi = torch.rand(Nc, generator=g, dtype=torch.float64) * 6.28
+    Nh, Nhw = 2 * H + 1, 2 * Hw + 1
+    S = torch.poisson(torch.rand(Ng, Nc, generator=g, dtype=torch.float64) * 6).double()
+    U = torch.poisson(torch.rand(Ng, Nc, generator=g, dtype=torch.float64) * 2).double()
+    with_dnu = Nb > 0
+    nb = max(Nb, 1)
+    batch = torch.randint(0, nb, (Nc,), generator=g)
+    Db = torch.stack([(batch == b).double() for b in range(nb)])
+    cond = {}
+    kw = dict(kind=kind, guide=guide, noisemodel=noise, with_delta_nu=with_dnu, H=H, S=S,
+              count_factor=0.1 * r(Nc), Db=Db, mu_nu=torch.cat([1.0 + 0.3 * r(Ng, 1), 0.2 * r(Ng, Nh - 1)], 1),
+              sd_nu=0.2 + 0.1 * torch.rand(Ng, Nh, generator=g, dtype=torch.float64),
+              phixy_prior=2.0 * torch.stack([torch.cos(phi), torch.sin(phi)], 1),
+              sd_dnu=(0.05 + 0.1 * torch.rand(nb, Ng, generator=g, dtype=torch.float64)) if kind == "phase" else 0.01,
+              sigma_ln_s=0.5 if kind == "phase" else 0.1)
+    if kind == "velocity":
+        cb = torch.randint(0, Nx, (Nc,), generator=g)
+        kw.update(U=U, D=torch.stack([(cb == x).double() for x in range(Nx)]), Hw=Hw,
+                  mu_gamma=0.1 * r(Ng), sd_gamma=torch.full((Ng,), 0.5, dtype=torch.float64),
+                  mu_beta=2.0 + 0.1 * r(Ng), sd_beta=torch.full((Ng,), 1.0, dtype=torch.float64),
+                  mu_nuw=torch.cat([0.4 + 0.05 * r(Nx, 1), 0.02 * r(Nx, Nhw - 1)], 1),
+                  sd_nuw=torch.full((Nx, Nhw), 0.1, dtype=torch.float64))
+    p = orc.Problem(**kw)
+    vals = {"ϕxy": p.phixy_prior + 0.1 * r(Nc, 2), "ν": p.mu_nu + 0.05 * r(Ng, Nh), "Δν": 0.01 * r(nb, Ng),
+            "shape_inv": 0.2 + torch.rand(Ng, generator=g, dtype=torch.float64),
+            "logγg": 0.1 * r(Ng), "logβg": 2 + 0.1 * r(Ng), "νω": 0.4 + 0.01 * r(max(Nx, 1), Nhw), "rho_real": 3 + 0.2 * r(Ng)}
+    p.condition_on = {s: vals[s] for s in cond_sites}
+    return p
+
+
+def _check(p, gpl=None, monkeypatch=None):
+    from tests.helpers import spec_from_problem
+    from velocycle_amd.engine import HipEngine
+    if gpl is not None:
+        monkeypatch.setenv("VC_GPL", str(gpl))
+    gen = torch.Generator().manual_seed(1)
+    first = orc.draw_eps(p, gen)
+    eps = orc.draw_eps(p, gen)
+    par = orc.init_params(p, first.get("_cov_factor_draw"))
+    for k in par:                                   # move off the prior means so that every term is exercised
+        if torch.isfinite(par[k]).all():
+            par[k] = par[k] + 0.05 * torch.randn(par[k].shape, generator=gen, dtype=torch.float64)
+    eng = HipEngine(spec_from_problem(p))
+    eng.set_params({k: v.float() for k, v in par.items()})
+    eng.elbo_grad(eps=eng.pack_eps({k: v.float() for k, v in eps.items() if not k.startswith("_")}))
+    torch.cuda.synchronize()
+    par32 = {k: v.float().double() for k, v in par.items()}
+    eps32 = {k: v.float().double() for k, v in eps.items() if not k.startswith("_")}
+    l64, g64, _, _ = orc.loss_and_grads(p, par32, eps32)
+    assert abs(eng.loss() - l64) <= 2e-5 * abs(l64) + 1e-3, (eng.loss(), l64)
+    for name, got in eng.named(eng.grad).items():
+        want = g64[name].numpy()
+        fin = np.isfinite(want)
+        err = np.abs(got.cpu().numpy()[fin] - want[fin]).max() if fin.any() else 0.0
+        assert err <= 3e-3 * max(np.abs(want[fin]).max() if fin.any() else 0, 1e-2), (name, err)
+    kind = eng.stats["main_kernel"]
+    eng.close()
+    return kind
+
+
+@pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 1, 2, 3, 4))))
+def test_phase_kernels(H, Nb, monkeypatch):
+    for noise, gpl in (("NegativeBinomial", None), ("Poisson", 4), ("Lognormal", 8)):
+        p = _problem("phase", "meanfield", noise, H, 0, Nb, 0, [], Nc=70 + 13 * H, Ng=9 + Nb, seed=H * 10 + Nb)
+        _check(p, gpl, monkeypatch)
+
+
+@pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 1, 2, 4))))
+def test_velocity_joint_kernels(H, Nb, monkeypatch):
+    for noise, guide, Hw, Nx, gpl in (("NegativeBinomial", "meanfield", 1, 2, None), ("Poisson", "lrmn", 0, 1, 4),
+                                      ("Lognormal", "meanfield", 2, 3, None)):
+        p = _problem("velocity", guide, noise, H, Hw, Nb, Nx, [], Nc=90 + 7 * Nb, Ng=7 + H, seed=100 + H * 10 + Nb)
+        k = _check(p, gpl, monkeypatch)
+        assert "vfull" in k
+
+
+@pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 2, 3))))
+def test_velocity_conditioned_kernels(H, Nb, monkeypatch):
+    full = ["ϕxy", "ν", "shape_inv"] + (["Δν"] if Nb else [])
+    for noise, guide, Hw, gpl in (("NegativeBinomial", "lrmn", 1, None), ("NegativeBinomial", "meanfield", 3, 4),
+                                  ("Poisson", "lrmn", 0, None)):
+        sites = [s for s in full if not (s == "shape_inv" and noise != "NegativeBinomial")]
+        p = _problem("velocity", guide, noise, H, Hw, Nb, 2, sites, Nc=130, Ng=11, seed=200 + H * 10 + Nb)
+        k = _check(p, gpl, monkeypatch)
+        assert "vu_" in k          # S term hoisted
+
+
+@pytest.mark.parametrize("sites", [["ϕxy"], ["ν"], ["shape_inv"], ["ν", "ϕxy"], ["logγg"], ["logβg", "νω"],
+                                   ["rho_real"], ["Δν", "logγg", "logβg", "νω", "rho_real"]])
+def test_partial_conditioning(sites, monkeypatch):
+    for guide in ("meanfield", "lrmn"):
+        s = [x for x in sites if not (x == "rho_real" and guide != "lrmn")]
+        p = _problem("velocity", guide, "NegativeBinomial", 1, 1, 2, 2, s, Nc=101, Ng=10, seed=7)
+        k = _check(p, None, monkeypatch)
+        assert "vfull" in k
+
+
+@pytest.mark.parametrize("Nc,Ng", [(1, 1), (3, 300), (65, 2), (64, 256), (257, 513), (700, 5)])
+def test_ragged_and_tiny_shapes(Nc, Ng, monkeypatch):
+    for gpl in (4, 8):
+        p = _problem("velocity", "meanfield", "NegativeBinomial", 1, 1, 1, 1, [], Nc=Nc, Ng=Ng, seed=Nc + Ng)
+        _check(p, gpl, monkeypatch)
+
+
+def test_unsupported_configurations_raise():
+    from tests.helpers import spec_from_problem
+    from velocycle_amd.engine import HipEngine
+    p = _problem("phase", "meanfield", "NegativeBinomial", 1, 0, 1, 0, [], Nc=20, Ng=5, seed=1)
+    sp = spec_from_problem(p)
+    sp.H = 4
+    sp.mu_nu = torch.zeros(5, 9)
+    sp.sd_nu = torch.ones(5, 9)
+    with pytest.raises(NotImplementedError):
+        HipEngine(sp)
+    sp2 = spec_from_problem(p)
+    sp2.noisemodel = "Gaussian"
+    with pytest.raises(ValueError, match="not allowed"):
+        HipEngine(sp2)
+    sp3 = spec_from_problem(p)
+    sp3.sd_nu = sp3.sd_nu * 0 - 1
+    with pytest.raises(ValueError):
+        HipEngine(sp3)
+    sp4 = spec_from_problem(p)
+    sp4.condition_on = {"nonsense": torch.zeros(3)}
+    with pytest.raises(ValueError):
+        HipEngine(sp4)
