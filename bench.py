@@ -77,8 +77,16 @@ def kernel_roofline(engine, run, steps):
     avg_s = ms / max(n, 1) * 1e-3
     st = engine.stats
     achieved = st["algorithmic_bytes"] / avg_s / 1e9
+    traffic, traffic_src = None, None
+    try:     # PMC numbers cannot be collected from inside the process: they come from the committed rocprofv3 passes
+        tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
+        ent = tj["kernels"].get(st["main_kernel"])
+        if ent and tj.get("workload") == f"{engine.spec.Nc}x{engine.spec.Ng}" and engine.world_size == 1:
+            traffic, traffic_src = int(ent["traffic_bytes"]), "profiles/latest_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per gfx950 note)"
+    except Exception:
+        pass
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": st["main_kernel"], "kernel_avg_us": round(avg_s * 1e6, 2), "launches": int(n),
             "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"]),
             "streamed_bytes_per_launch": int(st["streamed_bytes"]),
