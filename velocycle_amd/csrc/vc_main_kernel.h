@@ -222,9 +222,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
         if (HAS_U) {
           // eta_U = -log beta + log(relu(dd * omega + gamma) + 1e-5) + eta_S
           const v2f z = v2_fma(dd, rec.omega, gam[p]);
-          const v2f zp = v2f{fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)} + 1e-5f;
+          // relu and its derivative without compare/select: m = clamp(z * 2^100, 0, 1) is 1 for z > 0 and 0
+          // for z <= 0 (z in (0, 2^-100) cannot occur next to gamma = exp(.)), then relu(z) + 1e-5 = z*m + 1e-5 and d/dz = m / (relu(z) + 1e-5)
+          v2f m;      // one packed multiply with the clamp output modifier (hipcc does not fold fmed3 into v_pk_mul)
+          asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(m) : "v"(z), "v"(v2(1.2676506e30f)));
+          const v2f zp = v2_fma(z, m, v2(1e-5f));
           const v2f iz = v2_rcp(zp);
-          const v2f q = v2f{z.x > 0.f ? iz.x : 0.f, z.y > 0.f ? iz.y : 0.f};     // torch.relu': 0 at z <= 0
+          const v2f q = iz * m;                                                   // torch.relu': 0 at z <= 0
           const v2f eu2 = (es2 - lb2[p]) + v2_log2(zp);
           v2f aU;
           if (LN) vc_obs_lognormal(uv[p], eu2 * VC_LN2, inv_s2_u, aU, ll[p]);
