@@ -196,10 +196,13 @@ int vc_elbo_grad(vc_engine* e, const float* params, const float* eps, uint64_t s
 /* pyro.optim.ClippedAdam (pyro-ppl 1.8.6 optim/clipped_adam.py; call sites: tutorial cells 27/43/56)
  * as ONE launch on a flat buffer of n floats: lr_t = lr*lrd^t, g = clamp(g, +-clip_norm),
  * m/v moments, p -= lr_t*sqrt(1-beta2^t)/(1-beta1^t) * m/(sqrt(v)+eps).  t is the 1-based step, read
- * from t_dev (device int64) when non-NULL.  An alternative to the PyTorch-op update of svi.py. */
+ * from t_dev (device int64) when non-NULL.  An alternative to the PyTorch-op update of svi.py.
+ * loss_hdr / loss_ring (optional, may be NULL): after an all-reduce of the gradient header the summed loss
+ * (float hi + lo at loss_hdr[0..1]) is stored as a double into loss_ring[(t-1) % loss_slots]. */
 int vc_clipped_adam(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                     double lr, double lrd, double beta1, double beta2, double eps, double clip_norm,
-                    int64_t t, const int64_t* t_dev, void* hip_stream);
+                    int64_t t, const int64_t* t_dev, const float* loss_hdr, double* loss_ring,
+                    int64_t loss_slots, void* hip_stream);
 
 /* One whole SVI step (single rank): vc_elbo_grad with pyro's ClippedAdam merged into its last kernel -- 4
  * launches instead of 5.  exp_avg / exp_avg_sq: device float[total - header], zero-initialised by the caller;

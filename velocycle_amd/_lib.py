@@ -76,7 +76,7 @@ EXPORTS = {
                               C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "vc_clipped_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
-                                  C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vc_read_site": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "vc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(vc_stats)]),
     "vc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -214,4 +214,4 @@ void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* 
                         hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
                     double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
-                    hipStream_t st);
+                    const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st);

@@ -733,10 +733,12 @@ extern "C" int vc_get_timing(vc_engine* e, double* main_ms_total, int64_t* n_lau
 
 extern "C" int vc_clipped_adam(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                double lr, double lrd, double beta1, double beta2, double eps, double clip_norm,
-                               int64_t t, const int64_t* t_dev, void* hip_stream) {
+                               int64_t t, const int64_t* t_dev, const float* loss_hdr, double* loss_ring,
+                               int64_t loss_slots, void* hip_stream) {
   if (!params || !grad || !exp_avg || !exp_avg_sq || n < 0) return VC_ERR_ARG;
   if (n == 0) return VC_OK;
   vc_launch_adam(params, grad, exp_avg, exp_avg_sq, (long long)n, lr, lrd, beta1, beta2, (float)eps,
-                 (float)clip_norm, (long long)t, (const long long*)t_dev, (hipStream_t)hip_stream);
+                 (float)clip_norm, (long long)t, (const long long*)t_dev, loss_hdr, loss_ring, (long long)loss_slots,
+                 (hipStream_t)hip_stream);
   return hipGetLastError() == hipSuccess ? VC_OK : VC_ERR_HIP;
 }

@@ -624,8 +624,15 @@ __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, con
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       long long n, double lr0, double lrd, double b1, double b2,
                                                       float eps, float clip, long long t_host,
-                                                      const long long* __restrict__ t_dev) {
+                                                      const long long* __restrict__ t_dev,
+                                                      const float* __restrict__ loss_hdr,
+                                                      double* __restrict__ loss_ring, long long loss_slots) {
   __shared__ float s_step;
+  // multi-rank path: the all-reduced loss (float hi + lo in the gradient header) goes into the loss ring here
+  if (loss_ring && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long t1 = t_dev ? *t_dev : t_host;
+    loss_ring[loss_slots > 1 ? ((t1 - 1) % loss_slots) : 0] = (double)loss_hdr[0] + (double)loss_hdr[1];
+  }
   if (threadIdx.x == 0) {      // three fp64 pow() once per block instead of once per thread
     const double td = (double)(t_dev ? *t_dev : t_host);
     s_step = (float)(lr0 * pow(lrd, td) * sqrt(1.0 - pow(b2, td)) / (1.0 - pow(b1, td)));
@@ -703,12 +710,12 @@ void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* 
 
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
                     double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
-                    hipStream_t st) {
+                    const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st) {
   long long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(vc_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr0, lrd, b1, b2, eps,
-                     clip, t_host, t_dev);
+                     clip, t_host, t_dev, loss_hdr, loss_ring, loss_slots);
 }
 
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,

@@ -246,11 +246,15 @@ class HipEngine:
             C.c_void_p(self.grad.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()),
             C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, self._stream()))
 
-    def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None):
-        """Fused HIP ClippedAdam on flat float32 buffers (same stream)."""
+    def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
+        """Fused HIP ClippedAdam on flat float32 buffers (same stream); optionally files the (all-reduced) loss
+        found in `loss_hdr[0:2]` into `loss_ring[(t-1) % len]`."""
         rc = self.lib.vc_clipped_adam(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                       C.c_void_p(v.data_ptr()), p.numel(), lr, lrd, b1, b2, eps, clip, int(t),
-                                      C.c_void_p(t_dev.data_ptr()) if t_dev is not None else None, self._stream())
+                                      C.c_void_p(t_dev.data_ptr()) if t_dev is not None else None,
+                                      C.c_void_p(loss_hdr.data_ptr()) if loss_hdr is not None else None,
+                                      C.c_void_p(loss_ring.data_ptr()) if loss_ring is not None else None,
+                                      loss_ring.numel() if loss_ring is not None else 0, self._stream())
         if rc != _lib.VC_OK:
             raise HipEngineError("vc_clipped_adam failed")
 

@@ -63,11 +63,12 @@ class FlatClippedAdam:
             self._c = {k: torch.tensor(v, dtype=torch.float64, device=device)
                        for k, v in dict(lr0=self.lr0, lrd=self.lrd, b1=self.b1, b2=self.b2).items()}
 
-    def step(self, p: torch.Tensor, g: torch.Tensor, t_dev: Optional[torch.Tensor] = None):
+    def step(self, p: torch.Tensor, g: torch.Tensor, t_dev: Optional[torch.Tensor] = None, loss_hdr=None,
+             loss_ring=None):
         if self.impl == "hip":
             self.t += 1
             self.engine.clipped_adam(p, g, self.m, self.v, self.lr0, self.lrd, self.b1, self.b2, self.eps,
-                                     self.clip, t=self.t, t_dev=t_dev)
+                                     self.clip, t=self.t, t_dev=t_dev, loss_hdr=loss_hdr, loss_ring=loss_ring)
             return
         g = g.clamp(-self.clip, self.clip)
         self.m.lerp_(g, 1.0 - self.b1)
@@ -145,9 +146,9 @@ class SVIRunner:
             import torch.distributed as dist
             dist.all_reduce(self.e.grad[: self.e.header + self.e.n_global], group=self.pg)
 
-    def _update(self, t_dev=None):
+    def _update(self, t_dev=None, loss_hdr=None, loss_ring=None):
         h = self.e.header
-        self.opt.step(self.e.params[h:], self.e.grad[h:], t_dev=t_dev)
+        self.opt.step(self.e.params[h:], self.e.grad[h:], t_dev=t_dev, loss_hdr=loss_hdr, loss_ring=loss_ring)
 
     def step(self, eps: Optional[Dict[str, torch.Tensor]] = None) -> float:
         """One SVI step in parity mode; returns the loss like `svi.step` does."""
@@ -177,6 +178,9 @@ class SVIRunner:
         e.elbo_grad(eps=None, seed=self.seed, step=0, step_dev=self.step_dev, loss_buf=self.loss_hist)
         if self.do_reduce:
             self._reduce()
+            if self.opt.impl == "hip":     # the optimiser kernel files the reduced loss (no extra launches)
+                self._update(t_dev=self.step_dev, loss_hdr=e.grad, loss_ring=self.loss_hist)
+                return
             idx = (self.step_dev - 1) % self.loss_hist.shape[0]
             self.loss_hist.index_copy_(0, idx, e.grad[:2].double().sum().reshape(1))
         self._update(t_dev=self.step_dev)          # step_dev now holds the 1-based Adam step
