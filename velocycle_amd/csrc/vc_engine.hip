@@ -17,11 +17,6 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-};
-
 }  // namespace
 
 struct vc_engine {
