@@ -270,9 +270,30 @@ def make_preprocess():
     print("[preprocess] ok")
 
 
+def make_phase_prior():
+    """Phases.from_pca_heuristic / max_corr / rotate of the reference (the step right before phase inference)."""
+    d, ad, cyc, ph, Db = build_inputs(80, 12, 1, 1, seed=5)
+    vc.preprocessing.normalize_total(ad) if hasattr(ad.layers["spliced"], "toarray") else None
+    S = ad.layers["spliced"].astype(float)
+    ad.layers["S_sz"] = (S.sum(1).mean() / np.maximum(S.sum(1), 1) * S.T).T
+    out = {"S_sz": ad.layers["S_sz"], "umis": S.sum(1)}
+    for tag, kw in (("a", dict(concentration=5.0, small_count=1)),
+                    ("b", dict(concentration=1.0, small_count=0.1, zero_at_min_density=True, normalize_pcs=False))):
+        p = vc.phases.Phases.from_pca_heuristic(ad, layer="S_sz", **kw)
+        out["phixy_" + tag] = p.phi_xy.values
+        shift, c, corr = p.max_corr(S.sum(1), npoints=50)
+        out["maxcorr_" + tag] = np.array([shift, c])
+        out["corr_" + tag] = np.array(corr)
+        p.rotate(angle=-shift)
+        out["rot_" + tag] = p.phi_xy.values
+    np.savez_compressed(os.path.join(OUT, "ref_phase_prior.npz"), **out)
+    print("[phase prior] ok")
+
+
 if __name__ == "__main__":
     make_basis()
     make_preprocess()
+    make_phase_prior()
     only = sys.argv[1:]
     for nm, c in CASES.items():
         if only and nm not in only:

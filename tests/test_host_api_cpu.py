@@ -110,3 +110,20 @@ def test_flat_clipped_adam_matches_oracle_restatement():
         flat.step(p, g)
         par = oa.step(par, {"x": g})
     assert torch.allclose(p, par["x"], rtol=1e-6, atol=1e-7)
+
+
+def test_pca_phase_prior_matches_reference():
+    """Phases.from_pca_heuristic / max_corr / rotate against the reference's output on the same matrix."""
+    z = H.load_fixture(f"{H.GOLDEN}/ref_phase_prior.npz")
+    ad = AnnDataLite(z["S_sz"], z["S_sz"])
+    ad.layers["S_sz"] = z["S_sz"]
+    for tag, kw in (("a", dict(concentration=5.0, small_count=1)),
+                    ("b", dict(concentration=1.0, small_count=0.1, zero_at_min_density=True, normalize_pcs=False))):
+        p = C.Phases.from_pca_heuristic(ad, layer="S_sz", **kw)
+        assert np.allclose(p.phi_xy.values, z["phixy_" + tag], atol=1e-6), tag
+        shift, c, corr = p.max_corr(z["umis"], npoints=50)
+        assert np.allclose([shift, c], z["maxcorr_" + tag], atol=1e-6) and np.allclose(corr, z["corr_" + tag], atol=1e-6)
+        p.rotate(angle=-shift)
+        assert np.allclose(p.phi_xy.values, z["rot_" + tag], atol=1e-6)
+    with pytest.raises(ValueError):
+        C.Phases.from_pca_heuristic(ad, layer="nope")

@@ -223,11 +223,62 @@ class Phases:
         return out
 
     @classmethod
+    def from_pca_heuristic(cls, anndata_object, genes_to_use=None, concentration=1.0, layer="S_sz", small_count=1.0e-1,
+                           normalize_pcs=True, zero_at_min_density=False, random_state=0, plot=False, n_components=2):
+        """Phase prior from the angle in the plane of the first two principal components of the log counts
+        (reference phases.py:307-382; the step right before phase inference in the tutorials)."""
+        from sklearn.decomposition import PCA
+        if layer not in anndata_object.layers:
+            raise ValueError(f"{layer=} is not a valid entry anndata.obs")
+        sub = anndata_object if genes_to_use is None else \
+            anndata_object[:, [g in genes_to_use for g in anndata_object.var.index]]
+        mat = sub.layers[layer]
+        mat = mat.toarray() if hasattr(mat, "toarray") else np.asarray(mat)
+        X = np.log(mat + small_count)                                   # cells x genes
+        pca = PCA(n_components, random_state=random_state)
+        pcs = pca.fit_transform(X)
+        if normalize_pcs:
+            lo, hi, med = np.percentile(pcs, [0.5, 99.5, 50], 0)
+            pcs = (pcs - med) / (hi - lo)
+        angle = np.arctan2(pcs[:, 1], pcs[:, 0]) % (2 * np.pi)
+        if zero_at_min_density:          # put phase 0 right after the widest gap of the sorted angles
+            order = np.argsort(angle)
+            start = order[np.diff(angle[order]).argmax() + 1]
+            angle = (angle - angle[start]) % (2 * np.pi)
+        out = cls.from_array(np.vstack([np.cos(angle), np.sin(angle)]) * concentration,
+                             cell_names=anndata_object.obs.index)
+        out.pcs, out.pca = pcs, pca
+        return out
+
+    def max_corr(self, counts, npoints=100):
+        """Shift (out of `npoints` equally spaced ones) maximising the correlation of the phases with `counts`
+        (reference phases.py:450-469).  Returns (shift, correlation, all correlations)."""
+        shifts = np.arange(0, npoints) / npoints * 2 * np.pi
+        phis = self.phis.numpy()
+        corr = []
+        for s in shifts:
+            x = phis - s
+            x[x < 0] += 2 * np.pi
+            corr.append(np.corrcoef(x, counts)[0, 1])
+        i = int(np.argmax(np.array(corr)))
+        return shifts[i], corr[i], corr
+
+    def shift_zero(self, gene=None, phase=None):
+        if gene is not None:
+            raise Exception("Error: must phase for desired shift")
+        if phase is None:
+            raise Exception("Error: must specify gene or phase for desired shift")
+        ph = self.phis - phase
+        self.set_phixy(torch.stack([torch.cos(ph), torch.sin(ph)], dim=-1).T)
+
+    @classmethod
     def flat_prior(cls, anndata_object):
         n = anndata_object.shape[0]
         return cls.from_array(np.zeros((2, n)), cell_names=list(anndata_object.obs.index))
 
     def rotate(self, angle=None):
+        if angle is None:
+            raise Exception("Error: must specify angle for desired rotation")
         c, s = np.cos(angle), np.sin(angle)
         rot = np.array([[c, -s], [s, c]])
         self.phi_xy = pd.DataFrame(rot @ self.phi_xy.values, index=self.phi_xy.index, columns=self.phi_xy.columns)
