@@ -213,6 +213,13 @@ int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64_t seed, in
                 float* grad, double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
                 double lrd, double beta1, double beta2, double adam_eps, double clip_norm, void* hip_stream);
 
+/* One draw of the guide pushed through the deterministic part of the model (what
+ * `Predictive(model, guide=guide, num_samples=1)` evaluates for the latent and deterministic sites;
+ * velocity_inference_model.py:279-291, phase_inference_model.py:274-302): runs the sampling kernel only, no
+ * likelihood.  The site values are then available through vc_read_site. */
+int vc_sample_guide(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
+                    void* hip_stream);
+
 /* introspection ----------------------------------------------------------------------------- */
 /* Copies the value a site took in the last vc_elbo_grad to host memory (synchronises the stream). */
 int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream);

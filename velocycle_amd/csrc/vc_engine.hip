@@ -671,6 +671,17 @@ extern "C" int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64
   return VC_OK;
 }
 
+extern "C" int vc_sample_guide(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
+                               void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_sample_guide before vc_finalize");
+  if (!params) return e->fail(VC_ERR_ARG, "vc_sample_guide: null params");
+  vc_launch_pre(e->d, e->b, params, eps, seed, (long long)step, nullptr, 0, 0, (hipStream_t)hip_stream);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
 extern "C" int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream) {
   if (!e || !host_out) return VC_ERR_ARG;
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_read_site before vc_finalize");

@@ -258,6 +258,12 @@ class HipEngine:
         if rc != _lib.VC_OK:
             raise HipEngineError("vc_clipped_adam failed")
 
+    def sample_guide(self, eps: Optional[torch.Tensor] = None, seed: int = 0, step: int = 0):
+        """One guide draw + deterministic sites (no likelihood); read the values with read_site()."""
+        self._check(self.lib.vc_sample_guide(
+            self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(eps.data_ptr()) if eps is not None else None,
+            C.c_uint64(seed), C.c_int64(step), self._stream()))
+
     def loss(self) -> float:
         return float(self.loss_dev.item())
 

@@ -154,7 +154,7 @@ class _FitBase:
                  if self._site_exists(n)]
         acc = {n: [] for n in names + ["ϕ"] + (["ω"] if sp.kind == "velocity" else [])}
         for i in range(num_samples):
-            eng.elbo_grad(eps=None, seed=base, step=i)
+            eng.sample_guide(seed=base, step=i)
             for n in acc:
                 acc[n].append(eng.read_site(n))
         out = {n: torch.stack(v) for n, v in acc.items()}
