@@ -113,3 +113,29 @@ def test_perf_mode_fit_recovers_structure():
     assert len(fit.losses) == 300 and fit.losses[-1] < fit.losses[0]
     est = np.arctan2(fit.phis_pyro[1], fit.phis_pyro[0])
     assert circular_corrcoef(est, sp.truth["phis"].cpu().numpy()) > 0.8
+
+
+def test_early_exit_and_store_output_follow_the_reference_loop(monkeypatch):
+    """early_exit: armed after step 200, then checked every step (|mean(last 100) - mean(last 10)| < 5 -> break),
+    exactly as velocity_inference_model.py:147-151; store_output returns posterior snapshots."""
+    from velocycle_amd import preprocessing as P
+    from velocycle_amd.fit_models import PhaseFitModel
+    from velocycle_amd import svi
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fit_phase_nb.npz")
+    ad, cyc, ph, Db = _objects(z)
+    mp = P.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=int(z["in_H"]), with_delta_nu=False)
+    calls = {"n": 0}
+    real_step = svi.SVIRunner.step
+
+    def flat_step(self, eps=None):
+        real_step(self, eps)
+        calls["n"] += 1
+        return 1000.0 + (calls["n"] % 2)          # a converged, flat loss curve
+    monkeypatch.setattr(svi.SVIRunner, "step", flat_step)
+    fit = PhaseFitModel(mp, early_exit=True, num_samples=2, n_per_bin=2)
+    fit.fit(_opt(z), num_steps=400, verbose=False, mode="parity", seed=1)
+    assert len(fit.losses) == 203                 # steps 0..201 arm the check, step 202 breaks
+    fit2 = PhaseFitModel(mp, num_samples=2, n_per_bin=2)
+    out = fit2.fit(_opt(z), num_steps=5, verbose=False, mode="parity", seed=1, store_output=True,
+                   intermediate_output_step_size=2)
+    assert len(out) == 3 and out[0]["ν"].shape[0] == 2 and len(fit2.losses) == 5
