@@ -94,7 +94,7 @@ def test_velocity_joint_kernels(H, Nb, monkeypatch):
 def test_velocity_conditioned_kernels(H, Nb, monkeypatch):
     full = ["ϕxy", "ν", "shape_inv"] + (["Δν"] if Nb else [])
     for noise, guide, Hw, gpl in (("NegativeBinomial", "lrmn", 1, None), ("NegativeBinomial", "meanfield", 3, 4),
-                                  ("Poisson", "lrmn", 0, None)):
+                                  ("Poisson", "lrmn", 0, None), ("Lognormal", "meanfield", 1, None)):
         sites = [s for s in full if not (s == "shape_inv" and noise != "NegativeBinomial")]
         p = _problem("velocity", guide, noise, H, Hw, Nb, 2, sites, Nc=130, Ng=11, seed=200 + H * 10 + Nb)
         k = _check(p, gpl, monkeypatch)
