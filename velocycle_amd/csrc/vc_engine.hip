@@ -500,6 +500,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   d.nb_pre_cell = (d.Nc + 255) / 256;
   d.nb_post_gene = d.Ng_pad / 64;
   d.nb_post_cell = (d.Nc + 1023) / 1024;
+  d.debug_post = getenv("VC_DEBUG_POST") ? atoi(getenv("VC_DEBUG_POST")) : 0;
   d.hist_has_S = nb && d.kind != VC_KIND_VU;
   d.hist_has_U = nb && vel;
   d.nmat_r = nb ? (d.kind == VC_KIND_VFULL ? 2 : 1) : 0;

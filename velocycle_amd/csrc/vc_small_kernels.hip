@@ -360,63 +360,58 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
 #pragma unroll
   for (int q = 0; q < VC_MAXQ; ++q) sm[wave][q][lane] = acc[q];
   __syncthreads();
+  // Chain rule to the parameter gradients.  The work of one gene is split into independent ROLES and every
+  // role runs on its own wave (lane = gene), so that the serial path of the block is the longest role
+  // instead of their sum: role h < Nh: nu[h]; Nh + q: dnu[q]; 12: shape_inv (+ r-only loss terms);
+  // 13: log gamma / log beta (mean-field) or the LRMN core; 14: LRMN cov_factor row.
   double loss = 0.0;
-  if (wave == 0 && g < d.Ng) {
-    float T[VC_MAXQ];
+  const int role = wave;
+  auto T = [&](int q) {                 // reduced partial sum of output row q for this gene (fixed order)
+    float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < VC_MAXQ; ++q) {
-      float s = 0.f;
-      for (int w = 0; w < VC_PG_WAVES; ++w) s += sm[w][q][lane];
-      T[q] = s;
-    }
+    for (int w = 0; w < VC_PG_WAVES; ++w) t += sm[w][q][lane];
+    return t;
+  };
+  if (g < d.Ng) {
     const bool vel = d.model == VC_MODEL_VELOCITY;
     const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
     const bool nb = d.noise == VC_NOISE_NB;
     const int K = d.K, Nh = d.Nh;
     const float rw = d.root_w;
-    // upstream d loglik / d site
-    float U_lb = 0.f, U_lg = 0.f, U_r = 0.f;
-    const float gam = b.GT[(size_t)(K + 1) * d.Ng_pad + g];
-    const float r = b.GT[(size_t)(K + 2) * d.Ng_pad + g];
-    if (d.kind == VC_KIND_PHASE) U_r = T[K];
-    else if (d.kind == VC_KIND_VFULL) { U_lb = -T[K]; U_lg = T[K + 1] * gam; U_r = T[K + 2]; }
-    else { U_lb = -T[0]; U_lg = T[1] * gam; }
-
-    // ---- nu ----
-    for (int h = 0; h < Nh; ++h) {
+    if (role < Nh) {
+      // ---- nu[h] ----
+      const int h = role;
       const long long j = (long long)g * Nh + h;
       float gl = 0.f, gu = 0.f;
       if (!CND(VC_SITE_NU)) {
         const float x = b.lat[VC_SITE_NU][j];
         const float sd = b.sd_nu[j];
-        const float gx = T[h] - rw * (x - b.mu_nu[j]) / (sd * sd);
+        const float gx = T(h) - rw * (x - b.mu_nu[j]) / (sd * sd);
         const float e = b.eps_used[d.eoff[VC_E_NU] + j];
         gl = -gx;
         gu = -gx * expf(P[d.poff[VC_P_NU_USCALES] + j]) * e - rw;
       }
       G[d.poff[VC_P_NU_LOCS] + j] = gl;
       G[d.poff[VC_P_NU_USCALES] + j] = gu;
-    }
-    // ---- delta nu ----
-    for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
+    } else if (role < Nh + d.Nb && d.with_dnu) {
+      // ---- delta nu[q] ----
+      const int q = role - Nh;
       const long long j = (long long)q * d.Ng + g;
       float gl = 0.f;
       if (!CND(VC_SITE_DNU)) {
         const float x = b.lat[VC_SITE_DNU][j];
         const float sd = vel ? 0.01f : b.sd_dnu[j];
-        gl = -(T[Nh + q] - rw * x / (sd * sd));
+        gl = -(T(Nh + q) - rw * x / (sd * sd));
       }
       G[d.poff[VC_P_DNU_LOCS] + j] = gl;
-    }
-    // ---- shape_inv (negative binomial) ----
-    if (nb) {
-      // r-only terms of sum_c NB(k; r, eta): nmat*Nc*r*log r + sum_hist cnt*(lgamma(r+k)-lgamma(r))
-      const double lr = log((double)r);
+    } else if (role == 12 && nb) {
+      // ---- shape_inv: r-only terms of sum_c NB(k; r, eta): nmat*Nc*r*log r + sum_hist cnt*(lgamma(r+k)-lgamma(r))
+      const float r = b.GT[(size_t)(K + 2) * d.Ng_pad + g];
+      const float U_r = (d.kind == VC_KIND_PHASE) ? T(K) : (d.kind == VC_KIND_VFULL ? T(K + 2) : 0.f);
+      const double lr = (double)logf(r);
       double HLg = 0.0, HDg = 0.0;        // histogram task sums of this gene, fixed order
       for (int t = b.h_tptr[g]; t < b.h_tptr[g + 1]; ++t) { HLg += b.HL[t]; HDg += b.HD[t]; }
-      if (d.nmat_r > 0) {
-        loss -= (double)d.nmat_r * d.Nc * (double)r * lr + HLg;
-      }
+      if (d.nmat_r > 0) loss -= (double)d.nmat_r * d.Nc * (double)r * lr + HLg;
       float gu = 0.f;
       if (!CND(VC_SITE_SHAPE_INV)) {
         const float si = b.lat[VC_SITE_SHAPE_INV][g];
@@ -425,9 +420,12 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
         gu = (float)(-gsi * (double)si);
       }
       G[d.poff[VC_P_SHAPE_INV_ULOCS] + g] = gu;
-    }
-    // ---- log gamma / log beta ----
-    if (vel) {
+    } else if ((role == 13 || role == 14) && vel) {
+      // ---- log gamma / log beta ----
+      const float gam = b.GT[(size_t)(K + 1) * d.Ng_pad + g];
+      float U_lb, U_lg;
+      if (d.kind == VC_KIND_VFULL) { U_lb = -T(K); U_lg = T(K + 1) * gam; }
+      else { U_lb = -T(0); U_lg = T(1) * gam; }
       float g_lg = 0.f, g_lb = 0.f;   // total d log p / d site (0 when the site is conditioned)
       if (!CND(VC_SITE_LOGGAMMA)) {
         const float x = b.lat[VC_SITE_LOGGAMMA][g], sd = b.sd_g[g];
@@ -438,12 +436,14 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
         g_lb = U_lb - rw * (x - b.mu_b[g]) / (sd * sd);
       }
       if (!lrmn) {
-        const float eg = b.eps_used[d.eoff[VC_E_LOGGAMMA] + g], eb = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
-        const bool cg = CND(VC_SITE_LOGGAMMA), cb = CND(VC_SITE_LOGBETA);
-        G[d.poff[VC_P_LOGGAMMA_LOCS] + g] = -g_lg;
-        G[d.poff[VC_P_LOGGAMMA_USCALES] + g] = cg ? 0.f : -g_lg * expf(P[d.poff[VC_P_LOGGAMMA_USCALES] + g]) * eg - rw;
-        G[d.poff[VC_P_LOGBETA_LOCS] + g] = -g_lb;
-        G[d.poff[VC_P_LOGBETA_USCALES] + g] = cb ? 0.f : -g_lb * expf(P[d.poff[VC_P_LOGBETA_USCALES] + g]) * eb - rw;
+        if (role == 13) {
+          const float eg = b.eps_used[d.eoff[VC_E_LOGGAMMA] + g], eb = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
+          const bool cg = CND(VC_SITE_LOGGAMMA), cb = CND(VC_SITE_LOGBETA);
+          G[d.poff[VC_P_LOGGAMMA_LOCS] + g] = -g_lg;
+          G[d.poff[VC_P_LOGGAMMA_USCALES] + g] = cg ? 0.f : -g_lg * expf(P[d.poff[VC_P_LOGGAMMA_USCALES] + g]) * eg - rw;
+          G[d.poff[VC_P_LOGBETA_LOCS] + g] = -g_lb;
+          G[d.poff[VC_P_LOGBETA_USCALES] + g] = cb ? 0.f : -g_lb * expf(P[d.poff[VC_P_LOGBETA_USCALES] + g]) * eb - rw;
+        }
       } else {
         // q(log beta | log gamma) = N(a + rho s_b delta / s_gamma, s_b sqrt(1-rho^2)); log gamma = loc + delta
         const bool cb = CND(VC_SITE_LOGBETA);
@@ -455,25 +455,28 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
         const float sg = sigmoidf_(rho_real / d.rho_scale);
         const float rho = sg * 1.998f - 0.999f;
         const float om = 1.f - rho * rho, sq = sqrtf(om);
-        const float eb = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
-        G[d.poff[VC_P_LOGBETA_LOCS] + g] = -A;
-        G[d.poff[VC_P_LOGBETA_USCALES] + g] = -A * (rho * delta / sgam + sq * eb) * sb - ent;
-        float g_rho = -A * (sb * delta / sgam - sb * rho * eb / sq) + ent * rho / om;
-        float g_rr = g_rho * 1.998f * sg * (1.f - sg) / d.rho_scale;
-        if (!CND(VC_SITE_RHO_REAL)) g_rr += rw * (rho_real - d.rho_mean) / (d.rho_std * d.rho_std);
-        G[d.poff[VC_P_RHO_REAL_LOC] + g] = g_rr;
-        G[d.poff[VC_P_LRMN_LOC] + g] = -g_lg;
         const float dl_ddelta = -g_lg - A * rho * sb / sgam;
         const float dl_dsg = A * rho * sb * delta / (sgam * sgam);
-        for (int k = 0; k < d.R; ++k) {
-          const long long j = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k;
-          const float w = expf(P[j]);
-          const float ew = b.eps_used[d.eoff[VC_E_LRMN_W] + k];
-          G[j] = (w > 0.f) ? (dl_ddelta * ew + dl_dsg * w / sgam) * w : 0.f;
+        if (role == 13) {
+          const float eb = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
+          G[d.poff[VC_P_LOGBETA_LOCS] + g] = -A;
+          G[d.poff[VC_P_LOGBETA_USCALES] + g] = -A * (rho * delta / sgam + sq * eb) * sb - ent;
+          float g_rho = -A * (sb * delta / sgam - sb * rho * eb / sq) + ent * rho / om;
+          float g_rr = g_rho * 1.998f * sg * (1.f - sg) / d.rho_scale;
+          if (!CND(VC_SITE_RHO_REAL)) g_rr += rw * (rho_real - d.rho_mean) / (d.rho_std * d.rho_std);
+          G[d.poff[VC_P_RHO_REAL_LOC] + g] = g_rr;
+          G[d.poff[VC_P_LRMN_LOC] + g] = -g_lg;
+          const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
+          const float ed = b.eps_used[d.eoff[VC_E_LRMN_D] + g];
+          G[d.poff[VC_P_LRMN_UCOV_DIAG] + g] = (dl_ddelta * ed / (2.f * sqrtf(dg)) + dl_dsg / (2.f * sgam)) * dg;
+        } else {
+          for (int k = 0; k < d.R; ++k) {
+            const long long j = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k;
+            const float w = expf(P[j]);
+            const float ew = b.eps_used[d.eoff[VC_E_LRMN_W] + k];
+            G[j] = (w > 0.f) ? (dl_ddelta * ew + dl_dsg * w / sgam) * w : 0.f;
+          }
         }
-        const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
-        const float ed = b.eps_used[d.eoff[VC_E_LRMN_D] + g];
-        G[d.poff[VC_P_LRMN_UCOV_DIAG] + g] = (dl_ddelta * ed / (2.f * sqrtf(dg)) + dl_dsg / (2.f * sgam)) * dg;
       }
     }
   }
@@ -545,6 +548,8 @@ __global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcB
   // every reader of this step's counter (K_pre) has finished and nothing in this launch reads it:
   // advance it here, so that K_fin / the optimiser (which only read it) see step + 1 = the 1-based Adam step
   if (blockIdx.x == 0 && threadIdx.x == 0 && step_dev) *step_dev += 1;
+  if (d.debug_post == 1 && (int)blockIdx.x >= d.nb_post_gene) return;
+  if (d.debug_post == 2 && (int)blockIdx.x < d.nb_post_gene) return;
   if ((int)blockIdx.x < d.nb_post_gene) vc_post_gene_block(d, b, P, G, blockIdx.x);
   else vc_post_cell_block(d, b, G, blockIdx.x - d.nb_post_gene);
 }
