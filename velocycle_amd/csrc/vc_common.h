@@ -41,7 +41,6 @@ struct VcDims {
   long long eoff[VC_E_COUNT];   // eps offsets
   long long eps_n_global;
   int nb_pre_gene, nb_pre_cell, nb_post_gene, nb_post_cell, n_main_wg;
-  int debug_post;
 };
 
 struct VcBufs {

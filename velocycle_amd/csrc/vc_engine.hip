@@ -500,11 +500,10 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   d.nb_pre_cell = (d.Nc + 255) / 256;
   d.nb_post_gene = d.Ng_pad / 64;
   d.nb_post_cell = (d.Nc + 1023) / 1024;
-  d.debug_post = getenv("VC_DEBUG_POST") ? atoi(getenv("VC_DEBUG_POST")) : 0;
   d.hist_has_S = nb && d.kind != VC_KIND_VU;
   d.hist_has_U = nb && vel;
   d.nmat_r = nb ? (d.kind == VC_KIND_VFULL ? 2 : 1) : 0;
-  e->hist_each_step = nb && !cond(e, VC_SITE_SHAPE_INV) && !getenv("VC_DEBUG_SKIP_HIST");
+  e->hist_each_step = nb && !cond(e, VC_SITE_SHAPE_INV);
 
   // uploads
   TRY(upload(e, e->h_prior[VC_PRIOR_MU_NU], &b.mu_nu));

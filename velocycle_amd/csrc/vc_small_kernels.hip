@@ -548,8 +548,6 @@ __global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcB
   // every reader of this step's counter (K_pre) has finished and nothing in this launch reads it:
   // advance it here, so that K_fin / the optimiser (which only read it) see step + 1 = the 1-based Adam step
   if (blockIdx.x == 0 && threadIdx.x == 0 && step_dev) *step_dev += 1;
-  if (d.debug_post == 1 && (int)blockIdx.x >= d.nb_post_gene) return;
-  if (d.debug_post == 2 && (int)blockIdx.x < d.nb_post_gene) return;
   if ((int)blockIdx.x < d.nb_post_gene) vc_post_gene_block(d, b, P, G, blockIdx.x);
   else vc_post_cell_block(d, b, G, blockIdx.x - d.nb_post_gene);
 }
