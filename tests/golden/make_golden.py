@@ -290,8 +290,48 @@ def make_phase_prior():
     print("[phase prior] ok")
 
 
+def make_tutorial_flow():
+    """The tutorials' two-stage flow on a two-sample data set (Tutorial_Aissa_PC9_TwoSample cells 23-46): phase fit with a
+    per-batch sigma_dnu tensor, hand-over of phi_xy / nu / dnu / shape_inv exactly as tutorial cell 42 builds
+    `condition_on_dict`, then the default (LRMN) velocity fit with one angular speed per condition."""
+    n1, n2, seed = 20, 20, 21
+    d, ad, cyc, ph, Db = build_inputs(30, 10, 1, 2, seed=9)
+    s = torch.ones((2, 10, 1)); s[0] = 0.001; s[1] = 0.1
+    out = {"S": ad.layers["spliced"], "U": ad.layers["unspliced"], "batch": np.array(ad.obs["batch"]).astype(str),
+           "cyc_means": cyc.means.values, "cyc_stds": cyc.stds.values, "phi_xy": ph.phi_xy.values, "sd_dnu": s.numpy(),
+           "n1": np.array(n1), "n2": np.array(n2), "seed": np.array(seed)}
+    opt = lambda n: pyro.optim.ClippedAdam({"lr": 0.03, "lrd": (0.005 / 0.03) ** (1 / n), "betas": (0.80, 0.99)})
+    pyro.clear_param_store()
+    mp = vc.preprocessing.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=1, σΔν=s)
+    pf = vc.phase_inference_model.PhaseFitModel(mp, num_samples=4, n_per_bin=2)
+    torch.manual_seed(seed)
+    pf.fit(opt(n1), loss=pyro.infer.Trace_ELBO(num_particles=1), num_steps=n1, verbose=False)
+    out["phase_losses"] = np.array(pf.losses)
+    for a in ("phis_pyro", "fourier_coef", "fourier_coef_sd", "disp_pyro", "delta_nus"):
+        out["phase_" + a] = np.asarray(getattr(pf, a))
+    cycle_pyro, phase_pyro = pf.cycle_pyro, pf.phase_pyro
+    cond = {"ϕxy": phase_pyro.phi_xy_tensor.T, "ν": cycle_pyro.means_tensor.T.unsqueeze(-2),
+            "Δν": torch.tensor(pf.delta_nus), "shape_inv": torch.tensor(pf.disp_pyro).unsqueeze(-1)}
+    spd = vc.angularspeed.AngularSpeed.trivial_prior(condition_names=["b0", "b1"], harmonics=0)
+    pyro.clear_param_store()
+    mv = vc.preprocessing.preprocess_for_velocity_estimation(ad, cycle_pyro, phase_pyro, spd, Db.float(), Db.float(),
+                                                             n_harmonics=1, count_factor=mp.count_factor, ω_n_harmonics=0,
+                                                             condition_on=cond)
+    vf = vc.velocity_inference_model.VelocityFitModel(mv, condition_on=cond, num_samples=4, n_per_bin=2)
+    torch.manual_seed(seed + 1)
+    vf.fit(opt(n2), loss=pyro.infer.Trace_ELBO(num_particles=1), num_steps=n2, verbose=False)
+    out["vel_losses"] = np.array(vf.losses)
+    for a in ("phis_pyro", "fourier_coef", "disp_pyro", "log_betas", "delta_nus"):
+        out["vel_" + a] = np.asarray(getattr(vf, a))
+    out["vel_loc"] = pyro.param("loc").detach().numpy()
+    out["vel_logβg_scales"] = pyro.param("logβg_scales").detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_tutorial_flow.npz"), **out)
+    print(f"[tutorial flow] phase {pf.losses[-1]:.3f} velocity {vf.losses[-1]:.3f}")
+
+
 if __name__ == "__main__":
     make_basis()
+    make_tutorial_flow()
     make_preprocess()
     make_phase_prior()
     only = sys.argv[1:]

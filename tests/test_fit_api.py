@@ -139,3 +139,48 @@ def test_early_exit_and_store_output_follow_the_reference_loop(monkeypatch):
     out = fit2.fit(_opt(z), num_steps=5, verbose=False, mode="parity", seed=1, store_output=True,
                    intermediate_output_step_size=2)
     assert len(out) == 3 and out[0]["ν"].shape[0] == 2 and len(fit2.losses) == 5
+
+
+def test_two_stage_tutorial_flow_matches_reference():
+    """Phase fit -> hand-over built exactly like tutorial cell 42 -> default (LRMN) two-condition velocity fit,
+    against the same flow run with the reference's own classes (tests/golden/ref_tutorial_flow.npz)."""
+    from velocycle_amd import containers as C, preprocessing as P
+    from velocycle_amd.anndata_lite import AnnDataLite
+    from velocycle_amd.fit_models import PhaseFitModel, VelocityFitModel
+    from velocycle_amd.optim import ClippedAdam
+    from velocycle_amd import pyro_compat as pyro
+    z = H.load_fixture(f"{H.GOLDEN}/ref_tutorial_flow.npz")
+    ad = AnnDataLite(z["S"], z["U"])
+    ad.obs["batch"] = list(z["batch"])
+    cyc = C.Cycle.trivial_prior(list(ad.var.index), harmonics=1)
+    cyc.set_means(z["cyc_means"])
+    cyc.set_stds(z["cyc_stds"])
+    ph = C.Phases.from_array(z["phi_xy"], cell_names=list(ad.obs.index))
+    Db = P.make_design_matrix(ad, ids="batch")
+    n1, n2, seed = int(z["n1"]), int(z["n2"]), int(z["seed"])
+    opt = lambda n: ClippedAdam({"lr": 0.03, "lrd": (0.005 / 0.03) ** (1 / n), "betas": (0.80, 0.99)})
+    pyro.clear_param_store()
+    mp = P.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=1, σΔν=torch.tensor(z["sd_dnu"]))
+    PhaseFitModel._default_elbo_fresh = True
+    pf = PhaseFitModel(mp, num_samples=4, n_per_bin=2)
+    pf.fit(opt(n1), num_steps=n1, verbose=False, mode="parity", seed=seed)
+    assert np.allclose(pf.losses, z["phase_losses"], rtol=1e-4, atol=1e-2)
+    for a in ("phis_pyro", "fourier_coef", "fourier_coef_sd", "disp_pyro", "delta_nus"):
+        _close(getattr(pf, a), z["phase_" + a])
+    cond = {"ϕxy": pf.phase_pyro.phi_xy_tensor.T, "ν": pf.cycle_pyro.means_tensor.T.unsqueeze(-2),
+            "Δν": torch.tensor(pf.delta_nus), "shape_inv": torch.tensor(pf.disp_pyro).unsqueeze(-1)}
+    spd = C.AngularSpeed.trivial_prior(condition_names=["b0", "b1"], harmonics=0)
+    pyro.clear_param_store()
+    mv = P.preprocess_for_velocity_estimation(ad, pf.cycle_pyro, pf.phase_pyro, spd, Db.float(), Db.float(), n_harmonics=1,
+                                              count_factor=mp.count_factor, ω_n_harmonics=0, condition_on=cond)
+    assert mv.model_type == "lrmn" and mv.Nx == 2
+    VelocityFitModel._default_elbo_fresh = True
+    vf = VelocityFitModel(mv, condition_on=cond, num_samples=4, n_per_bin=2)
+    vf.fit(opt(n2), num_steps=n2, verbose=False, mode="parity", seed=seed + 1)
+    assert "vu_" in vf.engine.stats["main_kernel"]            # S term hoisted in the tutorial flow
+    assert np.allclose(vf.losses, z["vel_losses"], rtol=1e-4, atol=1e-2)
+    for a in ("phis_pyro", "fourier_coef", "disp_pyro", "log_betas", "delta_nus"):
+        _close(getattr(vf, a), z["vel_" + a])
+    _close(pyro.param("loc").numpy(), z["vel_loc"])
+    _close(pyro.param("logβg_scales").numpy(), z["vel_logβg_scales"])
+    assert vf.speed_pyro.means.shape == (1, 2) and list(vf.speed_pyro.conditions) == ["b0", "b1"]

@@ -197,3 +197,34 @@ def test_rccl_allreduce_inside_captured_step_single_rank():
         assert np.allclose(outs[0][1], outs[1][1], rtol=1e-6)      # reduced loss is float hi+lo
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["vjoint", "vcond"])
+def test_baseline_config_10k_x_500_against_oracle(mode):
+    """BASELINE.json configs[1]: synthetic 10k cells x 500 genes velocity inference, one step vs the float64 oracle."""
+    from velocycle_amd.workloads import make_velocity_spec
+    from velocycle_amd.rng import draw_eps
+    spec = make_velocity_spec(10000, 500, mode, n_conditions=1, Hw=1, seed=4)
+    eng = _mk(spec)
+    g = torch.Generator().manual_seed(2)
+    first = draw_eps(spec, g)
+    eng.init_params(first.get("_cov_factor_draw"))
+    eps = draw_eps(spec, g)
+    eng.elbo_grad(eps=eng.pack_eps(eps))
+    torch.cuda.synchronize()
+    kw = {k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in spec.__dict__.items() if k != "truth"}
+    kw["condition_on"] = {k: v.double() for k, v in spec.condition_on.items()}
+    p = orc.Problem(**kw)
+    par = {n: v.detach().cpu().double() for n, v in eng.named().items()}
+    e64 = {k: v.double() for k, v in eps.items() if not k.startswith("_")}
+    l64, g64, _, _ = orc.loss_and_grads(p, par, e64)
+    _, g32, _, _ = orc.loss_and_grads(p.to(torch.float32), {k: v.float() for k, v in par.items()},
+                                      {k: v.float() for k, v in e64.items()})
+    assert abs(eng.loss() - l64) <= 1e-5 * abs(l64)
+    for name, got in eng.named(eng.grad).items():
+        want = g64[name].numpy()
+        fin = np.isfinite(want)
+        err = np.abs(got.cpu().numpy()[fin] - want[fin]).max()
+        ref32 = np.abs(g32[name].numpy().astype(np.float64)[fin] - want[fin]).max()
+        assert err <= max(2e-3 * max(np.abs(want[fin]).max(), 1e-3), 4 * ref32), (name, err, ref32)
+    eng.close()
