@@ -100,6 +100,9 @@ class _FitBase:
                 elif step > 200 and self.early_exit:
                     early = True
         self.losses = losses
+        if not np.all(np.isfinite(np.asarray(losses, dtype=np.float64))):      # pyro.util.warn_if_nan(loss, "loss")
+            import warnings
+            warnings.warn("Encountered NaN/Inf: loss", UserWarning)
         self._extract()
         if self.get_posterior:
             self._posterior()
