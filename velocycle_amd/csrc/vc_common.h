@@ -68,6 +68,9 @@ struct VcBufs {
   float *PW;                                // [nb_post_cell][NW] partial angular-speed gradients
   double *HL, *HD;                          // per histogram task: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
   double const_loss;                        // step-invariant part of the loss
+#ifdef VC_DBG_TIMES
+  unsigned long long* dbg;                  // measurement aid: 4 wall-clock stamps per wave of K_main
+#endif
 };
 
 #ifdef __HIPCC__

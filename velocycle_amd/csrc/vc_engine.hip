@@ -232,6 +232,15 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
 
 extern "C" void vc_destroy(vc_engine* e) {
   if (!e) return;
+#ifdef VC_DBG_TIMES
+  if (e->b.dbg && getenv("VC_DBG_TIMES_OUT")) {
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)e->d.n_main_wg * 32);
+    (void)hipMemcpy(h.data(), e->b.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    FILE* f = fopen(getenv("VC_DBG_TIMES_OUT"), "wb");
+    if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+  }
+#endif
   for (void* p : e->allocs) (void)hipFree(p);
   for (float* r : e->raw) if (r) (void)hipFree(r);
   for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -440,9 +449,17 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   auto nco_of = [&](int kind) { return kind == VC_KIND_VFULL ? 3 : 1; };
   d.nq = nq_of(d.kind);
   d.nco = nco_of(d.kind);
-  // genes per lane: 8 wherever the kernel's per-gene state still fits 2 waves per SIMD without scratch
-  // (from -Rpass-analysis=kernel-resource-usage over the instantiations), else 4
-  d.gpl = (d.kind == VC_KIND_VU) ? 8 : (d.kind == VC_KIND_VFULL ? (d.K <= 4 ? 8 : 4) : (d.K <= 9 ? 8 : 4));
+  // genes per lane: 8 amortises the per-cell work over twice the genes and is chosen whenever that instantiation's
+  // per-gene state (latents + accumulators) fits 2 waves per SIMD without scratch, which the code object itself
+  // tells (private segment size 0); else 4.
+  d.gpl = 4;
+  {
+    const void* k8 = nullptr;
+    hipFuncAttributes fa;
+    if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, nullptr, &k8) && k8 &&
+        hipFuncGetAttributes(&fa, k8) == hipSuccess && fa.localSizeBytes == 0)
+      d.gpl = 8;
+  }
   if (const char* env = getenv("VC_GPL")) { if (atoi(env) == 4 || atoi(env) == 8) d.gpl = atoi(env); }
   d.gbw = 64 * d.gpl;
   d.nGB = (d.Ng + d.gbw - 1) / d.gbw;
@@ -537,6 +554,9 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.GO, (size_t)d.n_chunks * nq_max * d.Ng_pad));
   TRY(e->dalloc(&b.CO, (size_t)d.nGB * 3 * d.Nc));
   TRY(e->dalloc(&b.LO, (size_t)d.n_main_wg));
+#ifdef VC_DBG_TIMES
+  TRY(e->dalloc(&b.dbg, (size_t)d.n_main_wg * 32));
+#endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
   TRY(e->dalloc(&b.PW, (size_t)d.nb_post_cell * std::max(1, d.NW)));
 
