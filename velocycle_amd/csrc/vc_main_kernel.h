@@ -22,29 +22,13 @@
 #include "vc_common.h"
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 // build-time knobs (the defaults are the measured best)
 #ifndef VC_SCALAR_REC
 #define VC_SCALAR_REC 1
 #endif
-#ifndef VC_RED_LDS
-#define VC_RED_LDS 0     // per-cell sums through LDS (1) or by DPP wave reductions (0); see DESIGN.md section 5
-#endif
 #ifndef VC_PF
 #define VC_PF 1           // register path: cells in flight ahead of the one being processed
-#endif
-#ifndef VC_RED_ROWS
-#define VC_RED_ROWS 16   // cells per flush of the LDS-transposed per-cell sums (8, 16 or 32)
-#endif
-#ifndef VC_DMA_LATEWAIT
-#define VC_DMA_LATEWAIT 1
-#endif
-#ifndef VC_DMA_RECMASK
-#define VC_DMA_RECMASK 0
-#endif
-#ifndef VC_DMA_DEPTH
-#define VC_DMA_DEPTH 3      // LDS slots per wave of the count ring (1 = register prefetch only)
 #endif
 
 // Cell record as stored in the cell table: every value duplicated {x, x}, so that a scalar load
@@ -104,11 +88,6 @@ __device__ __forceinline__ v2f v2_exp2(v2f x) { return v2f{__builtin_amdgcn_exp2
 __device__ __forceinline__ v2f v2_log2(v2f x) { return v2f{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)}; }
 __device__ __forceinline__ v2f v2_rcp(v2f x) { return v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
 
-// 16 bytes per lane, global -> LDS without a VGPR destination; LDS address = dst (wave-uniform) + lane*16
-__device__ __forceinline__ void vc_glds16(const float* g, float4* dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-}
 
 // Observation model of a pair of counts k with mean mu (= exp of the log-mean, eta2 = log-mean*log2 e):
 //   a   = d loglik / d eta (natural units)
@@ -208,22 +187,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
   if (cbeg > d.Nc) cbeg = d.Nc;
   if (cend > d.Nc) cend = d.Nc;
 
-  // all LDS of the kernel is ONE array (a second __shared__ object next to an LDS-DMA target makes hipcc
-  // drain vmcnt before every ds_read): the DMA ring during the cell loop, the 4-wave combine afterwards
-  constexpr int DEPTH = VC_DMA_DEPTH;
-  constexpr bool DMA = (DEPTH > 1) && (GPL == 8) && (KIND == VC_KIND_VU);
-  constexpr int NLD = ((HAS_S ? 1 : 0) + (HAS_U ? 1 : 0)) * NV4;      // LDS-DMA instructions per cell
-  constexpr int CTW = 2 * (((2 * H + NB + 2) + 3) / 4 * 4);         // floats per cell record (= d.ctw)
-  constexpr int NRC = CTW / 4;                                       // 16-B chunks per record
-  constexpr int SLOT4 = (NLD + 1) * 64;                              // float4 per ring slot: counts + one record line
-  constexpr int RING4 = DMA ? VC_WAVES * DEPTH * SLOT4 : 0;
-  // per-cell sums over genes: transposed through LDS RB cells at a time (non-DMA kernels), see cell_sums below
-  constexpr bool RED_LDS = !DMA && VC_RED_LDS;
-  constexpr int RB = VC_RED_ROWS;       // 8, 16 or 32 cells per flush
-  static_assert(RB == 8 || RB == 16 || RB == 32, "VC_RED_ROWS");
-  constexpr int RED4 = RED_LDS ? VC_WAVES * NCO * RB * 16 : 0;
-  constexpr int EPI4 = (VC_WAVES * GBW + VC_WAVES + 3) / 4;
-  __shared__ float4 lds4[(RING4 + RED4) > EPI4 ? (RING4 + RED4) : EPI4];
+  __shared__ float4 lds4[(VC_WAVES * GBW + VC_WAVES + 3) / 4];      // staging area of the 4-wave combine
 
 #ifdef VC_DBG_TIMES
   asm volatile("" ::"v"(nu[0][0]), "v"(rr[0]));   // stamp 1 sits behind the latents' loads
@@ -234,9 +198,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
   const float* Up = HAS_U ? b.U + blk_base : nullptr;
 
   float keep0 = 0.f, keep1 = 0.f, keep2 = 0.f;
-  float* red = reinterpret_cast<float*>(lds4 + RING4) + wave * (NCO * RB * 64);
   // one cell against the lane's genes: sv/uv = the counts, rec = the cell record, i = staging lane of the cell
-  auto cell = [&](v2f* sv, v2f* uv, const VcCellRec<H, NB>& rec, const int i) __attribute__((always_inline)) {
+  auto cell = [&](const v2f* sv, const v2f* uv, const VcCellRec<H, NB>& rec, const int i) __attribute__((always_inline)) {
     v2f A1 = v2(0.f), A2 = v2(0.f), A3 = v2(0.f);
 #ifdef VC_STREAM_ONLY        // measurement aid: the loads and one fma per pair, nothing else (results are meaningless)
 #pragma unroll
@@ -260,18 +223,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
 #pragma unroll
       for (int q = 0; q < NB; ++q) es = v2_fma(nu[NH + q][p], rec.db[q], es);
 
-      v2f es2 = es * VC_LOG2E;
+      const v2f es2 = es * VC_LOG2E;
       v2f a = v2(0.f), w = v2(0.f), muS = v2(0.f);
-      if (DMA && VC_DMA_LATEWAIT && p == 0) {   // the counts' LDS reads were issued ahead of the record's math: retire them here
-        v2f es2w = es2;      // ties the wait behind this pair's record-only math, which then covers the LDS latency
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(es2w), "+v"(dd)::"memory");
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          if (HAS_S) asm volatile("" : "+v"(sv[q]));
-          if (HAS_U) asm volatile("" : "+v"(uv[q]));
-        }
-        es2 = es2w;
-      }
       if (HAS_S) {
         v2f aS;
         if (LN) vc_obs_lognormal(sv[p], es, inv_s2_s, aS, ll[p]);
@@ -327,14 +280,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
       if (HAS_U) A3 = v2_fma(w, dd, A3);
     }
     // per-cell sums over the genes of this wave
-    if constexpr (RED_LDS) {
-      // one LDS row of 64 lane partials per cell; every RB cells the rows are summed by flush() with the
-      // transposed access (a 64-lane DPP reduction per cell and per sum costs ~10 VALU issue slots, this ~2)
-      float* rw = red + (i & (RB - 1)) * 64 + lane;
-      if (KIND == VC_KIND_PHASE) rw[0] = A1.x + A1.y;
-      else if (KIND == VC_KIND_VU) rw[0] = A3.x + A3.y;
-      else { rw[0] = A1.x + A1.y; rw[RB * 64] = A2.x + A2.y; rw[2 * RB * 64] = A3.x + A3.y; }
-    } else if (KIND == VC_KIND_PHASE) {
+    if (KIND == VC_KIND_PHASE) {
       const float t0 = vc_wave_sum(A1.x + A1.y);
       keep0 = (lane == i) ? t0 : keep0;
     } else if (KIND == VC_KIND_VU) {
@@ -347,110 +293,15 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
       keep2 = (lane == i) ? t2 : keep2;
     }
   };
-  auto flush = [&](long long cb, int n) {      // store the per-cell sums of the last n cells (first of them: cb)
-    if constexpr (RED_LDS) {
-      // lane (r = lane % RB, grp = lane / RB) sums GPG = RB / 4 granules of 16 B (4 lane partials each) of row r; the
-      // granule read at step k is (GPG grp + k) ^ r, so that lanes reading different rows hit different granules
-      // (ds_read_b128 without bank conflicts) while every row still gets each of its 16 granules exactly once.
-      constexpr int GPG = RB / 4;
-      const int r = lane & (RB - 1), grp = lane / RB;
-      float tot[NCO];
-#pragma unroll
-      for (int v = 0; v < NCO; ++v) {
-        const float4* row = reinterpret_cast<const float4*>(red + (v * RB + r) * 64);
-        v2f s2 = v2(0.f), s3 = v2(0.f);
-#pragma unroll
-        for (int k = 0; k < GPG; ++k) {
-          const float4 x = row[(GPG * grp + k) ^ r];
-          s2 += v2f{x.x, x.y}; s3 += v2f{x.z, x.w};
-        }
-        s2 += s3;
-        float t = s2.x + s2.y;
-        // the 64 / RB groups of a row sit RB lanes apart: xor-combine them (ds_swizzle below 32, bpermute for 32)
-        if (RB <= 8) t += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, t), 0x201F));    // lane ^ 8
-        if (RB <= 16) t += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, t), 0x401F));   // lane ^ 16
-        t += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, t)));
-        tot[v] = t;
-      }
-      if (lane < n) {
-        float* co = b.CO + ((size_t)gb * NCO) * d.Nc + cb + lane;
-#pragma unroll
-        for (int v = 0; v < NCO; ++v) co[(size_t)v * d.Nc] = tot[v];
-      }
-    } else if (lane < n) {
+  auto flush = [&](long long cb, int n) {      // coalesced store of the staged per-cell sums of the last n <= 64 cells
+    if (lane < n) {
       float* co = b.CO + ((size_t)gb * NCO) * d.Nc + cb + lane;
       co[0] = keep0;
       if (NCO == 3) { co[(size_t)d.Nc] = keep1; co[2 * (size_t)d.Nc] = keep2; }
     }
   };
 
-  if constexpr (DMA) {
-    // LDS-DMA ring: the counts AND the cell record of the next DEPTH-1 cells are in flight into this wave's
-    // private LDS slots (global_load_lds_dwordx4: no VGPR destination, so the prefetch distance is not bounded
-    // by the register file).  The wave reads its own 16 B per load back with ds_read_b128 (lane-linear, no bank
-    // conflicts); the record is read as a broadcast.  Every load of the loop is a DMA, so vmcnt counts slots.
-    const int ncell = (int)(cend - cbeg);
-    float4* ring = lds4 + (size_t)wave * (DEPTH * SLOT4);
-    const unsigned ring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ring;
-    const float* ctp = b.CT + (lane < NRC ? lane * 4 : 0);
-    auto issue = [&](int i, int slot) {
-      const long long c = cbeg + (i < ncell ? i : ncell - 1);   // tail: re-fetch the last cell, keeps the count constant
-      const size_t off = (size_t)c * GBW;
-      float4* dst = ring + slot * SLOT4;
-#pragma unroll
-      for (int q4 = 0; q4 < NV4; ++q4) {
-        if (HAS_S) vc_glds16(Sp + off + 4 * q4, dst + q4 * 64);
-        if (HAS_U) vc_glds16(Up + off + 4 * q4, dst + ((HAS_S ? NV4 : 0) + q4) * 64);
-      }
-      if (VC_DMA_RECMASK) { if (lane < NRC) vc_glds16(ctp + (size_t)c * CTW, dst + NLD * 64); }
-      else vc_glds16(ctp + (size_t)c * CTW, dst + NLD * 64);   // lanes >= NRC re-read chunk 0 into unused LDS
-    };
-    if (ncell > 0) {
-#pragma unroll
-      for (int j = 0; j < DEPTH - 1; ++j) issue(j, j);
-      int slot_r = 0, slot_w = DEPTH - 1;
-      for (int i = 0; i < ncell; ++i) {
-        issue(i + DEPTH - 1, slot_w);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * (NLD + 1)) : "memory");
-        // Inline-asm LDS reads on purpose: hipcc drains vmcnt(0) in front of every LDS read it can see while
-        // an LDS-DMA is in flight, which would serialise the ring.  The lgkmcnt wait is therefore by hand too.
-        const unsigned slot_addr = ring_addr + (unsigned)slot_r * (SLOT4 * 16);
-        const unsigned own = slot_addr + lane * 16;
-        v4f ld[NLD], rc[NRC];
-#pragma unroll
-        for (int j = 0; j < NRC; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(rc[j]) : "v"(slot_addr), "n"(NLD * 1024 + j * 16));
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(ld[j]) : "v"(own), "n"(j * 1024));
-        // LDS returns in order: the record (needed first) is there once only the NLD count reads are outstanding
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(VC_DMA_LATEWAIT ? NLD : 0) : "memory");
-#pragma unroll
-        for (int j = 0; j < NRC; ++j) asm volatile("" : "+v"(rc[j]));      // uses stay behind the wait
-        if (!VC_DMA_LATEWAIT) {
-#pragma unroll
-          for (int j = 0; j < NLD; ++j) asm volatile("" : "+v"(ld[j]));
-        }
-        v2f sv[NP], uv[NP];
-#pragma unroll
-        for (int q4 = 0; q4 < NV4; ++q4) {
-          const v4f s4 = HAS_S ? ld[q4] : v4f{0.f, 0.f, 0.f, 0.f};
-          const v4f u4 = HAS_U ? ld[(HAS_S ? NV4 : 0) + q4] : v4f{0.f, 0.f, 0.f, 0.f};
-          sv[2 * q4] = v2f{s4.x, s4.y}; sv[2 * q4 + 1] = v2f{s4.z, s4.w};
-          uv[2 * q4] = v2f{u4.x, u4.y}; uv[2 * q4 + 1] = v2f{u4.z, u4.w};
-        }
-        v2f c2[2 * NRC];
-#pragma unroll
-        for (int j = 0; j < NRC; ++j) { c2[2 * j] = v2f{rc[j].x, rc[j].y}; c2[2 * j + 1] = v2f{rc[j].z, rc[j].w}; }
-        const VcCellRec<H, NB> rec = vc_cell_from_pairs<H, NB>(c2);
-        cell(sv, uv, rec, i & 63);
-        asm volatile("" ::: "memory");      // the slot's reads stay ahead of the DMA that refills it
-        slot_r = (slot_r + 1 == DEPTH) ? 0 : slot_r + 1;
-        slot_w = (slot_w + 1 == DEPTH) ? 0 : slot_w + 1;
-        if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                        // the ring is reused as the epilogue's staging area
-  } else {
+  {
     // register path: one flat loop over the wave's cells.  PF + 1 register buffers rotate: while buffer j is being
     // processed the loads of the next PF cells are in flight into the others (the tail re-fetches the last cell:
     // no branch around loads); the loop is unrolled PF + 1 times so that every buffer keeps its registers and no
@@ -486,12 +337,10 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
             uv[2 * q4 + 1] = HAS_U ? v2f{u_bf[j][q4].z, u_bf[j][q4].w} : v2(0.f);
           }
           cell(sv, uv, rec_bf[j], i & 63);
-          constexpr int FB = RED_LDS ? RB : 64;      // cells per flush
-          if ((i & (FB - 1)) == FB - 1 || i + 1 == ncell) flush(cbeg + (i & ~(FB - 1)), (i & (FB - 1)) + 1);
+          if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);
         }
       }
     }
-    if (RED_LDS) __syncthreads();             // the rows are reused as the epilogue's staging area
   }
 
   VC_STAMP(2);
