@@ -315,6 +315,12 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
         const long long cn = cbeg + (i < ncell ? i : ncell - 1);
 #pragma unroll
         for (int q4 = 0; q4 < NV4; ++q4) {
+#ifdef VC_DBG_HALF_BYTES      // measurement aid: what a 2-byte count storage could gain (loads half the bytes, results meaningless)
+          if (q4 > 0) { s_bf[j][q4] = s_bf[j][0]; u_bf[j][q4] = u_bf[j][0]; continue; }
+          if (HAS_S) s_bf[j][q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cn * (GBW / 2) - gl / 2 + 4 * q4);
+          if (HAS_U) u_bf[j][q4] = *reinterpret_cast<const float4*>(Up + (size_t)cn * (GBW / 2) - gl / 2 + 4 * q4);
+          continue;
+#endif
           if (HAS_S) s_bf[j][q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cn * GBW + 4 * q4);
           if (HAS_U) u_bf[j][q4] = *reinterpret_cast<const float4*>(Up + (size_t)cn * GBW + 4 * q4);
         }
