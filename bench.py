@@ -13,7 +13,8 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
                 fp32 count matrices read once, 8*Ng*Nc for the joint workload),
   cpu_baseline  the oracle restatement (op-by-op torch fp32 + autograd + ClippedAdam) timed on this
                 host's cores on a bounded sample of the same workload (rank 0, N=1 only),
-  modes         steps/s of the tutorial flow (conditioned, default LRMN guide) next to the headline.
+  modes         steps/s of the tutorial flow (velocity conditioned on the phase fit, default LRMN guide) and of
+                phase_inference at the same size, next to the headline.
 """
 import argparse
 import json
@@ -36,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cells", type=int, default=50000)
     ap.add_argument("--genes", type=int, default=2000)
-    ap.add_argument("--mode", default="vjoint", choices=["vjoint", "vcond", "vcond_mf"])
+    ap.add_argument("--mode", default="vjoint", choices=["vjoint", "vcond", "vcond_mf", "phase"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -168,12 +169,15 @@ def main():
 
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
-    from velocycle_amd.workloads import make_velocity_spec
+    from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
 
     optim = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / 10000), "betas": (0.80, 0.99)}
 
     def build(mode):
-        spec = make_velocity_spec(args.cells, args.genes, mode, 1, 1, seed=0, device=device)
+        if mode == "phase":
+            spec = make_phase_spec(args.cells, args.genes, seed=0, device=device)
+        else:
+            spec = make_velocity_spec(args.cells, args.genes, mode, 1, 1, seed=0, device=device)
         eng = HipEngine(spec, device=device, rank=rank, world_size=world)
         # N > 1: eager launches by default.  Capturing the RCCL all-reduce into the hipGraph works with a 1-rank
         # group on the 1-GPU box (tests/test_hip_svi.py) but cannot be exercised across ranks there, and a step of
@@ -192,14 +196,15 @@ def main():
     if dist_on:
         roof["note"] = f"per-rank kernel on {eng.Nc_local} of {args.cells} cells"
     out = {
-        "metric": "SVI steps/sec, velocity_inference 50k cells x 2k genes",
+        "metric": "SVI steps/sec, %s 50k cells x 2k genes" % ("phase_inference" if args.mode == "phase" else "velocity_inference"),
         "value": round(sps, 2), "unit": "SVI steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic {args.cells} cells x {args.genes} genes velocity_inference, "
+        "config": {"workload": f"synthetic {args.cells} cells x {args.genes} genes " + ("phase_inference" if args.mode == "phase" else "velocity_inference") + ", "
                                + {"vjoint": "mean-field guide, nothing conditioned (every gradient)",
                                   "vcond": "tutorial flow: LRMN guide conditioned on phixy, nu, shape_inv",
-                                  "vcond_mf": "mean-field guide conditioned on phixy, nu, shape_inv"}[args.mode]
+                                  "vcond_mf": "mean-field guide conditioned on phixy, nu, shape_inv",
+                                  "phase": "spliced matrix only, mean-field guide, nothing conditioned"}[args.mode]
                                + ", NegativeBinomial noise, H=1, Hw=1",
                    "cells": args.cells, "genes": args.genes, "mode": args.mode,
                    "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
@@ -212,7 +217,7 @@ def main():
     if not args.no_extra_modes and not dist_on:
         del run, eng, spec
         torch.cuda.empty_cache()
-        for m in [x for x in ("vcond", "vjoint") if x != args.mode]:
+        for m in [x for x in ("vcond", "phase", "vjoint") if x != args.mode][:2]:
             s2, e2, r2 = build(m)
             dt2 = time_steps(r2, args.steps, args.warmup, False, device)
             rf = kernel_roofline(e2, r2, min(args.steps, 100))
