@@ -26,6 +26,10 @@
  *                               for phase_latent_variable_model/guide (phase_inference_model.py:343-395,
  *                               phase_inference_guide.py:10-56) and velocity_latent_variable_model/guide
  *                               [_LRMN] (velocity_inference_model.py:304-471, velocity_inference_guide.py:9-141)
+ *   vc_sample_posterior         Predictive(model, guide=guide, num_samples=n) as used by posterior_sampling
+ *                               (velocity_inference_model.py:189-291, phase_inference_model.py:203-302)
+ *   vc_expected_logs            the ElogS / ElogU / ElogS2 / ElogU2 einsums of posterior_sampling
+ *                               (velocity_inference_model.py:236-258, phase_inference_model.py:248-262)
  *   vc_read_site                the sampled / deterministic sites a trace exposes
  *                               (pyro.deterministic calls at velocity_inference_model.py:327-369)
  */
@@ -219,6 +223,28 @@ int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64_t seed, in
  * likelihood.  The site values are then available through vc_read_site. */
 int vc_sample_guide(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
                     void* hip_stream);
+
+/* n_draws guide draws pushed through the deterministic part of the model, batched on the device: what
+ * `Predictive(model, guide=guide, num_samples=n_draws)` evaluates for the latent and deterministic sites
+ * (velocity_inference_model.py:279-291 / posterior_sampling :189-262, phase_inference_model.py:274-302).  Draw i
+ * uses the Philox stream (seed, step0 + i), i.e. it equals vc_sample_guide(e, params, NULL, seed, step0 + i).
+ * sites[k] is a VC_SITE_* id or VC_DET_PHI / VC_DET_OMEGA; out_dev[k] is DEVICE memory, float
+ * [n_draws][length of that site], filled draw-major.  Asynchronous on hip_stream: nothing is copied to the host. */
+int vc_sample_posterior(vc_engine* e, const float* params, uint64_t seed, int64_t step0, int64_t n_draws,
+                        int n_sites, const int* sites, float* const* out_dev, void* hip_stream);
+
+/* The dense E[log S] / E[log U] summaries that posterior_sampling adds to the posterior
+ * (velocity_inference_model.py:236-258, phase_inference_model.py:248-262), evaluated on the device:
+ *   out_S [g][c] = nu[g,:] . zeta(phi_c) + sum_b Db[b,c] dnu[b,g] + count_factor[c]
+ *   out_S2[g][c] = the same with the constant count factor cf_avg
+ *   out_U [g][c] = -logbeta[g] + log(relu(nu[g,:] . zeta'(phi_c) * omega[c] + gamma[g]) + 1e-5) + out_S[g][c]
+ *   out_U2       = the same on out_S2
+ * Every pointer is DEVICE memory: nu float[Ng][Nh], dnu float[Nb][Ng] (NULL without batches), phi / omega float[Nc_local],
+ * logbeta / gamma float[Ng]; outputs float[Ng][Nc_local] row-major.  omega, logbeta, gamma, out_U, out_U2 are NULL for the
+ * phase model.  count_factor and Db are the ones handed to vc_set_cell_data.  Asynchronous on hip_stream. */
+int vc_expected_logs(vc_engine* e, const float* nu, const float* dnu, const float* phi, const float* omega,
+                     const float* logbeta, const float* gamma, float cf_avg, float* out_S, float* out_S2,
+                     float* out_U, float* out_U2, void* hip_stream);
 
 /* introspection ----------------------------------------------------------------------------- */
 /* Copies the value a site took in the last vc_elbo_grad to host memory (synchronises the stream). */

@@ -78,6 +78,10 @@ EXPORTS = {
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vc_sample_guide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),
+    "vc_sample_posterior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "vc_expected_logs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vc_read_site": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "vc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(vc_stats)]),
     "vc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -203,6 +203,9 @@ vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gp
 
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
                            int Ng, int Nc, int nGB, int gbw, int log1p_transform, hipStream_t st);
+void vc_launch_expected_logs(const VcDims& d, const VcBufs& b, const float* nu, const float* dnu, const float* phi,
+                             const float* omega, const float* logbeta, const float* gamma, float cf_avg, float* out_S,
+                             float* out_S2, float* out_U, float* out_U2, hipStream_t st);
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
                    hipStream_t st);

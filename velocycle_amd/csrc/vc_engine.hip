@@ -702,18 +702,69 @@ extern "C" int vc_sample_guide(vc_engine* e, const float* params, const float* e
   return VC_OK;
 }
 
+// device pointer and length of a readable site (sampled or deterministic), nullptr if the id is unknown / absent
+static const float* site_source(vc_engine* e, int site, long long* sz) {
+  if (site >= 0 && site < VC_SITE_COUNT) {
+    if (!site_exists(e, site)) return nullptr;
+    *sz = site_size(e, site);
+    return e->b.lat[site];
+  }
+  if (site == VC_DET_PHI) { *sz = e->d.Nc; return e->b.lat_phi; }
+  if (site == VC_DET_OMEGA) { *sz = e->d.Nc; return e->b.lat_omega; }
+  if (site == VC_DET_EPS) { *sz = e->layout.eps_total; return e->b.eps_used; }
+  return nullptr;
+}
+
+extern "C" int vc_sample_posterior(vc_engine* e, const float* params, uint64_t seed, int64_t step0, int64_t n_draws,
+                                   int n_sites, const int* sites, float* const* out_dev, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_sample_posterior before vc_finalize");
+  if (!params || n_draws < 0 || n_sites < 0 || (n_sites > 0 && (!sites || !out_dev)))
+    return e->fail(VC_ERR_ARG, "vc_sample_posterior: bad arguments");
+  std::vector<const float*> src(n_sites);
+  std::vector<long long> len(n_sites);
+  for (int k = 0; k < n_sites; ++k) {
+    src[k] = (sites[k] == VC_DET_EPS) ? nullptr : site_source(e, sites[k], &len[k]);
+    if (!src[k]) return e->fail(VC_ERR_ARG, "vc_sample_posterior: site %d not in this model", sites[k]);
+    if (n_draws > 0 && !out_dev[k]) return e->fail(VC_ERR_ARG, "vc_sample_posterior: null output for site %d", sites[k]);
+  }
+  hipStream_t st = (hipStream_t)hip_stream;
+  for (int64_t i = 0; i < n_draws; ++i) {
+    vc_launch_pre(e->d, e->b, params, nullptr, seed, (long long)(step0 + i), nullptr, 0, 0, st);
+    for (int k = 0; k < n_sites; ++k)
+      HIPCHK(e, hipMemcpyAsync(out_dev[k] + (size_t)i * len[k], src[k], sizeof(float) * len[k], hipMemcpyDeviceToDevice, st));
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return e->fail(VC_ERR_HIP, "vc_sample_posterior: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
+extern "C" int vc_expected_logs(vc_engine* e, const float* nu, const float* dnu, const float* phi, const float* omega,
+                                const float* logbeta, const float* gamma, float cf_avg, float* out_S, float* out_S2,
+                                float* out_U, float* out_U2, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_expected_logs before vc_finalize");
+  const VcDims& d = e->d;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  if (!nu || !phi || !out_S || !out_S2) return e->fail(VC_ERR_ARG, "vc_expected_logs: null nu / phi / output");
+  if (d.Nb > 0 && !dnu) return e->fail(VC_ERR_ARG, "vc_expected_logs: the model has batches, dnu is required");
+  if (vel != (out_U != nullptr) || vel != (out_U2 != nullptr))
+    return e->fail(VC_ERR_ARG, "vc_expected_logs: out_U / out_U2 are required for the velocity model and only there");
+  if (vel && (!omega || !logbeta || !gamma)) return e->fail(VC_ERR_ARG, "vc_expected_logs: null omega / logbeta / gamma");
+  if (d.Nc == 0 || d.Ng == 0) return VC_OK;
+  vc_launch_expected_logs(d, e->b, nu, dnu, phi, omega, logbeta, gamma, cf_avg, out_S, out_S2, out_U, out_U2,
+                          (hipStream_t)hip_stream);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return e->fail(VC_ERR_HIP, "vc_expected_logs: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
 extern "C" int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream) {
   if (!e || !host_out) return VC_ERR_ARG;
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_read_site before vc_finalize");
-  const float* src = nullptr;
   long long sz = 0;
-  if (site >= 0 && site < VC_SITE_COUNT) {
-    if (!site_exists(e, site)) return e->fail(VC_ERR_ARG, "vc_read_site: site %d not in this model", site);
-    src = e->b.lat[site]; sz = site_size(e, site);
-  } else if (site == VC_DET_PHI) { src = e->b.lat_phi; sz = e->d.Nc; }
-  else if (site == VC_DET_OMEGA) { src = e->b.lat_omega; sz = e->d.Nc; }
-  else if (site == VC_DET_EPS) { src = e->b.eps_used; sz = e->layout.eps_total; }
-  else return e->fail(VC_ERR_ARG, "vc_read_site: unknown site %d", site);
+  const float* src = site_source(e, site, &sz);
+  if (!src) return e->fail(VC_ERR_ARG, "vc_read_site: site %d unknown or not in this model", site);
   if (n != sz) return e->fail(VC_ERR_ARG, "vc_read_site(%d): expected %lld values, got %lld", site, sz, (long long)n);
   HIPCHK(e, hipStreamSynchronize((hipStream_t)hip_stream));
   HIPCHK(e, hipMemcpy(host_out, src, sizeof(float) * sz, hipMemcpyDeviceToHost));

@@ -731,3 +731,65 @@ void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float*
   hipLaunchKernelGGL(vc_fin_kernel, dim3(1), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots, step,
                      step_dev);
 }
+
+// ---------------------------------------------------------------------------------------------
+// E[log S] / E[log U] summaries of posterior_sampling (velocity_inference_model.py:236-258): one thread per 4
+// consecutive cells of a gene row, float4 stores (write-bound: 4 outputs of Ng*Nc floats).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vc_expected_logs_kernel(const VcDims d, const float* __restrict__ cf,
+                                                               const float* __restrict__ Dbm,
+                                                               const float* __restrict__ nu, const float* __restrict__ dnu,
+                                                               const float* __restrict__ phi, const float* __restrict__ omega,
+                                                               const float* __restrict__ logbeta, const float* __restrict__ gamma,
+                                                               float cf_avg, float* __restrict__ oS, float* __restrict__ oS2,
+                                                               float* __restrict__ oU, float* __restrict__ oU2) {
+  const int g = blockIdx.y;
+  const long long c0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c0 >= d.Nc) return;
+  float nug[2 * 3 + 1];
+  for (int h = 0; h < d.Nh; ++h) nug[h] = nu[(size_t)g * d.Nh + h];
+  const float lb = logbeta ? logbeta[g] : 0.f, gm = gamma ? gamma[g] : 0.f;
+  float s[4], s2[4], u[4], u2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long c = c0 + j < d.Nc ? c0 + j : d.Nc - 1;
+    const float p = phi[c];
+    float es = nug[0], dd = 0.f;
+    for (int k = 1; k <= d.H; ++k) {
+      float sn, cs;
+      sincosf((float)k * p, &sn, &cs);
+      es += nug[2 * k - 1] * sn + nug[2 * k] * cs;
+      dd += (float)k * (nug[2 * k - 1] * cs - nug[2 * k] * sn);
+    }
+    for (int q = 0; q < d.Nb; ++q) es += Dbm[(size_t)q * d.Nc + c] * dnu[(size_t)q * d.Ng + g];
+    s[j] = es + cf[c];
+    s2[j] = es + cf_avg;
+    if (oU) {
+      const float core = -lb + logf(fmaxf(dd * omega[c] + gm, 0.f) + 1e-5f);
+      u[j] = core + s[j];
+      u2[j] = core + s2[j];
+    }
+  }
+  const size_t o = (size_t)g * d.Nc + c0;
+  if (c0 + 3 < d.Nc && (d.Nc & 3) == 0) {
+    *reinterpret_cast<float4*>(oS + o) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(oS2 + o) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    if (oU) {
+      *reinterpret_cast<float4*>(oU + o) = make_float4(u[0], u[1], u[2], u[3]);
+      *reinterpret_cast<float4*>(oU2 + o) = make_float4(u2[0], u2[1], u2[2], u2[3]);
+    }
+  } else {
+    for (int j = 0; j < 4 && c0 + j < d.Nc; ++j) {
+      oS[o + j] = s[j]; oS2[o + j] = s2[j];
+      if (oU) { oU[o + j] = u[j]; oU2[o + j] = u2[j]; }
+    }
+  }
+}
+
+void vc_launch_expected_logs(const VcDims& d, const VcBufs& b, const float* nu, const float* dnu, const float* phi,
+                             const float* omega, const float* logbeta, const float* gamma, float cf_avg, float* out_S,
+                             float* out_S2, float* out_U, float* out_U2, hipStream_t st) {
+  const unsigned nbx = (unsigned)((d.Nc + 1023) / 1024);
+  hipLaunchKernelGGL(vc_expected_logs_kernel, dim3(nbx, d.Ng), dim3(256), 0, st, d, b.cf, b.Dbm, nu, dnu, phi, omega,
+                     logbeta, gamma, cf_avg, out_S, out_S2, out_U, out_U2);
+}

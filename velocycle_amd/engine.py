@@ -264,22 +264,55 @@ class HipEngine:
             self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(eps.data_ptr()) if eps is not None else None,
             C.c_uint64(seed), C.c_int64(step), self._stream()))
 
+    def _site_id_shape(self, name: str):
+        if name in _lib.SITE_ID:
+            shape = (self.Nc_local, 2) if name == "ϕxy" else self.spec.site_shape(name)
+            return _lib.SITE_ID[name], tuple(shape)
+        if name == "ϕ":
+            return _lib.DET_PHI, (self.Nc_local,)
+        if name == "ω":
+            return _lib.DET_OMEGA, (self.Nc_local,)
+        if name == "eps":
+            return _lib.DET_EPS, (self.eps_total,)
+        raise KeyError(name)
+
+    def sample_posterior(self, names, n_draws: int, seed: int = 0, step0: int = 0) -> Dict[str, torch.Tensor]:
+        """n_draws guide draws + deterministic sites, batched on the device: {site: (n_draws, *site shape) DEVICE
+        tensor}.  Draw i equals sample_guide(seed=seed, step=step0 + i)."""
+        names = list(names)
+        ids, outs = [], {}
+        for n in names:
+            sid, shape = self._site_id_shape(n)
+            ids.append(sid)
+            outs[n] = torch.empty((n_draws,) + shape, dtype=torch.float32, device=self.device)
+        id_arr = (C.c_int * len(ids))(*ids)
+        ptr_arr = (C.c_void_p * len(ids))(*[outs[n].data_ptr() for n in names])
+        self._check(self.lib.vc_sample_posterior(
+            self._h, C.c_void_p(self.params.data_ptr()), C.c_uint64(seed), C.c_int64(step0), C.c_int64(n_draws),
+            len(ids), id_arr, ptr_arr, self._stream()))
+        return outs
+
+    def expected_logs(self, nu, phi, cf_avg: float, dnu=None, omega=None, logbeta=None, gamma=None):
+        """ElogS, ElogS2[, ElogU, ElogU2] of posterior_sampling as (Ng, Nc_local) DEVICE tensors (vc_expected_logs)."""
+        dev, sp = self.device, self.spec
+        f = lambda t, shape: None if t is None else torch.as_tensor(t, dtype=torch.float32).reshape(shape).to(dev).contiguous()
+        nu, phi = f(nu, (sp.Ng, sp.Nh)), f(phi, (self.Nc_local,))
+        dnu = f(dnu, (sp.Nb, sp.Ng)) if sp.with_delta_nu else None
+        vel = sp.kind == "velocity"
+        omega, logbeta, gamma = (f(omega, (self.Nc_local,)), f(logbeta, (sp.Ng,)), f(gamma, (sp.Ng,))) if vel else (None,) * 3
+        outs = [torch.empty((sp.Ng, self.Nc_local), dtype=torch.float32, device=dev) for _ in range(4 if vel else 2)]
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(self.lib.vc_expected_logs(
+            self._h, p(nu), p(dnu), p(phi), p(omega), p(logbeta), p(gamma), C.c_float(cf_avg), p(outs[0]), p(outs[1]),
+            p(outs[2]) if vel else None, p(outs[3]) if vel else None, self._stream()))
+        self._keep = (nu, dnu, phi, omega, logbeta, gamma)       # inputs must outlive the asynchronous launch
+        return outs
+
     def loss(self) -> float:
         return float(self.loss_dev.item())
 
     def read_site(self, name: str) -> torch.Tensor:
-        if name in _lib.SITE_ID:
-            sid, shape = _lib.SITE_ID[name], self.spec.site_shape(name)
-            if name == "ϕxy":
-                shape = (self.Nc_local, 2)
-        elif name == "ϕ":
-            sid, shape = _lib.DET_PHI, (self.Nc_local,)
-        elif name == "ω":
-            sid, shape = _lib.DET_OMEGA, (self.Nc_local,)
-        elif name == "eps":
-            sid, shape = _lib.DET_EPS, (self.eps_total,)
-        else:
-            raise KeyError(name)
+        sid, shape = self._site_id_shape(name)
         out = torch.empty(shape, dtype=torch.float32)
         self._check(self.lib.vc_read_site(self._h, sid, C.c_void_p(out.data_ptr()), out.numel(), self._stream()))
         return out

@@ -154,30 +154,36 @@ class _FitBase:
         eng, sp = self.engine, self.spec
         base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         names = [n for n in ("ν", "Δν", "ϕxy", "shape_inv", "logγg", "logβg", "νω", "rho_real")
-                 if self._site_exists(n)]
-        acc = {n: [] for n in names + ["ϕ"] + (["ω"] if sp.kind == "velocity" else [])}
-        for i in range(num_samples):
-            eng.sample_guide(seed=base, step=i)
-            for n in acc:
-                acc[n].append(eng.read_site(n))
-        out = {n: torch.stack(v) for n, v in acc.items()}
+                 if self._site_exists(n)] + ["ϕ"] + (["ω"] if sp.kind == "velocity" else [])
         n = num_samples
-        res = {"ν": out["ν"].reshape(n, sp.Ng, 1, sp.Nh), "ϕxy": out["ϕxy"].reshape(n, sp.Nc, 2), "ϕ": out["ϕ"]}
-        res["ζ"] = torch.stack([torch_fourier_basis(p, sp.H, der=0) for p in out["ϕ"]])
-        if "shape_inv" in out:
-            res["shape_inv"] = out["shape_inv"].reshape(n, sp.Ng, 1)
-        if "Δν" in out:
-            res["Δν"] = out["Δν"].reshape((n, sp.Nb, sp.Ng, 1) if sp.kind == "phase" else (n, sp.Nb, 1, 1, sp.Ng, 1))
+        # all draws in one library call (vc_sample_posterior); the sites stay on the device until they are complete
+        dev = eng.sample_posterior(names, n, seed=base, step0=0)
+        want = (lambda k: True) if rs is None else (lambda k: k in rs)
+
+        def basis(num_harmonics, der):          # torch_fourier_basis over every draw at once, (n, Nc, Nh)
+            return torch_fourier_basis(dev["ϕ"].reshape(-1), num_harmonics, der=der,
+                                       device=dev["ϕ"].device).reshape(n, sp.Nc, -1)
+
+        res = {}
+        if want("ν"): res["ν"] = dev["ν"].reshape(n, sp.Ng, 1, sp.Nh).cpu()
+        if want("ϕxy"): res["ϕxy"] = dev["ϕxy"].reshape(n, sp.Nc, 2).cpu()
+        if want("ϕ"): res["ϕ"] = dev["ϕ"].cpu()
+        if want("ζ"): res["ζ"] = basis(sp.H, 0).cpu()
+        if "shape_inv" in dev and want("shape_inv"):
+            res["shape_inv"] = dev["shape_inv"].reshape(n, sp.Ng, 1).cpu()
+        if "Δν" in dev and want("Δν"):
+            res["Δν"] = dev["Δν"].reshape((n, sp.Nb, sp.Ng, 1) if sp.kind == "phase" else (n, sp.Nb, 1, 1, sp.Ng, 1)).cpu()
         if sp.kind == "velocity":
-            res["logγg"] = out["logγg"].reshape(n, sp.Ng, 1)
-            res["γg"] = res["logγg"].exp()
-            res["logβg"] = out["logβg"].reshape(n, sp.Ng, 1)
-            res["νω"] = out["νω"].reshape(n, sp.Nx, sp.Nhw, 1, 1)
-            res["ζ_dϕ"] = torch.stack([torch_fourier_basis(p, sp.H, der=1) for p in out["ϕ"]])
-            res["ζω"] = torch.stack([torch_fourier_basis(p, sp.Hw, der=0).T for p in out["ϕ"]])
-            res["ω"] = out["ω"].reshape(n, 1, sp.Nc)
-            if "rho_real" in out:
-                res["rho_real"] = out["rho_real"].reshape(n, sp.Ng, 1)
+            if want("logγg") or want("γg"):
+                res["logγg"] = dev["logγg"].reshape(n, sp.Ng, 1).cpu()
+                res["γg"] = res["logγg"].exp()
+            if want("logβg"): res["logβg"] = dev["logβg"].reshape(n, sp.Ng, 1).cpu()
+            if want("νω"): res["νω"] = dev["νω"].reshape(n, sp.Nx, sp.Nhw, 1, 1).cpu()
+            if want("ζ_dϕ"): res["ζ_dϕ"] = basis(sp.H, 1).cpu()
+            if want("ζω"): res["ζω"] = basis(sp.Hw, 0).transpose(1, 2).contiguous().cpu()
+            if want("ω"): res["ω"] = dev["ω"].reshape(n, 1, sp.Nc).cpu()
+            if "rho_real" in dev and want("rho_real"):
+                res["rho_real"] = dev["rho_real"].reshape(n, sp.Ng, 1).cpu()
         if rs is not None:
             res = {k: v for k, v in res.items() if k in rs}
         return res
@@ -212,13 +218,11 @@ class PhaseFitModel(_FitBase):
         sp, mp = self.spec, self.metaparams
         post = self._binned_posterior()
         self.metaparams_avg = mp._replace(count_factor=torch.full_like(mp.count_factor, float(mp.count_factor.mean())))
-        ν = pyro_compat.param("ν_locs")
-        ζ = torch_fourier_basis(self.phase_pyro.phis, num_harmonics=sp.H, der=0)
-        base = torch.einsum("...gch,ch->gc", ν, ζ)
-        if sp.with_delta_nu:
-            base = base + torch.einsum("bgc,bgc->gc", mp.Db.cpu(), pyro_compat.param("Δν_locs"))
-        post["ElogS"] = (base + mp.count_factor.cpu()).squeeze()
-        post["ElogS2"] = (base + self.metaparams_avg.count_factor.cpu()).squeeze()
+        # ElogS = ν_locs·ζ(ϕ) + Db·Δν_locs + count_factor (ElogS2: with the averaged count factor), on the device
+        dnu = pyro_compat.param("Δν_locs") if sp.with_delta_nu else None
+        S, S2 = self.engine.expected_logs(pyro_compat.param("ν_locs"), self.phase_pyro.phis,
+                                          float(self.metaparams_avg.count_factor.reshape(-1)[0]), dnu=dnu)
+        post["ElogS"], post["ElogS2"] = S.cpu().squeeze(), S2.cpu().squeeze()
         self.posterior = post
 
 
@@ -252,23 +256,19 @@ class VelocityFitModel(_FitBase):
         sp, mp = self.spec, self.metaparams
         post = self._binned_posterior()
         self.metaparams_avg = mp._replace(count_factor=torch.full_like(mp.count_factor, float(mp.count_factor.float().mean())))
-        ν = pyro_compat.param("ν_locs")
         phis = self.phase_pyro.phis
-        ζ = torch_basis(phis, der=0, kind="fourier", num_harmonics=sp.H)
-        base = torch.einsum("...gch,ch->gc", ν, ζ)
-        if sp.with_delta_nu:
-            base = base + torch.einsum("bxhgc,bxhgc->gc", mp.Db.cpu().float(), pyro_compat.param("Δν_locs"))
-        ElogS = base + mp.count_factor.cpu()
-        ElogS2 = base + self.metaparams_avg.count_factor.cpu()
-        ζ_dϕ = torch_basis(phis, der=1, kind="fourier", num_harmonics=sp.H)
-        γg = post["γg"].mean(0).squeeze().unsqueeze(-1)
-        logβg = post["logβg"].mean(0).squeeze().unsqueeze(-1)
+        γg = post["γg"].mean(0).reshape(-1)
+        logβg = post["logβg"].mean(0).reshape(-1)
         ζω = torch_basis(phis, der=0, kind="fourier", num_harmonics=sp.Hw).T
         νω = post["νω"].mean(0)
-        ω = torch.einsum("...xhgc,hc,xhgc->gc", [νω, ζω, mp.D.cpu().float()])
-        core = -logβg + torch.log(torch.relu(torch.einsum("gch,ch->gc", ν, ζ_dϕ) * ω + γg) + 1e-5)
-        post["ElogS"], post["ElogU"] = ElogS.squeeze(), (core + ElogS).squeeze()
-        post["ElogS2"], post["ElogU2"] = ElogS2.squeeze(), (core + ElogS2).squeeze()
+        ω = torch.einsum("...xhgc,hc,xhgc->gc", [νω, ζω, mp.D.cpu().float()]).reshape(-1)     # one speed per cell (N2)
+        dnu = pyro_compat.param("Δν_locs") if sp.with_delta_nu else None
+        # the four dense (Ng, Nc) summaries of velocity_inference_model.py:236-258 in one device pass
+        S, S2, U, U2 = self.engine.expected_logs(pyro_compat.param("ν_locs"), phis,
+                                                 float(self.metaparams_avg.count_factor.reshape(-1)[0]), dnu=dnu,
+                                                 omega=ω, logbeta=logβg, gamma=γg)
+        post["ElogS"], post["ElogU"] = S.cpu().squeeze(), U.cpu().squeeze()
+        post["ElogS2"], post["ElogU2"] = S2.cpu().squeeze(), U2.cpu().squeeze()
         self.posterior = post
         if sp.guide == "lrmn":                      # velocity_inference_model.py:264-274
             self.log_gammas = post["logγg"].mean(0).squeeze().numpy().T
