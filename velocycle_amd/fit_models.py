@@ -148,15 +148,13 @@ class _FitBase:
         self.cycle_pyro, self.phase_pyro = new_cycle, new_phase
         return par
 
-    def sample_posterior(self, num_samples=1, rs=None, mp=None, take_mean=True):
-        """`Predictive(model, guide=guide, num_samples=n, return_sites=rs)`: n guide draws pushed through
-        the model; returns {site: (n, ...) CPU tensor} with Pyro's site shapes."""
+    def _draw_sites(self, n, rs=None) -> Dict[str, torch.Tensor]:
+        """n guide draws pushed through the deterministic part of the model, as DEVICE tensors with Pyro's site
+        shapes (leading dimension n).  One library call (vc_sample_posterior) makes all n draws."""
         eng, sp = self.engine, self.spec
         base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        names = [n for n in ("ν", "Δν", "ϕxy", "shape_inv", "logγg", "logβg", "νω", "rho_real")
-                 if self._site_exists(n)] + ["ϕ"] + (["ω"] if sp.kind == "velocity" else [])
-        n = num_samples
-        # all draws in one library call (vc_sample_posterior); the sites stay on the device until they are complete
+        names = [k for k in ("ν", "Δν", "ϕxy", "shape_inv", "logγg", "logβg", "νω", "rho_real")
+                 if self._site_exists(k)] + ["ϕ"] + (["ω"] if sp.kind == "velocity" else [])
         dev = eng.sample_posterior(names, n, seed=base, step0=0)
         want = (lambda k: True) if rs is None else (lambda k: k in rs)
 
@@ -165,28 +163,30 @@ class _FitBase:
                                        device=dev["ϕ"].device).reshape(n, sp.Nc, -1)
 
         res = {}
-        if want("ν"): res["ν"] = dev["ν"].reshape(n, sp.Ng, 1, sp.Nh).cpu()
-        if want("ϕxy"): res["ϕxy"] = dev["ϕxy"].reshape(n, sp.Nc, 2).cpu()
-        if want("ϕ"): res["ϕ"] = dev["ϕ"].cpu()
-        if want("ζ"): res["ζ"] = basis(sp.H, 0).cpu()
+        if want("ν"): res["ν"] = dev["ν"].reshape(n, sp.Ng, 1, sp.Nh)
+        if want("ϕxy"): res["ϕxy"] = dev["ϕxy"].reshape(n, sp.Nc, 2)
+        if want("ϕ"): res["ϕ"] = dev["ϕ"]
+        if want("ζ"): res["ζ"] = basis(sp.H, 0)
         if "shape_inv" in dev and want("shape_inv"):
-            res["shape_inv"] = dev["shape_inv"].reshape(n, sp.Ng, 1).cpu()
+            res["shape_inv"] = dev["shape_inv"].reshape(n, sp.Ng, 1)
         if "Δν" in dev and want("Δν"):
-            res["Δν"] = dev["Δν"].reshape((n, sp.Nb, sp.Ng, 1) if sp.kind == "phase" else (n, sp.Nb, 1, 1, sp.Ng, 1)).cpu()
+            res["Δν"] = dev["Δν"].reshape((n, sp.Nb, sp.Ng, 1) if sp.kind == "phase" else (n, sp.Nb, 1, 1, sp.Ng, 1))
         if sp.kind == "velocity":
-            if want("logγg") or want("γg"):
-                res["logγg"] = dev["logγg"].reshape(n, sp.Ng, 1).cpu()
-                res["γg"] = res["logγg"].exp()
-            if want("logβg"): res["logβg"] = dev["logβg"].reshape(n, sp.Ng, 1).cpu()
-            if want("νω"): res["νω"] = dev["νω"].reshape(n, sp.Nx, sp.Nhw, 1, 1).cpu()
-            if want("ζ_dϕ"): res["ζ_dϕ"] = basis(sp.H, 1).cpu()
-            if want("ζω"): res["ζω"] = basis(sp.Hw, 0).transpose(1, 2).contiguous().cpu()
-            if want("ω"): res["ω"] = dev["ω"].reshape(n, 1, sp.Nc).cpu()
+            if want("logγg"): res["logγg"] = dev["logγg"].reshape(n, sp.Ng, 1)
+            if want("γg"): res["γg"] = dev["logγg"].reshape(n, sp.Ng, 1).exp()
+            if want("logβg"): res["logβg"] = dev["logβg"].reshape(n, sp.Ng, 1)
+            if want("νω"): res["νω"] = dev["νω"].reshape(n, sp.Nx, sp.Nhw, 1, 1)
+            if want("ζ_dϕ"): res["ζ_dϕ"] = basis(sp.H, 1)
+            if want("ζω"): res["ζω"] = basis(sp.Hw, 0).transpose(1, 2)
+            if want("ω"): res["ω"] = dev["ω"].reshape(n, 1, sp.Nc)
             if "rho_real" in dev and want("rho_real"):
-                res["rho_real"] = dev["rho_real"].reshape(n, sp.Ng, 1).cpu()
-        if rs is not None:
-            res = {k: v for k, v in res.items() if k in rs}
+                res["rho_real"] = dev["rho_real"].reshape(n, sp.Ng, 1)
         return res
+
+    def sample_posterior(self, num_samples=1, rs=None, mp=None, take_mean=True):
+        """`Predictive(model, guide=guide, num_samples=n, return_sites=rs)`: n guide draws pushed through
+        the model; returns {site: (n, ...) CPU tensor} with Pyro's site shapes."""
+        return {k: v.cpu() for k, v in self._draw_sites(num_samples, rs).items()}
 
     def _site_exists(self, n):
         sp = self.spec
@@ -195,9 +195,17 @@ class _FitBase:
                 "rho_real": sp.kind == "velocity" and sp.guide == "lrmn"}[n]
 
     def _binned_posterior(self):
+        """num_samples draws in bins of n_per_bin (the reference's memory bound, velocity_inference_model.py:198-232);
+        every bin is copied from the device straight into its rows of the result."""
         nbins = int(np.ceil(self.num_samples / self.n_per_bin))
-        parts = [self.sample_posterior(num_samples=self.n_per_bin) for _ in range(nbins)]
-        return {k: torch.vstack([p[k] for p in parts]) for k in parts[0]}
+        out = {}
+        for i in range(nbins):
+            part = self._draw_sites(self.n_per_bin)
+            for k, v in part.items():
+                if k not in out:
+                    out[k] = torch.empty((nbins * self.n_per_bin,) + tuple(v.shape[1:]), dtype=v.dtype)
+                out[k][i * self.n_per_bin:(i + 1) * self.n_per_bin].copy_(v)
+        return out
 
     def check_model(self):
         st = self.engine.stats if self.engine else {}
