@@ -159,13 +159,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and not dist_on:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    device = torch.device(f"cuda:{local_rank}")
+    # test hook (tests/test_hip_multiproc.py): VC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and exchanges through
+    # gloo, so that the N > 1 path can be exercised end to end on a 1-GPU box.  Never set in a measured run.
+    one_device = os.environ.get("VC_BENCH_ONE_DEVICE", "0") == "1"
+    device = torch.device("cuda:0" if one_device else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if one_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
@@ -208,7 +214,7 @@ def main():
                                + ", NegativeBinomial noise, H=1, Hw=1",
                    "cells": args.cells, "genes": args.genes, "mode": args.mode,
                    "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
-                   "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + ("RCCL all-reduce -> " if dist_on else "")
+                   "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + (("gloo (test hook) " if one_device else "RCCL ") + "all-reduce -> " if dist_on else "")
                             + f"ClippedAdam ({run.adam_impl}), " + ("hipGraph replay" if run.use_graph else "eager launches"))},
         "roofline": roof,
         "loss_first_last": [losses[0], losses[-1]],

@@ -1,0 +1,49 @@
+"""GPU, two real processes: bench.py's N > 1 path end to end on a 1-GPU box.
+
+torch.distributed.run starts two ranks; the test hook VC_BENCH_ONE_DEVICE=1 puts both on cuda:0 and exchanges the
+gene-level gradient buffer through gloo instead of RCCL (RCCL refuses two ranks on one device).  Everything else is the
+path the driver launches on 8 GPUs: rendezvous, cell sharding with offsets, Philox eps sliced per shard, the all-reduce
+between the gradient kernels and the optimiser kernel, barrier + max-over-ranks timing, one JSON line from rank 0.
+The loss trajectory must equal the single-process run (shard-count invariance across processes)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIZE = ["--cells", "6000", "--genes", "300", "--steps", "30", "--warmup", "5"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_process_bench_matches_single_process():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, "bench.py", *SIZE, "--no-cpu-baseline", "--no-extra-modes", "--no-graph"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = _json_line(one.stdout)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", *SIZE],
+                         cwd=ROOT, env=dict(env, VC_BENCH_ONE_DEVICE="1"), capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j2 = _json_line(two.stdout)
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["steps"] == 30 and j2["scaling"] == "strong"
+    assert "all-reduce" in j2["config"]["step"] and "cpu_baseline" not in j2
+    assert j2["roofline"]["algorithmic_bytes_per_launch"] * 2 == j1["roofline"]["algorithmic_bytes_per_launch"]
+    for a, b in zip(j1["loss_first_last"], j2["loss_first_last"]):
+        assert abs(a - b) <= 1e-6 * abs(a), (j1["loss_first_last"], j2["loss_first_last"])
+    assert j1["loss_first_last"][1] < j1["loss_first_last"][0]
