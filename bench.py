@@ -30,6 +30,14 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 
+def baseline_metric():
+    """BASELINE.json's metric string (the file travels with the repo); literal fallback if it is missing."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "SVI steps/sec + ELBO-match, velocity_inference 50k cells\u00d72k genes, 1/2/4/8 GPU"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,13 +102,14 @@ def kernel_roofline(engine, run, steps):
             "method": "hipEvents around the kernel over eager SVI steps run right after the timed region"}
 
 
-def cpu_baseline(args, mode):
+def cpu_baseline(args, mode, device=None):
     """Oracle restatement timed on the host: same workload, first `cpu_sample_cells` cells, scaled."""
     from oracle import velocycle_oracle as orc
     from tests import helpers as H
-    from velocycle_amd.workloads import make_velocity_spec
+    from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
     nsample = min(args.cpu_sample_cells, args.cells)
-    spec = make_velocity_spec(nsample, args.genes, mode, 1, 1, seed=0, device="cpu")
+    spec = (make_phase_spec(nsample, args.genes, seed=0, device="cpu") if mode == "phase"
+            else make_velocity_spec(nsample, args.genes, mode, 1, 1, seed=0, device="cpu"))
     kw = {}
     for k, v in spec.__dict__.items():
         if k == "truth":
@@ -111,6 +120,23 @@ def cpu_baseline(args, mode):
     first = orc.draw_eps(p, gen)
     params = orc.init_params(p, first.get("_cov_factor_draw"))
     opt = orc.ClippedAdam({"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)})
+
+    # ELBO-match (the other half of BASELINE.json's metric): the HIP path and the oracle on identical (params, eps)
+    eps0 = orc.draw_eps(p, gen)
+    loss_cpu, _, _, _ = orc.loss_and_grads(p, params, eps0)
+    elbo_match = None
+    if device is not None:
+        from velocycle_amd.engine import HipEngine
+        eng = HipEngine(spec, device=device)
+        eng.set_params({k: v.float() for k, v in params.items()})
+        eng.elbo_grad(eps=eng.pack_eps({k: v.float() for k, v in eps0.items() if not k.startswith("_")}))
+        torch.cuda.synchronize(device)
+        loss_hip = eng.loss()
+        eng.close()
+        elbo_match = {"loss_hip": loss_hip, "loss_cpu_port": float(loss_cpu),
+                      "rel_err": abs(loss_hip - float(loss_cpu)) / abs(float(loss_cpu)),
+                      "note": "one ELBO evaluation on the CPU sample with identical params and eps; the port runs in "
+                              "float32, so this bounds both sides' rounding (tests compare against float64 at 1e-5)"}
 
     def one():
         nonlocal params
@@ -142,7 +168,7 @@ def cpu_baseline(args, mode):
     sps_sample = n / dt
     scale = nsample / args.cells
     return {"value": round(sps_sample * scale, 4), "unit": "SVI steps/s", "cores": best_nt,
-            "kind": "port",
+            "kind": "port", "elbo_match": elbo_match,
             "sample": f"oracle (op-by-op torch fp32 + autograd + ClippedAdam) on the first {nsample} of "
                       f"{args.cells} cells x {args.genes} genes, {n} steps in {dt:.1f}s = {sps_sample:.3f} steps/s, "
                       f"scaled by {scale:.3f} (cost is linear in cells); {best_nt} torch threads = fastest of sweep "
@@ -202,7 +228,7 @@ def main():
     if dist_on:
         roof["note"] = f"per-rank kernel on {eng.Nc_local} of {args.cells} cells"
     out = {
-        "metric": "SVI steps/sec, %s 50k cells x 2k genes" % ("phase_inference" if args.mode == "phase" else "velocity_inference"),
+        "metric": baseline_metric() if args.mode != "phase" else "SVI steps/sec, phase_inference",
         "value": round(sps, 2), "unit": "SVI steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -234,7 +260,7 @@ def main():
             torch.cuda.empty_cache()
         out["modes"] = extra
     if rank == 0 and not dist_on and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, args.mode)
+        out["cpu_baseline"] = cpu_baseline(args, args.mode, device)
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
