@@ -557,31 +557,36 @@ __global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcB
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, const float* P, float* G,
                                              double* loss_dev, long long loss_slots, long long step) {
-  __shared__ double sm_red[16];
+  // 1 + NW independent reductions (the loss; per angular-speed coefficient sum_c d loglik/d omega_c * D * zeta_omega),
+  // one wave each, all in flight at once, fixed order -> deterministic; a single barrier ends the phase
+  __shared__ double sm_loss;
   __shared__ float sm_up[VC_MAX_NW];
-  const int t = threadIdx.x;
-  double s = 0.0;
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int nlp = d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene;
-  for (int i = t; i < nlp; i += 256) s += b.LP[i];
-  for (int i = t; i < d.n_main_wg; i += 256) s -= (double)b.LO[i];   // loss = -loglik
-  const double tot = vc_block_sum_d(s, sm_red);
+  const int nred = 1 + (d.model == VC_MODEL_VELOCITY ? d.NW : 0);
+  for (int r = wv; r < nred; r += 4) {
+    double s = 0.0;
+    if (r == 0) {
+      for (int i = lane; i < nlp; i += 64) s += b.LP[i];
+      for (int i = lane; i < d.n_main_wg; i += 64) s -= (double)b.LO[i];   // loss = -loglik
+    } else {
+      for (int i = lane; i < d.nb_post_cell; i += 64) s += (double)b.PW[(size_t)i * d.NW + (r - 1)];
+    }
+    s = vc_wave_sum_d(s);
+    if (lane == 0) {
+      if (r == 0) sm_loss = s;
+      else sm_up[r - 1] = (float)s;
+    }
+  }
+  __syncthreads();
   if (t == 0) {
-    const double loss = tot + b.const_loss;
+    const double loss = sm_loss + b.const_loss;
     if (loss_dev) loss_dev[loss_slots > 1 ? (step % loss_slots) : 0] = loss;
     const float hi = (float)loss;
     G[0] = hi;
     G[1] = (float)(loss - (double)hi);
     G[2] = 0.f;
     G[3] = 0.f;
-  }
-  if (d.model == VC_MODEL_VELOCITY) {
-    for (int j = 0; j < d.NW; ++j) {     // deterministic block reduction of sum_c d loglik/d omega_c * D * zeta_omega
-      double u = 0.0;
-      for (int i = t; i < d.nb_post_cell; i += 256) u += (double)b.PW[(size_t)i * d.NW + j];
-      const double r = vc_block_sum_d(u, sm_red);
-      if (t == 0) sm_up[j] = (float)r;
-    }
-    __syncthreads();
   }
   if (d.model == VC_MODEL_VELOCITY && t < d.NW) {
     const int j = t;
@@ -625,8 +630,8 @@ __global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBuf
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
-                                                      long long n, double lr0, double lrd, double b1, double b2,
-                                                      float eps, float clip, long long t_host,
+                                                      long long n, double lr0, double lrd /* log */, double b1, double b2,
+                                                      double b1l, double b2l, float eps, float clip, long long t_host,
                                                       const long long* __restrict__ t_dev,
                                                       const float* __restrict__ loss_hdr,
                                                       double* __restrict__ loss_ring, long long loss_slots) {
@@ -636,9 +641,9 @@ __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, con
     const long long t1 = t_dev ? *t_dev : t_host;
     loss_ring[loss_slots > 1 ? ((t1 - 1) % loss_slots) : 0] = (double)loss_hdr[0] + (double)loss_hdr[1];
   }
-  if (threadIdx.x == 0) {      // three fp64 pow() once per block instead of once per thread
+  if (threadIdx.x == 0) {      // lrd^t, b^t as exp(t log .) once per block (the logs come from the host)
     const double td = (double)(t_dev ? *t_dev : t_host);
-    s_step = (float)(lr0 * pow(lrd, td) * sqrt(1.0 - pow(b2, td)) / (1.0 - pow(b1, td)));
+    s_step = (float)(lr0 * exp(td * lrd) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));   // lrd, b1l, b2l: logs
   }
   __syncthreads();
   const float step_size = s_step;
@@ -658,13 +663,14 @@ __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, con
 __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const VcBufs b, float* P, float* G,
                                                           double* loss_dev, long long loss_slots, long long step_host,
                                                           const long long* step_dev, float* __restrict__ m,
-                                                          float* __restrict__ v, double lr0, double lrd, double b1,
-                                                          double b2, float eps, float clip, int header, long long total) {
+                                                          float* __restrict__ v, double lr0, double lrd /* log */,
+                                                          double b1, double b2, double b1l, double b2l, float eps, float clip,
+                                                          int header, long long total) {
   __shared__ float s_step;
   const long long t1 = step_dev ? *step_dev : step_host + 1;        // 1-based optimiser step
   if (threadIdx.x == 0) {
     const double td = (double)t1;
-    s_step = (float)(lr0 * pow(lrd, td) * sqrt(1.0 - pow(b2, td)) / (1.0 - pow(b1, td)));
+    s_step = (float)(lr0 * exp(td * lrd) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));   // lrd, b1l, b2l: logs
   }
   // parameters whose gradient K_fin produces: nu_omega (mean-field) or the LRMN tail rows
   long long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -708,7 +714,7 @@ void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* 
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(vc_fin_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots,
-                     step, step_dev, m, v, lr0, lrd, b1, b2, eps, clip, header, total);
+                     step, step_dev, m, v, lr0, log(lrd), b1, b2, log(b1), log(b2), eps, clip, header, total);
 }
 
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
@@ -717,8 +723,8 @@ void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, d
   long long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(vc_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr0, lrd, b1, b2, eps,
-                     clip, t_host, t_dev, loss_hdr, loss_ring, loss_slots);
+  hipLaunchKernelGGL(vc_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr0, log(lrd), b1, b2, log(b1),
+                     log(b2), eps, clip, t_host, t_dev, loss_hdr, loss_ring, loss_slots);
 }
 
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,
