@@ -11,7 +11,7 @@ for ent in "$@"; do
     last="$fl"
   fi
   for mode in ${MODES:-vjoint vcond}; do
-    env $ev rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abm_${n}_$mode -- python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extra-modes --mode $mode > gpurun_out/abm_${n}_$mode.log 2>&1
+    env $ev rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abm_${n}_$mode -- python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extra-modes --mode $mode ${BENCH_ARGS} > gpurun_out/abm_${n}_$mode.log 2>&1
     python - <<PY
 import csv, glob, json
 f = glob.glob("gpurun_out/abm_${n}_$mode/**/*kernel_stats.csv", recursive=True)[0]

@@ -27,6 +27,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef VC_SCALAR_REC
 #define VC_SCALAR_REC 1
 #endif
+#ifndef VC_EPI_ROWS
+#define VC_EPI_ROWS 6     // output rows staged per epilogue pass (LDS: 4 waves x rows x 64*GPL floats)
+#endif
 #ifndef VC_PF
 #define VC_PF 1           // register path: cells in flight ahead of the one being processed
 #endif
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
   if (cbeg > d.Nc) cbeg = d.Nc;
   if (cend > d.Nc) cend = d.Nc;
 
-  __shared__ float4 lds4[(VC_WAVES * GBW + VC_WAVES + 3) / 4];      // staging area of the 4-wave combine
+  constexpr int RPP = NQ < VC_EPI_ROWS ? NQ : VC_EPI_ROWS;           // output rows staged per epilogue pass
+  __shared__ float4 lds4[(VC_WAVES * RPP * GBW + VC_WAVES + 3) / 4];  // staging area of the 4-wave combine
 
 #ifdef VC_DBG_TIMES
   asm volatile("" ::"v"(nu[0][0]), "v"(rr[0]));   // stamp 1 sits behind the latents' loads
@@ -360,8 +364,10 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
       gr[p] = (NOISE == VC_NOISE_NB && KIND != VC_KIND_VU) ? lt[p] * (-VC_LN2) - nobs - gnu[0][p] * v2_rcp(rr[p])
                                                            : v2(0.f);
   }
-  float (*sm)[GBW] = reinterpret_cast<float (*)[GBW]>(lds4);
-  float* sm_ll = reinterpret_cast<float*>(lds4) + VC_WAVES * GBW;
+  // RPP output rows are staged per pass (one barrier pair per pass instead of per row: the epilogue of the last
+  // workgroups is on the kernel's critical path)
+  float* sm = reinterpret_cast<float*>(lds4);                      // [VC_WAVES][RPP][GBW]
+  float* sm_ll = sm + VC_WAVES * RPP * GBW;
   {
     // likelihood partial in natural units: ln2 * (sum k (eta2 - log2 t) - r sum log2 t) for NB.
     // Padded genes are masked here (their nu~ is 0, so they never reached A1..A3).
@@ -376,23 +382,34 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
     if (lane == 0) sm_ll[wave] = l;
   }
   float* go = b.GO + ((size_t)chunk * NQ) * d.Ng_pad + gb * GBW;
-  auto row = [&](int q, const v2f* v) {      // one output row: stage the 4 waves' values, sum, store
-#pragma unroll
-    for (int q4 = 0; q4 < NV4; ++q4)
-      *reinterpret_cast<float4*>(&sm[wave][gl + 4 * q4]) =
-          make_float4(v[2 * q4].x, v[2 * q4].y, v[2 * q4 + 1].x, v[2 * q4 + 1].y);
-    __syncthreads();
-    for (int t = threadIdx.x; t < GBW; t += 256)
-      go[(size_t)q * d.Ng_pad + t] = (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
-    __syncthreads();
+  auto row_values = [&](int q) -> const v2f* {      // output row q (compile-time after unrolling) of this wave
+    if (KIND == VC_KIND_VU) return q == 0 ? gau : gw;
+    if (q < K) return gnu[q < K ? q : 0];
+    if (KIND == VC_KIND_PHASE) return gr;
+    return q == K ? gau : (q == K + 1 ? gw : gr);
   };
-  if (KIND == VC_KIND_VU) {
-    row(0, gau); row(1, gw);
-  } else {
 #pragma unroll
-    for (int k = 0; k < K; ++k) row(k, gnu[k]);
-    if (KIND == VC_KIND_PHASE) row(K, gr);
-    else { row(K, gau); row(K + 1, gw); row(K + 2, gr); }
+  for (int q0 = 0; q0 < NQ; q0 += RPP) {
+#pragma unroll
+    for (int r = 0; r < RPP; ++r) {
+      if (q0 + r < NQ) {
+        const v2f* v = row_values(q0 + r);
+#pragma unroll
+        for (int q4 = 0; q4 < NV4; ++q4)
+          *reinterpret_cast<float4*>(&sm[(wave * RPP + r) * GBW + gl + 4 * q4]) =
+              make_float4(v[2 * q4].x, v[2 * q4].y, v[2 * q4 + 1].x, v[2 * q4 + 1].y);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPP; ++r) {
+      if (q0 + r < NQ) {
+        for (int t = threadIdx.x; t < GBW; t += 256)
+          go[(size_t)(q0 + r) * d.Ng_pad + t] = (sm[(0 * RPP + r) * GBW + t] + sm[(1 * RPP + r) * GBW + t]) +
+                                                (sm[(2 * RPP + r) * GBW + t] + sm[(3 * RPP + r) * GBW + t]);
+      }
+    }
+    if (q0 + RPP < NQ) __syncthreads();
   }
   if (threadIdx.x == 0) b.LO[blockIdx.x] = (sm_ll[0] + sm_ll[1]) + (sm_ll[2] + sm_ll[3]);
   VC_STAMP(3);
