@@ -27,6 +27,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef VC_SCALAR_REC
 #define VC_SCALAR_REC 1
 #endif
+#ifndef VC_EARLY_FETCH
+#define VC_EARLY_FETCH 1   // issue the first cells' loads ahead of the per-gene latents' loads
+#endif
 #ifndef VC_EPI_ROWS
 #define VC_EPI_ROWS 6     // output rows staged per epilogue pass (LDS: 4 waves x rows x 64*GPL floats)
 #endif
@@ -149,9 +152,42 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
   const int gl = lane * GPL;            // gene offset inside the block
   const int g0 = gb * GBW + gl;
 
-  // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
+  // ---- this wave's cells; the loads of its first PF cells are issued before anything else, so that their latency
+  // runs in parallel with the loads of the per-gene latents below -------------------------------------------------
+  long long cbeg = (long long)chunk * (VC_WAVES * d.cw) + (long long)wave * d.cw;
+  long long cend = cbeg + d.cw;
+  if (cbeg > d.Nc) cbeg = d.Nc;
+  if (cend > d.Nc) cend = d.Nc;
+  const int ncell = (int)(cend - cbeg);
+  const size_t blk_base = ((size_t)gb * d.Nc) * GBW + gl;
+  const float* Sp = HAS_S ? b.S + blk_base : nullptr;
+  const float* Up = HAS_U ? b.U + blk_base : nullptr;
   constexpr int NP = GPL / 2;           // packed pairs per lane
   constexpr int NV4 = GPL / 4;          // dwordx4 loads per lane per matrix per cell
+  constexpr int PF = VC_PF, NBUF = PF + 1;
+  float4 s_bf[NBUF][NV4], u_bf[NBUF][NV4];
+  VcCellRec<H, NB> rec_bf[NBUF];
+  auto fetch = [&](int j, int i) {
+    const long long cn = cbeg + (i < ncell ? i : (ncell > 0 ? ncell - 1 : 0));
+#pragma unroll
+    for (int q4 = 0; q4 < NV4; ++q4) {
+#ifdef VC_DBG_HALF_BYTES      // measurement aid: what a 2-byte count storage could gain (loads half the bytes, results meaningless)
+      if (q4 > 0) { s_bf[j][q4] = s_bf[j][0]; u_bf[j][q4] = u_bf[j][0]; continue; }
+      if (HAS_S) s_bf[j][q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cn * (GBW / 2) - gl / 2 + 4 * q4);
+      if (HAS_U) u_bf[j][q4] = *reinterpret_cast<const float4*>(Up + (size_t)cn * (GBW / 2) - gl / 2 + 4 * q4);
+      continue;
+#endif
+      if (HAS_S) s_bf[j][q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cn * GBW + 4 * q4);
+      if (HAS_U) u_bf[j][q4] = *reinterpret_cast<const float4*>(Up + (size_t)cn * GBW + 4 * q4);
+    }
+    rec_bf[j] = vc_load_cell<H, NB>(b.CT + (size_t)cn * d.ctw);
+  };
+  if (VC_EARLY_FETCH && ncell > 0) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) fetch(j, j);
+  }
+
+  // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
   v2f nu[K][NP], lb2[NP], ib[NP], gam[NP], rr[NP];
   {
     const float* gt = b.GT + g0;
@@ -185,11 +221,6 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
     gau[p] = gw[p] = ll[p] = lt[p] = v2(0.f);
   }
 
-  long long cbeg = (long long)chunk * (VC_WAVES * d.cw) + (long long)wave * d.cw;
-  long long cend = cbeg + d.cw;
-  if (cbeg > d.Nc) cbeg = d.Nc;
-  if (cend > d.Nc) cend = d.Nc;
-
   constexpr int RPP = NQ < VC_EPI_ROWS ? NQ : VC_EPI_ROWS;           // output rows staged per epilogue pass
   __shared__ float4 lds4[(VC_WAVES * RPP * GBW + VC_WAVES + 3) / 4];  // staging area of the 4-wave combine
 
@@ -197,10 +228,6 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
   asm volatile("" ::"v"(nu[0][0]), "v"(rr[0]));   // stamp 1 sits behind the latents' loads
 #endif
   VC_STAMP(1);
-  const size_t blk_base = ((size_t)gb * d.Nc) * GBW + gl;
-  const float* Sp = HAS_S ? b.S + blk_base : nullptr;
-  const float* Up = HAS_U ? b.U + blk_base : nullptr;
-
   float keep0 = 0.f, keep1 = 0.f, keep2 = 0.f;
   // one cell against the lane's genes: sv/uv = the counts, rec = the cell record, i = staging lane of the cell
   auto cell = [&](const v2f* sv, const v2f* uv, const VcCellRec<H, NB>& rec, const int i) __attribute__((always_inline)) {
@@ -310,28 +337,11 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
     // processed the loads of the next PF cells are in flight into the others (the tail re-fetches the last cell:
     // no branch around loads); the loop is unrolled PF + 1 times so that every buffer keeps its registers and no
     // copies are needed.
-    constexpr int PF = VC_PF, NBUF = PF + 1;
-    const int ncell = (int)(cend - cbeg);
     if (ncell > 0) {
-      float4 s_bf[NBUF][NV4], u_bf[NBUF][NV4];
-      VcCellRec<H, NB> rec_bf[NBUF];
-      auto fetch = [&](int j, int i) {
-        const long long cn = cbeg + (i < ncell ? i : ncell - 1);
+      if (!VC_EARLY_FETCH) {
 #pragma unroll
-        for (int q4 = 0; q4 < NV4; ++q4) {
-#ifdef VC_DBG_HALF_BYTES      // measurement aid: what a 2-byte count storage could gain (loads half the bytes, results meaningless)
-          if (q4 > 0) { s_bf[j][q4] = s_bf[j][0]; u_bf[j][q4] = u_bf[j][0]; continue; }
-          if (HAS_S) s_bf[j][q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cn * (GBW / 2) - gl / 2 + 4 * q4);
-          if (HAS_U) u_bf[j][q4] = *reinterpret_cast<const float4*>(Up + (size_t)cn * (GBW / 2) - gl / 2 + 4 * q4);
-          continue;
-#endif
-          if (HAS_S) s_bf[j][q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cn * GBW + 4 * q4);
-          if (HAS_U) u_bf[j][q4] = *reinterpret_cast<const float4*>(Up + (size_t)cn * GBW + 4 * q4);
-        }
-        rec_bf[j] = vc_load_cell<H, NB>(b.CT + (size_t)cn * d.ctw);
-      };
-#pragma unroll
-      for (int j = 0; j < PF; ++j) fetch(j, j);
+        for (int j = 0; j < PF; ++j) fetch(j, j);
+      }
       for (int i0 = 0; i0 < ncell; i0 += NBUF) {
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
