@@ -588,31 +588,38 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
     G[2] = 0.f;
     G[3] = 0.f;
   }
-  if (d.model == VC_MODEL_VELOCITY && t < d.NW) {
-    const int j = t;
+  // angular-speed coefficient j: d/d(nu_omega_j) = up_j + prior term; one thread per OUTPUT element so that the
+  // dependent loads of an element (parameter, eps) are one round trip for all of them
+  if (d.model == VC_MODEL_VELOCITY) {
     const bool lrmn = d.guide == VC_GUIDE_LRMN;
-    const float up = sm_up[j];
-    float gx = 0.f;
-    const bool cnd = CND(VC_SITE_NUOMEGA);
-    if (!cnd) {
-      const float x = b.lat[VC_SITE_NUOMEGA][j], sd = b.sd_w[j];
-      gx = up - d.root_w * (x - b.mu_w[j]) / (sd * sd);
-    }
-    if (!lrmn) {
-      const float e = b.eps_used[d.eoff[VC_E_NUOMEGA] + j];
-      G[d.poff[VC_P_NUOMEGA_LOCS] + j] = -gx;
-      G[d.poff[VC_P_NUOMEGA_USCALES] + j] =
-          cnd ? 0.f : -gx * expf(P[d.poff[VC_P_NUOMEGA_USCALES] + j]) * e - d.root_w;
-    } else {
-      const long long i = (long long)d.Ng + j;
-      G[d.poff[VC_P_LRMN_LOC] + i] = -gx;
-      for (int k = 0; k < d.R; ++k) {
-        const long long q = d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + k;
-        const float w = expf(P[q]);
-        G[q] = (w > 0.f) ? -gx * b.eps_used[d.eoff[VC_E_LRMN_W] + k] * w : 0.f;
+    const int per = lrmn ? d.R + 2 : 2;                // outputs per coefficient
+    for (int tt = t; tt < d.NW * per; tt += 256) {
+      const int j = tt / per, c = tt % per;
+      const bool cnd = CND(VC_SITE_NUOMEGA);
+      float gx = 0.f;
+      if (!cnd) {
+        const float x = b.lat[VC_SITE_NUOMEGA][j], sd = b.sd_w[j];
+        gx = sm_up[j] - d.root_w * (x - b.mu_w[j]) / (sd * sd);
       }
-      const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + i]);
-      G[d.poff[VC_P_LRMN_UCOV_DIAG] + i] = -gx * b.eps_used[d.eoff[VC_E_LRMN_D] + i] / (2.f * sqrtf(dg)) * dg;
+      if (!lrmn) {
+        if (c == 0) G[d.poff[VC_P_NUOMEGA_LOCS] + j] = -gx;
+        else {
+          const float e = b.eps_used[d.eoff[VC_E_NUOMEGA] + j];
+          G[d.poff[VC_P_NUOMEGA_USCALES] + j] = cnd ? 0.f : -gx * expf(P[d.poff[VC_P_NUOMEGA_USCALES] + j]) * e - d.root_w;
+        }
+      } else {
+        const long long i = (long long)d.Ng + j;
+        if (c == 0) G[d.poff[VC_P_LRMN_LOC] + i] = -gx;
+        else if (c <= d.R) {
+          const int k = c - 1;
+          const long long q = d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + k;
+          const float w = expf(P[q]);
+          G[q] = (w > 0.f) ? -gx * b.eps_used[d.eoff[VC_E_LRMN_W] + k] * w : 0.f;
+        } else {
+          const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + i]);
+          G[d.poff[VC_P_LRMN_UCOV_DIAG] + i] = -gx * b.eps_used[d.eoff[VC_E_LRMN_D] + i] / (2.f * sqrtf(dg)) * dg;
+        }
+      }
     }
   }
 }
