@@ -1,6 +1,6 @@
 """Per-wave timeline of K_main (build the library with EXTRA=-DVC_DBG_TIMES first):
   make -C velocycle_amd/csrc clean; make -C velocycle_amd/csrc -j EXTRA=-DVC_DBG_TIMES
-  python profiles/tools/wave_timeline.py vjoint 4
+  python profiles/tools/wave_timeline.py vjoint 4 [cells]
 Every wave stamps the constant-rate clock at entry, after the per-gene latents are loaded, at the end of its cell loop and
 after the epilogue, plus HW_ID / XCC_ID; this prints the distributions and their breakdown by XCD, CU and dispatch order.
 (The tick is nominally 10 ns; on the boxes used it ran ~16 % fast against rocprofv3 durations.)"""
@@ -12,7 +12,8 @@ from velocycle_amd.svi import SVIRunner
 from velocycle_amd.workloads import make_velocity_spec
 mode = sys.argv[1] if len(sys.argv) > 1 else "vjoint"
 dev = torch.device("cuda:0")
-spec = make_velocity_spec(50000, 2000, mode, 1, 1, seed=0, device=dev)
+NC = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
+spec = make_velocity_spec(NC, 2000, mode, 1, 1, seed=0, device=dev)
 eng = HipEngine(spec, device=dev)
 run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=0, use_graph=False)
 run.run_perf(20, sync=True)
