@@ -245,11 +245,15 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
 #pragma unroll
       for (int k = 0; k < H; ++k) {
         const v2f ns = nu[2 * k + 1][p], nc = nu[2 * k + 2][p];
-        const v2f t = v2_fma(ns, rec.sn[k], nc * rec.cs[k]);
-        es += t;
+        if (FULL) {          // t = nu . zeta_k is needed on its own for zeta''
+          const v2f t = v2_fma(ns, rec.sn[k], nc * rec.cs[k]);
+          es += t;
+          e2 = (k == 0) ? -t : v2_fma(t, v2(-(float)((k + 1) * (k + 1))), e2);
+        } else {
+          es = v2_fma(ns, rec.sn[k], v2_fma(nc, rec.cs[k], es));
+        }
         const v2f u = v2_fma(ns, rec.cs[k], -(nc * rec.sn[k]));
         dd = (k == 0) ? u : v2_fma(u, v2((float)(k + 1)), dd);
-        e2 = (k == 0) ? -t : v2_fma(t, v2(-(float)((k + 1) * (k + 1))), e2);
       }
 #pragma unroll
       for (int q = 0; q < NB; ++q) es = v2_fma(nu[NH + q][p], rec.db[q], es);
