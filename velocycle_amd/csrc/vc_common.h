@@ -74,6 +74,11 @@ struct VcBufs {
 };
 
 #ifdef __HIPCC__
+#ifdef VC_DBG_TIMES      // measurement aid: per-block wall-clock stamps of the small kernels (kid 0 pre, 1 post, 2 fin)
+#define VC_KSTAMP(kid, k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) b.dbg[(size_t)d.n_main_wg * 32 + ((size_t)(kid) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define VC_KSTAMP(kid, k) do {} while (0)
+#endif
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions with DPP row operations; the total lands in lane 63.
 // ---------------------------------------------------------------------------------------------

@@ -235,7 +235,7 @@ extern "C" void vc_destroy(vc_engine* e) {
 #ifdef VC_DBG_TIMES
   if (e->b.dbg && getenv("VC_DBG_TIMES_OUT")) {
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h((size_t)e->d.n_main_wg * 32);
+    std::vector<unsigned long long> h((size_t)e->d.n_main_wg * 32 + 3 * 4096 * 8);
     (void)hipMemcpy(h.data(), e->b.dbg, h.size() * 8, hipMemcpyDeviceToHost);
     FILE* f = fopen(getenv("VC_DBG_TIMES_OUT"), "wb");
     if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
@@ -555,7 +555,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.CO, (size_t)d.nGB * 3 * d.Nc));
   TRY(e->dalloc(&b.LO, (size_t)d.n_main_wg));
 #ifdef VC_DBG_TIMES
-  TRY(e->dalloc(&b.dbg, (size_t)d.n_main_wg * 32));
+  TRY(e->dalloc(&b.dbg, (size_t)d.n_main_wg * 32 + 3 * 4096 * 8));   // + per-block stamps of K_pre / K_post / K_fin
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
   TRY(e->dalloc(&b.PW, (size_t)d.nb_post_cell * std::max(1, d.NW)));

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
                                                      int cond_only) {
   __shared__ double sm_red[16];
   __shared__ float s_nuw[VC_MAX_NW];
+  VC_KSTAMP(0, 0);
   const long long step = step_dev ? *step_dev : step_host;
   const bool vel = d.model == VC_MODEL_VELOCITY;
   const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
@@ -306,8 +307,10 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
       b.lat_domega[c] = domega;
     }
   }
+  VC_KSTAMP(0, 2);
   const double tot = vc_block_sum_d(loss, sm_red);
   if (threadIdx.x == 0) b.LP[blockIdx.x] = cond_only ? 0.0 : tot;
+  VC_KSTAMP(0, 3);
 }
 
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
@@ -330,42 +333,100 @@ void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const 
 // ---------------------------------------------------------------------------------------------
 #define VC_PG_WAVES 16
 #define VC_MAXQ (2 * VC_MAXH + 1 + VC_MAXNB + 3)
+// MQ = compiled bound of the number of partial-sum rows (nq): 2 (U-only kernel), 6 (S+U kernel with H = 1, no batches;
+// phase up to K = 5) or VC_MAXQ; the reduction loop keeps 4 x MQ loads in flight, so the small variants leave registers
+// for the role inputs that are fetched ahead of it.
 
+template <int MQ>
 __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs& b,
                                                    const float* __restrict__ P, float* __restrict__ G,
                                                    int gblock) {
-  __shared__ float sm[VC_PG_WAVES][VC_MAXQ][64];
+  __shared__ float sm[VC_PG_WAVES][MQ][64];
   __shared__ double sm_red[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = gblock * 64 + lane;
-  float acc[VC_MAXQ];
+  // Chain rule to the parameter gradients: the work of one gene is split into independent ROLES and every role runs
+  // on its own wave (lane = gene), so that the serial path of the block is the longest role instead of their sum:
+  // role h < Nh: nu[h]; Nh + q: dnu[q]; 12: shape_inv (+ r-only loss terms); 13: log gamma / log beta (mean-field) or
+  // the LRMN core; 14: LRMN cov_factor row.
+  // Everything a role reads besides the reduced sums (site values, priors, eps, parameters, histogram sums) does not
+  // depend on K_main's partials: it is fetched HERE, ahead of the reduction loop, whose latency then covers these
+  // (otherwise dependent) round trips.
+  const int role = wave;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+  const bool nb = d.noise == VC_NOISE_NB;
+  const int K = d.K, Nh = d.Nh;
+  const float rw = d.root_w;
+  constexpr int NIN = 11 + VC_MAX_RANK;   // role 13 uses in[0..13], role 14 in[0..10] + the R cov_factor entries
+  float in[NIN];
+  double HLg = 0.0, HDg = 0.0;            // histogram task sums of this gene, fixed order
 #pragma unroll
-  for (int q = 0; q < VC_MAXQ; ++q) acc[q] = 0.f;
+  for (int i = 0; i < NIN; ++i) in[i] = 0.f;
+  if (g < d.Ng) {
+    if (role < Nh) {
+      if (!CND(VC_SITE_NU)) {
+        const long long j = (long long)g * Nh + role;
+        in[0] = b.lat[VC_SITE_NU][j]; in[1] = b.sd_nu[j]; in[2] = b.mu_nu[j];
+        in[3] = b.eps_used[d.eoff[VC_E_NU] + j]; in[4] = P[d.poff[VC_P_NU_USCALES] + j];
+      }
+    } else if (role < Nh + d.Nb && d.with_dnu) {
+      if (!CND(VC_SITE_DNU)) {
+        const long long j = (long long)(role - Nh) * d.Ng + g;
+        in[0] = b.lat[VC_SITE_DNU][j]; in[1] = vel ? 0.01f : b.sd_dnu[j];
+      }
+    } else if (role == 12 && nb) {
+      in[0] = b.GT[(size_t)(K + 2) * d.Ng_pad + g];
+      if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
+      for (int t = b.h_tptr[g]; t < b.h_tptr[g + 1]; ++t) { HLg += b.HL[t]; HDg += b.HD[t]; }
+    } else if ((role == 13 || role == 14) && vel) {
+      in[0] = b.GT[(size_t)(K + 1) * d.Ng_pad + g];
+      if (!CND(VC_SITE_LOGGAMMA)) { in[1] = b.lat[VC_SITE_LOGGAMMA][g]; in[2] = b.sd_g[g]; in[3] = b.mu_g[g]; }
+      if (!CND(VC_SITE_LOGBETA)) { in[4] = b.lat[VC_SITE_LOGBETA][g]; in[5] = b.sd_b[g]; in[6] = b.mu_b[g]; }
+      if (!lrmn) {
+        if (role == 13) {
+          in[7] = b.eps_used[d.eoff[VC_E_LOGGAMMA] + g]; in[8] = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
+          in[9] = P[d.poff[VC_P_LOGGAMMA_USCALES] + g]; in[10] = P[d.poff[VC_P_LOGBETA_USCALES] + g];
+        }
+      } else {
+        in[7] = b.lat_delta[g]; in[8] = b.lat_sgam[g];
+        in[9] = P[d.poff[VC_P_LOGBETA_USCALES] + g]; in[10] = P[d.poff[VC_P_RHO_REAL_LOC] + g];
+        if (role == 13) {
+          in[11] = b.eps_used[d.eoff[VC_E_LOGBETA] + g]; in[12] = P[d.poff[VC_P_LRMN_UCOV_DIAG] + g];
+          in[13] = b.eps_used[d.eoff[VC_E_LRMN_D] + g];
+        } else {
+#pragma unroll
+          for (int k = 0; k < VC_MAX_RANK; ++k)
+            if (k < d.R) in[11 + k] = P[d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k];
+        }
+      }
+    }
+  }
+
+  float acc[MQ];
+#pragma unroll
+  for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
   for (int ch0 = wave; ch0 < d.n_chunks; ch0 += 4 * VC_PG_WAVES) {
-    float v[4][VC_MAXQ];
+    float v[4][MQ];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {        // issue the loads of 4 chunks before consuming any
       const int ch = ch0 + u * VC_PG_WAVES;
       const float* go = b.GO + ((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq) * d.Ng_pad + g;
 #pragma unroll
-      for (int q = 0; q < VC_MAXQ; ++q) v[u][q] = (q < d.nq) ? go[(size_t)q * d.Ng_pad] : 0.f;
+      for (int q = 0; q < MQ; ++q) v[u][q] = (q < d.nq) ? go[(size_t)q * d.Ng_pad] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (ch0 + u * VC_PG_WAVES < d.n_chunks) {
 #pragma unroll
-        for (int q = 0; q < VC_MAXQ; ++q) acc[q] += v[u][q];
+        for (int q = 0; q < MQ; ++q) acc[q] += v[u][q];
       }
   }
 #pragma unroll
-  for (int q = 0; q < VC_MAXQ; ++q) sm[wave][q][lane] = acc[q];
+  for (int q = 0; q < MQ; ++q) sm[wave][q][lane] = acc[q];
+  VC_KSTAMP(1, 1);
   __syncthreads();
-  // Chain rule to the parameter gradients.  The work of one gene is split into independent ROLES and every
-  // role runs on its own wave (lane = gene), so that the serial path of the block is the longest role
-  // instead of their sum: role h < Nh: nu[h]; Nh + q: dnu[q]; 12: shape_inv (+ r-only loss terms);
-  // 13: log gamma / log beta (mean-field) or the LRMN core; 14: LRMN cov_factor row.
   double loss = 0.0;
-  const int role = wave;
   auto T = [&](int q) {                 // reduced partial sum of output row q for this gene (fixed order)
     float t = 0.f;
 #pragma unroll
@@ -373,23 +434,16 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
     return t;
   };
   if (g < d.Ng) {
-    const bool vel = d.model == VC_MODEL_VELOCITY;
-    const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
-    const bool nb = d.noise == VC_NOISE_NB;
-    const int K = d.K, Nh = d.Nh;
-    const float rw = d.root_w;
     if (role < Nh) {
       // ---- nu[h] ----
       const int h = role;
       const long long j = (long long)g * Nh + h;
       float gl = 0.f, gu = 0.f;
       if (!CND(VC_SITE_NU)) {
-        const float x = b.lat[VC_SITE_NU][j];
-        const float sd = b.sd_nu[j];
-        const float gx = T(h) - rw * (x - b.mu_nu[j]) / (sd * sd);
-        const float e = b.eps_used[d.eoff[VC_E_NU] + j];
+        const float x = in[0], sd = in[1];
+        const float gx = T(h) - rw * (x - in[2]) / (sd * sd);
         gl = -gx;
-        gu = -gx * expf(P[d.poff[VC_P_NU_USCALES] + j]) * e - rw;
+        gu = -gx * expf(in[4]) * in[3] - rw;
       }
       G[d.poff[VC_P_NU_LOCS] + j] = gl;
       G[d.poff[VC_P_NU_USCALES] + j] = gu;
@@ -399,22 +453,19 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
       const long long j = (long long)q * d.Ng + g;
       float gl = 0.f;
       if (!CND(VC_SITE_DNU)) {
-        const float x = b.lat[VC_SITE_DNU][j];
-        const float sd = vel ? 0.01f : b.sd_dnu[j];
+        const float x = in[0], sd = in[1];
         gl = -(T(Nh + q) - rw * x / (sd * sd));
       }
       G[d.poff[VC_P_DNU_LOCS] + j] = gl;
     } else if (role == 12 && nb) {
       // ---- shape_inv: r-only terms of sum_c NB(k; r, eta): nmat*Nc*r*log r + sum_hist cnt*(lgamma(r+k)-lgamma(r))
-      const float r = b.GT[(size_t)(K + 2) * d.Ng_pad + g];
+      const float r = in[0];
       const float U_r = (d.kind == VC_KIND_PHASE) ? T(K) : (d.kind == VC_KIND_VFULL ? T(K + 2) : 0.f);
       const double lr = (double)logf(r);
-      double HLg = 0.0, HDg = 0.0;        // histogram task sums of this gene, fixed order
-      for (int t = b.h_tptr[g]; t < b.h_tptr[g + 1]; ++t) { HLg += b.HL[t]; HDg += b.HD[t]; }
       if (d.nmat_r > 0) loss -= (double)d.nmat_r * d.Nc * (double)r * lr + HLg;
       float gu = 0.f;
       if (!CND(VC_SITE_SHAPE_INV)) {
-        const float si = b.lat[VC_SITE_SHAPE_INV][g];
+        const float si = in[1];
         const double dr = (double)U_r + (double)d.nmat_r * d.Nc * (lr + 1.0) + HDg;
         const double gsi = -(double)r * (double)r * dr + (double)rw * ((d.gamma_alpha - 1.f) / si - d.gamma_beta);
         gu = (float)(-gsi * (double)si);
@@ -422,43 +473,37 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
       G[d.poff[VC_P_SHAPE_INV_ULOCS] + g] = gu;
     } else if ((role == 13 || role == 14) && vel) {
       // ---- log gamma / log beta ----
-      const float gam = b.GT[(size_t)(K + 1) * d.Ng_pad + g];
+      const float gam = in[0];
       float U_lb, U_lg;
       if (d.kind == VC_KIND_VFULL) { U_lb = -T(K); U_lg = T(K + 1) * gam; }
       else { U_lb = -T(0); U_lg = T(1) * gam; }
       float g_lg = 0.f, g_lb = 0.f;   // total d log p / d site (0 when the site is conditioned)
-      if (!CND(VC_SITE_LOGGAMMA)) {
-        const float x = b.lat[VC_SITE_LOGGAMMA][g], sd = b.sd_g[g];
-        g_lg = U_lg - rw * (x - b.mu_g[g]) / (sd * sd);
-      }
-      if (!CND(VC_SITE_LOGBETA)) {
-        const float x = b.lat[VC_SITE_LOGBETA][g], sd = b.sd_b[g];
-        g_lb = U_lb - rw * (x - b.mu_b[g]) / (sd * sd);
-      }
+      if (!CND(VC_SITE_LOGGAMMA)) g_lg = U_lg - rw * (in[1] - in[3]) / (in[2] * in[2]);
+      if (!CND(VC_SITE_LOGBETA)) g_lb = U_lb - rw * (in[4] - in[6]) / (in[5] * in[5]);
       if (!lrmn) {
         if (role == 13) {
-          const float eg = b.eps_used[d.eoff[VC_E_LOGGAMMA] + g], eb = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
+          const float eg = in[7], eb = in[8];
           const bool cg = CND(VC_SITE_LOGGAMMA), cb = CND(VC_SITE_LOGBETA);
           G[d.poff[VC_P_LOGGAMMA_LOCS] + g] = -g_lg;
-          G[d.poff[VC_P_LOGGAMMA_USCALES] + g] = cg ? 0.f : -g_lg * expf(P[d.poff[VC_P_LOGGAMMA_USCALES] + g]) * eg - rw;
+          G[d.poff[VC_P_LOGGAMMA_USCALES] + g] = cg ? 0.f : -g_lg * expf(in[9]) * eg - rw;
           G[d.poff[VC_P_LOGBETA_LOCS] + g] = -g_lb;
-          G[d.poff[VC_P_LOGBETA_USCALES] + g] = cb ? 0.f : -g_lb * expf(P[d.poff[VC_P_LOGBETA_USCALES] + g]) * eb - rw;
+          G[d.poff[VC_P_LOGBETA_USCALES] + g] = cb ? 0.f : -g_lb * expf(in[10]) * eb - rw;
         }
       } else {
         // q(log beta | log gamma) = N(a + rho s_b delta / s_gamma, s_b sqrt(1-rho^2)); log gamma = loc + delta
         const bool cb = CND(VC_SITE_LOGBETA);
         const float A = g_lb;
         const float ent = cb ? 0.f : rw;        // weight of the guide's -log(std) term
-        const float delta = b.lat_delta[g], sgam = b.lat_sgam[g];
-        const float sb = expf(P[d.poff[VC_P_LOGBETA_USCALES] + g]);
-        const float rho_real = P[d.poff[VC_P_RHO_REAL_LOC] + g];
+        const float delta = in[7], sgam = in[8];
+        const float sb = expf(in[9]);
+        const float rho_real = in[10];
         const float sg = sigmoidf_(rho_real / d.rho_scale);
         const float rho = sg * 1.998f - 0.999f;
         const float om = 1.f - rho * rho, sq = sqrtf(om);
         const float dl_ddelta = -g_lg - A * rho * sb / sgam;
         const float dl_dsg = A * rho * sb * delta / (sgam * sgam);
         if (role == 13) {
-          const float eb = b.eps_used[d.eoff[VC_E_LOGBETA] + g];
+          const float eb = in[11];
           G[d.poff[VC_P_LOGBETA_LOCS] + g] = -A;
           G[d.poff[VC_P_LOGBETA_USCALES] + g] = -A * (rho * delta / sgam + sq * eb) * sb - ent;
           float g_rho = -A * (sb * delta / sgam - sb * rho * eb / sq) + ent * rho / om;
@@ -466,20 +511,23 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
           if (!CND(VC_SITE_RHO_REAL)) g_rr += rw * (rho_real - d.rho_mean) / (d.rho_std * d.rho_std);
           G[d.poff[VC_P_RHO_REAL_LOC] + g] = g_rr;
           G[d.poff[VC_P_LRMN_LOC] + g] = -g_lg;
-          const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
-          const float ed = b.eps_used[d.eoff[VC_E_LRMN_D] + g];
+          const float dg = expf(in[12]);
+          const float ed = in[13];
           G[d.poff[VC_P_LRMN_UCOV_DIAG] + g] = (dl_ddelta * ed / (2.f * sqrtf(dg)) + dl_dsg / (2.f * sgam)) * dg;
         } else {
-          for (int k = 0; k < d.R; ++k) {
-            const long long j = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k;
-            const float w = expf(P[j]);
-            const float ew = b.eps_used[d.eoff[VC_E_LRMN_W] + k];
-            G[j] = (w > 0.f) ? (dl_ddelta * ew + dl_dsg * w / sgam) * w : 0.f;
-          }
+#pragma unroll
+          for (int k = 0; k < VC_MAX_RANK; ++k)
+            if (k < d.R) {
+              const long long j = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k;
+              const float w = expf(in[11 + k]);
+              const float ew = b.eps_used[d.eoff[VC_E_LRMN_W] + k];          // wave-uniform, a scalar-cache hit
+              G[j] = (w > 0.f) ? (dl_ddelta * ew + dl_dsg * w / sgam) * w : 0.f;
+            }
         }
       }
     }
   }
+  VC_KSTAMP(1, 2);
   const double tot = vc_block_sum_d(loss, sm_red);
   if (threadIdx.x == 0) b.LP[d.nb_pre_gene + d.nb_pre_cell + gblock] = tot;
 }
@@ -499,6 +547,7 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
     for (int gb = 0; gb < d.nGB; ++gb)
       for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + c];
     phi = b.lat_phi[c];
+    VC_KSTAMP(1, 1);
     if (d.poff[VC_P_PHIXY_LOCS] >= 0) {
       float gx = 0.f, gy = 0.f;
       if (!CND(VC_SITE_PHIXY)) {
@@ -543,13 +592,16 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
 }
 
 // one launch for both second-stage reductions: blocks [0, nb_post_gene) gene level, the rest cell level
+template <int MQ>
 __global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcBufs b, const float* __restrict__ P,
                                                        float* __restrict__ G, long long* __restrict__ step_dev) {
   // every reader of this step's counter (K_pre) has finished and nothing in this launch reads it:
   // advance it here, so that K_fin / the optimiser (which only read it) see step + 1 = the 1-based Adam step
+  VC_KSTAMP(1, 0);
   if (blockIdx.x == 0 && threadIdx.x == 0 && step_dev) *step_dev += 1;
-  if ((int)blockIdx.x < d.nb_post_gene) vc_post_gene_block(d, b, P, G, blockIdx.x);
+  if ((int)blockIdx.x < d.nb_post_gene) vc_post_gene_block<MQ>(d, b, P, G, blockIdx.x);
   else vc_post_cell_block(d, b, G, blockIdx.x - d.nb_post_gene);
+  VC_KSTAMP(1, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -557,30 +609,44 @@ __global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcB
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, const float* P, float* G,
                                              double* loss_dev, long long loss_slots, long long step) {
-  // 1 + NW independent reductions (the loss; per angular-speed coefficient sum_c d loglik/d omega_c * D * zeta_omega),
-  // one wave each, all in flight at once, fixed order -> deterministic; a single barrier ends the phase
-  __shared__ double sm_loss;
+  // 1 + NW independent reductions (the loss; per angular-speed coefficient sum_c d loglik/d omega_c * D * zeta_omega).
+  // Every load of the phase is issued before anything is summed: the loss partials are spread over all 256 threads,
+  // coefficient j over the lanes of wave j % 4; fixed order -> deterministic; a single barrier ends the phase.
+  __shared__ double sm_lossw[4];
   __shared__ float sm_up[VC_MAX_NW];
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int nlp = d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene;
-  const int nred = 1 + (d.model == VC_MODEL_VELOCITY ? d.NW : 0);
-  for (int r = wv; r < nred; r += 4) {
+  {
     double s = 0.0;
-    if (r == 0) {
-      for (int i = lane; i < nlp; i += 64) s += b.LP[i];
-      for (int i = lane; i < d.n_main_wg; i += 64) s -= (double)b.LO[i];   // loss = -loglik
-    } else {
-      for (int i = lane; i < d.nb_post_cell; i += 64) s += (double)b.PW[(size_t)i * d.NW + (r - 1)];
+#pragma unroll 4
+    for (int i = t; i < nlp; i += 256) s += b.LP[i];
+#pragma unroll 4
+    for (int i = t; i < d.n_main_wg; i += 256) s -= (double)b.LO[i];   // loss = -loglik
+    double u[2] = {0.0, 0.0};              // up to two coefficients per wave without a second round trip
+    const int nw = d.model == VC_MODEL_VELOCITY ? d.NW : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = wv + 4 * q;
+      if (j < nw)
+        for (int i = lane; i < d.nb_post_cell; i += 64) u[q] += (double)b.PW[(size_t)i * d.NW + j];
     }
     s = vc_wave_sum_d(s);
-    if (lane == 0) {
-      if (r == 0) sm_loss = s;
-      else sm_up[r - 1] = (float)s;
+    if (lane == 0) sm_lossw[wv] = s;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = wv + 4 * q;
+      if (j < nw) { const double r = vc_wave_sum_d(u[q]); if (lane == 0) sm_up[j] = (float)r; }
+    }
+    for (int j = wv + 8; j < nw; j += 4) {          // more than 8 coefficients: the rest one after the other
+      double r = 0.0;
+      for (int i = lane; i < d.nb_post_cell; i += 64) r += (double)b.PW[(size_t)i * d.NW + j];
+      r = vc_wave_sum_d(r);
+      if (lane == 0) sm_up[j] = (float)r;
     }
   }
   __syncthreads();
   if (t == 0) {
-    const double loss = sm_loss + b.const_loss;
+    const double loss = ((sm_lossw[0] + sm_lossw[1]) + (sm_lossw[2] + sm_lossw[3])) + b.const_loss;
     if (loss_dev) loss_dev[loss_slots > 1 ? (step % loss_slots) : 0] = loss;
     const float hi = (float)loss;
     G[0] = hi;
@@ -691,8 +757,10 @@ __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const 
       lo[2] = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)d.Ng * d.R; hi[2] = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)d.M * d.R;
     }
   }
+  VC_KSTAMP(2, 0);
   if (blockIdx.x == 0) vc_fin_block(d, b, P, G, loss_dev, loss_slots, t1 - 1);
   __syncthreads();
+  VC_KSTAMP(2, 1);
   const float step_size = s_step;
   const float fb1 = (float)b1, fb2 = (float)b2;
   auto upd = [&](long long idx) {
@@ -708,9 +776,11 @@ __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const 
     const bool tail = (idx >= lo[0] && idx < hi[0]) || (idx >= lo[1] && idx < hi[1]) || (idx >= lo[2] && idx < hi[2]);
     if (!tail) upd(idx);
   }
+  VC_KSTAMP(2, 2);
   if (blockIdx.x == 0)
     for (int q = 0; q < 3; ++q)
       for (long long idx = lo[q] + threadIdx.x; idx < hi[q]; idx += 256) upd(idx);
+  VC_KSTAMP(2, 3);
 }
 
 void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* grad, double* loss_dev,
@@ -736,8 +806,10 @@ void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, d
 
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,
                     hipStream_t st) {
-  hipLaunchKernelGGL(vc_post_kernel, dim3(d.nb_post_gene + d.nb_post_cell), dim3(1024), 0, st, d, b, params, grad,
-                     step_dev);
+  const dim3 grid(d.nb_post_gene + d.nb_post_cell), block(1024);
+  if (d.nq <= 2) hipLaunchKernelGGL(vc_post_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev);
+  else if (d.nq <= 6) hipLaunchKernelGGL(vc_post_kernel<6>, grid, block, 0, st, d, b, params, grad, step_dev);
+  else hipLaunchKernelGGL(vc_post_kernel<VC_MAXQ>, grid, block, 0, st, d, b, params, grad, step_dev);
 }
 void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev,
                    long long loss_slots, long long step, const long long* step_dev, hipStream_t st) {
