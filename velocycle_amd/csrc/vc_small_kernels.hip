@@ -543,20 +543,34 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
   const bool vel = d.model == VC_MODEL_VELOCITY;
   float A[3] = {0.f, 0.f, 0.f};
   float phi = 0.f;
+  float dx01[2] = {0.f, 0.f};             // design-matrix entries of the first two conditions
   if (c < d.Nc) {
+    // everything this cell needs is requested in one go (the partial sums and the site values are independent loads)
+    const bool need_xy = d.poff[VC_P_PHIXY_LOCS] >= 0 && !CND(VC_SITE_PHIXY);
+    float2 xy = make_float2(1.f, 0.f), pxy = make_float2(0.f, 0.f);
+    float om = 0.f, dom = 0.f;
+    phi = b.lat_phi[c];
+    if (vel) {
+      dx01[0] = b.Dm[c];
+      if (d.Nx > 1) dx01[1] = b.Dm[(size_t)d.Nc + c];
+    }
+    if (need_xy) {
+      xy = *reinterpret_cast<const float2*>(b.lat[VC_SITE_PHIXY] + 2 * (size_t)c);
+      pxy = *reinterpret_cast<const float2*>(b.pxy + 2 * (size_t)c);
+      if (d.kind == VC_KIND_VFULL) { om = b.lat_omega[c]; dom = b.lat_domega[c]; }
+    }
     for (int gb = 0; gb < d.nGB; ++gb)
       for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + c];
-    phi = b.lat_phi[c];
     VC_KSTAMP(1, 1);
     if (d.poff[VC_P_PHIXY_LOCS] >= 0) {
       float gx = 0.f, gy = 0.f;
       if (!CND(VC_SITE_PHIXY)) {
         float dphi = A[0];
-        if (d.kind == VC_KIND_VFULL) dphi += b.lat_omega[c] * A[1] + A[2] * b.lat_domega[c];
-        const float x = b.lat[VC_SITE_PHIXY][2 * c], y = b.lat[VC_SITE_PHIXY][2 * c + 1];
+        if (d.kind == VC_KIND_VFULL) dphi += om * A[1] + A[2] * dom;
+        const float x = xy.x, y = xy.y;
         const float inv = 1.0f / (x * x + y * y);
-        gx = -(dphi * (-y * inv) - (x - b.pxy[2 * c]));
-        gy = -(dphi * (x * inv) - (y - b.pxy[2 * c + 1]));
+        gx = -(dphi * (-y * inv) - (x - pxy.x));
+        gy = -(dphi * (x * inv) - (y - pxy.y));
       }
       G[d.poff[VC_P_PHIXY_LOCS] + 2LL * c] = gx;
       G[d.poff[VC_P_PHIXY_LOCS] + 2LL * c + 1] = gy;
@@ -574,7 +588,7 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
       ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
     }
     for (int xq = 0; xq < d.Nx; ++xq) {
-      const float dx = (c < d.Nc) ? b.Dm[(size_t)xq * d.Nc + c] : 0.f;
+      const float dx = (c < d.Nc) ? (xq < 2 ? dx01[xq] : b.Dm[(size_t)xq * d.Nc + c]) : 0.f;
       for (int h = 0; h < d.Nhw; ++h) {
         const float z = (h == 0) ? 1.f : ((h & 1) ? sk[(h - 1) >> 1] : ck[(h - 1) >> 1]);
         const float t = vc_wave_sum(a3 * dx * z);
@@ -616,6 +630,20 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
   __shared__ float sm_up[VC_MAX_NW];
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const int nlp = d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene;
+  // inputs of this thread's angular-speed output element (used after the reductions): x, sd, mu, parameter, eps
+  float fin_in[5] = {0.f, 1.f, 0.f, 0.f, 0.f};
+  const int fin_per = (d.model == VC_MODEL_VELOCITY && d.guide == VC_GUIDE_LRMN) ? d.R + 2 : 2, fin_tt = t;
+  if (d.model == VC_MODEL_VELOCITY && fin_tt < d.NW * fin_per) {
+    const int j = fin_tt / fin_per, c = fin_tt % fin_per;
+    if (!CND(VC_SITE_NUOMEGA)) { fin_in[0] = b.lat[VC_SITE_NUOMEGA][j]; fin_in[1] = b.sd_w[j]; fin_in[2] = b.mu_w[j]; }
+    if (d.guide != VC_GUIDE_LRMN) {
+      if (c == 1) { fin_in[3] = P[d.poff[VC_P_NUOMEGA_USCALES] + j]; fin_in[4] = b.eps_used[d.eoff[VC_E_NUOMEGA] + j]; }
+    } else {
+      const long long i = (long long)d.Ng + j;
+      if (c >= 1 && c <= d.R) { fin_in[3] = P[d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + (c - 1)]; fin_in[4] = b.eps_used[d.eoff[VC_E_LRMN_W] + (c - 1)]; }
+      else if (c == d.R + 1) { fin_in[3] = P[d.poff[VC_P_LRMN_UCOV_DIAG] + i]; fin_in[4] = b.eps_used[d.eoff[VC_E_LRMN_D] + i]; }
+    }
+  }
   {
     double s = 0.0;
 #pragma unroll 4
@@ -654,37 +682,51 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
     G[2] = 0.f;
     G[3] = 0.f;
   }
-  // angular-speed coefficient j: d/d(nu_omega_j) = up_j + prior term; one thread per OUTPUT element so that the
-  // dependent loads of an element (parameter, eps) are one round trip for all of them
+  // angular-speed coefficient j: d/d(nu_omega_j) = up_j + prior term; one thread per OUTPUT element (its inputs were
+  // requested ahead of the reductions, see fin_in above)
+  if (d.model == VC_MODEL_VELOCITY && fin_tt < d.NW * fin_per) {
+    const bool lrmn = d.guide == VC_GUIDE_LRMN;
+    const int j = fin_tt / fin_per, c = fin_tt % fin_per;
+    const bool cnd = CND(VC_SITE_NUOMEGA);
+    float gx = 0.f;
+    if (!cnd) gx = sm_up[j] - d.root_w * (fin_in[0] - fin_in[2]) / (fin_in[1] * fin_in[1]);
+    if (!lrmn) {
+      if (c == 0) G[d.poff[VC_P_NUOMEGA_LOCS] + j] = -gx;
+      else G[d.poff[VC_P_NUOMEGA_USCALES] + j] = cnd ? 0.f : -gx * expf(fin_in[3]) * fin_in[4] - d.root_w;
+    } else {
+      const long long i = (long long)d.Ng + j;
+      if (c == 0) G[d.poff[VC_P_LRMN_LOC] + i] = -gx;
+      else if (c <= d.R) {
+        const long long q = d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + (c - 1);
+        const float w = expf(fin_in[3]);
+        G[q] = (w > 0.f) ? -gx * fin_in[4] * w : 0.f;
+      } else {
+        const float dg = expf(fin_in[3]);
+        G[d.poff[VC_P_LRMN_UCOV_DIAG] + i] = -gx * fin_in[4] / (2.f * sqrtf(dg)) * dg;
+      }
+    }
+  }
+  // more than 256 output elements (NW * (R + 2) > 256): the rest the plain way
   if (d.model == VC_MODEL_VELOCITY) {
     const bool lrmn = d.guide == VC_GUIDE_LRMN;
-    const int per = lrmn ? d.R + 2 : 2;                // outputs per coefficient
-    for (int tt = t; tt < d.NW * per; tt += 256) {
-      const int j = tt / per, c = tt % per;
+    for (int tt = t + 256; tt < d.NW * fin_per; tt += 256) {
+      const int j = tt / fin_per, c = tt % fin_per;
       const bool cnd = CND(VC_SITE_NUOMEGA);
       float gx = 0.f;
       if (!cnd) {
         const float x = b.lat[VC_SITE_NUOMEGA][j], sd = b.sd_w[j];
         gx = sm_up[j] - d.root_w * (x - b.mu_w[j]) / (sd * sd);
       }
-      if (!lrmn) {
-        if (c == 0) G[d.poff[VC_P_NUOMEGA_LOCS] + j] = -gx;
-        else {
-          const float e = b.eps_used[d.eoff[VC_E_NUOMEGA] + j];
-          G[d.poff[VC_P_NUOMEGA_USCALES] + j] = cnd ? 0.f : -gx * expf(P[d.poff[VC_P_NUOMEGA_USCALES] + j]) * e - d.root_w;
-        }
+      const long long i = (long long)d.Ng + j;       // only LRMN reaches here (2 NW <= 128 otherwise)
+      if (!lrmn) continue;
+      if (c == 0) G[d.poff[VC_P_LRMN_LOC] + i] = -gx;
+      else if (c <= d.R) {
+        const long long q = d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + (c - 1);
+        const float w = expf(P[q]);
+        G[q] = (w > 0.f) ? -gx * b.eps_used[d.eoff[VC_E_LRMN_W] + (c - 1)] * w : 0.f;
       } else {
-        const long long i = (long long)d.Ng + j;
-        if (c == 0) G[d.poff[VC_P_LRMN_LOC] + i] = -gx;
-        else if (c <= d.R) {
-          const int k = c - 1;
-          const long long q = d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + k;
-          const float w = expf(P[q]);
-          G[q] = (w > 0.f) ? -gx * b.eps_used[d.eoff[VC_E_LRMN_W] + k] * w : 0.f;
-        } else {
-          const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + i]);
-          G[d.poff[VC_P_LRMN_UCOV_DIAG] + i] = -gx * b.eps_used[d.eoff[VC_E_LRMN_D] + i] / (2.f * sqrtf(dg)) * dg;
-        }
+        const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + i]);
+        G[d.poff[VC_P_LRMN_UCOV_DIAG] + i] = -gx * b.eps_used[d.eoff[VC_E_LRMN_D] + i] / (2.f * sqrtf(dg)) * dg;
       }
     }
   }
