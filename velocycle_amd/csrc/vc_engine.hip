@@ -513,7 +513,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
     d.n_chunks = (int)((d.Nc + per_wg - 1) / per_wg);
     d.n_main_wg = d.nGB * d.n_chunks;
   }
-  d.nb_pre_gene = d.Ng_pad / 256;
+  d.nb_pre_gene = d.Ng_pad / 64;       // 64 genes per block, the sites of a gene spread over its 4 waves
   d.nb_pre_cell = (d.Nc + 255) / 256;
   d.nb_post_gene = d.Ng_pad / 64;
   d.nb_post_cell = (d.Nc + 1023) / 1024;

@@ -106,104 +106,123 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
   }
   if ((int)blockIdx.x < d.nb_pre_gene) {
     // ------------------------------- gene part ------------------------------------------------
-    const int g = blockIdx.x * 256 + threadIdx.x;
+    // 64 genes per block (lane = gene); the sites of a gene are independent ROLES spread over the 4 waves, so that the
+    // serial path of a thread is one or two counter-RNG draws instead of the Nh + 2 of a whole gene:
+    //   role 0: log gamma / log beta (+ rho); 1 .. Nh: nu[h]; Nh + 1 .. Nh + Nb: delta nu; last: shape_inv.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + lane;
+    // LRMN: eps_W is the same for every gene: lane k of wave 0 draws eps_W[k] once, with all lanes active (the
+    // padded lanes of the last block included), and the role reads it with v_readlane
+    float ew_mine = 0.f;
+    if (wv == 0 && lrmn && !cond_only && lane < d.R)
+      ew_mine = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_W] + lane, d.eoff[VC_E_LRMN_W] + lane);
     if (g < d.Ng_pad) {
       float* GT = b.GT + g;
       const size_t NP = d.Ng_pad;
       if (g >= d.Ng) {   // padded gene: nu~ = 0 (never reaches a per-cell sum), loss masked in K_main
-        for (int k = 0; k < d.K; ++k) GT[k * NP] = 0.f;
-        GT[d.K * NP] = 0.f; GT[(d.K + 1) * NP] = 1.f; GT[(d.K + 2) * NP] = 1.f;
+        if (wv == 0) {
+          for (int k = 0; k < d.K; ++k) GT[k * NP] = 0.f;
+          GT[d.K * NP] = 0.f; GT[(d.K + 1) * NP] = 1.f; GT[(d.K + 2) * NP] = 1.f;
+        }
       } else {
         float logp = 0.f, logq = 0.f;
-        // ---- nu ----
-        for (int h = 0; h < d.Nh; ++h) {
-          const long long j = (long long)g * d.Nh + h;
-          float x;
-          if (cond_only) {
-            x = CND(VC_SITE_NU) ? b.cnd[VC_SITE_NU][j] : 0.f;
-          } else {
-            const float e = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_NU] + j, d.eoff[VC_E_NU] + j);
-            const float u = P[d.poff[VC_P_NU_USCALES] + j];
-            const float xg = P[d.poff[VC_P_NU_LOCS] + j] + expf(u) * e;
-            if (CND(VC_SITE_NU)) x = b.cnd[VC_SITE_NU][j];
-            else { x = xg; logq += -0.5f * e * e - u - 0.5f * VC_LOG_2PI; }
-            logp += vc_normal_lp(x, b.mu_nu[j], b.sd_nu[j]);
-            b.lat[VC_SITE_NU][j] = x;
-          }
-          GT[h * NP] = x;
-        }
-        // ---- delta nu (Delta guide) ----
-        for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
-          const long long j = (long long)q * d.Ng + g;
-          float x;
-          if (cond_only) x = CND(VC_SITE_DNU) ? b.cnd[VC_SITE_DNU][j] : 0.f;
-          else {
-            x = CND(VC_SITE_DNU) ? b.cnd[VC_SITE_DNU][j] : P[d.poff[VC_P_DNU_LOCS] + j];
-            logp += vc_normal_lp(x, 0.f, vel ? 0.01f : b.sd_dnu[j]);
-            b.lat[VC_SITE_DNU][j] = x;
-          }
-          GT[(d.Nh + q) * NP] = x;
-        }
-        // ---- shape_inv (Delta guide, positive) ----
-        float si = 1.f;
-        if (nb) {
-          if (cond_only) si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : 1.f;
-          else {
-            si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
-            logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) -
-                    d.gamma_beta * si - lgammaf(d.gamma_alpha);
-            b.lat[VC_SITE_SHAPE_INV][g] = si;
-          }
-        }
-        GT[(d.K + 2) * NP] = 1.0f / si;
-        // ---- log gamma, log beta ----
-        float lg = 0.f, lbv = 0.f;
-        if (vel && !cond_only) {
-          float lg_guide, lb_guide;
-          if (!lrmn) {
-            const float eg = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGGAMMA] + g, d.eoff[VC_E_LOGGAMMA] + g);
-            const float eb = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGBETA] + g, d.eoff[VC_E_LOGBETA] + g);
-            const float ug = P[d.poff[VC_P_LOGGAMMA_USCALES] + g], ub = P[d.poff[VC_P_LOGBETA_USCALES] + g];
-            lg_guide = P[d.poff[VC_P_LOGGAMMA_LOCS] + g] + expf(ug) * eg;
-            lb_guide = P[d.poff[VC_P_LOGBETA_LOCS] + g] + expf(ub) * eb;
-            if (!CND(VC_SITE_LOGGAMMA)) logq += -0.5f * eg * eg - ug - 0.5f * VC_LOG_2PI;
-            if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - ub - 0.5f * VC_LOG_2PI;
-          } else {
-            // LowRankMultivariateNormal.rsample: X = loc + W eps_W + sqrt(cov_diag) eps_D
-            float delta = 0.f, w2 = 0.f;
-            for (int k = 0; k < d.R; ++k) {
-              const float w = expf(P[d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k]);
-              const float ew = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_W] + k, d.eoff[VC_E_LRMN_W] + k);
-              delta += w * ew;
-              w2 += w * w;
+        const int nroles = d.Nh + d.Nb + 2;
+        for (int role = wv; role < nroles; role += 4) {
+          if (role >= 1 && role <= d.Nh) {
+            // ---- nu[h] ----
+            const int h = role - 1;
+            const long long j = (long long)g * d.Nh + h;
+            float x;
+            if (cond_only) {
+              x = CND(VC_SITE_NU) ? b.cnd[VC_SITE_NU][j] : 0.f;
+            } else {
+              const float e = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_NU] + j, d.eoff[VC_E_NU] + j);
+              const float u = P[d.poff[VC_P_NU_USCALES] + j];
+              const float xg = P[d.poff[VC_P_NU_LOCS] + j] + expf(u) * e;
+              if (CND(VC_SITE_NU)) x = b.cnd[VC_SITE_NU][j];
+              else { x = xg; logq += -0.5f * e * e - u - 0.5f * VC_LOG_2PI; }
+              logp += vc_normal_lp(x, b.mu_nu[j], b.sd_nu[j]);
+              b.lat[VC_SITE_NU][j] = x;
             }
-            const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
-            const float ed = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_D] + g, d.eoff[VC_E_LRMN_D] + g);
-            delta += sqrtf(dg) * ed;
-            const float sgam = sqrtf(w2 + dg);
-            lg_guide = P[d.poff[VC_P_LRMN_LOC] + g] + delta;
-            const float rho_real_g = P[d.poff[VC_P_RHO_REAL_LOC] + g];
-            const float rho = sigmoidf_(rho_real_g / d.rho_scale) * 1.998f - 0.999f;
-            const float ub = P[d.poff[VC_P_LOGBETA_USCALES] + g];
-            const float sb = expf(ub);
-            const float eb = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGBETA] + g, d.eoff[VC_E_LOGBETA] + g);
-            const float tt = sb * sqrtf(1.f - rho * rho);
-            lb_guide = P[d.poff[VC_P_LOGBETA_LOCS] + g] + rho * sb * delta / sgam + tt * eb;
-            if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - logf(tt) - 0.5f * VC_LOG_2PI;
-            b.lat_delta[g] = delta;
-            b.lat_sgam[g] = sgam;
-            const float rho_val = CND(VC_SITE_RHO_REAL) ? b.cnd[VC_SITE_RHO_REAL][g] : rho_real_g;
-            logp += vc_normal_lp(rho_val, d.rho_mean, d.rho_std);
-            b.lat[VC_SITE_RHO_REAL][g] = rho_val;
+            GT[h * NP] = x;
+          } else if (role > d.Nh && role <= d.Nh + d.Nb) {
+            // ---- delta nu (Delta guide) ----
+            const int q = role - d.Nh - 1;
+            const long long j = (long long)q * d.Ng + g;
+            float x = 0.f;
+            if (d.with_dnu) {
+              if (cond_only) x = CND(VC_SITE_DNU) ? b.cnd[VC_SITE_DNU][j] : 0.f;
+              else {
+                x = CND(VC_SITE_DNU) ? b.cnd[VC_SITE_DNU][j] : P[d.poff[VC_P_DNU_LOCS] + j];
+                logp += vc_normal_lp(x, 0.f, vel ? 0.01f : b.sd_dnu[j]);
+                b.lat[VC_SITE_DNU][j] = x;
+              }
+              GT[(d.Nh + q) * NP] = x;
+            }
+          } else if (role == nroles - 1) {
+            // ---- shape_inv (Delta guide, positive) ----
+            float si = 1.f;
+            if (nb) {
+              if (cond_only) si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : 1.f;
+              else {
+                si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
+                logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) -
+                        d.gamma_beta * si - lgammaf(d.gamma_alpha);
+                b.lat[VC_SITE_SHAPE_INV][g] = si;
+              }
+            }
+            GT[(d.K + 2) * NP] = 1.0f / si;
+          } else {
+            // ---- role 0: log gamma, log beta ----
+            float lg = 0.f, lbv = 0.f;
+            if (vel && !cond_only) {
+              float lg_guide, lb_guide;
+              if (!lrmn) {
+                const float eg = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGGAMMA] + g, d.eoff[VC_E_LOGGAMMA] + g);
+                const float eb = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGBETA] + g, d.eoff[VC_E_LOGBETA] + g);
+                const float ug = P[d.poff[VC_P_LOGGAMMA_USCALES] + g], ub = P[d.poff[VC_P_LOGBETA_USCALES] + g];
+                lg_guide = P[d.poff[VC_P_LOGGAMMA_LOCS] + g] + expf(ug) * eg;
+                lb_guide = P[d.poff[VC_P_LOGBETA_LOCS] + g] + expf(ub) * eb;
+                if (!CND(VC_SITE_LOGGAMMA)) logq += -0.5f * eg * eg - ug - 0.5f * VC_LOG_2PI;
+                if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - ub - 0.5f * VC_LOG_2PI;
+              } else {
+                // LowRankMultivariateNormal.rsample: X = loc + W eps_W + sqrt(cov_diag) eps_D
+                float delta = 0.f, w2 = 0.f;
+                for (int k = 0; k < d.R; ++k) {
+                  const float w = expf(P[d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k]);
+                  const float ew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ew_mine), k));
+                  delta += w * ew;
+                  w2 += w * w;
+                }
+                const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
+                const float ed = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_D] + g, d.eoff[VC_E_LRMN_D] + g);
+                delta += sqrtf(dg) * ed;
+                const float sgam = sqrtf(w2 + dg);
+                lg_guide = P[d.poff[VC_P_LRMN_LOC] + g] + delta;
+                const float rho_real_g = P[d.poff[VC_P_RHO_REAL_LOC] + g];
+                const float rho = sigmoidf_(rho_real_g / d.rho_scale) * 1.998f - 0.999f;
+                const float ub = P[d.poff[VC_P_LOGBETA_USCALES] + g];
+                const float sb = expf(ub);
+                const float eb = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LOGBETA] + g, d.eoff[VC_E_LOGBETA] + g);
+                const float tt = sb * sqrtf(1.f - rho * rho);
+                lb_guide = P[d.poff[VC_P_LOGBETA_LOCS] + g] + rho * sb * delta / sgam + tt * eb;
+                if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - logf(tt) - 0.5f * VC_LOG_2PI;
+                b.lat_delta[g] = delta;
+                b.lat_sgam[g] = sgam;
+                const float rho_val = CND(VC_SITE_RHO_REAL) ? b.cnd[VC_SITE_RHO_REAL][g] : rho_real_g;
+                logp += vc_normal_lp(rho_val, d.rho_mean, d.rho_std);
+                b.lat[VC_SITE_RHO_REAL][g] = rho_val;
+              }
+              lg = CND(VC_SITE_LOGGAMMA) ? b.cnd[VC_SITE_LOGGAMMA][g] : lg_guide;
+              lbv = CND(VC_SITE_LOGBETA) ? b.cnd[VC_SITE_LOGBETA][g] : lb_guide;
+              logp += vc_normal_lp(lg, b.mu_g[g], b.sd_g[g]) + vc_normal_lp(lbv, b.mu_b[g], b.sd_b[g]);
+              b.lat[VC_SITE_LOGGAMMA][g] = lg;
+              b.lat[VC_SITE_LOGBETA][g] = lbv;
+            }
+            GT[d.K * NP] = lbv;
+            GT[(d.K + 1) * NP] = expf(lg);
           }
-          lg = CND(VC_SITE_LOGGAMMA) ? b.cnd[VC_SITE_LOGGAMMA][g] : lg_guide;
-          lbv = CND(VC_SITE_LOGBETA) ? b.cnd[VC_SITE_LOGBETA][g] : lb_guide;
-          logp += vc_normal_lp(lg, b.mu_g[g], b.sd_g[g]) + vc_normal_lp(lbv, b.mu_b[g], b.sd_b[g]);
-          b.lat[VC_SITE_LOGGAMMA][g] = lg;
-          b.lat[VC_SITE_LOGBETA][g] = lbv;
         }
-        GT[d.K * NP] = lbv;
-        GT[(d.K + 1) * NP] = expf(lg);
         loss = -(double)d.root_w * ((double)logp - (double)logq);
       }
     }
