@@ -422,20 +422,23 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
     }
   }
 
+  // U chunk groups x MQ rows of loads are in flight per wave before any is consumed; U is chosen so that the usual
+  // one-round grid of K_main (<= 16 U chunks) is fetched in a single round trip
+  constexpr int U = MQ <= 2 ? 16 : (MQ <= 6 ? 8 : 4);
   float acc[MQ];
 #pragma unroll
   for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
-  for (int ch0 = wave; ch0 < d.n_chunks; ch0 += 4 * VC_PG_WAVES) {
-    float v[4][MQ];
+  for (int ch0 = wave; ch0 < d.n_chunks; ch0 += U * VC_PG_WAVES) {
+    float v[U][MQ];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {        // issue the loads of 4 chunks before consuming any
+    for (int u = 0; u < U; ++u) {
       const int ch = ch0 + u * VC_PG_WAVES;
       const float* go = b.GO + ((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq) * d.Ng_pad + g;
 #pragma unroll
       for (int q = 0; q < MQ; ++q) v[u][q] = (q < d.nq) ? go[(size_t)q * d.Ng_pad] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
       if (ch0 + u * VC_PG_WAVES < d.n_chunks) {
 #pragma unroll
         for (int q = 0; q < MQ; ++q) acc[q] += v[u][q];
