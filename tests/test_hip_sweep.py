@@ -118,6 +118,24 @@ def test_ragged_and_tiny_shapes(Nc, Ng, monkeypatch):
         _check(p, gpl, monkeypatch)
 
 
+@pytest.mark.parametrize("rank,Nx,Hw", [(1, 1, 0), (3, 2, 1), (8, 3, 2), (8, 9, 3)])
+def test_lrmn_ranks_and_many_speed_coefficients(rank, Nx, Hw, monkeypatch):
+    """LRMN guide with rank 1 / 3 / 8 (the compiled maximum) and up to Nx (2 Hw + 1) = 63 angular-speed coefficients:
+    the loops over the low-rank factors and over the nu_omega outputs in K_pre, K_post and K_fin."""
+    for sites in ([], ["ϕxy", "ν", "shape_inv"]):
+        p = _problem("velocity", "lrmn", "NegativeBinomial", 1, Hw, 0, Nx, sites, Nc=150, Ng=70, seed=300 + rank + Nx)
+        p.rho_rank = rank
+        _check(p, None, monkeypatch)
+
+
+@pytest.mark.parametrize("Ng", [1, 3, 65, 66, 129])
+def test_lrmn_with_a_nearly_empty_last_gene_block(Ng, monkeypatch):
+    """Fewer real genes in the last 64-gene block than low-rank factors: the eps_W broadcast of K_pre must not depend
+    on lanes that belong to padded genes (a cross-lane read after divergence did, caught at rank >= 7 with Ng = 70)."""
+    p = _problem("velocity", "lrmn", "NegativeBinomial", 1, 1, 0, 2, [], Nc=90, Ng=Ng, seed=400 + Ng)
+    _check(p, None, monkeypatch)
+
+
 def test_unsupported_configurations_raise():
     from tests.helpers import spec_from_problem
     from velocycle_amd.engine import HipEngine

@@ -116,6 +116,12 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
     float ew_mine = 0.f;
     if (wv == 0 && lrmn && !cond_only && lane < d.R)
       ew_mine = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_W] + lane, d.eoff[VC_E_LRMN_W] + lane);
+    // broadcast to wave-uniform values NOW, while every lane is active: after the divergence below the registers of the
+    // lanes that take the other path are free for the compiler to reuse
+    float ew_all[VC_MAX_RANK];
+#pragma unroll
+    for (int k = 0; k < VC_MAX_RANK; ++k)
+      ew_all[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ew_mine), k));
     if (g < d.Ng_pad) {
       float* GT = b.GT + g;
       const size_t NP = d.Ng_pad;
@@ -188,12 +194,13 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
               } else {
                 // LowRankMultivariateNormal.rsample: X = loc + W eps_W + sqrt(cov_diag) eps_D
                 float delta = 0.f, w2 = 0.f;
-                for (int k = 0; k < d.R; ++k) {
-                  const float w = expf(P[d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k]);
-                  const float ew = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ew_mine), k));
-                  delta += w * ew;
-                  w2 += w * w;
-                }
+#pragma unroll
+                for (int k = 0; k < VC_MAX_RANK; ++k)
+                  if (k < d.R) {
+                    const float w = expf(P[d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k]);
+                    delta += w * ew_all[k];
+                    w2 += w * w;
+                  }
                 const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
                 const float ed = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_D] + g, d.eoff[VC_E_LRMN_D] + g);
                 delta += sqrtf(dg) * ed;
