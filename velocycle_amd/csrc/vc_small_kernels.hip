@@ -368,7 +368,6 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
                                                    const float* __restrict__ P, float* __restrict__ G,
                                                    int gblock) {
   __shared__ float sm[VC_PG_WAVES][MQ][64];
-  __shared__ double sm_red[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = gblock * 64 + lane;
   // Chain rule to the parameter gradients: the work of one gene is split into independent ROLES and every role runs
@@ -557,8 +556,11 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
     }
   }
   VC_KSTAMP(1, 2);
-  const double tot = vc_block_sum_d(loss, sm_red);
-  if (threadIdx.x == 0) b.LP[d.nb_pre_gene + d.nb_pre_cell + gblock] = tot;
+  // only the shape_inv role (wave 12) carries loss terms: its wave sum is the block's partial, no block reduction
+  if (role == 12) {
+    const double tot = vc_wave_sum_d(loss);
+    if (lane == 0) b.LP[d.nb_pre_gene + d.nb_pre_cell + gblock] = tot;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
