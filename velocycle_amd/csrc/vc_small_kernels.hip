@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
       } else {
         float logp = 0.f, logq = 0.f;
         const int nroles = d.Nh + d.Nb + 2;
-        for (int role = wv; role < nroles; role += 4) {
+        // role 0 (two or more RNG draws) has wave 0 to itself; roles 1..3 go to waves 1..3, the rest round-robin over them
+        for (int role = 0; role < nroles; ++role) {
+          if ((role < 4 ? role : 1 + (role - 4) % 3) != wv) continue;
           if (role >= 1 && role <= d.Nh) {
             // ---- nu[h] ----
             const int h = role - 1;
