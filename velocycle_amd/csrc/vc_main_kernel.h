@@ -3,21 +3,23 @@
 // spends per SVI step in velocity_latent_variable_model (velocity_inference_model.py:344-386) /
 // phase_latent_variable_model (phase_inference_model.py:369-395).
 //
-// Mapping (CDNA4): lane = 4 consecutive genes, wave = one 256-gene block x `cw` consecutive cells,
-// workgroup = 4 waves on the same gene block (4*cw consecutive cells).
+// Mapping (CDNA4): lane = GPL (4 or 8) consecutive genes, wave = one gene block of 64*GPL genes x `cw` consecutive
+// cells, workgroup = 4 waves on the same gene block (4*cw consecutive cells); the grid is ONE resident round.
 //   * per-gene sampled latents (nu~, log beta, gamma, r) and the per-gene gradient accumulators stay
 //     in VGPRs for the whole cell loop -- no cross-lane traffic for gene-level sums;
 //   * the per-cell record (sin k phi, cos k phi, Db[:,c], omega_c, cf_c) is wave-uniform: it is read
-//     with scalar loads (s_load_dwordx8) and consumed as SGPR operands;
-//   * counts are streamed with one global_load_dwordx4 per lane per matrix per cell: 1 KiB
-//     contiguous per wave-instruction, each wave walking a private contiguous region of HBM
-//     ([gene block][cell][256] layout);
+//     through the constant address space with scalar loads (s_load_dwordx8) and consumed as SGPR pairs;
+//   * counts are streamed with GPL/4 global_load_dwordx4 per lane per matrix per cell (1 KiB contiguous per
+//     wave-instruction), each wave walking a private contiguous region of HBM ([gene block][cell][64*GPL]
+//     layout); two register buffers rotate so that the next cell is in flight while this one is processed;
 //   * per-cell sums over genes (for d/dphi and d/domega) are 64-lane DPP reductions, staged one
 //     lane per cell and flushed as a coalesced 256-B store every 64 cells;
-//   * gene-level partials of the 4 waves are combined through LDS and written once per workgroup;
-//     the second (deterministic) reduction stage is K_post.  No float atomics anywhere.
+//   * gene-level partials of the 4 waves are combined through LDS (up to 6 output rows per barrier pair) and
+//     written once per workgroup; the second (deterministic) reduction stage is K_post.  No float atomics.
 //
-// Bound: HBM.  Algorithmic bytes: 4*Ng*Nc per matrix read (S and U for VFULL, one matrix otherwise).
+// Bound: HBM by design (algorithmic bytes: 4*Ng*Nc per matrix read; S and U for VFULL, one matrix otherwise); measured,
+// the S+U kernel sits within 10 % of both that memory-side bound and its own arithmetic bound, the one-matrix kernels
+// at 95 % of their arithmetic (profiles/r01_d_kmain_bound.md).
 #pragma once
 #include "vc_common.h"
 
