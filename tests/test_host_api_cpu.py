@@ -127,3 +127,32 @@ def test_pca_phase_prior_matches_reference():
         assert np.allclose(p.phi_xy.values, z["rot_" + tag], atol=1e-6)
     with pytest.raises(ValueError):
         C.Phases.from_pca_heuristic(ad, layer="nope")
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_sparse_layers_give_the_same_containers_as_dense(normalize):
+    """.h5ad files hold scipy sparse layers; the stand-in AnnData keeps them sparse through gene selection
+    (`adata[:, genes].copy()`, preprocessing.py:20-63) and both preprocess_* produce the same tensors as from dense layers."""
+    import scipy.sparse as sps
+    from velocycle_amd import containers as C, preprocessing as P
+    from velocycle_amd.anndata_lite import AnnDataLite
+    from velocycle_amd.workloads import make_velocity_spec
+    sp = make_velocity_spec(300, 40, "vjoint", seed=3)
+    S, U = sp.S.t().numpy(), sp.U.t().numpy()
+    res = []
+    for sparse in (False, True):
+        ad = AnnDataLite(sps.csr_matrix(S) if sparse else S, sps.csc_matrix(U) if sparse else U)
+        genes = list(ad.var.index)[5:35]                     # the cycle prior knows a subset: intersection slices the layers
+        cyc = C.Cycle.from_array(sp.mu_nu.T.numpy()[:, 5:35], sp.sd_nu.T.numpy()[:, 5:35], genes)
+        ph = C.Phases.from_array(sp.phixy_prior.T.numpy(), cell_names=list(ad.obs.index))
+        mp = P.preprocess_for_phase_estimation(ad, cyc, ph, torch.ones(300, 1), n_harmonics=1, normalize=normalize)
+        spd = C.AngularSpeed.trivial_prior(["c0"], harmonics=1)
+        mv = P.preprocess_for_velocity_estimation(ad, cyc, ph, spd, torch.ones(300, 1), torch.ones(300, 1), n_harmonics=1,
+                                                  count_factor=mp.count_factor, normalize=normalize)
+        res.append((mp, mv))
+    for dense, sparse in zip(*res):
+        assert dense.Ng == sparse.Ng == 30
+        for f in dense._fields:
+            x, y = getattr(dense, f), getattr(sparse, f)
+            if isinstance(x, torch.Tensor):
+                assert torch.equal(x, y), f

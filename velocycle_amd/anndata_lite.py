@@ -10,9 +10,10 @@ import pandas as pd
 
 class AnnDataLite:
     def __init__(self, spliced, unspliced, gene_names=None, cell_names=None, obs=None):
-        spliced = np.asarray(spliced)
-        unspliced = np.asarray(unspliced)
-        assert spliced.shape == unspliced.shape and spliced.ndim == 2
+        # dense arrays or scipy sparse matrices (what .h5ad files usually hold); sparse layers stay sparse
+        spliced = spliced if _is_sparse(spliced) else np.asarray(spliced)
+        unspliced = unspliced if _is_sparse(unspliced) else np.asarray(unspliced)
+        assert spliced.shape == unspliced.shape and len(spliced.shape) == 2
         nc, ng = spliced.shape
         if gene_names is None:
             gene_names = ["G" + str(i).zfill(5) for i in range(ng)]
@@ -37,7 +38,7 @@ class AnnDataLite:
 
     def copy(self):
         out = AnnDataLite.__new__(AnnDataLite)
-        out.layers = {k: np.array(v, copy=True) for k, v in self.layers.items()}
+        out.layers = {k: (v.copy() if _is_sparse(v) else np.array(v, copy=True)) for k, v in self.layers.items()}
         out.var = self.var.copy()
         out.obs = self.obs.copy()
         out.X = out.layers["spliced"]
@@ -54,11 +55,16 @@ class AnnDataLite:
         if (np.asarray(cidx) < 0).any() or (np.asarray(ridx) < 0).any():
             raise KeyError("unknown gene / cell name")
         out = AnnDataLite.__new__(AnnDataLite)
-        out.layers = {k: np.asarray(v)[np.ix_(ridx, cidx)] for k, v in self.layers.items()}
+        out.layers = {k: (v.tocsr()[ridx][:, cidx] if _is_sparse(v) else np.asarray(v)[np.ix_(ridx, cidx)])
+                      for k, v in self.layers.items()}
         out.var = self.var.iloc[cidx].copy()
         out.obs = self.obs.iloc[ridx].copy()
         out.X = out.layers["spliced"]
         return out
+
+
+def _is_sparse(x):
+    return hasattr(x, "toarray") and hasattr(x, "tocsr")
 
 
 def _is_names(k):
