@@ -50,6 +50,7 @@ extern "C" {
 #define VC_ERR_HIP (-2)          /* a HIP runtime call failed */
 #define VC_ERR_UNSUPPORTED (-3)  /* configuration outside the compiled kernel set */
 #define VC_ERR_STATE (-4)        /* call order violated (e.g. step before finalize) */
+#define VC_ERR_NONFINITE (-5)    /* a step produced a NaN / Inf loss (vc_get_status) */
 
 /* model / guide / noise selectors */
 #define VC_MODEL_PHASE 0         /* phase_latent_variable_model */
@@ -250,6 +251,14 @@ int vc_expected_logs(vc_engine* e, const float* nu, const float* dnu, const floa
 /* Copies the value a site took in the last vc_elbo_grad to host memory (synchronises the stream). */
 int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream);
 int vc_get_stats(const vc_engine* e, vc_stats* out);
+/* Failure detection (the reference's counterpart: pyro.util.warn_if_nan(loss, "loss") inside SVI.step, call sites
+ * phase_inference_model.py:169 / velocity_inference_model.py:120).  The last kernel of every step checks this rank's
+ * loss on the device and latches the first step whose loss was NaN / Inf, so the check costs no host round trip per
+ * step.  Synchronises `hip_stream`, returns VC_OK, or VC_ERR_NONFINITE with *first_bad_step (may be NULL) = the
+ * 0-based index of the first such step and *n_bad (may be NULL) = how many steps were affected since vc_finalize /
+ * the last vc_clear_status. */
+int vc_get_status(vc_engine* e, int64_t* first_bad_step, int64_t* n_bad, void* hip_stream);
+int vc_clear_status(vc_engine* e, void* hip_stream);
 /* Kernel timing for bench.py's roofline: while enabled, every vc_elbo_grad brackets the likelihood
  * kernel with a pair of hipEvents recorded on the launch stream (not capturable into a hipGraph).
  * vc_get_timing synchronises the pending events and returns the accumulated duration (ms) and the

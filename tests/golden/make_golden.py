@@ -226,6 +226,22 @@ def make_case(name, c, seed=11):
                      "log_gammas", "log_betas", "velocity_coef", "velocity_coef_sd"):
             if hasattr(fitm, attr):
                 fo["attr_" + attr] = np.asarray(getattr(fitm, attr))
+        # the reference's own posterior summaries (velocity_inference_model.py:236-262, phase_inference_model.py:248-265)
+        # together with the draw-dependent inputs they were computed from, so that the engine's vc_expected_logs can be
+        # checked against the reference's numbers without sharing its RNG stream
+        post = fitm.posterior
+        for k in ("ElogS", "ElogS2", "ElogU", "ElogU2"):
+            if k in post:
+                fo["post_" + k] = post[k].detach().numpy()
+        fo["post_phis"] = fitm.phase_pyro.phis.detach().numpy()
+        fo["post_cf_avg"] = np.array(float(fitm.metaparams_avg.count_factor.reshape(-1)[0]))
+        if c["kind"] == "velocity":
+            fo["post_gamma_mean"] = post["γg"].mean(0).reshape(-1).numpy()
+            fo["post_logbeta_mean"] = post["logβg"].mean(0).reshape(-1).numpy()
+            fo["post_nuw_mean"] = post["νω"].mean(0).reshape(p32.Nx, p32.Nhw).numpy()
+            fo["post_omega_draws"] = post["ω"].reshape(post["ω"].shape[0], -1).numpy()
+            fo["post_nuw_draws"] = post["νω"].reshape(post["νω"].shape[0], p32.Nx, p32.Nhw).numpy()
+            fo["post_phi_draws"] = post["ϕ"].reshape(post["ϕ"].shape[0], -1).numpy()
         np.savez_compressed(os.path.join(OUT, f"ref_fit_{name}.npz"), **fo)
         print(f"[fit ] {name}: {n} steps, ref final loss {fitm.losses[-1]:.4f}, oracle {o_losses[-1]:.4f}")
 

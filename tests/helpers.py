@@ -65,3 +65,58 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     scale = max(np.abs(b).max(), 1e-30)
     return float(np.abs(a - b).max() / scale)
+
+
+def problem_from_spec(spec, dtype=torch.float64) -> orc.Problem:
+    """The oracle's view of a product ModelSpec (CPU, `dtype`)."""
+    kw = {}
+    for k, v in spec.__dict__.items():
+        if k == "truth":
+            continue
+        kw[k] = v.detach().cpu().to(dtype) if (isinstance(v, torch.Tensor) and v.is_floating_point()) else v
+    kw["condition_on"] = {k: v.detach().cpu().to(dtype) for k, v in spec.condition_on.items()}
+    return orc.Problem(**kw)
+
+
+def assert_step_matches_oracle(eng, spec, eps, loss_rtol=1e-5, grad_rtol=2e-3):
+    """One ELBO + gradient evaluation already launched on `eng` with the host eps dict `eps`: loss within `loss_rtol`
+    of the float64 oracle, every gradient block within `grad_rtol` of its max-norm -- or no worse than 4x the error of
+    the oracle's own float32 run (= what the reference computes in) where the 1/(z + 1e-5) relu kink amplifies rounding."""
+    torch.cuda.synchronize()
+    p64 = problem_from_spec(spec, torch.float64)
+    par = {n: v.detach().cpu().double() for n, v in eng.named().items()}
+    e64 = {k: v.double() for k, v in eps.items() if not k.startswith("_")}
+    l64, g64, _, _ = orc.loss_and_grads(p64, par, e64)
+    _, g32, _, _ = orc.loss_and_grads(p64.to(torch.float32), {k: v.float() for k, v in par.items()},
+                                      {k: v.float() for k, v in e64.items()})
+    assert abs(eng.loss() - l64) <= loss_rtol * abs(l64), (eng.loss(), l64)
+    for name, got in eng.named(eng.grad).items():
+        want = g64[name].numpy()
+        fin = np.isfinite(want)
+        err = np.abs(got.cpu().numpy()[fin] - want[fin]).max()
+        ref32 = np.abs(g32[name].numpy().astype(np.float64)[fin] - want[fin]).max()
+        assert err <= max(grad_rtol * max(np.abs(want[fin]).max(), 1e-3), 4 * ref32), (name, err, ref32)
+    return l64, g64
+
+
+def assert_trajectory_within_float32_spread(spec, opt, n, seed, losses, named_params):
+    """SURVEY §8(d) ELBO-match over n SVI steps on the same host eps stream: the first steps agree with the float64
+    oracle to 1e-5; afterwards float32 and float64 Adam trajectories separate by themselves, so the yardstick is the
+    oracle's own float32 run (x4); fitted parameters within 1e-3 of each block's max-norm wherever float32 itself is."""
+    p64 = problem_from_spec(spec, torch.float64)
+    l64, par64 = orc.fit(p64, opt, n, seed=seed)
+    l32, par32 = orc.fit(p64.to(torch.float32), opt, n, seed=seed)
+    l64, l32, losses = np.array(l64), np.array(l32), np.array(losses)
+    rel_hip, rel_32 = np.abs(losses - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
+    assert rel_hip[:5].max() <= 1e-5, rel_hip[:5]
+    assert (rel_hip <= np.maximum(1e-5, 4 * np.maximum.accumulate(rel_32))).all(), (rel_hip.max(), rel_32.max())
+    for k, v in named_params.items():
+        want, got = par64[k].numpy(), v.detach().cpu().numpy().astype(np.float64)
+        ref32 = par32[k].double().numpy()
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin), k
+        if not fin.any():
+            continue
+        scale = max(np.abs(want[fin]).max(), 1e-2)
+        err, spread = np.abs(got[fin] - want[fin]).max(), np.abs(ref32[fin] - want[fin]).max()
+        assert err <= max(1e-3 * scale, 4 * spread), (k, err, spread, scale)

@@ -143,3 +143,45 @@ def test_two_rank_svi_equals_single_process(case):
     xy = np.concatenate([r[3] for r in res]).reshape(-1, 2)
     assert np.allclose(xy, par["ϕxy_locs"].numpy(), rtol=1e-4, atol=1e-5)
     assert res[0][4][1] == res[1][4][0] and res[1][4][1] == p64.Nc       # contiguous, complete shards
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from velocycle_amd.distributed import broadcast_int, dist_context, gather_cells
+    from velocycle_amd.engine import shard_bounds
+    Nc = 11
+    sizes = [b - a for a, b in (shard_bounds(Nc, r, world) for r in range(world))]
+    c0, c1 = shard_bounds(Nc, rank, world)
+    full = torch.arange(3 * Nc * 2, dtype=torch.float32).reshape(3, Nc, 2)       # (draws, cells, xy)
+    got = gather_cells(full[:, c0:c1], 1, sizes)
+    rows = gather_cells(full[0, c0:c1], 0, sizes)
+    seed = broadcast_int(1234 + rank)
+    q.put((rank, dist_context()[:2], torch.equal(got, full), torch.equal(rows, full[0]), seed, sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_cells_and_seed_agreement_two_ranks():
+    """The once-per-fit exchanges of the sharded fit(): unequal shards (6 + 5 cells) gathered along any axis give the
+    full array on every rank; rank 0's seed reaches every rank."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, (rank, ctxinfo, ok3, ok2, seed, sizes) in enumerate(res):
+        assert ctxinfo == (r, 2) and ok3 and ok2 and seed == 1234 and sizes == [6, 5]
+
+
+def test_gather_cells_without_process_group_is_identity():
+    from velocycle_amd.distributed import broadcast_int, dist_context, gather_cells
+    assert dist_context() == (0, 1, None)
+    x = torch.arange(6.).reshape(2, 3)
+    assert torch.equal(gather_cells(x, 1, [3]), x) and broadcast_int(7) == 7

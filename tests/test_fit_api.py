@@ -50,6 +50,9 @@ def test_phase_fit_drop_in():
     assert post["ν"].shape == (6, mp.Ng, 1, 3) and post["ϕxy"].shape == (6, mp.Nc, 2)
     assert post["ζ"].shape == (6, mp.Nc, 3) and post["shape_inv"].shape == (6, mp.Ng, 1)
     assert post["ElogS"].shape == (mp.Ng, mp.Nc) and torch.isfinite(post["ElogS2"]).all()
+    # the deterministic posterior summaries against the reference's own posterior (phase_inference_model.py:248-265)
+    _close(post["ElogS"], z["post_ElogS"], 5e-3)
+    _close(post["ElogS2"], z["post_ElogS2"], 5e-3)
     # posterior draws scatter around the fitted means with the fitted scales
     assert np.allclose(post["ϕxy"].mean(0).numpy(), fit.phis_pyro.T, atol=2.0)
     # a second fit of the same class skips Trace_ELBO's warm-up pass, like the reference's shared loss object
@@ -89,6 +92,10 @@ def test_velocity_fit_drop_in(case):
         assert np.abs(fit.log_gammas - loc[: mp.Ng]).max() < 2.0
         assert fit.speed_pyro.means.shape == (2 * Hw + 1, 1)
     assert fit.posterior["ElogU"].shape == (mp.Ng, mp.Nc) and fit.posterior["ω"].shape == (6, 1, mp.Nc)
+    # ElogS / ElogS2 depend on the fitted ν_locs and phases only: equal to the reference's posterior
+    # (velocity_inference_model.py:236-247); ElogU additionally on the draw means (own RNG stream) -> tests/test_hip_posterior.py
+    _close(fit.posterior["ElogS"], z["post_ElogS"], 5e-3)
+    _close(fit.posterior["ElogS2"], z["post_ElogS2"], 5e-3)
     assert fit.speed_pyro.conditions == ["b0"]
 
 

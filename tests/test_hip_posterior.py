@@ -148,3 +148,37 @@ def test_expected_logs_at_a_ragged_larger_size():
         err = (a.cpu().double() - b).abs()
         assert bool((err <= _tolerance(spec, nu, phi, omega, gamma, k, b)).all()), f"output {k}: {float(err.max())}"
     eng.close()
+
+
+@pytest.mark.parametrize("case", H.FIT_CASES)
+def test_expected_logs_match_the_reference_posterior(case):
+    """vc_expected_logs against the numbers the REFERENCE's own posterior_sampling produced after its fit()
+    (`fitm.posterior["ElogS" / "ElogS2" / "ElogU" / "ElogU2"]`, velocity_inference_model.py:236-262,
+    phase_inference_model.py:248-265; stored by tests/golden/make_golden.py together with the fitted ν_locs, the
+    fitted phases and the draw means γ, log β, νω they were computed from)."""
+    from velocycle_amd.engine import HipEngine
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fit_{case}.npz")
+    spec = H.spec_from_fixture(z)
+    eng = HipEngine(spec)
+    nu = torch.tensor(z["reffit_ν_locs"])
+    phis = torch.tensor(z["post_phis"])
+    dnu = torch.tensor(z["reffit_Δν_locs"]) if spec.with_delta_nu else None
+    kw = {}
+    if spec.kind == "velocity":
+        nuw = torch.tensor(z["post_nuw_mean"]).double()                      # (Nx, Nhw)
+        p = phis.double()
+        zw = torch.stack([torch.ones_like(p)] + [f((k + 1) * p) for k in range(spec.Hw) for f in (torch.sin, torch.cos)])
+        omega = ((nuw @ zw) * spec.D.double()).sum(0)                        # one speed per cell (N2)
+        kw = dict(omega=omega.float(), logbeta=torch.tensor(z["post_logbeta_mean"]), gamma=torch.tensor(z["post_gamma_mean"]))
+        # the reference's draws of the deterministic site ω are that same contraction at each draw's νω and ϕ
+        pd, nd = torch.tensor(z["post_phi_draws"]).double(), torch.tensor(z["post_nuw_draws"]).double()
+        zd = torch.stack([torch.ones_like(pd)] + [f((k + 1) * pd) for k in range(spec.Hw) for f in (torch.sin, torch.cos)], 1)
+        om_d = torch.einsum("nxh,nhc,xc->nc", nd, zd, spec.D.double())
+        assert np.allclose(om_d.numpy(), z["post_omega_draws"], rtol=1e-5, atol=1e-6)
+    outs = eng.expected_logs(nu, phis, float(z["post_cf_avg"]), dnu=dnu, **kw)
+    torch.cuda.synchronize()
+    names = ["ElogS", "ElogS2"] + (["ElogU", "ElogU2"] if spec.kind == "velocity" else [])
+    for n, o in zip(names, outs):
+        want = z["post_" + n]
+        assert np.allclose(o.cpu().numpy(), want, rtol=2e-5, atol=2e-5), (n, np.abs(o.cpu().numpy() - want).max())
+    eng.close()

@@ -1,0 +1,244 @@
+"""CPU: what can be pinned INDEPENDENTLY at the Pyro boundary (pyro-ppl 1.8.6 is not installable here).
+
+The oracle and `oracle/pyro_shim` restate Pyro's arithmetic; agreement between the two says nothing about Pyro itself.
+These tests check every restated piece against an implementation that shares no code with either:
+`torch.distributions` (NegativeBinomial, Normal, Gamma, Independent, LowRankMultivariateNormal) and `torch.optim.Adam`.
+  * GammaPoisson(c, rate).log_prob == NegativeBinomial(total_count=c, logits=log(mean) - log(c)).log_prob
+    (velocity_inference_model.py:386-387, phase_inference_model.py:393-395 call sites)
+  * the whole -ELBO of Trace_ELBO(num_particles=1) assembled from torch.distributions objects only
+  * ClippedAdam == torch.optim.Adam where the two coincide (eps = 0, lrd = 1, clip >> |g|), and its documented
+    differences (lr decay before the update, elementwise clamp, eps outside the bias correction) in closed form
+  * LowRankMultivariateNormal.rsample's draw order (eps_W, then eps_D) and value loc + W eps_W + sqrt(D) eps_D
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributions as td
+
+from oracle import velocycle_oracle as orc
+from tests import helpers as H
+
+SHIM = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "pyro_shim")
+
+
+def _shim():
+    if SHIM not in sys.path:
+        sys.path.insert(0, SHIM)
+    import pyro  # noqa: F401  (the shim)
+    import pyro.distributions as pd
+    import pyro.optim as po
+    return pd, po
+
+
+def test_gamma_poisson_equals_torch_negative_binomial():
+    pd, _ = _shim()
+    g = torch.Generator().manual_seed(0)
+    r = torch.exp(torch.empty(400, dtype=torch.float64).uniform_(math.log(0.1), math.log(100.0), generator=g))
+    eta = torch.empty(400, dtype=torch.float64).uniform_(-4.0, 8.0, generator=g)
+    k = torch.cat([torch.arange(0, 50, dtype=torch.float64), torch.tensor([99., 1000., 4095., 1e4])])
+    R, E, K = r[:, None], eta[:, None], k[None, :]
+    want = td.NegativeBinomial(total_count=R, logits=E - R.log()).log_prob(K)
+    rate = R / E.exp()                 # GammaPoisson(1/shape_inv, 1/(shape_inv * exp(eta)))
+    got_oracle = orc.gamma_poisson_log_prob(R, rate, K)
+    got_shim = pd.GammaPoisson(R, rate).log_prob(K)
+    assert torch.allclose(got_oracle, want, rtol=1e-10, atol=1e-9), (got_oracle - want).abs().max()
+    assert torch.allclose(got_shim, want, rtol=1e-10, atol=1e-9), (got_shim - want).abs().max()
+    # and its gradients w.r.t. eta and r (what the kernels hard-code in closed form)
+    E2 = E.clone().requires_grad_(True)
+    R2 = R.clone().requires_grad_(True)
+    td.NegativeBinomial(total_count=R2, logits=E2 - R2.log()).log_prob(K).sum().backward()
+    mu = E.exp()
+    d_eta = (R * (K - mu) / (R + mu)).sum(1, keepdim=True)
+    assert torch.allclose(E2.grad, d_eta, rtol=1e-9, atol=1e-8)
+    d_r = (torch.digamma(R + K) - torch.digamma(R) + R.log() + 1 - (R + mu).log() - (R + K) / (R + mu)).sum(1, keepdim=True)
+    assert torch.allclose(R2.grad, d_r, rtol=1e-8, atol=1e-7)
+
+
+def _elbo_from_torch_distributions(p, par, eps):
+    """-ELBO of the mean-field programs written with torch.distributions objects only (independent of the oracle's
+    hand-written log-densities): guide sites Normal(loc, scale) at loc + scale * eps, Delta sites contribute 0,
+    conditioned sites are observed in the model and absent from the guide."""
+    c = orc.constrained(par)
+    hid = set(p.condition_on)
+    val, logq = {}, 0.0
+
+    def gsite(name, loc, scale, e):
+        nonlocal logq
+        x = loc + scale * e
+        val[name] = x
+        if name not in hid:
+            logq = logq + td.Normal(loc, scale).log_prob(x).sum()
+    if p.kind == "velocity":
+        gsite("logγg", c["logγg_locs"], c["logγg_scales"], eps["logγg"])
+        gsite("logβg", c["logβg_locs"], c["logβg_scales"], eps["logβg"])
+    gsite("ν", c["ν_locs"], c["ν_scales"], eps["ν"])
+    if p.kind == "velocity":
+        gsite("νω", c["νω_locs"], c["νω_scales"], eps["νω"])
+    gsite("ϕxy", c["ϕxy_locs"], torch.ones_like(c["ϕxy_locs"]), eps["ϕxy"])
+    if p.with_delta_nu:
+        val["Δν"] = c["Δν_locs"]
+    if p.noisemodel == "NegativeBinomial":
+        val["shape_inv"] = c["shape_inv_locs"]
+    for n in hid:
+        val[n] = p.cond(n)
+    lp = td.Independent(td.Normal(p.mu_nu, p.sd_nu), 1).log_prob(val["ν"]).sum()
+    lp = lp + td.Independent(td.Normal(p.phixy_prior, 1.0), 1).log_prob(val["ϕxy"]).sum()
+    if p.with_delta_nu:
+        sd = p.sd_dnu if p.kind == "phase" else 0.01
+        lp = lp + td.Normal(torch.zeros_like(val["Δν"]), sd).log_prob(val["Δν"]).sum()
+    phi = torch.atan2(val["ϕxy"][:, 1], val["ϕxy"][:, 0])
+    ks = torch.arange(1, p.H + 1, dtype=p.dtype)
+    sn, cs = torch.sin(phi[:, None] * ks), torch.cos(phi[:, None] * ks)
+    zeta = torch.cat([torch.ones_like(phi)[:, None]] + [torch.stack([sn[:, i], cs[:, i]], 1) for i in range(p.H)], 1)
+    zeta_d = torch.cat([torch.zeros_like(phi)[:, None]] +
+                       [torch.stack([ks[i] * cs[:, i], -ks[i] * sn[:, i]], 1) for i in range(p.H)], 1)
+    ElogS = val["ν"] @ zeta.T + p.count_factor[None, :]
+    if p.with_delta_nu:
+        ElogS = ElogS + val["Δν"].T @ p.Db
+    obs = [(p.S, ElogS)]
+    if p.kind == "velocity":
+        lp = lp + td.Normal(p.mu_gamma, p.sd_gamma).log_prob(val["logγg"]).sum()
+        lp = lp + td.Normal(p.mu_beta, p.sd_beta).log_prob(val["logβg"]).sum()
+        lp = lp + td.Normal(p.mu_nuw, p.sd_nuw).log_prob(val["νω"]).sum()
+        kw = torch.arange(1, p.Hw + 1, dtype=p.dtype)
+        zw = torch.cat([torch.ones_like(phi)[:, None]] +
+                       [torch.stack([torch.sin(phi * kw[i]), torch.cos(phi * kw[i])], 1) for i in range(p.Hw)], 1)
+        omega = ((val["νω"] @ zw.T) * p.D).sum(0)
+        z = (val["ν"] @ zeta_d.T) * omega[None, :] + val["logγg"].exp()[:, None]
+        ElogU = -val["logβg"][:, None] + torch.log(torch.relu(z) + 1e-5) + ElogS
+        obs.append((p.U, ElogU))
+    if p.noisemodel == "NegativeBinomial":
+        si = val["shape_inv"]
+        lp = lp + td.Gamma(torch.as_tensor(p.gamma_alpha, dtype=p.dtype), torch.as_tensor(p.gamma_beta, dtype=p.dtype)).log_prob(si).sum()
+        r = (1.0 / si)[:, None]
+        for k, e in obs:
+            lp = lp + td.NegativeBinomial(total_count=r, logits=e - r.log()).log_prob(k).sum()
+    elif p.noisemodel == "Poisson":
+        for k, e in obs:
+            lp = lp + td.Poisson(e.exp()).log_prob(k).sum()
+    else:
+        for (k, e), s in zip(obs, (p.sigma_ln_s, p.sigma_ln_u)):
+            lp = lp + td.Normal(e, s).log_prob(torch.log(k.double() + 1 + 1e-16).float().to(p.dtype)).sum()   # logS is stored float32 (preprocessing.py:154)
+    return -(lp - logq)
+
+
+@pytest.mark.parametrize("case", ["phase_nb", "phase_nb_dnu2", "phase_poisson", "phase_lognormal", "vel_mf_joint",
+                                  "vel_mf_joint_dnu2", "vel_mf_cond", "vel_mf_poisson", "vel_mf_lognormal"])
+def test_elbo_assembled_from_torch_distributions_equals_oracle_and_reference(case):
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
+    p = H.problem_from_fixture(z)
+    par = {k[4:]: torch.tensor(v).double() for k, v in z.items() if k.startswith("par_")}
+    eps = {k[4:]: torch.tensor(v).double() for k, v in z.items() if k.startswith("eps_")}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in par.items()}
+    loss = _elbo_from_torch_distributions(p, leaves, eps)
+    l_or, g_or, _, _ = orc.loss_and_grads(p, par, eps)
+    assert abs(float(loss.detach()) - l_or) <= 1e-9 * abs(l_or), (float(loss.detach()), l_or)
+    assert abs(float(loss.detach()) - float(z["ref_loss"])) <= 2e-5 * abs(l_or)            # the reference's own float32 value
+    loss.backward()
+    for k, v in leaves.items():
+        g = torch.zeros_like(v) if v.grad is None else torch.nan_to_num(v.grad, nan=0.0)
+        assert torch.allclose(g, g_or[k], rtol=1e-7, atol=1e-8), (k, (g - g_or[k]).abs().max())
+
+
+def test_clipped_adam_equals_torch_adam_where_they_coincide():
+    """eps = 0, lrd = 1, |g| << clip_norm: pyro's ClippedAdam is torch.optim.Adam exactly; 50 steps, 3 tensors."""
+    _, po = _shim()
+    from velocycle_amd.svi import FlatClippedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7, 3), (11,), (2, 5)]
+    p0 = [torch.randn(s, dtype=torch.float64, generator=g) for s in shapes]
+    args = {"lr": 0.03, "betas": (0.8, 0.99), "eps": 0.0, "lrd": 1.0, "clip_norm": 1e9}
+    ref_p = [torch.nn.Parameter(x.clone()) for x in p0]
+    ref = torch.optim.Adam(ref_p, lr=0.03, betas=(0.8, 0.99), eps=0.0)
+    shim_p = [x.clone().requires_grad_(True) for x in p0]
+    shim = po.ClippedAdam(dict(args))
+    o_par = {str(i): x.clone() for i, x in enumerate(p0)}
+    o_opt = orc.ClippedAdam(dict(args))
+    n = sum(x.numel() for x in p0)
+    flat = torch.cat([x.reshape(-1) for x in p0]).float()
+    f_opt = FlatClippedAdam(n, args, "cpu")
+    for t in range(50):
+        grads = [torch.randn(s, dtype=torch.float64, generator=g) * (1.0 + 0.1 * t) + 0.3 for s in shapes]
+        for q, gr in zip(ref_p, grads):
+            q.grad = gr.clone()
+        ref.step()
+        for q, gr in zip(shim_p, grads):
+            q.grad = gr.clone()
+        shim(shim_p)
+        o_par = o_opt.step(o_par, {str(i): gr for i, gr in enumerate(grads)})
+        f_opt.step(flat, torch.cat([gr.reshape(-1) for gr in grads]).float())
+    for i, q in enumerate(ref_p):
+        assert torch.allclose(shim_p[i].data, q.data, rtol=1e-12, atol=1e-13)
+        assert torch.allclose(o_par[str(i)], q.data, rtol=1e-12, atol=1e-13)
+    assert torch.allclose(flat.double(), torch.cat([q.data.reshape(-1) for q in ref_p]), rtol=2e-5, atol=2e-6)
+
+
+def test_clipped_adam_documented_differences_in_closed_form():
+    """One step from zero state with g = 25 (clamped to 10), lrd = 0.9, eps = 1e-8:
+    lr_1 = lr*lrd; m = (1-b1)*10; v = (1-b2)*100; p -= lr_1*sqrt(1-b2)/(1-b1) * m/(sqrt(v)+eps)."""
+    _, po = _shim()
+    from velocycle_amd.svi import FlatClippedAdam
+    lr, lrd, b1, b2, e = 0.03, 0.9, 0.8, 0.99, 1e-8
+    gc = 10.0
+    m, v = (1 - b1) * gc, (1 - b2) * gc * gc
+    want = 1.0 - lr * lrd * math.sqrt(1 - b2) / (1 - b1) * m / (math.sqrt(v) + e)
+    args = {"lr": lr, "lrd": lrd, "betas": (b1, b2), "eps": e, "clip_norm": 10.0}
+    q = torch.ones(1, dtype=torch.float64, requires_grad=True)
+    q.grad = torch.tensor([25.0], dtype=torch.float64)
+    po.ClippedAdam(dict(args))([q])
+    assert abs(float(q) - want) < 1e-14
+    out = orc.ClippedAdam(dict(args)).step({"a": torch.ones(1, dtype=torch.float64)}, {"a": torch.tensor([25.0], dtype=torch.float64)})
+    assert abs(float(out["a"]) - want) < 1e-14
+    flat = torch.ones(1)
+    FlatClippedAdam(1, args, "cpu").step(flat, torch.tensor([25.0]))
+    assert abs(float(flat) - want) < 1e-6
+    # second step of pyro's schedule: lr decays BEFORE each update -> lr*lrd^2 at t = 2
+    o = orc.ClippedAdam(dict(args))
+    pr = {"a": torch.ones(1, dtype=torch.float64)}
+    for _ in range(2):
+        pr = o.step(pr, {"a": torch.tensor([1.0], dtype=torch.float64)})
+    m2, v2 = b1 * (1 - b1) + (1 - b1), b2 * (1 - b2) + (1 - b2)
+    p1 = 1.0 - lr * lrd * math.sqrt(1 - b2) / (1 - b1) * (1 - b1) / (math.sqrt(1 - b2) + e)
+    want2 = p1 - lr * lrd ** 2 * math.sqrt(1 - b2 ** 2) / (1 - b1 ** 2) * m2 / (math.sqrt(v2) + e)
+    assert abs(float(pr["a"]) - want2) < 1e-14
+
+
+def test_lowrank_mvn_rsample_draw_order_and_value():
+    """LowRankMultivariateNormal.rsample draws eps_W (rank) first, then eps_D (dims), each with
+    torch.empty(shape).normal_() on the default generator, and returns loc + W eps_W + sqrt(D) eps_D -- the order
+    `rng.draw_eps` / `oracle.draw_eps` assume for the LRMN guide (velocity_inference_guide.py:95-97)."""
+    dims, rank = 13, 5
+    g = torch.Generator().manual_seed(1)
+    loc = torch.randn(dims, generator=g)
+    W = torch.randn(dims, rank, generator=g).abs() * 0.1
+    D = torch.rand(dims, generator=g) + 0.1
+    torch.manual_seed(77)
+    x = td.LowRankMultivariateNormal(loc, W, D).rsample()
+    torch.manual_seed(77)
+    eW = torch.empty(rank).normal_()
+    eD = torch.empty(dims).normal_()
+    assert torch.allclose(x, loc + W @ eW + D.sqrt() * eD, rtol=1e-6, atol=1e-6)
+    # the host eps stream of the product consumes the generator the same way
+    from velocycle_amd.rng import draw_eps
+    from velocycle_amd.workloads import make_velocity_spec
+    sp = make_velocity_spec(40, 8, "vcond", 1, 1, seed=0)
+    gen = torch.Generator().manual_seed(5)
+    e = draw_eps(sp, gen)
+    gen2 = torch.Generator().manual_seed(5)
+    M = sp.Ng + sp.Nx * sp.Nhw
+    cov = torch.normal(torch.zeros((M, sp.rho_rank)), torch.ones((M, sp.rho_rank)) * 0.02, generator=gen2)
+    assert torch.equal(e["_cov_factor_draw"], cov)
+    assert torch.equal(e["eps_W"], torch.empty(sp.rho_rank).normal_(generator=gen2))
+    assert torch.equal(e["eps_D"], torch.empty(M).normal_(generator=gen2))
+
+
+def test_delta_and_normal_of_the_shim_are_torch_semantics():
+    pd, _ = _shim()
+    v = torch.tensor([0.3, -1.2])
+    assert float(pd.Delta(v).log_prob(v).sum()) == 0.0
+    x = torch.tensor([[0.1, 0.2], [0.3, 0.4]])
+    assert torch.equal(pd.Normal(x, 1.0).to_event(1).log_prob(x + 1), td.Independent(td.Normal(x, 1.0), 1).log_prob(x + 1))

@@ -9,11 +9,13 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvelocycle_hip.so")
+# VC_LIB_PATH selects another build of the same ABI (A/B measurements of kernel variants, profiles/tools/ab_libs.sh)
+# without touching the in-tree product library; it must still be a HIP build of this ABI -- there is no fallback.
+LIB_PATH = os.environ.get("VC_LIB_PATH") or os.path.join(HERE, "libvelocycle_hip.so")
 
 VC_ABI_VERSION = 1
 VC_OK = 0
-VC_ERR_ARG, VC_ERR_HIP, VC_ERR_UNSUPPORTED, VC_ERR_STATE = -1, -2, -3, -4
+VC_ERR_ARG, VC_ERR_HIP, VC_ERR_UNSUPPORTED, VC_ERR_STATE, VC_ERR_NONFINITE = -1, -2, -3, -4, -5
 MODEL = {"phase": 0, "velocity": 1}
 GUIDE = {"meanfield": 0, "lrmn": 1}
 NOISE = {"NegativeBinomial": 0, "Poisson": 1, "Lognormal": 2}
@@ -84,6 +86,8 @@ EXPORTS = {
                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vc_read_site": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "vc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(vc_stats)]),
+    "vc_get_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    "vc_clear_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vc_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

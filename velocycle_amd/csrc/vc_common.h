@@ -68,6 +68,7 @@ struct VcBufs {
   float *PW;                                // [nb_post_cell][NW] partial angular-speed gradients
   double *HL, *HD;                          // per histogram task: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
   double const_loss;                        // step-invariant part of the loss
+  long long* status;                        // [0] number of steps with a non-finite loss, [1] 1 + index of the first one
 #ifdef VC_DBG_TIMES
   unsigned long long* dbg;                  // measurement aid: 4 wall-clock stamps per wave of K_main
 #endif

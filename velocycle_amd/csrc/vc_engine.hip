@@ -559,6 +559,8 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
   TRY(e->dalloc(&b.PW, (size_t)d.nb_post_cell * std::max(1, d.NW)));
+  TRY(e->dalloc(&b.status, 2));
+  HIPCHK(e, hipMemset(b.status, 0, 2 * sizeof(long long)));
 
   // histograms + step-invariant constants -----------------------------------------------------
   double lg_S = 0.0, lg_U = 0.0;   // sum lgamma(k+1)
@@ -782,6 +784,26 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   out->main_block = 256;
   out->main_kind = d.kind;
   snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d>", d.H, d.Nb, e->main_name, d.gpl);
+  return VC_OK;
+}
+
+extern "C" int vc_get_status(vc_engine* e, int64_t* first_bad_step, int64_t* n_bad, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_get_status before vc_finalize");
+  long long h[2] = {0, 0};
+  HIPCHK(e, hipStreamSynchronize((hipStream_t)hip_stream));
+  HIPCHK(e, hipMemcpy(h, e->b.status, sizeof h, hipMemcpyDeviceToHost));
+  if (first_bad_step) *first_bad_step = h[1] - 1;
+  if (n_bad) *n_bad = h[0];
+  if (h[0] > 0)
+    return e->fail(VC_ERR_NONFINITE, "non-finite loss in %lld step(s), first at step %lld", h[0], h[1] - 1);
+  return VC_OK;
+}
+
+extern "C" int vc_clear_status(vc_engine* e, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_clear_status before vc_finalize");
+  HIPCHK(e, hipMemsetAsync(e->b.status, 0, 2 * sizeof(long long), (hipStream_t)hip_stream));
   return VC_OK;
 }
 

@@ -709,6 +709,10 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
   if (t == 0) {
     const double loss = ((sm_lossw[0] + sm_lossw[1]) + (sm_lossw[2] + sm_lossw[3])) + b.const_loss;
     if (loss_dev) loss_dev[loss_slots > 1 ? (step % loss_slots) : 0] = loss;
+    if (!isfinite(loss)) {                 // failure detection: latch the first step whose loss is NaN / Inf
+      b.status[0] += 1;
+      if (b.status[1] == 0) b.status[1] = step + 1;
+    }
     const float hi = (float)loss;
     G[0] = hi;
     G[1] = (float)(loss - (double)hi);

@@ -317,6 +317,18 @@ class HipEngine:
         self._check(self.lib.vc_read_site(self._h, sid, C.c_void_p(out.data_ptr()), out.numel(), self._stream()))
         return out
 
+    def status(self):
+        """(ok, first_bad_step, n_bad): the device-side failure latch (vc_get_status) -- ok is False once any step of
+        this engine produced a NaN / Inf loss; synchronises the stream."""
+        first, n = C.c_int64(-1), C.c_int64(0)
+        rc = self.lib.vc_get_status(self._h, C.byref(first), C.byref(n), self._stream())
+        if rc not in (_lib.VC_OK, _lib.VC_ERR_NONFINITE):
+            self._check(rc)
+        return rc == _lib.VC_OK, int(first.value), int(n.value)
+
+    def clear_status(self):
+        self._check(self.lib.vc_clear_status(self._h, self._stream()))
+
     def set_timing(self, enable: bool):
         self._check(self.lib.vc_set_timing(self._h, int(enable)))
 

@@ -7,6 +7,11 @@ same attributes after the fit (`losses`, `phis_pyro`, `fourier_coef`, `fourier_c
          step replayed from a hipGraph, losses read back at the end;
          "parity": eps drawn on the host from torch's default generator in Pyro's order, so that
          `torch.manual_seed(s); fit(...)` reproduces the reference run with the same seed.
+  process_group   cells sharded over the ranks of a `torch.distributed` group (default: the world group when
+         torch.distributed is initialised): every rank passes the SAME full-size metaparams, keeps
+         its contiguous block of cells on its GPU, the step all-reduces the gene-level gradients once, and at the
+         end the per-cell results are gathered so that every rank holds the same full-`Nc` attributes as a
+         single-process fit (shard-count invariant: same Philox / host eps streams, sliced by cell offset).
 """
 from __future__ import annotations
 
@@ -20,7 +25,8 @@ import torch
 
 from . import pyro_compat
 from .containers import AngularSpeed, Cycle, Phases
-from .engine import HipEngine
+from .distributed import broadcast_int, dist_context, gather_cells
+from .engine import HipEngine, shard_bounds
 from .spec import ModelSpec, spec_from_metaparams
 from .svi import SVIRunner, optim_args_of
 from .utils import torch_basis, torch_fourier_basis
@@ -48,35 +54,48 @@ class _FitBase:
         self.engine: Optional[HipEngine] = None
 
     # ------------------------------------------------------------------------------------------
-    def _make_engine(self, device=None):
+    def _make_engine(self, device=None, process_group=None):
         spec = spec_from_metaparams(self.metaparams, self._kind, self.condition)
         dev = device if device is not None else getattr(self.metaparams, "device", None)
         if dev is None or torch.device(dev).type != "cuda":
             dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         self.spec = spec
-        self.engine = HipEngine(spec, device=dev)          # raises without a GPU: no CPU fallback
+        self._rank, self._world, self._pg = dist_context(process_group)
+        self._shard_sizes = [b - a for a, b in (shard_bounds(spec.Nc, r, self._world) for r in range(self._world))]
+        # raises without a GPU: no CPU fallback
+        self.engine = HipEngine(spec, device=dev, rank=self._rank, world_size=self._world)
         return self.engine
+
+    def _gather(self, local: torch.Tensor, dim: int) -> torch.Tensor:
+        """This rank's block of cells along `dim` -> the full-Nc CPU tensor, on every rank."""
+        return gather_cells(local, dim, self._shard_sizes, self._pg)
 
     def _warn_sizes(self):
         pass
 
     def fit(self, optimizer, loss=None, num_steps=1000, intermediate_output_step_size=100, store_output=False,
-            verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None):
+            verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None, process_group=None):
         self._warn_sizes()
         if self.engine is None:
-            self._make_engine(device)
+            self._make_engine(device, process_group)
         eng = self.engine
         args = optim_args_of(optimizer)
         exact = mode == "parity" or self.early_exit or store_output
         if mode == "parity":
             gen_seed = seed
+            if gen_seed is None and self._world > 1:
+                # sharded: every rank must draw the same host eps stream -> rank 0's global seed, as an explicit
+                # generator (equal to the global RNG right after torch.manual_seed(s))
+                gen_seed = broadcast_int(torch.initial_seed() % (2 ** 63), self._pg, eng.device)
             warm = type(self)._default_elbo_fresh if loss is None else bool(getattr(loss, "fresh", True))
-            run = SVIRunner(eng, args, mode="parity", seed=gen_seed, warmup_draw=warm)   # seed None -> torch's global RNG
+            run = SVIRunner(eng, args, mode="parity", seed=gen_seed, warmup_draw=warm,   # seed None -> torch's global RNG
+                            process_group=self._pg)
             if loss is None:
                 type(self)._default_elbo_fresh = False
         else:
             s = int(torch.initial_seed() % (2 ** 63)) if seed is None else int(seed)
-            run = SVIRunner(eng, args, mode="perf", seed=s)
+            s = broadcast_int(s, self._pg, eng.device)
+            run = SVIRunner(eng, args, mode="perf", seed=s, process_group=self._pg)
         self._runner = run
         losses, intermediate_output = [], []
         if mode == "perf" and not exact:
@@ -100,9 +119,11 @@ class _FitBase:
                 elif step > 200 and self.early_exit:
                     early = True
         self.losses = losses
-        if not np.all(np.isfinite(np.asarray(losses, dtype=np.float64))):      # pyro.util.warn_if_nan(loss, "loss")
+        ok, first_bad, n_bad = eng.status()                                     # device-side latch of the C ABI
+        if not ok or not np.all(np.isfinite(np.asarray(losses, dtype=np.float64))):   # pyro.util.warn_if_nan(loss, "loss")
             import warnings
-            warnings.warn("Encountered NaN/Inf: loss", UserWarning)
+            warnings.warn("Encountered NaN/Inf: loss" + ("" if ok else f" (first at step {first_bad}, {n_bad} steps)"),
+                          UserWarning)
         self._extract()
         if self.get_posterior:
             self._posterior()
@@ -114,7 +135,8 @@ class _FitBase:
         from ._lib import POSITIVE_PARAMS
         out = {}
         for k, v in self.engine.named().items():
-            v = v.detach().cpu().clone()
+            # ϕxy_locs is the only rank-local block: gather the shards once at the end
+            v = self._gather(v, 0) if k == "ϕxy_locs" else v.detach().cpu().clone()
             out[k] = v.exp() if k in POSITIVE_PARAMS else v
         return out
 
@@ -152,10 +174,17 @@ class _FitBase:
         """n guide draws pushed through the deterministic part of the model, as DEVICE tensors with Pyro's site
         shapes (leading dimension n).  One library call (vc_sample_posterior) makes all n draws."""
         eng, sp = self.engine, self.spec
-        base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        base = broadcast_int(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), self._pg, eng.device)
         names = [k for k in ("ν", "Δν", "ϕxy", "shape_inv", "logγg", "logβg", "νω", "rho_real")
                  if self._site_exists(k)] + ["ϕ"] + (["ω"] if sp.kind == "velocity" else [])
         dev = eng.sample_posterior(names, n, seed=base, step0=0)
+        if self._world > 1:
+            # gene-level / global sites are identical on every rank (same Philox key); per-cell sites are this
+            # rank's block of the global stream: gather them (cells are dimension 1 of the (n, Nc_local, ...) draws)
+            for k in ("ϕxy", "ϕ", "ω"):
+                if k in dev:
+                    dev[k] = self._gather(dev[k], 1)
+            dev = {k: v.cpu() for k, v in dev.items()}
         want = (lambda k: True) if rs is None else (lambda k: k in rs)
 
         def basis(num_harmonics, der):          # torch_fourier_basis over every draw at once, (n, Nc, Nh)
@@ -228,9 +257,10 @@ class PhaseFitModel(_FitBase):
         self.metaparams_avg = mp._replace(count_factor=torch.full_like(mp.count_factor, float(mp.count_factor.mean())))
         # ElogS = ν_locs·ζ(ϕ) + Db·Δν_locs + count_factor (ElogS2: with the averaged count factor), on the device
         dnu = pyro_compat.param("Δν_locs") if sp.with_delta_nu else None
-        S, S2 = self.engine.expected_logs(pyro_compat.param("ν_locs"), self.phase_pyro.phis,
+        sl = slice(self.engine.c0, self.engine.c1)
+        S, S2 = self.engine.expected_logs(pyro_compat.param("ν_locs"), torch.as_tensor(self.phase_pyro.phis)[sl],
                                           float(self.metaparams_avg.count_factor.reshape(-1)[0]), dnu=dnu)
-        post["ElogS"], post["ElogS2"] = S.cpu().squeeze(), S2.cpu().squeeze()
+        post["ElogS"], post["ElogS2"] = self._gather(S, 1).squeeze(), self._gather(S2, 1).squeeze()
         self.posterior = post
 
 
@@ -272,11 +302,12 @@ class VelocityFitModel(_FitBase):
         ω = torch.einsum("...xhgc,hc,xhgc->gc", [νω, ζω, mp.D.cpu().float()]).reshape(-1)     # one speed per cell (N2)
         dnu = pyro_compat.param("Δν_locs") if sp.with_delta_nu else None
         # the four dense (Ng, Nc) summaries of velocity_inference_model.py:236-258 in one device pass
-        S, S2, U, U2 = self.engine.expected_logs(pyro_compat.param("ν_locs"), phis,
+        sl = slice(self.engine.c0, self.engine.c1)
+        S, S2, U, U2 = self.engine.expected_logs(pyro_compat.param("ν_locs"), torch.as_tensor(phis)[sl],
                                                  float(self.metaparams_avg.count_factor.reshape(-1)[0]), dnu=dnu,
-                                                 omega=ω, logbeta=logβg, gamma=γg)
-        post["ElogS"], post["ElogU"] = S.cpu().squeeze(), U.cpu().squeeze()
-        post["ElogS2"], post["ElogU2"] = S2.cpu().squeeze(), U2.cpu().squeeze()
+                                                 omega=ω[sl], logbeta=logβg, gamma=γg)
+        post["ElogS"], post["ElogU"] = self._gather(S, 1).squeeze(), self._gather(U, 1).squeeze()
+        post["ElogS2"], post["ElogU2"] = self._gather(S2, 1).squeeze(), self._gather(U2, 1).squeeze()
         self.posterior = post
         if sp.guide == "lrmn":                      # velocity_inference_model.py:264-274
             self.log_gammas = post["logγg"].mean(0).squeeze().numpy().T

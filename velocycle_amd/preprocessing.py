@@ -101,8 +101,14 @@ def preprocess_for_phase_estimation(anndata, cycle_obj, phase_obj, design_mtx, n
         S = torch.tensor(_dense(anndata.layers["S_sz"]).astype(float))
         U = torch.tensor(_dense(anndata.layers["U_sz"]).astype(float))
     else:
-        S = torch.tensor(_dense(anndata.layers["spliced"]).astype(np.int64))
-        U = torch.tensor(_dense(anndata.layers["unspliced"]).astype(np.int64))
+        # preprocessing.py:141-147: layers with an `.A` attribute (scipy sparse, np.matrix) are cast to int64; a dense
+        # ndarray has none, lands in the reference's `except` branch and stays float (non-integer values survive,
+        # e.g. pre-normalised data for the Lognormal model)
+        def counts(layer):
+            if hasattr(layer, "A") or hasattr(layer, "toarray"):
+                return torch.tensor(_dense(layer).astype(np.int64))
+            return torch.tensor(np.asarray(layer).astype(float))
+        S, U = counts(anndata.layers["spliced"]), counts(anndata.layers["unspliced"])
     s_umi = torch.tensor(np.asarray(_dense(anndata.layers["spliced"]).sum(1)).reshape(-1).astype(np.int64)).float()
     count_factor = torch.log(s_umi / torch.mean(s_umi))
     anndata.layers["logS"] = np.log(S.numpy() + 1 + 1e-16)

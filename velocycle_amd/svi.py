@@ -86,8 +86,24 @@ class FlatClippedAdam:
                 torch.sqrt(1.0 - torch.pow(c["b2"], self.t_dev)) / (1.0 - torch.pow(c["b1"], self.t_dev))
             p.sub_((self.m / denom) * step_size.float())
 
-    def state_dict(self):
-        return dict(m=self.m.clone(), v=self.v.clone(), t=self.t if not self.capturable else int(self.t_dev.item()))
+    def steps_done(self, step_dev: Optional[torch.Tensor] = None) -> int:
+        """1-based Adam step of the last update: the host counter, the torch-op device counter, or (impl="hip" in a
+        replayed graph) the engine's device step counter that the kernels read."""
+        if self.impl == "torch" and self.capturable:
+            return int(self.t_dev.item())
+        if self.impl == "hip" and step_dev is not None:
+            return int(step_dev.item())
+        return self.t
+
+    def state_dict(self, step_dev: Optional[torch.Tensor] = None):
+        return dict(m=self.m.detach().cpu().clone(), v=self.v.detach().cpu().clone(), t=self.steps_done(step_dev))
+
+    def load_state_dict(self, sd):
+        self.m.copy_(torch.as_tensor(sd["m"]).to(self.m.device))
+        self.v.copy_(torch.as_tensor(sd["v"]).to(self.v.device))
+        self.t = int(sd["t"])
+        if self.impl == "torch" and self.capturable:
+            self.t_dev.fill_(float(self.t))
 
 
 class SVIRunner:
@@ -188,6 +204,8 @@ class SVIRunner:
     def run_perf(self, n_steps: int, sync: bool = True) -> None:
         """n_steps back-to-back SVI steps with no host round trip (losses stay on the device)."""
         e = self.e
+        if n_steps <= 0:          # nothing to do: in particular no graph warm-up pass, which is one real step
+            return
         if self.loss_hist is None or self.loss_hist.shape[0] < self.step_idx + n_steps:
             new = torch.zeros(max(2 * (self.step_idx + n_steps), 1024), dtype=torch.float64, device=e.device)
             if self.loss_hist is not None:
@@ -200,13 +218,12 @@ class SVIRunner:
             with torch.cuda.stream(s):
                 self._perf_body()                      # warm-up (allocator, lazy init) outside capture
                 torch.cuda.synchronize()
-                if self.do_reduce:
-                    # ProcessGroupNCCL's watchdog polls the events of collectives issued before the capture;
-                    # on ROCm such a query during capture aborts (hipErrorCapturedEvent) -> let it retire them
-                    import time
-                    time.sleep(2.0)
+                # ProcessGroupNCCL's watchdog thread polls the events of the collectives issued before the capture;
+                # under the default "global" capture mode such a query from ANOTHER thread invalidates the capture on
+                # ROCm (hipErrorStreamCaptureUnsafe).  "thread_local" restricts the check to the capturing thread, which
+                # issues only capturable work here -- deterministic, no waiting for the watchdog to go idle.
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s):
+                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local" if self.do_reduce else "global"):
                     self._perf_body()
             torch.cuda.current_stream(e.device).wait_stream(s)
             # the warm-up pass was one real step (capture only records)
@@ -224,4 +241,71 @@ class SVIRunner:
 
     def perf_losses(self) -> List[float]:
         torch.cuda.synchronize(self.e.device)
+        if self.loss_hist is None:
+            return []
         return self.loss_hist[: self.step_idx].cpu().tolist()
+
+    # ------------------------------------------------------------------------------------------
+    # checkpoint / resume of a fit (the reference's analogue: pyro.get_param_store().get_state()/set_state(),
+    # tutorials/1D_Pancreas_Analysis.ipynb cell 26; here the optimiser moments, the step counter and the RNG position
+    # are part of the snapshot, so a resumed run continues the SAME trajectory bit for bit)
+    def _layout_key(self) -> str:
+        e = self.e
+        return repr((e.spec.kind, e.spec.guide, e.spec.noisemodel, e.header, e.n_global, e.n_local, e.rank,
+                     e.world_size, sorted(e.param_slices.items())))
+
+    def state_dict(self) -> dict:
+        """Everything needed to continue this run: flat unconstrained parameters (this rank's block of ϕxy_locs
+        included), ClippedAdam moments, steps done, seed / host generator state, the losses so far."""
+        e = self.e
+        torch.cuda.synchronize(e.device)
+        opt = self.opt.state_dict(self.step_dev if self.mode == "perf" else None)
+        sd = dict(layout=self._layout_key(), mode=self.mode, seed=self.seed, step_idx=self.step_idx,
+                  params=e.params.detach().cpu().clone(), m=opt["m"], v=opt["v"], t=opt["t"],
+                  losses=torch.tensor(self.perf_losses() if self.mode == "perf" else self.losses, dtype=torch.float64))
+        if self.gen is not None:
+            sd["gen_state"] = self.gen.get_state()
+        return sd
+
+    def load_state_dict(self, sd: dict) -> None:
+        e = self.e
+        if sd["layout"] != self._layout_key():
+            raise ValueError("checkpoint does not match this engine's parameter layout / rank")
+        if sd["mode"] != self.mode:
+            raise ValueError(f"checkpoint was written in mode={sd['mode']!r}, this runner is mode={self.mode!r}")
+        e.params.copy_(torch.as_tensor(sd["params"]).to(e.device))
+        self.opt.load_state_dict(dict(m=sd["m"], v=sd["v"], t=sd["t"]))
+        self.step_idx, self.seed = int(sd["step_idx"]), int(sd["seed"])
+        losses = torch.as_tensor(sd["losses"], dtype=torch.float64)
+        if self.mode == "perf":
+            self.step_dev.fill_(self.step_idx)
+            n = max(2 * self.step_idx, 1024)
+            if self.loss_hist is None or self.loss_hist.shape[0] < n:
+                self.loss_hist = torch.zeros(n, dtype=torch.float64, device=e.device)
+                self._graph = None          # the captured graph holds the old ring's address
+            self.loss_hist[: losses.numel()] = losses.to(e.device)
+        else:
+            self.losses = losses.tolist()
+            self._first, self._pending = None, None
+            if "gen_state" in sd and self.gen is not None:
+                self.gen.set_state(sd["gen_state"])
+
+    def save(self, path: str) -> None:
+        import numpy as np
+        sd = self.state_dict()
+        np.savez(path, **{k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()})
+
+    def load(self, path: str) -> None:
+        import numpy as np
+        if not path.endswith(".npz"):
+            path += ".npz"
+        z = np.load(path, allow_pickle=False)
+        sd = {k: z[k] for k in z.files}
+        for k in ("layout", "mode"):
+            sd[k] = str(sd[k])
+        for k in ("seed", "step_idx", "t"):
+            sd[k] = int(sd[k])
+        for k in ("params", "m", "v", "losses", "gen_state"):
+            if k in sd:
+                sd[k] = torch.from_numpy(np.array(sd[k]))
+        self.load_state_dict(sd)
