@@ -8,9 +8,15 @@ A "step" is one full SVI step of velocity inference on the BASELINE.json workloa
 cell shards when N > 1] -> ClippedAdam update.  N > 1: launched by torch.distributed.run, one rank per
 GPU, cells sharded contiguously (strong scaling: the problem is fixed, value = steps/s of the job).
 
+The timed region of --steps K steps (after --warmup W untimed ones), bracketed by barrier + synchronize and
+maximised over ranks, is REPEATED (--repeats, default 9): `value` / `ms_per_step` are the MEDIAN repeat, `repeat_ms`
+lists every repeat (the first ones show a clock that has not ramped yet: K = 20 steps are 4 ms of GPU work),
+`device_clock_mhz` is the shader clock measured on the device right after the timed region.
+
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline      HIP-event timing of the likelihood kernel against the HBM roof (ALGORITHMIC bytes:
-                fp32 count matrices read once, 8*Ng*Nc for the joint workload),
+  roofline      HIP-event timing of the likelihood kernel (>= 100 launches) against the HBM roof (ALGORITHMIC
+                bytes: fp32 count matrices read once, 8*Ng*Nc for the joint workload) and, under `valu`, against the
+                kernel's own arithmetic bound (static VALU count of the cell loop x measured issue cost),
   cpu_baseline  the oracle restatement (op-by-op torch fp32 + autograd + ClippedAdam) timed on this
                 host's cores on a bounded sample of the same workload (rank 0, N=1 only),
   modes         steps/s of the tutorial flow (velocity conditioned on the phase fit, default LRMN guide) and of
@@ -49,28 +55,61 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=5000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=10000)
+    ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--roofline-launches", type=int, default=100)
     return ap.parse_args()
 
 
-def time_steps(run, steps, warmup, dist_on, device):
+def time_steps(run, steps, warmup, dist_on, device, repeats=1):
+    """`warmup` untimed steps, then `repeats` timed regions of exactly `steps` steps each; every region is bracketed by
+    barrier + synchronize on both sides and its wall time is the max over ranks.  Returns the list of region times."""
     import torch.distributed as dist
     run.run_perf(warmup, sync=True)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    run.run_perf(steps, sync=False)
-    torch.cuda.synchronize(device)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    out = []
+    for _ in range(max(1, repeats)):
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        run.run_perf(steps, sync=False)
+        torch.cuda.synchronize(device)
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(dt)
+    return out
+
+
+def median(xs):
+    ys = sorted(xs)
+    n = len(ys)
+    return ys[n // 2] if n % 2 else 0.5 * (ys[n // 2 - 1] + ys[n // 2])
+
+
+def valu_bound(engine, kernel_avg_s):
+    """The kernel's own arithmetic bound: static VALU count of the cell loop (profiles/valu_model.json, written by
+    profiles/tools/valu_count.py from the gfx950 assembly) x measured issue cost per wave64 instruction, times the
+    cell iterations one SIMD executes (gene blocks x cells / (CUs x 4 SIMDs))."""
+    try:
+        vm = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
+        ent = vm["kernels"][engine.stats["main_kernel"]]
+    except Exception:
+        return None
+    ncu = torch.cuda.get_device_properties(engine.device).multi_processor_count
+    gbw = 64 * ent["genes_per_lane"]
+    iters = ((engine.spec.Ng + gbw - 1) // gbw) * engine.Nc_local / (ncu * 4.0)
+    bound_us = ent["issue_ns_per_cell_iter"] * iters * 1e-3
+    return {"bound_us": round(bound_us, 1), "frac": round(bound_us / (kernel_avg_s * 1e6), 4),
+            "valu_per_cell_iter": ent["valu_per_cell_iter"], "transcendental_per_cell_iter": ent["trans_per_cell_iter"],
+            "issue_ns": vm["issue_ns"], "cell_iters_per_simd": round(iters, 1),
+            "source": "profiles/valu_model.json (static count of the cell loop in the code object; issue costs measured "
+                      "with profiles/tools/valu_rate.hip)"}
 
 
 def kernel_roofline(engine, run, steps):
@@ -96,87 +135,116 @@ def kernel_roofline(engine, run, steps):
         pass
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "valu": valu_bound(engine, avg_s),
             "kernel": st["main_kernel"], "kernel_avg_us": round(avg_s * 1e6, 2), "launches": int(n),
             "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"]),
             "streamed_bytes_per_launch": int(st["streamed_bytes"]),
-            "method": "hipEvents around the kernel over eager SVI steps run right after the timed region"}
+            "method": "hipEvents recorded by the library on the launch stream around that kernel only, over eager SVI "
+                      "steps run right after the timed region"}
 
 
 def cpu_baseline(args, mode, device=None):
-    """Oracle restatement timed on the host: same workload, first `cpu_sample_cells` cells, scaled."""
+    """Oracle restatement (kind "port": the reference's Pyro path cannot run here) timed on the host at
+    TWO sample sizes of the same workload -- the first n and the first 4n cells -- so that the cells-exponent of its
+    cost is measured, not assumed; the reported value extrapolates the larger sample to the full size with the
+    measured exponent (it comes out ~1: the op-by-op path is memory-streaming over (Ng, Nc) temporaries)."""
+    import math
     from oracle import velocycle_oracle as orc
-    from tests import helpers as H
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
-    nsample = min(args.cpu_sample_cells, args.cells)
-    spec = (make_phase_spec(nsample, args.genes, seed=0, device="cpu") if mode == "phase"
-            else make_velocity_spec(nsample, args.genes, mode, 1, 1, seed=0, device="cpu"))
-    kw = {}
-    for k, v in spec.__dict__.items():
-        if k == "truth":
-            continue
-        kw[k] = v.contiguous() if isinstance(v, torch.Tensor) else v
-    p = orc.Problem(**kw)
-    gen = torch.Generator().manual_seed(0)
-    first = orc.draw_eps(p, gen)
-    params = orc.init_params(p, first.get("_cov_factor_draw"))
-    opt = orc.ClippedAdam({"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)})
+    n_big = min(args.cpu_sample_cells, args.cells)
+    n_small = max(n_big // 4, 1)
 
-    # ELBO-match (the other half of BASELINE.json's metric): the HIP path and the oracle on identical (params, eps)
-    eps0 = orc.draw_eps(p, gen)
-    loss_cpu, _, _, _ = orc.loss_and_grads(p, params, eps0)
+    def problem(nsample):
+        spec = (make_phase_spec(nsample, args.genes, seed=0, device="cpu") if mode == "phase"
+                else make_velocity_spec(nsample, args.genes, mode, 1, 1, seed=0, device="cpu"))
+        kw = {}
+        for k, v in spec.__dict__.items():
+            if k == "truth":
+                continue
+            kw[k] = v.contiguous() if isinstance(v, torch.Tensor) else v
+        return spec, orc.Problem(**kw)
+
+    def stepper(p):
+        gen = torch.Generator().manual_seed(0)
+        first = orc.draw_eps(p, gen)
+        st = {"params": orc.init_params(p, first.get("_cov_factor_draw"))}
+        opt = orc.ClippedAdam({"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)})
+
+        def one():
+            eps = orc.draw_eps(p, gen)
+            _, grads, _, _ = orc.loss_and_grads(p, st["params"], eps)
+            st["params"] = opt.step(st["params"], grads)
+        return one, st, gen
+
+    spec_s, p_s = problem(n_small)
+    # ELBO-match (the other half of BASELINE.json's metric): the HIP path and the port on identical (params, eps)
+    one_s, st_s, gen_s = stepper(p_s)
+    eps0 = orc.draw_eps(p_s, gen_s)
+    loss_cpu, _, _, _ = orc.loss_and_grads(p_s, st_s["params"], eps0)
     elbo_match = None
     if device is not None:
         from velocycle_amd.engine import HipEngine
-        eng = HipEngine(spec, device=device)
-        eng.set_params({k: v.float() for k, v in params.items()})
+        eng = HipEngine(spec_s, device=device)
+        eng.set_params({k: v.float() for k, v in st_s["params"].items()})
         eng.elbo_grad(eps=eng.pack_eps({k: v.float() for k, v in eps0.items() if not k.startswith("_")}))
         torch.cuda.synchronize(device)
         loss_hip = eng.loss()
         eng.close()
         elbo_match = {"loss_hip": loss_hip, "loss_cpu_port": float(loss_cpu),
                       "rel_err": abs(loss_hip - float(loss_cpu)) / abs(float(loss_cpu)),
-                      "note": "one ELBO evaluation on the CPU sample with identical params and eps; the port runs in "
-                              "float32, so this bounds both sides' rounding (tests compare against float64 at 1e-5)"}
-
-    def one():
-        nonlocal params
-        eps = orc.draw_eps(p, gen)
-        _, grads, _, _ = orc.loss_and_grads(p, params, eps)
-        params = opt.step(params, grads)
-    one()                                   # warm-up
-    # the op-by-op torch path does not scale to every hardware thread of a big host: pick the thread count
-    # that is fastest on this box (short sweep), then time with it
+                      "note": f"one ELBO evaluation on the {n_small}-cell sample with identical params and eps; the port "
+                              "runs in float32, so this bounds both sides' rounding (tests compare against float64 at 1e-5)"}
+    # the op-by-op torch path does not scale to every hardware thread of a big host: pick the thread count that is
+    # fastest on this box (short sweep on the small sample), then time both samples with it
     default_nt = torch.get_num_threads()
+    one_s()
     sweep = {}
     for nt in sorted({8, 16, 32, 64, default_nt}):
         if nt > (os.cpu_count() or nt):
             continue
         torch.set_num_threads(nt)
-        one()
+        one_s()
         t0 = time.perf_counter()
-        one()
+        one_s()
         sweep[nt] = time.perf_counter() - t0
     best_nt = min(sweep, key=sweep.get)
     torch.set_num_threads(best_nt)
-    t0 = time.perf_counter()
-    n = 0
-    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 50):
+
+    def timed(one, budget_s, nmin=3, nmax=40):
         one()
-        n += 1
-    dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        n = 0
+        while n < nmin or (time.perf_counter() - t0 < budget_s and n < nmax):
+            one()
+            n += 1
+        return n, time.perf_counter() - t0
+    ns, dts = timed(one_s, 4.0)
+    del p_s, st_s
+    _, p_b = problem(n_big)
+    one_b, _, _ = stepper(p_b)
+    nb, dtb = timed(one_b, 12.0)
     torch.set_num_threads(default_nt)
-    sps_sample = n / dt
-    scale = nsample / args.cells
-    return {"value": round(sps_sample * scale, 4), "unit": "SVI steps/s", "cores": best_nt,
-            "kind": "port", "elbo_match": elbo_match,
-            "sample": f"oracle (op-by-op torch fp32 + autograd + ClippedAdam) on the first {nsample} of "
-                      f"{args.cells} cells x {args.genes} genes, {n} steps in {dt:.1f}s = {sps_sample:.3f} steps/s, "
-                      f"scaled by {scale:.3f} (cost is linear in cells); {best_nt} torch threads = fastest of sweep "
-                      f"{ {k: round(v, 2) for k, v in sweep.items()} } s/step; host cpu_count={os.cpu_count()}"}
+    t_small, t_big = dts / ns, dtb / nb
+    expo = math.log(t_big / t_small) / math.log(n_big / n_small) if n_big > n_small else 1.0
+    t_full = t_big * (args.cells / n_big) ** expo
+    return {"value": round(1.0 / t_full, 4), "unit": "SVI steps/s", "cores": best_nt,
+            "kind": "port", "elbo_match": elbo_match, "cells_exponent": round(expo, 3),
+            "sample": f"oracle (op-by-op torch fp32 + autograd + ClippedAdam) on the first {n_small} and the first {n_big} of "
+                      f"{args.cells} cells x {args.genes} genes: {ns} steps in {dts:.1f}s = {t_small:.3f} s/step and {nb} steps "
+                      f"in {dtb:.1f}s = {t_big:.3f} s/step -> measured cost exponent in cells {expo:.3f}; value = the "
+                      f"{n_big}-cell time scaled by ({args.cells}/{n_big})^{expo:.3f}; {best_nt} torch threads = fastest of "
+                      f"sweep { {k: round(v, 2) for k, v in sweep.items()} } s/step; host cpu_count={os.cpu_count()}"}
+
+
+def device_identity(device):
+    pr = torch.cuda.get_device_properties(device)
+    return {"name": pr.name, "uuid": str(getattr(pr, "uuid", "")), "gcn_arch": getattr(pr, "gcnArchName", ""),
+            "cus": pr.multi_processor_count, "hbm_gb": round(pr.total_memory / 2 ** 30, 1)}
 
 
 def main():
     args = parse()
+    # torchrun sets these before this process touches the GPU; nothing below re-executes the process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -190,14 +258,18 @@ def main():
     one_device = os.environ.get("VC_BENCH_ONE_DEVICE", "0") == "1"
     device = torch.device("cuda:0" if one_device else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    if dist_on:
+    # VC_BENCH_NCCL_GROUP=1: a 1-rank nccl group at N = 1, so that the N > 1 code path (all-reduce between the gradient
+    # kernels and the optimiser) can be timed on one GPU and compared with the plain N = 1 line (profiles/)
+    solo_group = (not dist_on) and os.environ.get("VC_BENCH_NCCL_GROUP", "0") == "1"
+    if dist_on or solo_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if one_device:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
@@ -206,32 +278,56 @@ def main():
     optim = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / 10000), "betas": (0.80, 0.99)}
 
     def build(mode):
+        t0 = time.perf_counter()
         if mode == "phase":
             spec = make_phase_spec(args.cells, args.genes, seed=0, device=device)
         else:
             spec = make_velocity_spec(args.cells, args.genes, mode, 1, 1, seed=0, device=device)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
         eng = HipEngine(spec, device=device, rank=rank, world_size=world)
-        # N > 1: eager launches by default.  Capturing the RCCL all-reduce into the hipGraph works with a 1-rank
-        # group on the 1-GPU box (tests/test_hip_svi.py) but cannot be exercised across ranks there, and a step of
-        # 6 asynchronous launches stays GPU-bound anyway; VC_BENCH_DIST_GRAPH=1 opts in.
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        # N > 1: the whole step, RCCL all-reduce included, is replayed from one hipGraph (capture is per rank; RCCL
+        # supports captured collectives, exercised with a 1-rank group in tests/test_hip_svi.py and A/B-timed against
+        # eager launches at N = 1 with VC_BENCH_NCCL_GROUP=1, profiles/r02_*).  VC_BENCH_DIST_GRAPH=0 falls back to eager.
         graph = None
-        if args.no_graph or (dist_on and os.environ.get("VC_BENCH_DIST_GRAPH", "0") != "1"):
+        if args.no_graph or (dist_on and (one_device or os.environ.get("VC_BENCH_DIST_GRAPH", "1") != "1")):
             graph = False
-        run = SVIRunner(eng, optim, mode="perf", seed=0, use_graph=graph)
-        return spec, eng, run
+        run = SVIRunner(eng, optim, mode="perf", seed=0, use_graph=graph, force_reduce=solo_group)
+        return spec, eng, run, {"synthetic_data_s": round(t1 - t0, 3), "engine_setup_s": round(t2 - t1, 3)}
 
-    spec, eng, run = build(args.mode)
-    dt = time_steps(run, args.steps, args.warmup, dist_on, device)
+    spec, eng, run, setup = build(args.mode)
+    clock_before = eng.device_clock_mhz()
+    times = time_steps(run, args.steps, args.warmup, dist_on, device, args.repeats)
+    clock_after = eng.device_clock_mhz()
+    dt = median(times)
     sps = args.steps / dt
     losses = run.perf_losses()
-    roof = kernel_roofline(eng, run, min(args.steps, 100))
+    ok, first_bad, n_bad = eng.status()
+    roof = kernel_roofline(eng, run, max(args.roofline_launches, 100))
     if dist_on:
         roof["note"] = f"per-rank kernel on {eng.Nc_local} of {args.cells} cells"
+    # "loss read back each step unless stated" -- the headline keeps the losses on the device and reads them
+    # once at the end; this is the same step with the loss copied to the host after every step
+    t0 = time.perf_counter()
+    nrb = 100
+    for _ in range(nrb):
+        run.run_perf(1, sync=False)
+        float(run.loss_hist[run.step_idx - 1].item())
+    rb_sps = nrb / (time.perf_counter() - t0)
     out = {
         "metric": baseline_metric() if args.mode != "phase" else "SVI steps/sec, phase_inference",
         "value": round(sps, 2), "unit": "SVI steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeats": len(times), "repeat_ms_per_step": [round(1e3 * t / args.steps, 4) for t in times],
+        "ms_per_step_min_max": [round(1e3 * min(times) / args.steps, 4), round(1e3 * max(times) / args.steps, 4)],
+        "timing": "value / ms_per_step = MEDIAN of `repeats` timed regions of exactly `steps` steps each (barrier + "
+                  "synchronize on both sides, max over ranks); repeat_ms_per_step lists all of them in order",
+        "device_clock_mhz": {"before_timed_region": round(clock_before, 1), "after_timed_region": round(clock_after, 1),
+                             "method": "s_memtime ticks per 200 us of s_memrealtime, one wave (vc_device_clock_mhz)"},
+        "setup_s": setup,
         "config": {"workload": f"synthetic {args.cells} cells x {args.genes} genes " + ("phase_inference" if args.mode == "phase" else "velocity_inference") + ", "
                                + {"vjoint": "mean-field guide, nothing conditioned (every gradient)",
                                   "vcond": "tutorial flow: LRMN guide conditioned on phixy, nu, shape_inv",
@@ -240,28 +336,42 @@ def main():
                                + ", NegativeBinomial noise, H=1, Hw=1",
                    "cells": args.cells, "genes": args.genes, "mode": args.mode,
                    "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
-                   "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + (("gloo (test hook) " if one_device else "RCCL ") + "all-reduce -> " if dist_on else "")
-                            + f"ClippedAdam ({run.adam_impl}), " + ("hipGraph replay" if run.use_graph else "eager launches"))},
+                   "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + (("gloo (test hook) " if one_device else "RCCL ") + "all-reduce -> " if (dist_on or solo_group) else "")
+                            + f"ClippedAdam ({run.adam_impl}), " + ("hipGraph replay" if run.use_graph else "eager launches")
+                            + "; losses stay in a device ring and are read back ONCE after the timed region "
+                              "(with_loss_readback_each_step gives the rate with a host read-back after every step)")},
+        "with_loss_readback_each_step": {"value": round(rb_sps, 2), "unit": "SVI steps/s", "steps": nrb},
         "roofline": roof,
         "loss_first_last": [losses[0], losses[-1]],
+        "nonfinite_loss_steps": n_bad,
     }
+    if dist_on or solo_group:
+        import torch.distributed as dist
+        me = dict(device_identity(device), rank=rank, local_rank=local_rank, cells=eng.Nc_local, pid=os.getpid())
+        ids = [None] * dist.get_world_size()
+        dist.all_gather_object(ids, me)
+        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ids,
+                              "distinct_devices": len({(i["uuid"], i["local_rank"]) for i in ids}),
+                              "step_launch": "hipGraph replay (RCCL all-reduce captured)" if run.use_graph else "eager"}
+    else:
+        out["device"] = device_identity(device)
     extra = {}
     if not args.no_extra_modes and not dist_on:
         del run, eng, spec
         torch.cuda.empty_cache()
         for m in [x for x in ("vcond", "phase", "vjoint") if x != args.mode][:2]:
-            s2, e2, r2 = build(m)
-            dt2 = time_steps(r2, args.steps, args.warmup, False, device)
-            rf = kernel_roofline(e2, r2, min(args.steps, 100))
-            extra[m] = {"steps_per_s": round(args.steps / dt2, 2), "kernel": rf["kernel"],
+            s2, e2, r2, _ = build(m)
+            ts2 = time_steps(r2, args.steps, args.warmup, False, device, args.repeats)
+            rf = kernel_roofline(e2, r2, max(args.roofline_launches, 100))
+            extra[m] = {"steps_per_s": round(args.steps / median(ts2), 2), "kernel": rf["kernel"],
                         "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"],
-                        "hbm_frac": rf["frac"]}
+                        "hbm_frac": rf["frac"], "valu_frac": (rf["valu"] or {}).get("frac")}
             del s2, e2, r2
             torch.cuda.empty_cache()
         out["modes"] = extra
     if rank == 0 and not dist_on and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.mode, device)
-    if dist_on:
+    if dist_on or solo_group:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -263,6 +263,10 @@ int vc_clear_status(vc_engine* e, void* hip_stream);
  * kernel with a pair of hipEvents recorded on the launch stream (not capturable into a hipGraph).
  * vc_get_timing synchronises the pending events and returns the accumulated duration (ms) and the
  * number of launches since timing was enabled. */
+/* Shader clock the device is running at right now, measured on the device: one wave spins for `window_us` of the
+ * constant 100 MHz wall clock (s_memrealtime) and counts shader-clock ticks (s_memtime).  Lets bench.py tell a
+ * clock that has not ramped from a slower kernel.  Synchronises `hip_stream`. */
+int vc_device_clock_mhz(double window_us, double* mhz_out, void* hip_stream);
 int vc_set_timing(vc_engine* e, int enable);
 int vc_get_timing(vc_engine* e, double* main_ms_total, int64_t* n_launches);
 

@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Static VALU count of the likelihood kernel's cell loop, from the device assembly hipcc emits.
+
+For every requested instantiation of vc_main_kernel the main loop (the largest innermost loop of the kernel: two cells
+per trip, the rotating register buffers) is located in `hipcc --cuda-device-only -S` output and its VALU instructions
+are counted: all `v_*` (one issue slot per wave64 instruction; packed-math ops retire two genes per slot) and, among
+them, the transcendentals (v_exp/v_log/v_rcp/v_rsq/v_sqrt/v_sin/v_cos: quarter rate).  With the issue costs measured by
+profiles/tools/valu_rate.hip (ns per wave64 instruction and SIMD) this gives the kernel's arithmetic bound that
+bench.py reports next to the HBM roofline (`roofline.valu`).  Runs without a GPU.
+
+  python profiles/tools/valu_count.py            -> writes profiles/valu_model.json
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "velocycle_amd", "csrc")
+TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
+# (translation unit, H, NB, KIND, NOISE, GPL, cells per loop trip) -- the instantiations bench.py runs
+KERNELS = [("vc_main_vfull_nb.hip", 1, 0, 1, 0, 8), ("vc_main_vu_nb.hip", 1, 0, 2, 0, 8), ("vc_main_phase_nb.hip", 1, 0, 0, 0, 8),
+           ("vc_main_vfull_nb.hip", 1, 2, 1, 0, 8), ("vc_main_vfull_nb.hip", 1, 2, 1, 0, 4), ("vc_main_vu_nb.hip", 1, 2, 2, 0, 8)]
+KIND_NAME = {0: "phase", 1: "vfull", 2: "vu"}
+NOISE_NAME = {0: "nb", 1: "poisson", 2: "lognormal"}
+ISSUE_NS = {"valu": 2.28, "trans": 4.3}     # profiles/r01_d_kmain_bound.md section 2b (valu_rate.hip on MI355X)
+
+
+def device_asm(tu, cache={}):
+    if tu not in cache:
+        out = os.path.join(tempfile.mkdtemp(), tu.replace(".hip", ".s"))
+        extra = os.environ.get("EXTRA", "").split()
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                        *extra, os.path.join(CSRC, tu), "-o", out], check=True, stderr=subprocess.DEVNULL)
+        cache[tu] = open(out).read().splitlines()
+    return cache[tu]
+
+
+def kernel_body(lines, sym):
+    start = next(i for i, l in enumerate(lines) if l.startswith(sym + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    return lines[start:end + 1]
+
+
+def main_loop(body):
+    """(first, last) line index of the largest loop: a label and the last backward branch to it."""
+    labels = {l.split(":")[0]: i for i, l in enumerate(body) if l.startswith(".LBB")}
+    best = None
+    for i, l in enumerate(body):
+        m = re.match(r"\s+s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            span = (labels[m.group(1)], i)
+            if best is None or span[1] - span[0] > best[1] - best[0]:
+                best = span
+    return best
+
+
+def count(tu, H, NB, KIND, NOISE, GPL):
+    sym = f"_Z14vc_main_kernelILi{H}ELi{NB}ELi{KIND}ELi{NOISE}ELi{GPL}EEv6VcDims6VcBufs"
+    body = kernel_body(device_asm(tu), sym)
+    a, b = main_loop(body)
+    ops = [l.split()[0] for l in body[a:b + 1] if l.startswith("\t") and not l.strip().startswith((";", "."))]
+    valu = [o for o in ops if o.startswith("v_")]
+    trans = [o for o in valu if TRANS.match(o)]
+    pk = [o for o in valu if o.startswith("v_pk_")]
+    vmem = [o for o in ops if o.startswith(("global_load", "buffer_load"))]
+    cells = 2                                                    # NBUF = VC_PF + 1 cells per loop trip
+    meta = {l.split()[0]: l.split()[1] for l in device_asm(tu) if False}
+    res = {"valu_per_cell_iter": len(valu) / cells, "trans_per_cell_iter": len(trans) / cells,
+           "packed_per_cell_iter": len(pk) / cells, "vmem_loads_per_cell_iter": len(vmem) / cells,
+           "salu_per_cell_iter": len([o for o in ops if o.startswith("s_")]) / cells,
+           "genes_per_lane": GPL,
+           "issue_ns_per_cell_iter": ((len(valu) - len(trans)) * ISSUE_NS["valu"] + len(trans) * ISSUE_NS["trans"]) / cells}
+    return f"vc_main_kernel<{H},{NB},{KIND_NAME[KIND]}_{NOISE_NAME[NOISE]},gpl{GPL}>", res
+
+
+def main():
+    out = {"issue_ns": ISSUE_NS,
+           "note": "static counts of the cell loop in the gfx950 assembly (profiles/tools/valu_count.py); per wave64 "
+                   "instruction issue costs measured on MI355X (profiles/tools/valu_rate.hip, r01_d_kmain_bound.md 2b); "
+                   "arithmetic bound of a launch = issue_ns_per_cell_iter x (gene blocks x cells) / (CUs x 4 SIMDs)",
+           "kernels": {}}
+    for k in KERNELS:
+        name, res = count(*k)
+        out["kernels"][name] = res
+        print(name, res)
+    path = os.environ.get("VALU_MODEL_OUT", os.path.join(ROOT, "profiles", "valu_model.json"))
+    json.dump(out, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,7 @@ EXPORTS = {
     "vc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(vc_stats)]),
     "vc_get_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "vc_clear_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vc_device_clock_mhz": (C.c_int, [C.c_double, C.POINTER(C.c_double), C.c_void_p]),
     "vc_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "vc_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

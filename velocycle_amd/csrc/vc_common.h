@@ -207,6 +207,7 @@ typedef void (*vc_main_launch_fn)(const VcDims& d, const VcBufs& b, hipStream_t 
 vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, const char** name,
                                       const void** kernel);
 
+void vc_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* out2, hipStream_t st);
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
                            int Ng, int Nc, int nGB, int gbw, int log1p_transform, hipStream_t st);
 void vc_launch_expected_logs(const VcDims& d, const VcBufs& b, const float* nu, const float* dnu, const float* phi,

@@ -807,6 +807,21 @@ extern "C" int vc_clear_status(vc_engine* e, void* hip_stream) {
   return VC_OK;
 }
 
+extern "C" int vc_device_clock_mhz(double window_us, double* mhz_out, void* hip_stream) {
+  if (!mhz_out || !(window_us > 0.0) || window_us > 1e6) return VC_ERR_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  unsigned long long* dev = nullptr;
+  if (hipMalloc((void**)&dev, 2 * sizeof(unsigned long long)) != hipSuccess) return VC_ERR_HIP;
+  unsigned long long h[2] = {0, 0};
+  vc_launch_clock_probe((unsigned long long)(window_us * 100.0), dev, st);        // wall clock: 100 MHz
+  hipError_t err = hipStreamSynchronize(st);
+  if (err == hipSuccess) err = hipMemcpy(h, dev, sizeof h, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (err != hipSuccess || h[1] == 0) return VC_ERR_HIP;
+  *mhz_out = (double)h[0] / ((double)h[1] / 100.0);
+  return VC_OK;
+}
+
 extern "C" int vc_set_timing(vc_engine* e, int enable) {
   if (!e) return VC_ERR_ARG;
   if (enable && e->ev_pool.empty()) {

@@ -38,6 +38,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef VC_PF
 #define VC_PF 1           // register path: cells in flight ahead of the one being processed
 #endif
+#ifndef VC_PF_SINGLE
+#define VC_PF_SINGLE VC_PF   // the same for the one-matrix kernels (phase, U-only): half the bytes in flight per cell
+#endif
+#ifndef VC_LB_SINGLE
+#define VC_LB_SINGLE 2    // minimum waves per SIMD the one-matrix kernels (8 genes per lane) are compiled for
+#endif
+#ifndef VC_RCP_MERGE
+#define VC_RCP_MERGE 0    // 1: one reciprocal of t_U * zp instead of rcp(t_U) and rcp(zp) (S+U negative-binomial kernel)
+#endif
 
 // Cell record as stored in the cell table: every value duplicated {x, x}, so that a scalar load
 // delivers it as an SGPR pair that v_pk_*_f32 consume directly as a packed operand (no per-cell
@@ -128,7 +137,7 @@ __device__ __forceinline__ void vc_obs_lognormal(v2f y, v2f eta, float inv_s2, v
 // the genes and is faster whenever its accumulators still fit 2 waves per SIMD (launch bound) -- the host
 // picks GPL per (kind, K); the HBM layout [gene block][cell][64*GPL] follows it.
 template <int H, int NB, int KIND, int NOISE, int GPL>
-__global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const VcDims d, const VcBufs b) {
+__global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB_SINGLE) : 1)) void vc_main_kernel(const VcDims d, const VcBufs b) {
   constexpr int GBW = 64 * GPL;
   constexpr int NH = 2 * H + 1;
   constexpr int K = NH + NB;
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
   const float* Up = HAS_U ? b.U + blk_base : nullptr;
   constexpr int NP = GPL / 2;           // packed pairs per lane
   constexpr int NV4 = GPL / 4;          // dwordx4 loads per lane per matrix per cell
-  constexpr int PF = VC_PF, NBUF = PF + 1;
+  constexpr int PF = FULL ? VC_PF : VC_PF_SINGLE, NBUF = PF + 1;
   float4 s_bf[NBUF][NV4], u_bf[NBUF][NV4];
   VcCellRec<H, NB> rec_bf[NBUF];
   auto fetch = [&](int j, int i) {
@@ -279,18 +288,31 @@ __global__ __launch_bounds__(256, (GPL == 8 ? 2 : 1)) void vc_main_kernel(const 
         v2f m;      // one packed multiply with the clamp output modifier (hipcc does not fold fmed3 into v_pk_mul)
         asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(m) : "v"(z), "v"(v2(1.2676506e30f)));
         const v2f zp = v2_fma(z, m, v2(1e-5f));
-        const v2f iz = v2_rcp(zp);
-        const v2f q = iz * m;                                                   // torch.relu': 0 at z <= 0
         const v2f eu2 = (es2 - lb2[p]) + v2_log2(zp);
         v2f aU;
-        if (LN) vc_obs_lognormal(uv[p], eu2 * VC_LN2, inv_s2_u, aU, ll[p]);
-        else {
-          // exp(eta_U) = exp(eta_S) * zp / beta: no second exponential when exp(eta_S) is at hand
+        if (VC_RCP_MERGE && NOISE == VC_NOISE_NB) {
+          // one reciprocal for 1/t_U and 1/zp: R = 1/(t_U zp), a_U = r (k - mu) zp R, w = a_U m / zp = r (k - mu) m R
           const v2f muU = FULL ? muS * (ib[p] * zp) : v2_exp2(eu2);
-          vc_obs_counts<NOISE>(uv[p], eu2, muU, rr[p], aU, ll[p], lt[p]);
+          const v2f t = rr[p] + muU;
+          const v2f lt2 = v2_log2(t);
+          const v2f R = v2_rcp(t * zp);
+          const v2f num = rr[p] * (uv[p] - muU);
+          aU = num * (R * zp);
+          w = num * (R * m);                                                    // torch.relu': 0 at z <= 0
+          ll[p] = v2_fma(uv[p], eu2 - lt2, ll[p]);
+          lt[p] += lt2;
+        } else {
+          const v2f iz = v2_rcp(zp);
+          const v2f q = iz * m;                                                 // torch.relu': 0 at z <= 0
+          if (LN) vc_obs_lognormal(uv[p], eu2 * VC_LN2, inv_s2_u, aU, ll[p]);
+          else {
+            // exp(eta_U) = exp(eta_S) * zp / beta: no second exponential when exp(eta_S) is at hand
+            const v2f muU = FULL ? muS * (ib[p] * zp) : v2_exp2(eu2);
+            vc_obs_counts<NOISE>(uv[p], eu2, muU, rr[p], aU, ll[p], lt[p]);
+          }
+          w = aU * q;
         }
         a += aU;
-        w = aU * q;
         gau[p] += aU;
         gw[p] += w;
       }

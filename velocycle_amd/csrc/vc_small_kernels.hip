@@ -13,6 +13,21 @@
 #define CND(site) ((d.cond >> (site)) & 1u)
 
 // ---------------------------------------------------------------------------------------------
+// clock probe: shader-clock ticks (s_memtime) elapsed while the constant 100 MHz wall clock (s_memrealtime) advances
+// by `wall_ticks`
+__global__ void vc_clock_probe_kernel(unsigned long long wall_ticks, unsigned long long* out2) {
+  const unsigned long long w0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long w = w0;
+  while (w - w0 < wall_ticks) { __builtin_amdgcn_s_sleep(8); w = __builtin_amdgcn_s_memrealtime(); }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { out2[0] = c1 - c0; out2[1] = w - w0; }
+}
+
+void vc_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* out2, hipStream_t st) {
+  hipLaunchKernelGGL(vc_clock_probe_kernel, dim3(1), dim3(64), 0, st, wall_ticks, out2);
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                       long long gs, long long cs, int Ng, int Nc, int nGB, int gbw, int log1p_t) {
   const long long total = (long long)nGB * Nc * gbw;

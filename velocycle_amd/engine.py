@@ -329,6 +329,14 @@ class HipEngine:
     def clear_status(self):
         self._check(self.lib.vc_clear_status(self._h, self._stream()))
 
+    def device_clock_mhz(self, window_us: float = 200.0) -> float:
+        """Shader clock measured on the device right now (vc_device_clock_mhz)."""
+        mhz = C.c_double()
+        rc = self.lib.vc_device_clock_mhz(C.c_double(window_us), C.byref(mhz), self._stream())
+        if rc != _lib.VC_OK:
+            raise HipEngineError("vc_device_clock_mhz failed")
+        return mhz.value
+
     def set_timing(self, enable: bool):
         self._check(self.lib.vc_set_timing(self._h, int(enable)))
 
