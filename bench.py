@@ -56,7 +56,10 @@ def parse():
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=10000)
-    ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed regions of --steps steps each, the median is reported; 0 = max(9, ceil(1000 / steps)): "
+                         "short regions are repeated until ~1000 steps are timed (memory / fabric clocks take ~30 ms of "
+                         "GPU work to ramp, a 20-step region is 4 ms)")
     ap.add_argument("--roofline-launches", type=int, default=100)
     return ap.parse_args()
 
@@ -144,15 +147,16 @@ def kernel_roofline(engine, run, steps):
 
 
 def cpu_baseline(args, mode, device=None):
-    """Oracle restatement (kind "port": the reference's Pyro path cannot run here) timed on the host at
-    TWO sample sizes of the same workload -- the first n and the first 4n cells -- so that the cells-exponent of its
-    cost is measured, not assumed; the reported value extrapolates the larger sample to the full size with the
-    measured exponent (it comes out ~1: the op-by-op path is memory-streaming over (Ng, Nc) temporaries)."""
+    """Oracle restatement (kind "port": the reference's Pyro path cannot run here) timed on the host cores.
+    The op-by-op path streams ~110 full-size (Ng, Nc) temporaries per step, so its cost per cell depends on whether they
+    fit the host's last-level cache: it is timed at a 10 000-cell sample AND, when the host has the memory for it
+    (>= 2.5 x the ~110 temporaries), at the FULL size, which is then the reported value; otherwise the value is the
+    10 000-cell time scaled linearly in cells and says so.  The cells-exponent between the sizes is reported."""
     import math
     from oracle import velocycle_oracle as orc
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
-    n_big = min(args.cpu_sample_cells, args.cells)
-    n_small = max(n_big // 4, 1)
+    n_mid = min(args.cpu_sample_cells, args.cells)
+    n_small = max(n_mid // 4, 1)
 
     def problem(nsample):
         spec = (make_phase_spec(nsample, args.genes, seed=0, device="cpu") if mode == "phase"
@@ -195,45 +199,65 @@ def cpu_baseline(args, mode, device=None):
                       "note": f"one ELBO evaluation on the {n_small}-cell sample with identical params and eps; the port "
                               "runs in float32, so this bounds both sides' rounding (tests compare against float64 at 1e-5)"}
     # the op-by-op torch path does not scale to every hardware thread of a big host: pick the thread count that is
-    # fastest on this box (short sweep on the small sample), then time both samples with it
+    # fastest on this box (short sweep on the mid-size sample, which is past the cache-resident regime), then time with it
     default_nt = torch.get_num_threads()
-    one_s()
+    del p_s, st_s, one_s
+    _, p_m = problem(n_mid)
+    one_m, _, _ = stepper(p_m)
+    one_m()
     sweep = {}
-    for nt in sorted({8, 16, 32, 64, default_nt}):
+    for nt in sorted({16, 32, 64, min(default_nt, 128)}):
         if nt > (os.cpu_count() or nt):
             continue
         torch.set_num_threads(nt)
-        one_s()
+        one_m()
         t0 = time.perf_counter()
-        one_s()
+        one_m()
         sweep[nt] = time.perf_counter() - t0
     best_nt = min(sweep, key=sweep.get)
     torch.set_num_threads(best_nt)
 
     def timed(one, budget_s, nmin=3, nmax=40):
-        one()
         t0 = time.perf_counter()
         n = 0
         while n < nmin or (time.perf_counter() - t0 < budget_s and n < nmax):
             one()
             n += 1
         return n, time.perf_counter() - t0
-    ns, dts = timed(one_s, 4.0)
-    del p_s, st_s
-    _, p_b = problem(n_big)
-    one_b, _, _ = stepper(p_b)
-    nb, dtb = timed(one_b, 12.0)
+    nm, dtm = timed(one_m, 4.0)
+    t_mid = dtm / nm
+    del p_m, one_m
+    # full size, if the host can hold it
+    nmat = 1 if mode == "phase" else 2
+    need = 2.5 * 55 * nmat * 4.0 * args.genes * args.cells
+    try:
+        import psutil
+        avail = float(psutil.virtual_memory().available)
+    except Exception:
+        avail = 0.0
+    full = None
+    if args.cells > n_mid and avail >= need:
+        _, p_f = problem(args.cells)
+        one_f, _, _ = stepper(p_f)
+        one_f()                                           # warm-up (allocator)
+        nf, dtf = timed(one_f, 0.0, nmin=3, nmax=3)
+        full = (nf, dtf)
+        del p_f, one_f
     torch.set_num_threads(default_nt)
-    t_small, t_big = dts / ns, dtb / nb
-    expo = math.log(t_big / t_small) / math.log(n_big / n_small) if n_big > n_small else 1.0
-    t_full = t_big * (args.cells / n_big) ** expo
+    if full is not None:
+        t_full = full[1] / full[0]
+        expo = math.log(t_full / t_mid) / math.log(args.cells / n_mid)
+        how = (f"FULL size {args.cells} cells x {args.genes} genes: {full[0]} steps in {full[1]:.1f}s = {t_full:.2f} s/step (the value); "
+               f"{n_mid}-cell sample: {nm} steps in {dtm:.1f}s = {t_mid:.3f} s/step -> measured cost exponent in cells {expo:.2f}")
+    else:
+        t_full = t_mid * args.cells / n_mid
+        expo = None
+        how = (f"first {n_mid} of {args.cells} cells x {args.genes} genes: {nm} steps in {dtm:.1f}s = {t_mid:.3f} s/step, scaled "
+               f"LINEARLY in cells (the host has {avail / 2 ** 30:.0f} GiB available, the full size needs ~{need / 2 ** 30:.0f} GiB)")
     return {"value": round(1.0 / t_full, 4), "unit": "SVI steps/s", "cores": best_nt,
-            "kind": "port", "elbo_match": elbo_match, "cells_exponent": round(expo, 3),
-            "sample": f"oracle (op-by-op torch fp32 + autograd + ClippedAdam) on the first {n_small} and the first {n_big} of "
-                      f"{args.cells} cells x {args.genes} genes: {ns} steps in {dts:.1f}s = {t_small:.3f} s/step and {nb} steps "
-                      f"in {dtb:.1f}s = {t_big:.3f} s/step -> measured cost exponent in cells {expo:.3f}; value = the "
-                      f"{n_big}-cell time scaled by ({args.cells}/{n_big})^{expo:.3f}; {best_nt} torch threads = fastest of "
-                      f"sweep { {k: round(v, 2) for k, v in sweep.items()} } s/step; host cpu_count={os.cpu_count()}"}
+            "kind": "port", "elbo_match": elbo_match, "cells_exponent": None if expo is None else round(expo, 3),
+            "sample": "oracle (op-by-op torch fp32 + autograd + ClippedAdam), " + how + f"; {best_nt} torch threads = fastest of "
+                      f"sweep { {k: round(v, 3) for k, v in sweep.items()} } s/step on {n_mid} cells; host cpu_count={os.cpu_count()}"}
 
 
 def device_identity(device):
@@ -244,6 +268,8 @@ def device_identity(device):
 
 def main():
     args = parse()
+    if args.repeats <= 0:
+        args.repeats = max(9, -(-1000 // max(args.steps, 1)))
     # torchrun sets these before this process touches the GPU; nothing below re-executes the process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -305,7 +331,8 @@ def main():
     sps = args.steps / dt
     losses = run.perf_losses()
     ok, first_bad, n_bad = eng.status()
-    roof = kernel_roofline(eng, run, max(args.roofline_launches, 100))
+    n_timed = args.warmup + args.steps * len(times)          # steps run up to the end of the last timed region
+    roof = kernel_roofline(eng, run, args.roofline_launches)
     if dist_on:
         roof["note"] = f"per-rank kernel on {eng.Nc_local} of {args.cells} cells"
     # "loss read back each step unless stated" -- the headline keeps the losses on the device and reads them
@@ -326,7 +353,9 @@ def main():
         "timing": "value / ms_per_step = MEDIAN of `repeats` timed regions of exactly `steps` steps each (barrier + "
                   "synchronize on both sides, max over ranks); repeat_ms_per_step lists all of them in order",
         "device_clock_mhz": {"before_timed_region": round(clock_before, 1), "after_timed_region": round(clock_after, 1),
-                             "method": "s_memtime ticks per 200 us of s_memrealtime, one wave (vc_device_clock_mhz)"},
+                             "method": "shader clock: s_memtime ticks per 200 us of s_memrealtime, one wave "
+                                       "(vc_device_clock_mhz); memory / fabric clocks are not observable from a kernel -- "
+                                       "their ramp shows in the first entries of repeat_ms_per_step"},
         "setup_s": setup,
         "config": {"workload": f"synthetic {args.cells} cells x {args.genes} genes " + ("phase_inference" if args.mode == "phase" else "velocity_inference") + ", "
                                + {"vjoint": "mean-field guide, nothing conditioned (every gradient)",
@@ -342,7 +371,7 @@ def main():
                               "(with_loss_readback_each_step gives the rate with a host read-back after every step)")},
         "with_loss_readback_each_step": {"value": round(rb_sps, 2), "unit": "SVI steps/s", "steps": nrb},
         "roofline": roof,
-        "loss_first_last": [losses[0], losses[-1]],
+        "loss_first_last": [losses[0], losses[n_timed - 1]],
         "nonfinite_loss_steps": n_bad,
     }
     if dist_on or solo_group:
@@ -362,7 +391,7 @@ def main():
         for m in [x for x in ("vcond", "phase", "vjoint") if x != args.mode][:2]:
             s2, e2, r2, _ = build(m)
             ts2 = time_steps(r2, args.steps, args.warmup, False, device, args.repeats)
-            rf = kernel_roofline(e2, r2, max(args.roofline_launches, 100))
+            rf = kernel_roofline(e2, r2, args.roofline_launches)
             extra[m] = {"steps_per_s": round(args.steps / median(ts2), 2), "kernel": rf["kernel"],
                         "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"],
                         "hbm_frac": rf["frac"], "valu_frac": (rf["valu"] or {}).get("frac")}

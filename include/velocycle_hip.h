@@ -159,8 +159,9 @@ typedef struct vc_stats {
   int64_t streamed_bytes;         /* bytes the main kernel actually streams (padded layout) */
   int64_t main_grid, main_block;  /* launch geometry of the likelihood kernel */
   int32_t main_kind;              /* 0 phase(S) 1 velocity(S+U) 2 velocity, S-term hoisted (U only) */
-  int32_t reserved;
+  int32_t hist_on_device;         /* 1: the per-gene count histograms were built on the device during the re-layout */
   char main_kernel_name[96];
+  int64_t setup_transient_bytes;  /* device memory vc_finalize held only while it ran (histogram tables, owned uploads) */
 } vc_stats;
 
 /* lifecycle ------------------------------------------------------------------------------- */
@@ -173,9 +174,19 @@ const char* vc_last_error(const vc_engine* e);
 /* inputs (call before vc_finalize) ---------------------------------------------------------- */
 /* Count matrices, element (g, c) at ptr[g*gene_stride + c*cell_stride] (so both the reference's
  * `S.T.float()` view -- gene_stride 1, cell_stride Ng -- and a contiguous (Ng,Nc) array work).
- * U may be NULL for the phase model.  on_device: pointers are device (1) or host (0) memory. */
+ * U may be NULL for the phase model.  on_device: pointers are device (1) or host (0) memory.  Device memory is NOT
+ * copied: it is read by vc_finalize and must stay valid until vc_finalize has returned.  Host memory is uploaded
+ * row by row (this rank's cells only).  Values must be finite and >= 0 (checked on the device; vc_finalize returns
+ * VC_ERR_ARG otherwise). */
 int vc_set_counts(vc_engine* e, const float* S, const float* U, int64_t gene_stride,
                   int64_t cell_stride, int on_device);
+/* The same matrices as canonical CSR (rows = this rank's cells, columns = genes; no duplicate entries): what AnnData
+ * layers hold before the reference densifies them (preprocessing.py:141-147 `.A`, 243-252).  which: 0 = spliced,
+ * 1 = unspliced (velocity model).  indptr int64[Nc_local + 1], indices int32[nnz], data float[nnz]; on_device as above
+ * (device arrays must stay valid until vc_finalize has returned).  The dense matrix is never formed on the host: the
+ * blocked HBM layout is filled by a scatter kernel that also builds the per-gene count histograms. */
+int vc_set_counts_csr(vc_engine* e, int which, const int64_t* indptr, const int32_t* indices, const float* data,
+                      int64_t nnz, int on_device);
 /* count_factor (Nc_local), D (Nx, Nc_local) row-major [NULL for phase], Db (Nb, Nc_local) row-major
  * [NULL when Nb == 0], phixy_prior (Nc_local, 2).  Host pointers. */
 int vc_set_cell_data(vc_engine* e, const float* count_factor, const float* D, const float* Db,
@@ -218,6 +229,21 @@ int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64_t seed, in
                 float* grad, double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
                 double lrd, double beta1, double beta2, double adam_eps, double clip_norm, void* hip_stream);
 
+/* One whole SVI step (single rank) in THREE launches, every O(Ng + Nc) latency chain of the step run once: the
+ * likelihood kernel; a per-gene-block / per-cell-block kernel that finishes the reductions, applies the chain rule,
+ * pyro's ClippedAdam AND draws the guide sample of the next step from the fresh parameters (gene table, cell table,
+ * prior / guide log-densities); and a small kernel for the one global dependency, the angular-speed coefficients
+ * (gradient, optimiser, next sample, omega_c into the cell records) that also assembles the loss of the finished step.
+ * eps is the Philox stream (seed, step, index) only.  step_dev (device int64, required) holds the number of finished
+ * steps t: the call evaluates step t, stores its loss into loss_dev[t % loss_slots] and leaves step_dev = t + 1.
+ * prime != 0: first draw the sample of step t from `params` as they are (needed for the first call, and again after the
+ * caller has changed params / step_dev / seed behind the engine's back, e.g. on resume); prime = 0 continues from the
+ * tables the previous call left.  Same trajectory as vc_svi_step (tests/test_hip_fused.py).  VC_ERR_STATE when
+ * world_size > 1. */
+int vc_svi_step_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad, double* loss_dev,
+                      int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr, double lrd, double beta1,
+                      double beta2, double adam_eps, double clip_norm, int prime, void* hip_stream);
+
 /* One draw of the guide pushed through the deterministic part of the model (what
  * `Predictive(model, guide=guide, num_samples=1)` evaluates for the latent and deterministic sites;
  * velocity_inference_model.py:279-291, phase_inference_model.py:274-302): runs the sampling kernel only, no
@@ -251,6 +277,11 @@ int vc_expected_logs(vc_engine* e, const float* nu, const float* dnu, const floa
 /* Copies the value a site took in the last vc_elbo_grad to host memory (synchronises the stream). */
 int vc_read_site(vc_engine* e, int site, float* host_out, int64_t n, void* hip_stream);
 int vc_get_stats(const vc_engine* e, vc_stats* out);
+/* The per-gene count histograms vc_finalize built (CSR over [S genes..., U genes...]: ptr int32[2*Ng + 1], distinct
+ * non-zero count values and their multiplicities) -- the sufficient statistic of the negative binomial's lgamma /
+ * digamma terms.  Pass NULL arrays to query *n_entries first.  Lets tests hold the device-built histograms against the
+ * host pass (VC_HOST_HIST=1). */
+int vc_get_histogram(const vc_engine* e, int64_t* n_entries, int32_t* ptr_out, float* val_out, float* cnt_out);
 /* Failure detection (the reference's counterpart: pyro.util.warn_if_nan(loss, "loss") inside SVI.step, call sites
  * phase_inference_model.py:169 / velocity_inference_model.py:120).  The last kernel of every step checks this rank's
  * loss on the device and latches the first step whose loss was NaN / Inf, so the check costs no host round trip per

@@ -87,6 +87,7 @@ def test_device_side_failure_latch():
     r.run_perf(5)
     assert e.status() == (True, -1, 0)
     e.view(e.params, "ν_locs")[0, 0] = float("nan")
+    r.invalidate()                 # params edited behind the runner's back: the next step re-draws its sample from them
     r.run_perf(3)
     ok, first, n = e.status()
     assert not ok and first == 5 and n == 3

@@ -22,18 +22,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _tb(err):
+    i = err.find("Traceback")
+    return err[i:i + 4000] if i >= 0 else err[-3000:]
+
+
 @pytest.mark.parametrize("mode", ["perf", "parity"])
 def test_sharded_fit_equals_single_process_fit(mode, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
     r1 = subprocess.run([sys.executable, "tests/fit_shard_worker.py", one, mode], cwd=ROOT, env=env,
                         capture_output=True, text=True, timeout=900)
-    assert r1.returncode == 0, r1.stderr[-3000:]
+    assert r1.returncode == 0, _tb(r1.stderr)
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                          "tests/fit_shard_worker.py", two, mode],
                         cwd=ROOT, env=dict(env, VC_BENCH_ONE_DEVICE="1"), capture_output=True, text=True, timeout=900)
-    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert r2.returncode == 0, _tb(r2.stderr)
     a, b = np.load(one), np.load(two)
     assert int(a["world"]) == 1 and int(b["world"]) == 2 and int(b["nc_local"]) == 1501
     assert "vu_" in str(b["vel_kernel"])                       # tutorial flow: S term hoisted, on every shard

@@ -1,0 +1,90 @@
+"""GPU: the three-launch fused step (vc_svi_step_fused: K_main -> K_tail -> K_omega, SVIRunner adam_impl="fused3") against
+the unfused kernel sequence it replaces (K_pre -> K_main -> K_post -> K_fin -> ClippedAdam, adam_impl="hip" / "fused"):
+same Philox stream, same arithmetic statement by statement, so the trajectories must coincide -- parameters and
+optimiser moments to float32 rounding of a few reassociated sums (observed: bit-identical in most configurations), losses
+to 1e-9 relative (the fp64 loss assembly adds its terms in a different order).  Every model / guide / noise /
+conditioning combination of the step fixtures, plus medium sizes with ragged tiles and several gene blocks."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+OPT = {"lr": 0.03, "lrd": 0.995, "betas": (0.8, 0.99)}
+
+
+def _run(spec, impl, n, use_graph, seed=7):
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    e = HipEngine(spec)
+    r = SVIRunner(e, OPT, mode="perf", seed=seed, use_graph=use_graph, adam_impl=impl)
+    r.run_perf(n)
+    out = dict(p=e.params.clone().cpu(), l=np.array(r.perf_losses()), m=r.opt.m.clone().cpu(), v=r.opt.v.clone().cpu(),
+               g=e.grad.clone().cpu(), sd=int(r.step_dev.item()), status=e.status())
+    e.close()
+    return out
+
+
+def _same(a, b, what, rtol=2e-5, atol=2e-6):
+    a, b = a.double().numpy(), b.double().numpy()
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin), what
+    assert np.allclose(a[fin], b[fin], rtol=rtol, atol=atol), (what, np.abs(a[fin] - b[fin]).max())
+
+
+@pytest.mark.parametrize("case", H.STEP_CASES)
+def test_fused_step_equals_unfused_sequence(case):
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
+    spec = H.spec_from_fixture(z)
+    n = 15
+    ref = _run(spec, "hip", n, False)
+    for use_graph in (False, True):
+        got = _run(spec, "fused3", n, use_graph)
+        assert got["sd"] == n and ref["sd"] == n and got["status"][0]
+        assert len(got["l"]) == n and np.allclose(got["l"], ref["l"], rtol=1e-9, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
+        _same(got["p"], ref["p"], f"{case}: params")
+        _same(got["m"], ref["m"], f"{case}: exp_avg")
+        _same(got["v"], ref["v"], f"{case}: exp_avg_sq", rtol=1e-4)
+        _same(got["g"][4:], ref["g"][4:], f"{case}: last gradient", rtol=1e-4, atol=1e-4)
+    # graph replay == eager launches of the fused step, bit for bit
+    a, b = _run(spec, "fused3", n, True), _run(spec, "fused3", n, False)
+    nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+    assert torch.equal(nz(a["p"]), nz(b["p"])) and np.array_equal(a["l"], b["l"])
+
+
+@pytest.mark.parametrize("mode,ncond,cw", [("vjoint", 1, "37"), ("vcond", 2, None), ("vjoint", 2, "29"), ("vcond_mf", 1, None)])
+def test_fused_step_medium_sizes(mode, ncond, cw, monkeypatch):
+    """3001 (x n_conditions) cells x 300 genes: several gene blocks, many cell blocks, ragged tails, Nx = Nb = 2."""
+    from velocycle_amd.workloads import make_velocity_spec
+    if cw:
+        monkeypatch.setenv("VC_CELLS_PER_WAVE", cw)
+    spec = make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5)
+    ref, got = _run(spec, "hip", 12, False), _run(spec, "fused3", 12, True)
+    assert np.allclose(got["l"], ref["l"], rtol=1e-8, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
+    _same(got["p"], ref["p"], "params", rtol=1e-4, atol=1e-5)
+    _same(got["m"], ref["m"], "exp_avg", rtol=1e-4, atol=1e-5)
+
+
+def test_fused_phase_medium_and_resume_mid_run():
+    """phase model at 3000 x 200, and: a run interrupted by state_dict()/load_state_dict() into a new engine continues
+    the same trajectory (the next step's sample is re-drawn from the restored parameters)."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    from velocycle_amd.workloads import make_phase_spec
+    spec = make_phase_spec(3000, 200, seed=5)
+    ref, got = _run(spec, "hip", 12, False), _run(spec, "fused3", 12, True)
+    assert np.allclose(got["l"], ref["l"], rtol=1e-8, atol=0)
+    _same(got["p"], ref["p"], "params", rtol=1e-4, atol=1e-5)
+    e1 = HipEngine(spec)
+    r1 = SVIRunner(e1, OPT, mode="perf", seed=7)
+    assert r1.adam_impl == "fused3"
+    r1.run_perf(5)
+    sd = r1.state_dict()
+    e2 = HipEngine(spec)
+    r2 = SVIRunner(e2, OPT, mode="perf", seed=7)
+    r2.load_state_dict(sd)
+    r2.run_perf(7)
+    assert torch.equal(e2.params.cpu(), got["p"]) and np.array_equal(np.array(r2.perf_losses()), got["l"])
+    e1.close()
+    e2.close()

@@ -15,7 +15,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIZE = ["--cells", "6000", "--genes", "300", "--steps", "30", "--warmup", "5"]
+SIZE = ["--cells", "6000", "--genes", "300", "--steps", "30", "--warmup", "5", "--repeats", "1", "--roofline-launches", "20"]
 
 
 def _free_port():

@@ -57,7 +57,8 @@ class vc_layout(C.Structure):
 class vc_stats(C.Structure):
     _fields_ = [("algorithmic_bytes", C.c_int64), ("streamed_bytes", C.c_int64),
                 ("main_grid", C.c_int64), ("main_block", C.c_int64), ("main_kind", C.c_int32),
-                ("reserved", C.c_int32), ("main_kernel_name", C.c_char * 96)]
+                ("hist_on_device", C.c_int32), ("main_kernel_name", C.c_char * 96),
+                ("setup_transient_bytes", C.c_int64)]
 
 
 EXPORTS = {
@@ -66,6 +67,8 @@ EXPORTS = {
     "vc_destroy": (None, [C.c_void_p]),
     "vc_last_error": (C.c_char_p, [C.c_void_p]),
     "vc_set_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
+    "vc_set_counts_csr": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    "vc_get_histogram": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]),
     "vc_set_cell_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vc_set_prior": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "vc_set_conditioned": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
@@ -76,6 +79,9 @@ EXPORTS = {
     "vc_svi_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
                               C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "vc_svi_step_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_int, C.c_void_p]),
     "vc_clipped_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

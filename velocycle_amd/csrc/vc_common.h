@@ -41,6 +41,7 @@ struct VcDims {
   long long eoff[VC_E_COUNT];   // eps offsets
   long long eps_n_global;
   int nb_pre_gene, nb_pre_cell, nb_post_gene, nb_post_cell, n_main_wg;
+  int nlpf;               // fused pipeline: loss slots per half of LPF = nb_post_gene + nb_post_cell + 1
 };
 
 struct VcBufs {
@@ -69,6 +70,11 @@ struct VcBufs {
   double *HL, *HD;                          // per histogram task: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
   double const_loss;                        // step-invariant part of the loss
   long long* status;                        // [0] number of steps with a non-finite loss, [1] 1 + index of the first one
+  // fused single-rank pipeline (vc_svi_step_fused)
+  long long* step_ctr;                      // non-null: K_main advances this device step counter (block 0)
+  double* LPF;                              // [2][nlpf] prior / guide loss terms of the samples of step s in half s & 1
+  double* LPP;                              // [nb_post_gene] r-only likelihood terms of the gene blocks (K_tail)
+  float* NWS;                               // [4][VC_MAX_NW * (VC_MAX_RANK + 2)] snapshot of the nu_omega parameters, moments, value
 #ifdef VC_DBG_TIMES
   unsigned long long* dbg;                  // measurement aid: 4 wall-clock stamps per wave of K_main
 #endif
@@ -200,6 +206,52 @@ __device__ __forceinline__ void vc_lgamma_digamma_diff(float x, float k, float& 
   dl = (y - 0.5f) * l1 + k * (logf(z) - 1.0f) + (Sz - Sy) + lp;
   dd = l1 - 0.5f * (iz - iy) - (Tz - Ty) + rs;
 }
+
+#define CND(site) ((d.cond >> (site)) & 1u)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// pyro.optim.ClippedAdam for one element (the arithmetic of vc_adam_kernel): returns the new parameter value
+__device__ __forceinline__ float vc_adam_elem(float p, float g, float& m, float& v, float step_size, float fb1, float fb2,
+                                              float eps, float clip) {
+  const float gi = fminf(fmaxf(g, -clip), clip);
+  m = fb1 * m + (1.f - fb1) * gi;
+  v = fb2 * v + (1.f - fb2) * gi * gi;
+  return p - step_size * (m / (sqrtf(v) + eps));
+}
+// step size of the 1-based optimiser step t: lr0 lrd^t sqrt(1 - b2^t) / (1 - b1^t); lrd_l, b1l, b2l are natural logs
+__device__ __forceinline__ float vc_adam_step_size(long long t, double lr0, double lrd_l, double b1l, double b2l) {
+  const double td = (double)t;
+  return (float)(lr0 * exp(td * lrd_l) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));
+}
+
+// One wave per histogram TASK (<= 64 distinct count values of one gene and matrix, one per lane), so the
+// latency of the kernel is one pass whatever the spread of a gene's counts; K_post adds the few task sums of
+// a gene in fixed order.
+__device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, const float* __restrict__ P,
+                                             int cond_only, int task, int lane) {
+  const int g = b.h_task[4 * task], m = b.h_task[4 * task + 1];
+  const int beg = b.h_task[4 * task + 2], end = b.h_task[4 * task + 3];
+  double hl = 0.0, hd = 0.0;
+  if ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U)) {
+    float si;
+    if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
+    else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
+    const float r = 1.0f / si;
+    const int i = beg + lane;
+    if (i < end) {
+      float dl, dd;
+      vc_lgamma_digamma_diff(r, b.h_val[i], dl, dd);
+      const double n = (double)b.h_cnt[i];
+      hl = n * (double)dl;
+      hd = n * (double)dd;
+    }
+    hl = vc_wave_sum_d(hl);
+    hd = vc_wave_sum_d(hd);
+  }
+  if (lane == 0) { b.HL[task] = hl; b.HD[task] = hd; }
+}
+
 #endif  // __HIPCC__
 
 // launchers implemented in the .hip translation units -----------------------------------------
@@ -208,8 +260,14 @@ vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gp
                                       const void** kernel);
 
 void vc_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* out2, hipStream_t st);
+// re-layout of one count matrix into [gene block][cell][gbw] (+ log(k+1) for Lognormal noise); with tab != nullptr the
+// per-gene count histogram is built on the device in the same pass (vc_small_kernels.hip)
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
-                           int Ng, int Nc, int nGB, int gbw, int log1p_transform, hipStream_t st);
+                           int Ng, int Nc, int nGB, int gbw, int log1p_transform, unsigned* tab, float* ovf_val,
+                           int* ovf_gene, unsigned* ovf_n, unsigned ovf_cap, int* bad, hipStream_t st);
+void vc_launch_scatter_csr(const long long* indptr, const int* indices, const float* data, float* dst, int Ng, int Nc,
+                           int gbw, int log1p_transform, unsigned* tab, float* ovf_val, int* ovf_gene, unsigned* ovf_n,
+                           unsigned ovf_cap, int* bad, hipStream_t st);
 void vc_launch_expected_logs(const VcDims& d, const VcBufs& b, const float* nu, const float* dnu, const float* phi,
                              const float* omega, const float* logbeta, const float* gamma, float cf_avg, float* out_S,
                              float* out_S2, float* out_U, float* out_U2, hipStream_t st);
@@ -225,6 +283,20 @@ void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* 
                         long long loss_slots, long long step, long long* step_dev, float* m, float* v, double lr0,
                         double lrd, double b1, double b2, float eps, float clip, int header, long long total,
                         hipStream_t st);
+// hyper-parameters of pyro's ClippedAdam as the fused kernels take them (logs precomputed on the host)
+struct VcAdamArgs {
+  float* m;            // exp_avg    [total - header]
+  float* v;            // exp_avg_sq [total - header]
+  double lr0, lrd_l, b1l, b2l;
+  float b1, b2, eps, clip;
+  int header;
+};
+// fused single-rank step (vc_svi_step_fused): K_main(t) -> K_tail(t) -> K_omega(t); boot = 1: sampling only (primes the
+// tables for the step *step_dev)
+void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                    const VcAdamArgs& a, int boot, hipStream_t st);
+void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                     const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
                     double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
                     const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st);

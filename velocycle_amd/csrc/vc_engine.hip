@@ -1,5 +1,6 @@
 // Host side of the engine behind the C ABI of include/velocycle_hip.h: configuration, HBM layout,
-// count histograms, workspaces, kernel sequencing.  No exception leaves this file.
+// count histograms, workspaces, kernel sequencing.  No exception leaves this file (VC_GUARD_* around every entry
+// point that allocates host memory).
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "vc_common.h"
+#include "vc_host_logic.h"
 
 namespace {
 
@@ -30,14 +32,35 @@ struct vc_engine {
   bool have_counts = false, have_cells = false;
   bool prior_set[VC_PRIOR_COUNT] = {};
   // host copies needed at finalize
-  std::vector<float> hS, hU;            // dense (Ng, Nc) gene-major copies for histogram building
+  std::vector<float> hS, hU;            // VC_HOST_HIST=1 only (the host histogram pass kept as the checker of the device one)
+  bool host_hist = false;
   std::vector<float> h_prior[VC_PRIOR_COUNT];
   std::vector<float> h_cond[VC_SITE_COUNT];
-  float* raw[2] = {nullptr, nullptr};   // device copies of S / U in the caller's strides (until finalize)
+  // the count matrices as handed over, until vc_finalize re-lays them out: dense strided (device pointer: the caller's
+  // when on_device, else an owned compact upload) or CSR (cells x genes)
+  struct CountSrc {
+    int kind = 0;                       // 0 none, 1 dense, 2 CSR
+    const float* dense = nullptr;
+    const long long* indptr = nullptr;
+    const int* indices = nullptr;
+    const float* data = nullptr;
+    long long nnz = 0;
+    void* owned[3] = {nullptr, nullptr, nullptr};
+    void release() {
+      for (void*& p : owned) { if (p) (void)hipFree(p); p = nullptr; }
+      kind = 0; dense = nullptr; indptr = nullptr; indices = nullptr; data = nullptr; nnz = 0;
+    }
+  } src[2];
+  // what the last vc_finalize measured about its own set-up
+  std::vector<int> h_ptr_host;          // the histogram CSR as uploaded (vc_get_histogram)
+  std::vector<float> h_val_host, h_cnt_host;
+  size_t setup_transient_bytes = 0;     // peak device memory held only during vc_finalize
+  int hist_on_device = 0;
   vc_main_launch_fn main_fn = nullptr;
   vc_main_launch_fn phase_fn = nullptr;  // S-only kernel used once to hoist the S term (VU kind)
   const char* main_name = "";
   long long gs = 0, cs = 0;          // strides of the host copies hS / hU
+  long long dgs = 0, dcs = 0;        // strides of the dense device sources
   bool hist_each_step = false;
   // optional hipEvent timing of the likelihood kernel (bench.py roofline)
   bool timing = false;
@@ -89,6 +112,17 @@ struct vc_engine {
     int _rc = (x);             \
     if (_rc != VC_OK) return _rc; \
   } while (0)
+
+// Every entry point that allocates host memory runs its body through this guard: no C++ exception crosses the C ABI.
+#define VC_GUARD_BEGIN try {
+#define VC_GUARD_END(e_)                                                                         \
+  } catch (const std::bad_alloc&) {                                                              \
+    return (e_) ? (e_)->fail(VC_ERR_ARG, "out of host memory") : VC_ERR_ARG;                     \
+  } catch (const std::exception& ex) {                                                           \
+    return (e_) ? (e_)->fail(VC_ERR_STATE, "internal error: %s", ex.what()) : VC_ERR_STATE;      \
+  } catch (...) {                                                                                \
+    return (e_) ? (e_)->fail(VC_ERR_STATE, "internal error") : VC_ERR_STATE;                     \
+  }
 
 static bool cond(const vc_engine* e, int site) { return (e->d.cond >> site) & 1u; }
 
@@ -242,7 +276,7 @@ extern "C" void vc_destroy(vc_engine* e) {
   }
 #endif
   for (void* p : e->allocs) (void)hipFree(p);
-  for (float* r : e->raw) if (r) (void)hipFree(r);
+  for (auto& c : e->src) c.release();
   for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete e;
 }
@@ -256,6 +290,7 @@ extern "C" int vc_get_layout(const vc_engine* e, vc_layout* out) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int vc_set_counts(vc_engine* e, const float* S, const float* U, int64_t gs, int64_t cs, int on_device) {
   if (!e) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
   if (e->finalized) return e->fail(VC_ERR_STATE, "vc_set_counts after vc_finalize");
   VcDims& d = e->d;
   const bool vel = d.model == VC_MODEL_VELOCITY;
@@ -264,25 +299,87 @@ extern "C" int vc_set_counts(vc_engine* e, const float* S, const float* U, int64
   const size_t span = (size_t)(d.Ng - 1) * gs + (size_t)(d.Nc - 1) * cs + 1;
   const float* src[2] = {S, vel ? U : nullptr};
   std::vector<float>* hcopy[2] = {&e->hS, &e->hU};
+  e->host_hist = getenv("VC_HOST_HIST") && atoi(getenv("VC_HOST_HIST")) != 0;
+  long long ngs = gs, ncs = cs;
   for (int m = 0; m < 2; ++m) {
+    e->src[m].release();
     if (!src[m]) continue;
-    // device copy in the caller's strides; re-laid-out by vc_finalize once the kernel (and with it the
-    // gene-block width of the HBM layout) is known
-    if (e->raw[m]) { (void)hipFree(e->raw[m]); e->raw[m] = nullptr; }
-    HIPCHK(e, hipMalloc((void**)&e->raw[m], span * sizeof(float)));
-    HIPCHK(e, hipMemcpy(e->raw[m], src[m], span * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    // host copy (raw counts) for the histograms / lgamma(k+1) constant
-    if (d.noise != VC_NOISE_LOGNORMAL) {
+    e->src[m].kind = 1;
+    if (e->host_hist && d.noise != VC_NOISE_LOGNORMAL) {     // checker path: host copy of the raw counts
       std::vector<float> tmp(span);
       if (on_device) HIPCHK(e, hipMemcpy(tmp.data(), src[m], span * sizeof(float), hipMemcpyDeviceToHost));
       else memcpy(tmp.data(), src[m], span * sizeof(float));
       hcopy[m]->swap(tmp);
     }
+    if (on_device) {
+      // no copy: the caller's buffer is read by vc_finalize (it must stay valid until vc_finalize has returned)
+      e->src[m].dense = src[m];
+      continue;
+    }
+    // host memory: upload THIS shard only, row by row when one of the strides is 1 (a column slice of a gene-major
+    // matrix spans almost the whole matrix, but only Nc_local values per row are this rank's)
+    float* dev = nullptr;
+    if (gs == 1 && cs >= d.Ng) {
+      HIPCHK(e, hipMalloc((void**)&dev, (size_t)d.Ng * d.Nc * sizeof(float)));
+      e->src[m].owned[0] = dev;
+      HIPCHK(e, hipMemcpy2D(dev, (size_t)d.Ng * 4, src[m], (size_t)cs * 4, (size_t)d.Ng * 4, d.Nc, hipMemcpyHostToDevice));
+      ngs = 1; ncs = d.Ng;
+    } else if (cs == 1 && gs >= d.Nc) {
+      HIPCHK(e, hipMalloc((void**)&dev, (size_t)d.Ng * d.Nc * sizeof(float)));
+      e->src[m].owned[0] = dev;
+      HIPCHK(e, hipMemcpy2D(dev, (size_t)d.Nc * 4, src[m], (size_t)gs * 4, (size_t)d.Nc * 4, d.Ng, hipMemcpyHostToDevice));
+      ngs = d.Nc; ncs = 1;
+    } else {
+      HIPCHK(e, hipMalloc((void**)&dev, span * sizeof(float)));
+      e->src[m].owned[0] = dev;
+      HIPCHK(e, hipMemcpy(dev, src[m], span * sizeof(float), hipMemcpyHostToDevice));
+    }
+    e->src[m].dense = dev;
   }
-  e->gs = gs;
-  e->cs = cs;
+  e->gs = gs; e->cs = cs;            // strides of the host copies (checker path)
+  e->dgs = ngs; e->dcs = ncs;        // strides of the device sources
   e->have_counts = true;
   return VC_OK;
+  VC_GUARD_END(e)
+}
+
+extern "C" int vc_set_counts_csr(vc_engine* e, int which, const int64_t* indptr, const int32_t* indices, const float* data,
+                                 int64_t nnz, int on_device) {
+  if (!e) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
+  if (e->finalized) return e->fail(VC_ERR_STATE, "vc_set_counts_csr after vc_finalize");
+  VcDims& d = e->d;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  if (which < 0 || which > 1 || (which == 1 && !vel)) return e->fail(VC_ERR_ARG, "vc_set_counts_csr: bad matrix id %d", which);
+  if (!indptr || nnz < 0 || (nnz > 0 && (!indices || !data))) return e->fail(VC_ERR_ARG, "vc_set_counts_csr: null array");
+  auto& c = e->src[which];
+  c.release();
+  if (on_device) {
+    c.indptr = (const long long*)indptr; c.indices = indices; c.data = data;
+  } else {
+    if (indptr[0] != 0 || indptr[d.Nc] != nnz) return e->fail(VC_ERR_ARG, "vc_set_counts_csr: indptr[0] / indptr[Nc] do not match nnz");
+    for (int64_t r = 0; r < d.Nc; ++r)
+      if (indptr[r + 1] < indptr[r]) return e->fail(VC_ERR_ARG, "vc_set_counts_csr: indptr is not non-decreasing");
+    void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+    HIPCHK(e, hipMalloc(&p0, (size_t)(d.Nc + 1) * sizeof(long long)));
+    c.owned[0] = p0;
+    HIPCHK(e, hipMalloc(&p1, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int)));
+    c.owned[1] = p1;
+    HIPCHK(e, hipMalloc(&p2, (size_t)std::max<int64_t>(nnz, 1) * sizeof(float)));
+    c.owned[2] = p2;
+    HIPCHK(e, hipMemcpy(p0, indptr, (size_t)(d.Nc + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+      HIPCHK(e, hipMemcpy(p1, indices, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+      HIPCHK(e, hipMemcpy(p2, data, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c.indptr = (const long long*)p0; c.indices = (const int*)p1; c.data = (const float*)p2;
+  }
+  c.kind = 2;
+  c.nnz = nnz;
+  e->host_hist = false;
+  e->have_counts = e->src[0].kind != 0 && (!vel || e->src[1].kind != 0);
+  return VC_OK;
+  VC_GUARD_END(e)
 }
 
 extern "C" int vc_set_cell_data(vc_engine* e, const float* count_factor, const float* D, const float* Db,
@@ -323,6 +420,7 @@ static long long prior_size(const vc_engine* e, int which) {
 
 extern "C" int vc_set_prior(vc_engine* e, int which, const float* data, int64_t n) {
   if (!e) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
   if (e->finalized) return e->fail(VC_ERR_STATE, "vc_set_prior after vc_finalize");
   if (which < 0 || which >= VC_PRIOR_COUNT || !data) return e->fail(VC_ERR_ARG, "vc_set_prior: bad id / null data");
   if (n != prior_size(e, which))
@@ -336,10 +434,12 @@ extern "C" int vc_set_prior(vc_engine* e, int which, const float* data, int64_t 
   e->h_prior[which].assign(data, data + n);
   e->prior_set[which] = true;
   return VC_OK;
+  VC_GUARD_END(e)
 }
 
 extern "C" int vc_set_conditioned(vc_engine* e, int site, const float* values, int64_t n) {
   if (!e) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
   if (e->finalized) return e->fail(VC_ERR_STATE, "vc_set_conditioned after vc_finalize");
   if (site < 0 || site >= VC_SITE_COUNT || !values) return e->fail(VC_ERR_ARG, "vc_set_conditioned: bad site / null data");
   if (!site_exists(e, site)) return e->fail(VC_ERR_ARG, "vc_set_conditioned: site %d does not exist in this model", site);
@@ -348,65 +448,7 @@ extern "C" int vc_set_conditioned(vc_engine* e, int site, const float* values, i
   e->h_cond[site].assign(values, values + n);
   e->d.cond |= (1u << site);
   return VC_OK;
-}
-
-// per-gene histograms of the non-zero counts of one matrix; returns sum lgamma(k+1)
-static double build_hist(const std::vector<float>& M, long long gs, long long cs, int Ng, int Nc,
-                         std::vector<int>& ptr_out, std::vector<float>& val, std::vector<float>& cnt) {
-  const int CAP = 2048;
-  std::vector<std::vector<std::pair<float, float>>> per_gene(Ng);
-  std::vector<double> lg(Ng, 0.0);
-  unsigned nt = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  nt = std::min<unsigned>(nt, (unsigned)Ng);
-  auto work = [&](int ga, int gb) {
-    const int n = gb - ga;
-    std::vector<unsigned> dense((size_t)n * CAP, 0u);
-    std::vector<std::map<float, unsigned>> over(n);
-    auto put = [&](int gi, float v) {
-      if (v == 0.f) return;
-      const int iv = (int)v;
-      if (v > 0.f && iv < CAP && (float)iv == v) dense[(size_t)gi * CAP + iv]++;
-      else over[gi][v]++;
-    };
-    if (gs <= cs) {
-      for (int c = 0; c < Nc; ++c) {
-        const float* row = M.data() + (long long)c * cs;
-        for (int g = ga; g < gb; ++g) put(g - ga, row[(long long)g * gs]);
-      }
-    } else {
-      for (int g = ga; g < gb; ++g) {
-        const float* row = M.data() + (long long)g * gs;
-        for (int c = 0; c < Nc; ++c) put(g - ga, row[(long long)c * cs]);
-      }
-    }
-    for (int gi = 0; gi < n; ++gi) {
-      auto& out = per_gene[ga + gi];
-      double s = 0.0;
-      for (int k = 1; k < CAP; ++k) {
-        const unsigned m = dense[(size_t)gi * CAP + k];
-        if (m) { out.emplace_back((float)k, (float)m); s += (double)m * std::lgamma((double)k + 1.0); }
-      }
-      for (auto& kv : over[gi]) {
-        out.emplace_back(kv.first, (float)kv.second);
-        s += (double)kv.second * std::lgamma((double)kv.first + 1.0);
-      }
-      lg[ga + gi] = s;
-    }
-  };
-  std::vector<std::thread> th;
-  const int per = (Ng + (int)nt - 1) / (int)nt;
-  for (unsigned t = 0; t < nt; ++t) {
-    const int ga = (int)t * per, gb = std::min(Ng, ga + per);
-    if (ga < gb) th.emplace_back(work, ga, gb);
-  }
-  for (auto& t : th) t.join();
-  double tot = 0.0;
-  for (int g = 0; g < Ng; ++g) {
-    ptr_out.push_back((int)val.size());
-    for (auto& kv : per_gene[g]) { val.push_back(kv.first); cnt.push_back(kv.second); }
-    tot += lg[g];
-  }
-  return tot;
+  VC_GUARD_END(e)
 }
 
 template <class T>
@@ -418,8 +460,15 @@ static int upload(vc_engine* e, const std::vector<T>& h, const T** dev) {
   return VC_OK;
 }
 
+static int finalize_impl(vc_engine* e, void* hip_stream);
 extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
+  return finalize_impl(e, hip_stream);
+  VC_GUARD_END(e)
+}
+
+static int finalize_impl(vc_engine* e, void* hip_stream) {
   if (e->finalized) return e->fail(VC_ERR_STATE, "vc_finalize called twice");
   if (!e->have_counts || !e->have_cells) return e->fail(VC_ERR_STATE, "vc_finalize: counts / cell data not set");
   hipStream_t st = (hipStream_t)hip_stream;
@@ -471,21 +520,75 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
     e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, nullptr, nullptr);
     if (!e->phase_fn) return e->fail(VC_ERR_UNSUPPORTED, "no S-only kernel for the hoisted term");
   }
-  // HBM layout of the counts: [gene block][cell][gbw], zero padded in genes
+  // HBM layout of the counts: [gene block][cell][gbw], zero padded in genes; the per-gene count histograms are built on
+  // the device in the same pass (dense bins + overflow list), so that no dense matrix crosses back to the host
+  const bool want_hist = d.noise != VC_NOISE_LOGNORMAL;
+  const bool dev_hist = want_hist && !e->host_hist;
+  const unsigned OVF_CAP = 1u << 22;
+  unsigned* tab[2] = {nullptr, nullptr};
+  float* ovf_val[2] = {nullptr, nullptr};
+  int* ovf_gene[2] = {nullptr, nullptr};
+  unsigned* ovf_n = nullptr;
+  int* bad = nullptr;
+  size_t transient = 0;
+  auto tmalloc = [&](void** p, size_t bytes) -> int {
+    hipError_t er = hipMalloc(p, bytes);
+    if (er != hipSuccess) return e->fail(VC_ERR_HIP, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(er));
+    transient += bytes;
+    return VC_OK;
+  };
+  auto free_transients = [&]() {
+    for (int m = 0; m < 2; ++m) {
+      if (tab[m]) (void)hipFree(tab[m]);
+      if (ovf_val[m]) (void)hipFree(ovf_val[m]);
+      if (ovf_gene[m]) (void)hipFree(ovf_gene[m]);
+      tab[m] = nullptr; ovf_val[m] = nullptr; ovf_gene[m] = nullptr;
+    }
+    if (ovf_n) (void)hipFree(ovf_n);
+    if (bad) (void)hipFree(bad);
+    ovf_n = nullptr; bad = nullptr;
+  };
+  TRY(tmalloc((void**)&ovf_n, 2 * sizeof(unsigned)));
+  TRY(tmalloc((void**)&bad, 2 * sizeof(int)));
+  HIPCHK(e, hipMemsetAsync(ovf_n, 0, 2 * sizeof(unsigned), st));
+  HIPCHK(e, hipMemsetAsync(bad, 0, 2 * sizeof(int), st));
   {
     const size_t blocked = (size_t)d.nGB * d.Nc * d.gbw;
     const float** dstp[2] = {&b.S, &b.U};
     for (int m = 0; m < 2; ++m) {
       *dstp[m] = nullptr;
-      if (!e->raw[m]) continue;
+      auto& c = e->src[m];
+      if (c.kind == 0) continue;
+      for (void* p : c.owned) if (p) transient += 0;   // owned uploads are released below
       float* packed = nullptr;
       TRY(e->dalloc(&packed, blocked));
-      vc_launch_pack_counts(e->raw[m], packed, e->gs, e->cs, d.Ng, d.Nc, d.nGB, d.gbw, d.noise == VC_NOISE_LOGNORMAL, st);
+      if (dev_hist) {
+        int rc = tmalloc((void**)&tab[m], (size_t)d.Ng * VC_HIST_CAP * sizeof(unsigned));
+        if (rc == VC_OK) rc = tmalloc((void**)&ovf_val[m], (size_t)OVF_CAP * sizeof(float));
+        if (rc == VC_OK) rc = tmalloc((void**)&ovf_gene[m], (size_t)OVF_CAP * sizeof(int));
+        if (rc != VC_OK) { free_transients(); return rc; }
+        HIPCHK(e, hipMemsetAsync(tab[m], 0, (size_t)d.Ng * VC_HIST_CAP * sizeof(unsigned), st));
+      }
+      const int ln = d.noise == VC_NOISE_LOGNORMAL;
+      if (c.kind == 1) {
+        vc_launch_pack_counts(c.dense, packed, e->dgs, e->dcs, d.Ng, d.Nc, d.nGB, d.gbw, ln, tab[m], ovf_val[m], ovf_gene[m],
+                              ovf_n + m, OVF_CAP, bad, st);
+      } else {
+        HIPCHK(e, hipMemsetAsync(packed, 0, blocked * sizeof(float), st));
+        vc_launch_scatter_csr(c.indptr, c.indices, c.data, packed, d.Ng, d.Nc, d.gbw, ln, tab[m], ovf_val[m], ovf_gene[m],
+                              ovf_n + m, OVF_CAP, bad, st);
+      }
       HIPCHK(e, hipStreamSynchronize(st));
-      (void)hipFree(e->raw[m]);
-      e->raw[m] = nullptr;
+      HIPCHK(e, hipGetLastError());
+      if (c.owned[0]) transient += (c.kind == 1 ? (size_t)d.Ng * d.Nc * 4 : (size_t)(d.Nc + 1) * 8 + (size_t)c.nnz * 8);
       *dstp[m] = packed;
     }
+  }
+  {
+    int hbad[2] = {0, 0};
+    HIPCHK(e, hipMemcpy(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost));
+    if (hbad[1]) { free_transients(); return e->fail(VC_ERR_ARG, "vc_set_counts_csr: gene index outside [0, Ng)"); }
+    if (hbad[0]) { free_transients(); return e->fail(VC_ERR_ARG, "count matrices must be finite and >= 0 (NaN / Inf / negative value found)"); }
   }
   // tiling: one balanced round.  The grid is sized to the workgroups the chip holds at once for
   // this kernel (occupancy x 256 CUs); each wave gets an equal share of the cells of its gene block,
@@ -559,6 +662,14 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
   TRY(e->dalloc(&b.PW, (size_t)d.nb_post_cell * std::max(1, d.NW)));
+  d.nlpf = d.nb_post_gene + d.nb_post_cell + 1;
+  TRY(e->dalloc(&b.LPF, 2 * (size_t)d.nlpf));
+  HIPCHK(e, hipMemset(b.LPF, 0, 2 * sizeof(double) * d.nlpf));
+  TRY(e->dalloc(&b.LPP, (size_t)d.nb_post_gene));
+  HIPCHK(e, hipMemset(b.LPP, 0, sizeof(double) * d.nb_post_gene));
+  TRY(e->dalloc(&b.NWS, 4 * (size_t)VC_MAX_NW * (VC_MAX_RANK + 2)));
+  HIPCHK(e, hipMemset(b.NWS, 0, 4 * sizeof(float) * VC_MAX_NW * (VC_MAX_RANK + 2)));
+  b.step_ctr = nullptr;
   TRY(e->dalloc(&b.status, 2));
   HIPCHK(e, hipMemset(b.status, 0, 2 * sizeof(long long)));
 
@@ -567,24 +678,56 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   {
     std::vector<int> ptr;
     std::vector<float> val, cnt;
-    if (d.noise != VC_NOISE_LOGNORMAL) {
-      lg_S = build_hist(e->hS, e->gs, e->cs, d.Ng, d.Nc, ptr, val, cnt);
-      if (vel) lg_U = build_hist(e->hU, e->gs, e->cs, d.Ng, d.Nc, ptr, val, cnt);
-      else for (int g = 0; g < d.Ng; ++g) ptr.push_back((int)val.size());
+    if (want_hist) {
+      bool bad_host = false, fallback = false;
+      unsigned novf[2] = {0, 0};
+      if (dev_hist) {
+        HIPCHK(e, hipMemcpy(novf, ovf_n, sizeof novf, hipMemcpyDeviceToHost));
+        fallback = novf[0] > OVF_CAP || novf[1] > OVF_CAP;     // mostly non-integer data: the overflow list does not hold it
+      }
+      if (dev_hist && !fallback) {
+        std::vector<unsigned> htab((size_t)d.Ng * VC_HIST_CAP);
+        for (int m = 0; m < (vel ? 2 : 1); ++m) {
+          HIPCHK(e, hipMemcpy(htab.data(), tab[m], htab.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+          std::vector<float> ov(novf[m]);
+          std::vector<int> og(novf[m]);
+          if (novf[m]) {
+            HIPCHK(e, hipMemcpy(ov.data(), ovf_val[m], novf[m] * sizeof(float), hipMemcpyDeviceToHost));
+            HIPCHK(e, hipMemcpy(og.data(), ovf_gene[m], novf[m] * sizeof(int), hipMemcpyDeviceToHost));
+          }
+          std::vector<std::pair<int, float>> ovf(novf[m]);
+          for (unsigned i = 0; i < novf[m]; ++i) ovf[i] = {og[i], ov[i]};
+          const double lg = vc_compact_hist(htab.data(), d.Ng, ovf, ptr, val, cnt);
+          (m == 0 ? lg_S : lg_U) = lg;
+        }
+        if (!vel) for (int g = 0; g < d.Ng; ++g) ptr.push_back((int)val.size());
+        e->hist_on_device = 1;
+      } else {
+        // checker path (VC_HOST_HIST=1) or fallback: histograms from a host copy of the raw counts
+        if (e->hS.empty()) {
+          if (e->src[0].kind != 1) { free_transients(); return e->fail(VC_ERR_UNSUPPORTED, "CSR input with more than %u non-integer / large counts per matrix", OVF_CAP); }
+          const size_t span = (size_t)(d.Ng - 1) * e->dgs + (size_t)(d.Nc - 1) * e->dcs + 1;
+          e->hS.resize(span);
+          HIPCHK(e, hipMemcpy(e->hS.data(), e->src[0].dense, span * sizeof(float), hipMemcpyDeviceToHost));
+          if (vel) { e->hU.resize(span); HIPCHK(e, hipMemcpy(e->hU.data(), e->src[1].dense, span * sizeof(float), hipMemcpyDeviceToHost)); }
+          e->gs = e->dgs; e->cs = e->dcs;
+        }
+        lg_S = vc_build_hist_host(e->hS.data(), e->gs, e->cs, d.Ng, d.Nc, ptr, val, cnt, &bad_host);
+        if (vel) lg_U = vc_build_hist_host(e->hU.data(), e->gs, e->cs, d.Ng, d.Nc, ptr, val, cnt, &bad_host);
+        else for (int g = 0; g < d.Ng; ++g) ptr.push_back((int)val.size());
+        e->hist_on_device = 0;
+        if (bad_host) { free_transients(); return e->fail(VC_ERR_ARG, "count matrices must be finite and >= 0 (NaN / Inf / negative value found)"); }
+      }
     } else {
       ptr.assign(2 * (size_t)d.Ng, 0);
     }
     ptr.push_back((int)val.size());
+    free_transients();
+    for (auto& c : e->src) c.release();
+    e->setup_transient_bytes = transient;
     // tasks: runs of <= 64 histogram entries of one gene and matrix, sorted by gene
     std::vector<int> task, tptr;
-    for (int g = 0; g < d.Ng; ++g) {
-      tptr.push_back((int)task.size() / 4);
-      for (int m = 0; m < 2; ++m)
-        for (int beg = ptr[(size_t)m * d.Ng + g], end = ptr[(size_t)m * d.Ng + g + 1]; beg < end; beg += 64) {
-          task.insert(task.end(), {g, m, beg, std::min(end, beg + 64)});
-        }
-    }
-    tptr.push_back((int)task.size() / 4);
+    vc_build_hist_tasks(ptr, d.Ng, task, tptr);
     b.n_tasks = (int)task.size() / 4;
     TRY(upload(e, task, &b.h_task));
     TRY(upload(e, tptr, &b.h_tptr));
@@ -595,6 +738,7 @@ extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
     TRY(upload(e, ptr, &b.h_ptr));
     TRY(upload(e, val, &b.h_val));
     TRY(upload(e, cnt, &b.h_cnt));
+    e->h_ptr_host = ptr; e->h_val_host = val; e->h_cnt_host = cnt;
     std::vector<float>().swap(e->hS);
     std::vector<float>().swap(e->hU);
   }
@@ -693,6 +837,49 @@ extern "C" int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64
   return VC_OK;
 }
 
+extern "C" int vc_svi_step_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad,
+                                 double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
+                                 double lrd, double beta1, double beta2, double adam_eps, double clip_norm, int prime,
+                                 void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_step_fused before vc_finalize");
+  if (e->cfg.world_size != 1)
+    return e->fail(VC_ERR_STATE, "vc_svi_step_fused applies the optimiser inside the gradient kernels: single rank only "
+                                 "(use vc_elbo_grad + all-reduce + vc_clipped_adam when cells are sharded)");
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev)
+    return e->fail(VC_ERR_ARG, "vc_svi_step_fused: null buffer (the device step counter is required)");
+  if (!(lr > 0.0) || !(lrd > 0.0) || !(beta1 > 0.0 && beta1 < 1.0) || !(beta2 > 0.0 && beta2 < 1.0))
+    return e->fail(VC_ERR_ARG, "vc_svi_step_fused: lr, lrd must be positive and the betas inside (0, 1)");
+  hipStream_t st = (hipStream_t)hip_stream;
+  VcAdamArgs a;
+  a.m = exp_avg; a.v = exp_avg_sq;
+  a.lr0 = lr; a.lrd_l = log(lrd); a.b1l = log(beta1); a.b2l = log(beta2);
+  a.b1 = (float)beta1; a.b2 = (float)beta2; a.eps = (float)adam_eps; a.clip = (float)clip_norm;
+  a.header = (int)e->layout.header;
+  const long long* sd = (const long long*)step_dev;
+  const int with_hist = e->hist_each_step ? 1 : 0;
+  if (prime) {       // sample the step *step_dev from the parameters as they are: tables, site values, prior terms
+    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 1, st);
+    vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 1, with_hist, st);
+  }
+  VcBufs b2 = e->b;
+  b2.step_ctr = (long long*)step_dev;
+  if (e->timing) {
+    if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
+    auto& pr = e->ev_pool[e->ev_used++];
+    HIPCHK(e, hipEventRecord(pr.first, st));
+    e->main_fn(e->d, b2, st);
+    HIPCHK(e, hipEventRecord(pr.second, st));
+  } else {
+    e->main_fn(e->d, b2, st);
+  }
+  vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, st);
+  vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
 extern "C" int vc_sample_guide(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,
                                void* hip_stream) {
   if (!e) return VC_ERR_ARG;
@@ -720,6 +907,7 @@ static const float* site_source(vc_engine* e, int site, long long* sz) {
 extern "C" int vc_sample_posterior(vc_engine* e, const float* params, uint64_t seed, int64_t step0, int64_t n_draws,
                                    int n_sites, const int* sites, float* const* out_dev, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_sample_posterior before vc_finalize");
   if (!params || n_draws < 0 || n_sites < 0 || (n_sites > 0 && (!sites || !out_dev)))
     return e->fail(VC_ERR_ARG, "vc_sample_posterior: bad arguments");
@@ -739,6 +927,7 @@ extern "C" int vc_sample_posterior(vc_engine* e, const float* params, uint64_t s
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "vc_sample_posterior: %s", hipGetErrorString(err));
   return VC_OK;
+  VC_GUARD_END(e)
 }
 
 extern "C" int vc_expected_logs(vc_engine* e, const float* nu, const float* dnu, const float* phi, const float* omega,
@@ -783,7 +972,19 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   out->main_grid = d.n_main_wg;
   out->main_block = 256;
   out->main_kind = d.kind;
+  out->hist_on_device = e->hist_on_device;
+  out->setup_transient_bytes = (int64_t)e->setup_transient_bytes;
   snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d>", d.H, d.Nb, e->main_name, d.gpl);
+  return VC_OK;
+}
+
+extern "C" int vc_get_histogram(const vc_engine* e, int64_t* n_entries, int32_t* ptr_out, float* val_out, float* cnt_out) {
+  if (!e || !n_entries) return VC_ERR_ARG;
+  if (!e->finalized) return VC_ERR_STATE;
+  *n_entries = (int64_t)e->h_val_host.size();
+  if (ptr_out) memcpy(ptr_out, e->h_ptr_host.data(), e->h_ptr_host.size() * sizeof(int));
+  if (val_out) memcpy(val_out, e->h_val_host.data(), e->h_val_host.size() * sizeof(float));
+  if (cnt_out) memcpy(cnt_out, e->h_cnt_host.data(), e->h_cnt_host.size() * sizeof(float));
   return VC_OK;
 }
 

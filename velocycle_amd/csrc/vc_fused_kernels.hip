@@ -1,0 +1,764 @@
+// Fused single-rank SVI step (vc_svi_step_fused): three launches per step instead of four, and every O(Ng + Nc)
+// latency chain of the step run once instead of twice.
+//
+//   K_main(t)    the likelihood kernel, unchanged (it also advances the device step counter: s = t + 1)
+//   K_tail(t)    per gene block / per cell block, everything that is LOCAL to a gene or a cell, back to back in one
+//                thread: second-stage reduction of K_main's partials -> chain rule to the parameter gradients (what
+//                K_post does) -> pyro's ClippedAdam on exactly those parameters (what the optimiser kernel does) ->
+//                the guide sample of step t + 1 from the fresh parameters, its prior / guide log-densities, the gene
+//                table and the cell table of step t + 1 (what K_pre of the next step does)
+//   K_omega(t)   the one GLOBAL dependency of the step: the angular-speed coefficients nu_omega.  Every block reduces
+//                the per-block partials of d loglik / d nu_omega (a few hundred floats) redundantly, applies the
+//                optimiser to those few parameters (block 0 stores them), samples nu_omega(t + 1) and fills
+//                omega_c(t + 1) into the cell records of its 256 cells; block 0 also assembles the loss of step t
+//                (fp64, fixed order); extra blocks evaluate the negative-binomial histogram terms for shape_inv(t + 1).
+//
+// The arithmetic of every piece is the one of vc_small_kernels.hip (K_pre / K_post / K_fin / ClippedAdam), statement by
+// statement; tests/test_hip_fused.py holds the two paths against each other.  eps comes from the Philox stream only
+// (seed, step, index): the host-eps parity path stays on the unfused kernels.
+// Reference semantics restated: velocity_inference_guide.py:9-141, phase_inference_guide.py:10-56, priors of
+// velocity_inference_model.py:322-353,383 / phase_inference_model.py:360-366,392, pyro ClippedAdam.
+#include "vc_common.h"
+
+#define VC_PG_WAVES 16
+#define VC_MAXQ (2 * VC_MAXH + 1 + VC_MAXNB + 3)
+#define VC_MAXOWN 5      // parameters one (gene, role) thread owns (the LRMN cov_factor row is split over two roles)
+#define VC_COVW 4        // cov_factor entries per role: role 14 holds k = 0..3, role 15 k = 4..7
+
+struct VcOpt { float step_size, b1, b2, eps, clip; };
+
+#define VC_NWE (VC_MAX_NW * (VC_MAX_RANK + 2))      // nu_omega-related parameter elements at most
+
+// flat offset of element `ce` of angular-speed coefficient j: mean-field {loc, log scale}; LRMN tail row i = Ng + j
+// {loc, R cov_factor entries, cov_diag}
+__device__ __forceinline__ long long vc_nuw_elem_off(const VcDims& d, bool lrmn, int j, int ce) {
+  if (!lrmn) return (ce == 0 ? d.poff[VC_P_NUOMEGA_LOCS] : d.poff[VC_P_NUOMEGA_USCALES]) + j;
+  const long long i = (long long)d.Ng + j;
+  return ce == 0 ? d.poff[VC_P_LRMN_LOC] + i
+                 : (ce <= d.R ? d.poff[VC_P_LRMN_UCOV_FACTOR] + i * d.R + (ce - 1) : d.poff[VC_P_LRMN_UCOV_DIAG] + i);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_tail, gene block: 1024 threads = 16 waves (roles) x 64 genes
+// ---------------------------------------------------------------------------------------------
+template <int MQ>
+__device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs& b, float* __restrict__ P,
+                                                   float* __restrict__ G, float* __restrict__ Mm, float* __restrict__ Vv,
+                                                   int header, int gblock, long long s, uint64_t seed, const VcOpt o,
+                                                   int boot) {
+  __shared__ float sm[VC_PG_WAVES][MQ][64];
+  __shared__ double sm_ls[VC_PG_WAVES];
+  __shared__ float sm_ws[2][64][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = gblock * 64 + lane;
+  const int role = wave;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+  const bool nb = d.noise == VC_NOISE_NB;
+  const int K = d.K, Nh = d.Nh;
+  const float rw = d.root_w;
+  const size_t NP = d.Ng_pad;
+  const bool live = g < d.Ng;
+  // role kinds
+  const bool r_nu = role < Nh;
+  const bool r_dnu = !r_nu && role < Nh + d.Nb && d.with_dnu;
+  const bool r_si = role == 12 && nb;
+  const bool r_mf = role == 13 && vel && !lrmn;
+  const bool r_core = role == 13 && lrmn;
+  const bool r_cov = (role == 14 || role == 15) && lrmn;
+  const int kbase = (role - 14) * VC_COVW;            // first cov_factor column of a cov role
+
+  // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k draws, readlane
+  // broadcasts while every lane is active (the eps_used copy is not used: another block may already hold step s there)
+  float ew_old[VC_MAX_RANK], ew_new[VC_MAX_RANK];
+  {
+    float mine_old = 0.f, mine_new = 0.f;
+    if (r_cov && lane < d.R) {
+      if (!boot) mine_old = vc_philox_normal(seed, s - 1, d.eoff[VC_E_LRMN_W] + lane);
+      mine_new = vc_philox_normal(seed, s, d.eoff[VC_E_LRMN_W] + lane);
+      if (gblock == 0 && role == 14) b.eps_used[d.eoff[VC_E_LRMN_W] + lane] = mine_new;
+    }
+#pragma unroll
+    for (int k = 0; k < VC_MAX_RANK; ++k) {
+      ew_old[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_old), k));
+      ew_new[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_new), k));
+    }
+  }
+
+  // ---- owned parameters of this (gene, role) and everything else that does not depend on K_main's partials --------
+  int off[VC_MAXOWN];
+  float pp[VC_MAXOWN], pm[VC_MAXOWN], pv[VC_MAXOWN], gg[VC_MAXOWN];
+  int nown = 0;
+#pragma unroll
+  for (int k = 0; k < VC_MAXOWN; ++k) { off[k] = 0; pp[k] = 0.f; pm[k] = 0.f; pv[k] = 0.f; gg[k] = 0.f; }
+  constexpr int NIN = 12;
+  float in[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) in[i] = 0.f;
+  double HLg = 0.0, HDg = 0.0;
+  float e0 = 0.f, e1 = 0.f;        // the Philox draws of step s this role needs
+  long long jj = 0;                // flat index of the role's site element
+  if (live) {
+    if (r_nu) {
+      jj = (long long)g * Nh + role;
+      off[0] = (int)(d.poff[VC_P_NU_LOCS] + jj); off[1] = (int)(d.poff[VC_P_NU_USCALES] + jj); nown = 2;
+      in[1] = b.sd_nu[jj]; in[2] = b.mu_nu[jj];
+      if (!boot && !CND(VC_SITE_NU)) { in[0] = b.lat[VC_SITE_NU][jj]; in[3] = b.eps_used[d.eoff[VC_E_NU] + jj]; }
+      e0 = vc_philox_normal(seed, s, d.eoff[VC_E_NU] + jj);
+    } else if (r_dnu) {
+      jj = (long long)(role - Nh) * d.Ng + g;
+      off[0] = (int)(d.poff[VC_P_DNU_LOCS] + jj); nown = 1;
+      in[1] = vel ? 0.01f : b.sd_dnu[jj];
+      if (!boot && !CND(VC_SITE_DNU)) in[0] = b.lat[VC_SITE_DNU][jj];
+    } else if (r_si) {
+      off[0] = (int)(d.poff[VC_P_SHAPE_INV_ULOCS] + g); nown = 1;
+      if (!boot) {
+        in[0] = b.GT[(size_t)(K + 2) * NP + g];
+        if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
+        for (int t = b.h_tptr[g]; t < b.h_tptr[g + 1]; ++t) { HLg += b.HL[t]; HDg += b.HD[t]; }
+      }
+    } else if (r_mf || r_core || r_cov) {
+      in[2] = b.sd_g[g]; in[3] = b.mu_g[g]; in[5] = b.sd_b[g]; in[6] = b.mu_b[g];
+      if (!boot) {
+        in[0] = b.GT[(size_t)(K + 1) * NP + g];
+        if (!CND(VC_SITE_LOGGAMMA)) in[1] = b.lat[VC_SITE_LOGGAMMA][g];
+        if (!CND(VC_SITE_LOGBETA)) in[4] = b.lat[VC_SITE_LOGBETA][g];
+      }
+      if (r_mf) {
+        off[0] = (int)(d.poff[VC_P_LOGGAMMA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGGAMMA_USCALES] + g);
+        off[2] = (int)(d.poff[VC_P_LOGBETA_LOCS] + g); off[3] = (int)(d.poff[VC_P_LOGBETA_USCALES] + g); nown = 4;
+        if (!boot) { in[7] = b.eps_used[d.eoff[VC_E_LOGGAMMA] + g]; in[8] = b.eps_used[d.eoff[VC_E_LOGBETA] + g]; }
+        e0 = vc_philox_normal(seed, s, d.eoff[VC_E_LOGGAMMA] + g);
+        e1 = vc_philox_normal(seed, s, d.eoff[VC_E_LOGBETA] + g);
+      } else {
+        if (!boot) { in[7] = b.lat_delta[g]; in[8] = b.lat_sgam[g]; }
+        if (r_core) {
+          off[0] = (int)(d.poff[VC_P_LOGBETA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGBETA_USCALES] + g);
+          off[2] = (int)(d.poff[VC_P_RHO_REAL_LOC] + g); off[3] = (int)(d.poff[VC_P_LRMN_LOC] + g);
+          off[4] = (int)(d.poff[VC_P_LRMN_UCOV_DIAG] + g); nown = 5;
+          if (!boot) { in[9] = b.eps_used[d.eoff[VC_E_LOGBETA] + g]; in[10] = b.eps_used[d.eoff[VC_E_LRMN_D] + g]; }
+          e0 = vc_philox_normal(seed, s, d.eoff[VC_E_LRMN_D] + g);
+          e1 = vc_philox_normal(seed, s, d.eoff[VC_E_LOGBETA] + g);
+        } else {
+#pragma unroll
+          for (int k = 0; k < VC_COVW; ++k)
+            if (kbase + k < d.R) off[k] = (int)(d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + kbase + k);
+          nown = d.R - kbase < 0 ? 0 : (d.R - kbase > VC_COVW ? VC_COVW : d.R - kbase);
+          if (!boot) { in[9] = P[d.poff[VC_P_LOGBETA_USCALES] + g]; in[10] = P[d.poff[VC_P_RHO_REAL_LOC] + g]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < VC_MAXOWN; ++k)
+      if (k < nown) {
+        pp[k] = P[off[k]];
+        if (!boot) { pm[k] = Mm[off[k] - header]; pv[k] = Vv[off[k] - header]; }
+      }
+  }
+
+  double loss_post = 0.0;
+  if (!boot) {
+    // ---- second-stage reduction of K_main's gene-level partials (as K_post) ------------------------------------
+    constexpr int U = MQ <= 2 ? 16 : (MQ <= 6 ? 8 : 2);     // chunk groups in flight per wave (register budget: 128)
+    float acc[MQ];
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
+    for (int ch0 = wave; ch0 < d.n_chunks; ch0 += U * VC_PG_WAVES) {
+      float v[U][MQ];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ch = ch0 + u * VC_PG_WAVES;
+        const float* go = b.GO + ((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq) * NP + g;
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) v[u][q] = (q < d.nq) ? go[(size_t)q * NP] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ch0 + u * VC_PG_WAVES < d.n_chunks) {
+#pragma unroll
+          for (int q = 0; q < MQ; ++q) acc[q] += v[u][q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) sm[wave][q][lane] = acc[q];
+    __syncthreads();
+    auto T = [&](int q) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < VC_PG_WAVES; ++w) t += sm[w][q][lane];
+      return t;
+    };
+    // ---- chain rule to the gradients of the owned parameters (statement by statement vc_post_gene_block) -------
+    if (live) {
+      if (r_nu) {
+        if (!CND(VC_SITE_NU)) {
+          const float x = in[0], sd = in[1];
+          const float gx = T(role) - rw * (x - in[2]) / (sd * sd);
+          gg[0] = -gx;
+          gg[1] = -gx * expf(pp[1]) * in[3] - rw;
+        }
+      } else if (r_dnu) {
+        if (!CND(VC_SITE_DNU)) {
+          const float x = in[0], sd = in[1];
+          gg[0] = -(T(role) - rw * x / (sd * sd));
+        }
+      } else if (r_si) {
+        const float r = in[0];
+        const float U_r = (d.kind == VC_KIND_PHASE) ? T(K) : (d.kind == VC_KIND_VFULL ? T(K + 2) : 0.f);
+        const double lr = (double)logf(r);
+        if (d.nmat_r > 0) loss_post -= (double)d.nmat_r * d.Nc * (double)r * lr + HLg;
+        if (!CND(VC_SITE_SHAPE_INV)) {
+          const float si = in[1];
+          const double dr = (double)U_r + (double)d.nmat_r * d.Nc * (lr + 1.0) + HDg;
+          const double gsi = -(double)r * (double)r * dr + (double)rw * ((d.gamma_alpha - 1.f) / si - d.gamma_beta);
+          gg[0] = (float)(-gsi * (double)si);
+        }
+      } else if (r_mf || r_core || r_cov) {
+        const float gam = in[0];
+        float U_lb, U_lg;
+        if (d.kind == VC_KIND_VFULL) { U_lb = -T(K); U_lg = T(K + 1) * gam; }
+        else { U_lb = -T(0); U_lg = T(1) * gam; }
+        float g_lg = 0.f, g_lb = 0.f;
+        if (!CND(VC_SITE_LOGGAMMA)) g_lg = U_lg - rw * (in[1] - in[3]) / (in[2] * in[2]);
+        if (!CND(VC_SITE_LOGBETA)) g_lb = U_lb - rw * (in[4] - in[6]) / (in[5] * in[5]);
+        if (r_mf) {
+          const float eg = in[7], eb = in[8];
+          const bool cg = CND(VC_SITE_LOGGAMMA), cb = CND(VC_SITE_LOGBETA);
+          gg[0] = -g_lg;
+          gg[1] = cg ? 0.f : -g_lg * expf(pp[1]) * eg - rw;
+          gg[2] = -g_lb;
+          gg[3] = cb ? 0.f : -g_lb * expf(pp[3]) * eb - rw;
+        } else {
+          const bool cb = CND(VC_SITE_LOGBETA);
+          const float A = g_lb;
+          const float ent = cb ? 0.f : rw;
+          const float delta = in[7], sgam = in[8];
+          const float sb = expf(r_core ? pp[1] : in[9]);
+          const float rho_real = r_core ? pp[2] : in[10];
+          const float sg = sigmoidf_(rho_real / d.rho_scale);
+          const float rho = sg * 1.998f - 0.999f;
+          const float om = 1.f - rho * rho, sq = sqrtf(om);
+          const float dl_ddelta = -g_lg - A * rho * sb / sgam;
+          const float dl_dsg = A * rho * sb * delta / (sgam * sgam);
+          if (r_core) {
+            const float eb = in[9];
+            gg[0] = -A;
+            gg[1] = -A * (rho * delta / sgam + sq * eb) * sb - ent;
+            float g_rho = -A * (sb * delta / sgam - sb * rho * eb / sq) + ent * rho / om;
+            float g_rr = g_rho * 1.998f * sg * (1.f - sg) / d.rho_scale;
+            if (!CND(VC_SITE_RHO_REAL)) g_rr += rw * (rho_real - d.rho_mean) / (d.rho_std * d.rho_std);
+            gg[2] = g_rr;
+            gg[3] = -g_lg;
+            const float dg = expf(pp[4]);
+            const float ed = in[10];
+            gg[4] = (dl_ddelta * ed / (2.f * sqrtf(dg)) + dl_dsg / (2.f * sgam)) * dg;
+          } else {
+#pragma unroll
+            for (int k = 0; k < VC_COVW; ++k)
+              if (k < nown) {
+                const float w = expf(pp[k]);
+                const float ew = kbase ? ew_old[VC_COVW + k] : ew_old[k];
+                gg[k] = (w > 0.f) ? (dl_ddelta * ew + dl_dsg * w / sgam) * w : 0.f;
+              }
+          }
+        }
+      }
+      // ---- gradient out, ClippedAdam on the owned parameters ---------------------------------------------------
+#pragma unroll
+      for (int k = 0; k < VC_MAXOWN; ++k)
+        if (k < nown) {
+          G[off[k]] = gg[k];
+          const float np = vc_adam_elem(pp[k], gg[k], pm[k], pv[k], o.step_size, o.b1, o.b2, o.eps, o.clip);
+          Mm[off[k] - header] = pm[k];
+          Vv[off[k] - header] = pv[k];
+          P[off[k]] = np;
+          pp[k] = np;
+        }
+    }
+    if (role == 12) {
+      const double tot = vc_wave_sum_d(loss_post);
+      if (lane == 0) b.LPP[gblock] = tot;
+    }
+  }
+
+  // ---- the guide sample of step s from the fresh parameters (statement by statement vc_pre_kernel) ---------------
+  float logp = 0.f, logq = 0.f;
+  if (g < d.Ng_pad && !live) {
+    if (boot && wave == 0) {       // padded gene: nu~ = 0 (never reaches a per-cell sum), loss masked in K_main
+      float* GT = b.GT + g;
+      for (int k = 0; k < K; ++k) GT[k * NP] = 0.f;
+      GT[K * NP] = 0.f; GT[(K + 1) * NP] = 1.f; GT[(K + 2) * NP] = 1.f;
+    }
+  }
+  if (live) {
+    float* GT = b.GT + g;
+    if (r_nu) {
+      const float e = e0;
+      b.eps_used[d.eoff[VC_E_NU] + jj] = e;
+      const float u = pp[1];
+      const float xg = pp[0] + expf(u) * e;
+      float x;
+      if (CND(VC_SITE_NU)) x = b.cnd[VC_SITE_NU][jj];
+      else { x = xg; logq += -0.5f * e * e - u - 0.5f * VC_LOG_2PI; }
+      logp += vc_normal_lp(x, in[2], in[1]);
+      b.lat[VC_SITE_NU][jj] = x;
+      GT[role * NP] = x;
+    } else if (r_dnu) {
+      const float x = CND(VC_SITE_DNU) ? b.cnd[VC_SITE_DNU][jj] : pp[0];
+      logp += vc_normal_lp(x, 0.f, in[1]);
+      b.lat[VC_SITE_DNU][jj] = x;
+      GT[role * NP] = x;
+    } else if (r_si) {
+      const float si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : expf(pp[0]);
+      logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) - d.gamma_beta * si -
+              lgammaf(d.gamma_alpha);
+      b.lat[VC_SITE_SHAPE_INV][g] = si;
+      GT[(K + 2) * NP] = 1.0f / si;
+    } else if (role == 12 && boot && !nb) {
+      GT[(K + 2) * NP] = 1.0f;
+    } else if (r_mf) {
+      const float eg = e0, eb = e1;
+      b.eps_used[d.eoff[VC_E_LOGGAMMA] + g] = eg;
+      b.eps_used[d.eoff[VC_E_LOGBETA] + g] = eb;
+      const float ug = pp[1], ub = pp[3];
+      const float lg_guide = pp[0] + expf(ug) * eg;
+      const float lb_guide = pp[2] + expf(ub) * eb;
+      if (!CND(VC_SITE_LOGGAMMA)) logq += -0.5f * eg * eg - ug - 0.5f * VC_LOG_2PI;
+      if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - ub - 0.5f * VC_LOG_2PI;
+      const float lg = CND(VC_SITE_LOGGAMMA) ? b.cnd[VC_SITE_LOGGAMMA][g] : lg_guide;
+      const float lbv = CND(VC_SITE_LOGBETA) ? b.cnd[VC_SITE_LOGBETA][g] : lb_guide;
+      logp += vc_normal_lp(lg, in[3], in[2]) + vc_normal_lp(lbv, in[6], in[5]);
+      b.lat[VC_SITE_LOGGAMMA][g] = lg;
+      b.lat[VC_SITE_LOGBETA][g] = lbv;
+      GT[K * NP] = lbv;
+      GT[(K + 1) * NP] = expf(lg);
+    } else if (r_cov) {
+      // LowRankMultivariateNormal.rsample, low-rank part: sum_k W[g,k] eps_W[k] and sum_k W[g,k]^2 -> role 13
+      float dW = 0.f, w2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < VC_COVW; ++k)
+        if (k < nown) {
+          const float w = expf(pp[k]);
+          dW += w * (kbase ? ew_new[VC_COVW + k] : ew_new[k]);
+          w2 += w * w;
+        }
+      sm_ws[role - 14][lane][0] = dW;
+      sm_ws[role - 14][lane][1] = w2;
+    }
+  }
+  if (lrmn) __syncthreads();
+  if (live && r_core) {
+    float* GT = b.GT + g;
+    const float ed = e0, eb = e1;
+    b.eps_used[d.eoff[VC_E_LRMN_D] + g] = ed;
+    b.eps_used[d.eoff[VC_E_LOGBETA] + g] = eb;
+    // columns 0..3 summed by role 14, 4..7 by role 15: for rank <= 5 (the reference's default) the same order of
+    // additions as the sequential loop of vc_pre_kernel
+    float delta = sm_ws[0][lane][0];
+    float w2 = sm_ws[0][lane][1];
+    if (d.R > VC_COVW) { delta += sm_ws[1][lane][0]; w2 += sm_ws[1][lane][1]; }
+    const float dg = expf(pp[4]);
+    delta += sqrtf(dg) * ed;
+    const float sgam = sqrtf(w2 + dg);
+    const float lg_guide = pp[3] + delta;
+    const float rho_real_g = pp[2];
+    const float rho = sigmoidf_(rho_real_g / d.rho_scale) * 1.998f - 0.999f;
+    const float ub = pp[1];
+    const float sb = expf(ub);
+    const float tt = sb * sqrtf(1.f - rho * rho);
+    const float lb_guide = pp[0] + rho * sb * delta / sgam + tt * eb;
+    if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - logf(tt) - 0.5f * VC_LOG_2PI;
+    b.lat_delta[g] = delta;
+    b.lat_sgam[g] = sgam;
+    const float rho_val = CND(VC_SITE_RHO_REAL) ? b.cnd[VC_SITE_RHO_REAL][g] : rho_real_g;
+    logp += vc_normal_lp(rho_val, d.rho_mean, d.rho_std);
+    b.lat[VC_SITE_RHO_REAL][g] = rho_val;
+    const float lg = CND(VC_SITE_LOGGAMMA) ? b.cnd[VC_SITE_LOGGAMMA][g] : lg_guide;
+    const float lbv = CND(VC_SITE_LOGBETA) ? b.cnd[VC_SITE_LOGBETA][g] : lb_guide;
+    logp += vc_normal_lp(lg, in[3], in[2]) + vc_normal_lp(lbv, in[6], in[5]);
+    b.lat[VC_SITE_LOGGAMMA][g] = lg;
+    b.lat[VC_SITE_LOGBETA][g] = lbv;
+    GT[K * NP] = lbv;
+    GT[(K + 1) * NP] = expf(lg);
+  }
+  if (live && !vel && role == 13 && boot) {      // phase model: the velocity rows of the gene table are constants
+    b.GT[(size_t)K * NP + g] = 0.f;
+    b.GT[(size_t)(K + 1) * NP + g] = 1.f;
+  }
+  // prior / guide terms of the step-s sample: fp64 block sum in fixed order
+  {
+    const double lt = live ? -(double)rw * ((double)logp - (double)logq) : 0.0;
+    const double ws = vc_wave_sum_d(lt);
+    if (lane == 0) sm_ls[wave] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < VC_PG_WAVES; ++w) t += sm_ls[w];
+      b.LPF[(size_t)(s & 1) * d.nlpf + gblock] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_tail, cell block: 1024 cells
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs& b, float* __restrict__ P,
+                                                   float* __restrict__ G, float* __restrict__ Mm, float* __restrict__ Vv,
+                                                   int header, int cblock, long long s, uint64_t seed, const VcOpt o,
+                                                   int boot) {
+  __shared__ float sm_w[16][VC_MAX_NW];
+  __shared__ double sm_lc[16];
+  const int c = cblock * 1024 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  const bool in_range = c < d.Nc;
+  const bool cxy = CND(VC_SITE_PHIXY);
+  float A[3] = {0.f, 0.f, 0.f};
+  float phi = 0.f;
+  float dx01[2] = {0.f, 0.f};
+  float2 pp = make_float2(0.f, 0.f), pm = pp, pv = pp, pxy = pp;
+  float ex = 0.f, ey = 0.f;
+  double loss = 0.0;
+  const long long poff = d.poff[VC_P_PHIXY_LOCS] + 2LL * c;
+  if (in_range) {
+    pp = *reinterpret_cast<const float2*>(P + poff);
+    pxy = *reinterpret_cast<const float2*>(b.pxy + 2 * (size_t)c);
+    const long long gi = d.eoff[VC_E_PHIXY] + 2LL * (d.cell_offset + c);
+    ex = vc_philox_normal(seed, s, gi);
+    ey = vc_philox_normal(seed, s, gi + 1);
+    if (!boot) {
+      float2 xy = make_float2(1.f, 0.f);
+      float om = 0.f, dom = 0.f;
+      phi = b.lat_phi[c];
+      pm = *reinterpret_cast<const float2*>(Mm + (poff - header));
+      pv = *reinterpret_cast<const float2*>(Vv + (poff - header));
+      if (vel) {
+        dx01[0] = b.Dm[c];
+        if (d.Nx > 1) dx01[1] = b.Dm[(size_t)d.Nc + c];
+      }
+      if (!cxy) {
+        xy = *reinterpret_cast<const float2*>(b.lat[VC_SITE_PHIXY] + 2 * (size_t)c);
+        if (d.kind == VC_KIND_VFULL) { om = b.lat_omega[c]; dom = b.lat_domega[c]; }
+      }
+      for (int gb = 0; gb < d.nGB; ++gb)
+        for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + c];
+      float gx = 0.f, gy = 0.f;
+      if (!cxy) {
+        float dphi = A[0];
+        if (d.kind == VC_KIND_VFULL) dphi += om * A[1] + A[2] * dom;
+        const float x = xy.x, y = xy.y;
+        const float inv = 1.0f / (x * x + y * y);
+        gx = -(dphi * (-y * inv) - (x - pxy.x));
+        gy = -(dphi * (x * inv) - (y - pxy.y));
+      }
+      *reinterpret_cast<float2*>(G + poff) = make_float2(gx, gy);
+      pp.x = vc_adam_elem(pp.x, gx, pm.x, pv.x, o.step_size, o.b1, o.b2, o.eps, o.clip);
+      pp.y = vc_adam_elem(pp.y, gy, pm.y, pv.y, o.step_size, o.b1, o.b2, o.eps, o.clip);
+      *reinterpret_cast<float2*>(Mm + (poff - header)) = pm;
+      *reinterpret_cast<float2*>(Vv + (poff - header)) = pv;
+      *reinterpret_cast<float2*>(P + poff) = pp;
+    }
+  }
+  if (vel && !boot) {
+    // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c) at the phases of step s - 1
+    const float a3 = in_range ? (d.kind == VC_KIND_VFULL ? A[2] : A[0]) : 0.f;
+    float s1, c1;
+    sincosf(phi, &s1, &c1);
+    float sk[VC_MAXH], ck[VC_MAXH];
+    sk[0] = s1; ck[0] = c1;
+    for (int k = 1; k < d.Hw && k < VC_MAXH; ++k) {
+      sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
+      ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
+    }
+    for (int xq = 0; xq < d.Nx; ++xq) {
+      const float dx = in_range ? (xq < 2 ? dx01[xq] : b.Dm[(size_t)xq * d.Nc + c]) : 0.f;
+      for (int h = 0; h < d.Nhw; ++h) {
+        const float z = (h == 0) ? 1.f : ((h & 1) ? sk[(h - 1) >> 1] : ck[(h - 1) >> 1]);
+        const float t = vc_wave_sum(a3 * dx * z);
+        if (lane == 0) sm_w[wave][xq * d.Nhw + h] = t;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < d.NW) {
+      const int j = threadIdx.x;
+      float t = 0.f;
+      for (int w = 0; w < 16; ++w) t += sm_w[w][j];
+      b.PW[(size_t)cblock * d.NW + j] = t;
+    }
+  }
+  // ---- snapshot of the nu_omega-related parameters, their moments and the nu_omega value of the step being finished:
+  // K_omega's blocks all READ this copy while its block 0 stores the updated values (no reader ever races the writer)
+  if (vel && cblock == 0) {
+    const bool lrmn = d.guide == VC_GUIDE_LRMN;
+    const int fin_per = lrmn ? d.R + 2 : 2;
+    for (int tt = threadIdx.x; tt < d.NW * fin_per; tt += 1024) {
+      const long long off = vc_nuw_elem_off(d, lrmn, tt / fin_per, tt % fin_per);
+      b.NWS[tt] = P[off];
+      b.NWS[VC_NWE + tt] = Mm[off - header];
+      b.NWS[2 * VC_NWE + tt] = Vv[off - header];
+    }
+    if ((int)threadIdx.x < d.NW) b.NWS[3 * VC_NWE + threadIdx.x] = b.lat[VC_SITE_NUOMEGA][threadIdx.x];
+  }
+  // ---- phi_xy sample of step s, phase, Fourier basis, cell record (omega is filled by K_omega) -------------------
+  if (in_range) {
+    const long long li = d.eoff[VC_E_PHIXY] + 2LL * c;
+    b.eps_used[li] = ex;
+    b.eps_used[li + 1] = ey;
+    float x, y;
+    const float px = pxy.x, py = pxy.y;
+    if (cxy) {
+      x = b.cnd[VC_SITE_PHIXY][2 * c]; y = b.cnd[VC_SITE_PHIXY][2 * c + 1];
+      loss += 0.5 * ((double)(x - px) * (x - px) + (double)(y - py) * (y - py)) + (double)VC_LOG_2PI;
+    } else {
+      x = pp.x + ex;
+      y = pp.y + ey;
+      loss += 0.5 * ((double)(x - px) * (x - px) + (double)(y - py) * (y - py)) - 0.5 * ((double)ex * ex + (double)ey * ey);
+    }
+    *reinterpret_cast<float2*>(b.lat[VC_SITE_PHIXY] + 2 * (size_t)c) = make_float2(x, y);
+    const float ph = atan2f(y, x);
+    float s1, c1;
+    sincosf(ph, &s1, &c1);
+    float sk[VC_MAXH], ck[VC_MAXH];
+    sk[0] = s1; ck[0] = c1;
+    for (int k = 1; k < d.H && k < VC_MAXH; ++k) {
+      sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
+      ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
+    }
+    float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
+    for (int k = 0; k < d.H; ++k) { ct[2 * k] = make_float2(sk[k], sk[k]); ct[2 * k + 1] = make_float2(ck[k], ck[k]); }
+    if (boot) {              // step-invariant entries of the record
+      for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
+        const float v = b.Dbm[(size_t)q * d.Nc + c];
+        ct[2 * d.H + q] = make_float2(v, v);
+      }
+      const int nbk = d.with_dnu ? d.Nb : 0;
+      if (!vel) ct[2 * d.H + nbk] = make_float2(0.f, 0.f);
+      ct[2 * d.H + nbk + 1] = make_float2(b.cf[c], b.cf[c]);
+      if (!vel) { b.lat_omega[c] = 0.f; b.lat_domega[c] = 0.f; }
+    }
+    b.lat_phi[c] = ph;
+  }
+  {
+    const double ws = vc_wave_sum_d(loss);
+    if (lane == 0) sm_lc[wave] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < 16; ++w) t += sm_lc[w];
+      b.LPF[(size_t)(s & 1) * d.nlpf + d.nb_post_gene + cblock] = t;
+    }
+  }
+}
+
+template <int MQ>
+__global__ __launch_bounds__(1024) void vc_tail_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
+                                                       float* __restrict__ G, const long long* __restrict__ step_dev,
+                                                       uint64_t seed, const VcAdamArgs a, int boot) {
+  // s: index of the step whose sample this launch draws (boot: the step about to run; else K_main has advanced the
+  // counter, s = t + 1 is also the 1-based optimiser step of the update applied here)
+  const long long s = *step_dev;
+  VcOpt o;
+  o.step_size = boot ? 0.f : vc_adam_step_size(s, a.lr0, a.lrd_l, a.b1l, a.b2l);
+  o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip;
+  if ((int)blockIdx.x < d.nb_post_gene) vc_tail_gene_block<MQ>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, boot);
+  else vc_tail_cell_block(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, boot);
+}
+
+void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                    const VcAdamArgs& a, int boot, hipStream_t st) {
+  const dim3 grid(d.nb_post_gene + d.nb_post_cell), block(1024);
+  if (d.nq <= 2) hipLaunchKernelGGL(vc_tail_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
+  else if (d.nq <= 6) hipLaunchKernelGGL(vc_tail_kernel<6>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
+  else hipLaunchKernelGGL(vc_tail_kernel<VC_MAXQ>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_omega: nu_omega (gradient, optimiser, next sample) redundantly per block, omega_c into the cell records,
+// the loss of the finished step (block 0), negative-binomial histogram terms of the next step (extra blocks)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
+                                                       float* __restrict__ G, const long long* __restrict__ step_dev,
+                                                       uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
+                                                       long long loss_slots, int boot, int nb_cell) {
+  __shared__ double sm_lossw[4];
+  __shared__ float sm_up[VC_MAX_NW];
+  __shared__ float s_np[VC_NWE];
+  __shared__ float s_nuw[VC_MAX_NW];
+  __shared__ double sm_lq[VC_MAX_NW];
+  const long long s = *step_dev;
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  if ((int)blockIdx.x >= nb_cell) {
+    const int task = (blockIdx.x - nb_cell) * 4 + wv;
+    if (task < b.n_tasks) vc_hist_wave(d, b, P, 0, task, lane);
+    return;
+  }
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+  const bool first = blockIdx.x == 0;
+  const int nw = vel ? d.NW : 0;
+  const int fin_per = lrmn ? d.R + 2 : 2;
+  const int nelem = nw * fin_per;
+  const bool cnd = CND(VC_SITE_NUOMEGA);
+  // this block's cells: the basis of the next phase (written by K_tail) is requested now
+  const int c = blockIdx.x * 256 + t;
+  float s1 = 0.f, c1 = 1.f;
+  if (vel && c < d.Nc) {
+    const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)c * d.ctw);
+    s1 = ct[0].x; c1 = ct[1].x;
+  }
+  // ---- reductions: per-coefficient sums of the cell blocks' partials (every block), loss terms (block 0) -----------
+  if (!boot) {
+    double sl = 0.0;
+    if (first) {
+      const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
+#pragma unroll 4
+      for (int i = t; i < d.nlpf; i += 256) sl += lpf[i];
+#pragma unroll 4
+      for (int i = t; i < d.nb_post_gene; i += 256) sl += b.LPP[i];
+#pragma unroll 4
+      for (int i = t; i < d.n_main_wg; i += 256) sl -= (double)b.LO[i];
+    }
+    double u[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = wv + 4 * q;
+      if (j < nw)
+        for (int i = lane; i < d.nb_post_cell; i += 64) u[q] += (double)b.PW[(size_t)i * d.NW + j];
+    }
+    if (first) {
+      sl = vc_wave_sum_d(sl);
+      if (lane == 0) sm_lossw[wv] = sl;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = wv + 4 * q;
+      if (j < nw) { const double r = vc_wave_sum_d(u[q]); if (lane == 0) sm_up[j] = (float)r; }
+    }
+    for (int j = wv + 8; j < nw; j += 4) {
+      double r = 0.0;
+      for (int i = lane; i < d.nb_post_cell; i += 64) r += (double)b.PW[(size_t)i * d.NW + j];
+      r = vc_wave_sum_d(r);
+      if (lane == 0) sm_up[j] = (float)r;
+    }
+  }
+  __syncthreads();
+  if (first && t == 0 && !boot) {
+    const double loss = ((sm_lossw[0] + sm_lossw[1]) + (sm_lossw[2] + sm_lossw[3])) + b.const_loss;
+    const long long step = s - 1;
+    if (loss_dev) loss_dev[loss_slots > 1 ? (step % loss_slots) : 0] = loss;
+    if (!isfinite(loss)) {
+      b.status[0] += 1;
+      if (b.status[1] == 0) b.status[1] = step + 1;
+    }
+    const float hi = (float)loss;
+    G[0] = hi;
+    G[1] = (float)(loss - (double)hi);
+    G[2] = 0.f;
+    G[3] = 0.f;
+  }
+  if (!vel) return;
+  // ---- gradient + ClippedAdam of the nu_omega-related parameters: one thread per element, every block alike ----------
+  const float step_size = boot ? 0.f : vc_adam_step_size(s, a.lr0, a.lrd_l, a.b1l, a.b2l);
+  for (int tt = t; tt < nelem; tt += 256) {
+    const int j = tt / fin_per, ce = tt % fin_per;
+    const long long i = (long long)d.Ng + j;
+    const long long off = vc_nuw_elem_off(d, lrmn, j, ce);
+    float p = b.NWS[tt];                       // the snapshot K_tail took: block 0 overwrites P / m / v below
+    if (!boot) {
+      float gx = 0.f;
+      if (!cnd) {
+        const float x = b.NWS[3 * VC_NWE + j], sd = b.sd_w[j];
+        gx = sm_up[j] - d.root_w * (x - b.mu_w[j]) / (sd * sd);
+      }
+      float gv;
+      if (!lrmn) {
+        if (ce == 0) gv = -gx;
+        else gv = cnd ? 0.f : -gx * expf(p) * vc_philox_normal(seed, s - 1, d.eoff[VC_E_NUOMEGA] + j) - d.root_w;
+      } else {
+        if (ce == 0) gv = -gx;
+        else if (ce <= d.R) {
+          const float w = expf(p);
+          const float ew = vc_philox_normal(seed, s - 1, d.eoff[VC_E_LRMN_W] + (ce - 1));
+          gv = (w > 0.f) ? -gx * ew * w : 0.f;
+        } else {
+          const float dg = expf(p);
+          gv = -gx * vc_philox_normal(seed, s - 1, d.eoff[VC_E_LRMN_D] + i) / (2.f * sqrtf(dg)) * dg;
+        }
+      }
+      float mm = b.NWS[VC_NWE + tt], vv = b.NWS[2 * VC_NWE + tt];
+      p = vc_adam_elem(p, gv, mm, vv, step_size, a.b1, a.b2, a.eps, a.clip);
+      if (first) { G[off] = gv; a.m[off - a.header] = mm; a.v[off - a.header] = vv; P[off] = p; }
+    }
+    s_np[tt] = p;
+  }
+  __syncthreads();
+  // ---- the nu_omega sample of step s ------------------------------------------------------------------------------
+  if (t < VC_MAX_NW) sm_lq[t] = 0.0;
+  for (int j = t; j < nw; j += 256) {
+    const float* np = s_np + j * fin_per;
+    float val, lq = 0.f;
+    const long long i = (long long)d.Ng + j;
+    if (!lrmn) {
+      const float e = vc_philox_normal(seed, s, d.eoff[VC_E_NUOMEGA] + j);
+      if (first) b.eps_used[d.eoff[VC_E_NUOMEGA] + j] = e;
+      const float u = np[1];
+      val = np[0] + expf(u) * e;
+      lq = -0.5f * e * e - u - 0.5f * VC_LOG_2PI;
+    } else {
+      float delta = 0.f;
+      for (int k = 0; k < d.R; ++k) delta += expf(np[1 + k]) * vc_philox_normal(seed, s, d.eoff[VC_E_LRMN_W] + k);
+      const float ed = vc_philox_normal(seed, s, d.eoff[VC_E_LRMN_D] + i);
+      if (first) b.eps_used[d.eoff[VC_E_LRMN_D] + i] = ed;
+      delta += sqrtf(expf(np[d.R + 1])) * ed;
+      val = np[0] + delta;
+      if (first) b.lat_delta[i] = delta;
+    }
+    const float x = cnd ? b.cnd[VC_SITE_NUOMEGA][j] : val;
+    if (first) {
+      b.lat[VC_SITE_NUOMEGA][j] = x;
+      const float lp = vc_normal_lp(x, b.mu_w[j], b.sd_w[j]);
+      sm_lq[j] = -(double)d.root_w * ((double)lp - ((cnd || lrmn) ? 0.0 : (double)lq));
+    }
+    s_nuw[j] = x;
+  }
+  __syncthreads();
+  if (first && t == 0) {
+    double tot = 0.0;
+    for (int j = 0; j < nw; ++j) tot += sm_lq[j];
+    b.LPF[(size_t)(s & 1) * d.nlpf + d.nlpf - 1] = tot;
+  }
+  // ---- omega_c and d omega / d phi of step s into the cell records ---------------------------------------------------
+  if (c < d.Nc) {
+    float sk[VC_MAXH], ck[VC_MAXH];
+    sk[0] = s1; ck[0] = c1;
+    for (int k = 1; k < d.Hw && k < VC_MAXH; ++k) {
+      sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
+      ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
+    }
+    float omega = 0.f, domega = 0.f;
+    for (int xq = 0; xq < d.Nx; ++xq) {
+      const float* nwp = s_nuw + xq * d.Nhw;
+      float om = nwp[0], dd = 0.f;
+      for (int k = 0; k < d.Hw; ++k) {
+        om += nwp[2 * k + 1] * sk[k] + nwp[2 * k + 2] * ck[k];
+        dd += (float)(k + 1) * (nwp[2 * k + 1] * ck[k] - nwp[2 * k + 2] * sk[k]);
+      }
+      const float dx = b.Dm[(size_t)xq * d.Nc + c];
+      omega += dx * om;
+      domega += dx * dd;
+    }
+    float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
+    const int nbk = d.with_dnu ? d.Nb : 0;
+    ct[2 * d.H + nbk] = make_float2(omega, omega);
+    b.lat_omega[c] = omega;
+    b.lat_domega[c] = domega;
+  }
+}
+
+void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                     const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st) {
+  const int nb_cell = d.model == VC_MODEL_VELOCITY ? (d.Nc + 255) / 256 : 1;
+  const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
+  hipLaunchKernelGGL(vc_omega_kernel, dim3(nb_cell + nb_hist), dim3(256), 0, st, d, b, params, grad, step_dev, seed, a,
+                     loss_dev, loss_slots, boot, nb_cell);
+}

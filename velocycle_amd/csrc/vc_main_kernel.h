@@ -450,6 +450,9 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     if (q0 + RPP < NQ) __syncthreads();
   }
   if (threadIdx.x == 0) b.LO[blockIdx.x] = (sm_ll[0] + sm_ll[1]) + (sm_ll[2] + sm_ll[3]);
+  // fused pipeline (vc_svi_step_fused): nothing in this launch reads the device step counter, so it is advanced here;
+  // the two launches that follow read s = t + 1 (= the 1-based optimiser step, = the index of the next sample)
+  if (b.step_ctr && blockIdx.x == 0 && threadIdx.x == 0) *b.step_ctr += 1;
   VC_STAMP(3);
 #ifdef VC_DBG_TIMES
   if ((threadIdx.x & 63) == 0) {

@@ -9,8 +9,8 @@
 // Reference semantics restated: velocity_inference_guide.py:9-141, phase_inference_guide.py:10-56,
 // priors of velocity_inference_model.py:322-353,383 / phase_inference_model.py:360-366,392.
 #include "vc_common.h"
+#include "vc_host_logic.h"     // VC_HIST_CAP
 
-#define CND(site) ((d.cond >> (site)) & 1u)
 
 // ---------------------------------------------------------------------------------------------
 // clock probe: shader-clock ticks (s_memtime) elapsed while the constant 100 MHz wall clock (s_memrealtime) advances
@@ -28,8 +28,33 @@ void vc_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* ou
 }
 
 // ---------------------------------------------------------------------------------------------
+// Per-gene count histogram entry of one matrix element, built on the device while the matrix is re-laid-out (so that no
+// dense matrix ever crosses back to the host): counts 1 .. VC_HIST_CAP-1 increment a dense per-gene bin (integer atomics:
+// order-independent, deterministic); the rare other non-zero values (>= VC_HIST_CAP, non-integer) go to an overflow list
+// that the host merges; negative / NaN / infinite values raise a flag (vc_finalize -> VC_ERR_ARG).
+struct VcHistDev {
+  unsigned* tab;            // [Ng][VC_HIST_CAP], nullptr: no histogram wanted (Lognormal noise)
+  float* ovf_val;           // overflow entries
+  int* ovf_gene;
+  unsigned* ovf_n;          // entries appended (may exceed ovf_cap: then the host falls back to its own pass)
+  unsigned ovf_cap;
+  int* bad;                 // [0] invalid count value seen, [1] invalid CSR index seen
+};
+
+__device__ __forceinline__ void vc_hist_put(const VcHistDev& h, int g, float v) {
+  if (!h.tab) return;
+  if (!(v >= 0.f && v <= 3.0e38f)) { *h.bad = 1; return; }
+  if (v == 0.f) return;
+  if (v < (float)VC_HIST_CAP && (float)(int)v == v) atomicAdd(&h.tab[(size_t)g * VC_HIST_CAP + (int)v], 1u);
+  else {
+    const unsigned i = atomicAdd(h.ovf_n, 1u);
+    if (i < h.ovf_cap) { h.ovf_val[i] = v; h.ovf_gene[i] = g; }
+  }
+}
+
 __global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                      long long gs, long long cs, int Ng, int Nc, int nGB, int gbw, int log1p_t) {
+                                      long long gs, long long cs, int Ng, int Nc, int nGB, int gbw, int log1p_t,
+                                      VcHistDev h) {
   const long long total = (long long)nGB * Nc * gbw;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -41,48 +66,57 @@ __global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __re
     float v = 0.f;
     if (g < Ng) {
       v = src[(long long)g * gs + (long long)c * cs];
+      vc_hist_put(h, g, v);
       if (log1p_t) v = (float)log((double)v + 1.0 + 1e-16);   // preprocessing.py:154 / :267
     }
     dst[i] = v;
   }
 }
 
+// CSR (cells x genes, canonical: no duplicate entries) -> the blocked layout, one wave per cell; dst is pre-zeroed.
+// Reference counterpart: the `.A` / `.toarray()` densification of preprocessing.py:141-147, 243-252.
+__global__ __launch_bounds__(256) void vc_scatter_csr_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
+                                                             const float* __restrict__ data, float* __restrict__ dst, int Ng,
+                                                             int Nc, int gbw, int log1p_t, VcHistDev h) {
+  const int lane = threadIdx.x & 63;
+  for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c < Nc; c += (long long)gridDim.x * 4) {
+    const long long beg = indptr[c], end = indptr[c + 1];
+    for (long long k = beg + lane; k < end; k += 64) {
+      const int g = indices[k];
+      if (g < 0 || g >= Ng) { h.bad[1] = 1; continue; }
+      float v = data[k];
+      vc_hist_put(h, g, v);
+      if (log1p_t) v = (float)log((double)v + 1.0 + 1e-16);
+      dst[((size_t)(g / gbw) * Nc + c) * gbw + (g % gbw)] = v;
+    }
+  }
+}
+
+static VcHistDev vc_hist_dev(unsigned* tab, float* ovf_val, int* ovf_gene, unsigned* ovf_n, unsigned ovf_cap, int* bad) {
+  VcHistDev h;
+  h.tab = tab; h.ovf_val = ovf_val; h.ovf_gene = ovf_gene; h.ovf_n = ovf_n; h.ovf_cap = ovf_cap; h.bad = bad;
+  return h;
+}
+
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
-                           int Ng, int Nc, int nGB, int gbw, int log1p_transform, hipStream_t st) {
+                           int Ng, int Nc, int nGB, int gbw, int log1p_transform, unsigned* tab, float* ovf_val,
+                           int* ovf_gene, unsigned* ovf_n, unsigned ovf_cap, int* bad, hipStream_t st) {
   hipLaunchKernelGGL(vc_pack_counts_kernel, dim3(2048), dim3(256), 0, st, src, dst, gene_stride,
-                     cell_stride, Ng, Nc, nGB, gbw, log1p_transform);
+                     cell_stride, Ng, Nc, nGB, gbw, log1p_transform, vc_hist_dev(tab, ovf_val, ovf_gene, ovf_n, ovf_cap, bad));
+}
+
+void vc_launch_scatter_csr(const long long* indptr, const int* indices, const float* data, float* dst, int Ng, int Nc,
+                           int gbw, int log1p_transform, unsigned* tab, float* ovf_val, int* ovf_gene, unsigned* ovf_n,
+                           unsigned ovf_cap, int* bad, hipStream_t st) {
+  int nb = (Nc + 3) / 4;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(vc_scatter_csr_kernel, dim3(nb), dim3(256), 0, st, indptr, indices, data, dst, Ng, Nc, gbw,
+                     log1p_transform, vc_hist_dev(tab, ovf_val, ovf_gene, ovf_n, ovf_cap, bad));
 }
 
 // ---------------------------------------------------------------------------------------------
 // K_hist (NB): one wave per gene, fp64 -- also runs as extra blocks of K_pre
 // ---------------------------------------------------------------------------------------------
-// One wave per histogram TASK (<= 64 distinct count values of one gene and matrix, one per lane), so the
-// latency of the kernel is one pass whatever the spread of a gene's counts; K_post adds the few task sums of
-// a gene in fixed order.
-__device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, const float* __restrict__ P,
-                                             int cond_only, int task, int lane) {
-  const int g = b.h_task[4 * task], m = b.h_task[4 * task + 1];
-  const int beg = b.h_task[4 * task + 2], end = b.h_task[4 * task + 3];
-  double hl = 0.0, hd = 0.0;
-  if ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U)) {
-    float si;
-    if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
-    else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
-    const float r = 1.0f / si;
-    const int i = beg + lane;
-    if (i < end) {
-      float dl, dd;
-      vc_lgamma_digamma_diff(r, b.h_val[i], dl, dd);
-      const double n = (double)b.h_cnt[i];
-      hl = n * (double)dl;
-      hd = n * (double)dd;
-    }
-    hl = vc_wave_sum_d(hl);
-    hd = vc_wave_sum_d(hd);
-  }
-  if (lane == 0) { b.HL[task] = hl; b.HD[task] = hd; }
-}
-
 __global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBufs b,
                                                       const float* __restrict__ P, int cond_only) {
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -96,8 +130,6 @@ void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int c
 // ---------------------------------------------------------------------------------------------
 // K_pre
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
 __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBufs b,
                                                      const float* __restrict__ P,
                                                      const float* __restrict__ eps_in, uint64_t seed,

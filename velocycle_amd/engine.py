@@ -91,22 +91,41 @@ class HipEngine:
     def _setup(self):
         sp, lib, h = self.spec, self.lib, self._h
         sl = slice(self.c0, self.c1)
-        # counts: pass the caller's storage as it is (strided view, host or device)
-        S = sp.S[:, sl]
-        U = sp.U[:, sl] if sp.U is not None else None
-        for m in (S, U):
-            if m is not None and m.dtype != torch.float32:
-                raise ValueError("count matrices must be float32 (the reference passes S.T.float())")
-        on_dev = int(S.is_cuda)
-        if U is not None and U.is_cuda != S.is_cuda:
-            raise ValueError("S and U must live on the same device")
-        norm = lambda m: m if (m is None or (m.stride(0) > 0 and m.stride(1) > 0)) else m.contiguous()
-        S, U = norm(S), norm(U)
-        if U is not None and U.stride() != S.stride():
-            S, U = S.contiguous(), U.contiguous()
-        gs, cs = S.stride()
-        self._check(lib.vc_set_counts(h, C.c_void_p(S.data_ptr()),
-                                      C.c_void_p(U.data_ptr()) if U is not None else None, gs, cs, on_dev))
+        if sp.S_csr is not None and (sp.kind == "phase" or sp.U_csr is not None):
+            # CSR ingest (cells x genes, e.g. AnnData layers): this rank's rows go to the device as they are and a
+            # scatter kernel fills the blocked HBM layout; the dense matrices are never formed or uploaded
+            import numpy as np
+            for which, mat in ((0, sp.S_csr), (1, sp.U_csr if sp.kind == "velocity" else None)):
+                if mat is None:
+                    continue
+                m = mat.tocsr()[self.c0:self.c1]
+                m.sum_duplicates()
+                indptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+                indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+                data = np.ascontiguousarray(m.data, dtype=np.float32)
+                if m.shape != (self.Nc_local, sp.Ng):
+                    raise ValueError(f"CSR counts must be (cells, genes) = {(sp.Nc, sp.Ng)}")
+                self._check(lib.vc_set_counts_csr(h, which, indptr.ctypes.data_as(C.c_void_p),
+                                                  indices.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p),
+                                                  int(m.nnz), 0))
+        else:
+            # counts: pass the caller's storage as it is (strided view, host or device); device memory is not copied
+            S = sp.S[:, sl]
+            U = sp.U[:, sl] if sp.U is not None else None
+            for m in (S, U):
+                if m is not None and m.dtype != torch.float32:
+                    raise ValueError("count matrices must be float32 (the reference passes S.T.float())")
+            on_dev = int(S.is_cuda)
+            if U is not None and U.is_cuda != S.is_cuda:
+                raise ValueError("S and U must live on the same device")
+            norm = lambda m: m if (m is None or (m.stride(0) > 0 and m.stride(1) > 0)) else m.contiguous()
+            S, U = norm(S), norm(U)
+            if U is not None and U.stride() != S.stride():
+                S, U = S.contiguous(), U.contiguous()
+            gs, cs = S.stride()
+            self._counts_keepalive = (S, U)          # read by vc_finalize below
+            self._check(lib.vc_set_counts(h, C.c_void_p(S.data_ptr()),
+                                          C.c_void_p(U.data_ptr()) if U is not None else None, gs, cs, on_dev))
         cf = _f32c(sp.count_factor.reshape(-1)[sl])
         D = _f32c(sp.D[:, sl]) if sp.D is not None else None
         Db = _f32c(sp.Db[:, sl]) if (sp.with_delta_nu and sp.Nb > 0) else None
@@ -135,6 +154,7 @@ class HipEngine:
             t = t.contiguous().reshape(-1)
             self._check(lib.vc_set_conditioned(h, _lib.SITE_ID[name], C.c_void_p(t.data_ptr()), t.numel()))
         self._check(lib.vc_finalize(h, self._stream()))
+        self._counts_keepalive = None
         self.layout = _lib.vc_layout()
         self._check(lib.vc_get_layout(h, C.byref(self.layout)))
         L = self.layout
@@ -149,7 +169,8 @@ class HipEngine:
         self._check(lib.vc_get_stats(h, C.byref(st)))
         self.stats = dict(algorithmic_bytes=st.algorithmic_bytes, streamed_bytes=st.streamed_bytes,
                           main_grid=st.main_grid, main_block=st.main_block, main_kind=st.main_kind,
-                          main_kernel=st.main_kernel_name.decode())
+                          main_kernel=st.main_kernel_name.decode(), hist_on_device=bool(st.hist_on_device),
+                          setup_transient_bytes=st.setup_transient_bytes)
 
     # ------------------------------------------------------------------------------------------
     def param_shape(self, name):
@@ -246,6 +267,16 @@ class HipEngine:
             C.c_void_p(self.grad.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()),
             C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, self._stream()))
 
+    def svi_step_fused(self, m, v, lr, lrd, b1, b2, adam_eps, clip, seed, step_dev, loss_buf=None, prime=False):
+        """One whole SVI step in three launches (vc_svi_step_fused): K_main -> K_tail -> K_omega; `prime` draws the
+        sample of the current step first (first call / after params were changed from outside)."""
+        lb = self.loss_dev if loss_buf is None else loss_buf
+        self._check(self.lib.vc_svi_step_fused(
+            self._h, C.c_void_p(self.params.data_ptr()), C.c_uint64(seed), C.c_void_p(step_dev.data_ptr()),
+            C.c_void_p(self.grad.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()),
+            C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, int(bool(prime)),
+            self._stream()))
+
     def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
         """Fused HIP ClippedAdam on flat float32 buffers (same stream); optionally files the (all-reduced) loss
         found in `loss_hdr[0:2]` into `loss_ring[(t-1) % len]`."""
@@ -336,6 +367,18 @@ class HipEngine:
         if rc != _lib.VC_OK:
             raise HipEngineError("vc_device_clock_mhz failed")
         return mhz.value
+
+    def histogram(self):
+        """(ptr int32[2*Ng+1], values float32[n], multiplicities float32[n]): the per-gene count histograms vc_finalize
+        built (vc_get_histogram)."""
+        import numpy as np
+        n = C.c_int64()
+        self._check(self.lib.vc_get_histogram(self._h, C.byref(n), None, None, None))
+        ptr = np.zeros(2 * self.spec.Ng + 1, dtype=np.int32)
+        val, cnt = np.zeros(n.value, dtype=np.float32), np.zeros(n.value, dtype=np.float32)
+        self._check(self.lib.vc_get_histogram(self._h, C.byref(n), ptr.ctypes.data_as(C.c_void_p),
+                                              val.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+        return ptr, val, cnt
 
     def set_timing(self, enable: bool):
         self._check(self.lib.vc_set_timing(self._h, int(enable)))

@@ -42,6 +42,18 @@ def _dense(x):
     return np.asarray(x)
 
 
+def _csr_counts(layer):
+    """scipy sparse layer -> canonical float32 CSR (cells x genes) with the reference's int64 truncation applied, or None
+    for dense layers.  Carried in the container next to the dense S / U (which the reference's contract requires) so
+    that the engine can ingest the sparse form directly (vc_set_counts_csr) without uploading the dense matrices."""
+    if not (hasattr(layer, "tocsr") and hasattr(layer, "toarray")):
+        return None
+    m = layer.tocsr().astype(np.int64).astype(np.float32)
+    m.sum_duplicates()
+    m.eliminate_zeros()
+    return m
+
+
 def _container(fields: dict):
     names = [unicodedata.normalize("NFKC", k) for k in fields]       # Python normalises identifiers (SURVEY F8)
     return namedtuple("MetaparContainer", names)(*fields.values())
@@ -131,7 +143,9 @@ def preprocess_for_phase_estimation(anndata, cycle_obj, phase_obj, design_mtx, n
         condition=np.array(list(condition_on.keys())),
         logS=torch.tensor(anndata.layers["logS"]).float().T.to(device),
         logU=torch.tensor(anndata.layers["logU"]).float().T.to(device),
-        beta0=torch.tensor(beta0).to(device), beta1=torch.tensor(beta1).to(device))
+        beta0=torch.tensor(beta0).to(device), beta1=torch.tensor(beta1).to(device),
+        S_csr=None if normalize else _csr_counts(anndata.layers["spliced"]),
+        U_csr=None if normalize else _csr_counts(anndata.layers["unspliced"]))
     return _container(fields)
 
 
@@ -188,5 +202,7 @@ def preprocess_for_velocity_estimation(anndata, cycle_obj, phase_obj, speed_obj,
         logU=torch.tensor(anndata.layers["logU"]).float().T.to(device),
         condition=np.array(list(condition_on.keys())), device=device, model_type=model_type,
         rho_mean=torch.as_tensor(rho_mean).to(device), rho_std=torch.as_tensor(rho_std).to(device),
-        rho_scale=torch.as_tensor(rho_scale).to(device), rho_rank=torch.as_tensor(rho_rank).to(device))
+        rho_scale=torch.as_tensor(rho_scale).to(device), rho_rank=torch.as_tensor(rho_rank).to(device),
+        S_csr=None if normalize else _csr_counts(anndata.layers[lay[0]]),
+        U_csr=None if normalize else _csr_counts(anndata.layers[lay[1]]))
     return _container(fields)

@@ -15,7 +15,7 @@ class ModelSpec:
     noisemodel: str              # "NegativeBinomial" | "Poisson" | "Lognormal"
     with_delta_nu: bool
     H: int
-    S: torch.Tensor              # (Ng, Nc) float32, any strides, CPU or GPU
+    S: Optional[torch.Tensor]    # (Ng, Nc) float32, any strides, CPU or GPU (may be None when S_csr is given)
     count_factor: torch.Tensor   # (Nc,)
     Db: torch.Tensor             # (Nb, Nc)
     mu_nu: torch.Tensor          # (Ng, Nh)
@@ -41,11 +41,15 @@ class ModelSpec:
     rho_scale: float = 1.0
     rho_rank: int = 5
     condition_on: Dict[str, torch.Tensor] = field(default_factory=dict)
+    # the same count matrices as scipy CSR (cells x genes), e.g. AnnData layers as read from an .h5ad: when present the
+    # engine ingests these (vc_set_counts_csr) and never forms / uploads the dense matrices
+    S_csr: object = None
+    U_csr: object = None
 
     @property
-    def Ng(self): return int(self.S.shape[0])
+    def Ng(self): return int(self.S.shape[0]) if self.S is not None else int(self.S_csr.shape[1])
     @property
-    def Nc(self): return int(self.S.shape[1])
+    def Nc(self): return int(self.S.shape[1]) if self.S is not None else int(self.S_csr.shape[0])
     @property
     def Nb(self): return int(self.Db.shape[0])
     @property
@@ -72,7 +76,8 @@ def spec_from_metaparams(mp, kind: str, condition_on=None) -> ModelSpec:
         mu_nu=f(mp.μνg).reshape(Ng, -1), sd_nu=f(mp.σνg).reshape(Ng, -1),
         phixy_prior=f(mp.φxy_prior).reshape(Nc, 2), mu_dnu=float(mp.μΔν),
         gamma_alpha=float(mp.gamma_alpha), gamma_beta=float(mp.gamma_beta),
-        condition_on={k: f(v) for k, v in condition_on.items()})
+        condition_on={k: f(v) for k, v in condition_on.items()},
+        S_csr=getattr(mp, "S_csr", None))
     if kind == "phase":
         sd = f(mp.σΔν)
         return ModelSpec(guide="meanfield", H=int(mp.num_harmonics_S),
@@ -88,4 +93,4 @@ def spec_from_metaparams(mp, kind: str, condition_on=None) -> ModelSpec:
         mu_nuw=f(mp.μνω).reshape(Nx, -1), sd_nuw=f(mp.σνω).reshape(Nx, -1),
         sd_dnu=0.01, sigma_ln_s=float(mp.σsgc), sigma_ln_u=float(mp.σugc),
         rho_mean=float(mp.rho_mean), rho_std=float(mp.rho_std), rho_scale=float(mp.rho_scale),
-        rho_rank=int(mp.rho_rank), **common)
+        rho_rank=int(mp.rho_rank), U_csr=getattr(mp, "U_csr", None), **common)

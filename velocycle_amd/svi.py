@@ -122,13 +122,22 @@ class SVIRunner:
         # force_reduce: issue the all-reduce even with one rank (exercises the RCCL-in-graph path on one GPU)
         self.do_reduce = self.world > 1 or force_reduce
         self.use_graph = (mode == "perf") if use_graph is None else use_graph
+        if self.do_reduce and self.use_graph:
+            import torch.distributed as dist
+            if dist.get_backend(process_group) != "nccl":
+                # only RCCL collectives are stream work that a hipGraph can capture; gloo (CPU / one-device tests)
+                # completes its all-reduce on the host -> eager launches
+                self.use_graph = False
         # "torch": PyTorch ops; "hip": one kernel after the gradient; "fused": merged with the last gradient kernel
-        self.adam_impl = adam_impl or (("hip" if self.do_reduce else "fused") if mode == "perf" else "torch")
-        if self.adam_impl == "fused" and (self.do_reduce or mode != "perf"):
-            raise ValueError("adam_impl='fused' needs mode='perf' on a single rank")
+        # (4 launches per step); "fused3": the three-launch step of vc_svi_step_fused (reductions + chain rule + optimiser +
+        # the NEXT step's guide sample in one kernel) -- the single-rank default
+        self.adam_impl = adam_impl or (("hip" if self.do_reduce else "fused3") if mode == "perf" else "torch")
+        if self.adam_impl in ("fused", "fused3") and (self.do_reduce or mode != "perf"):
+            raise ValueError(f"adam_impl={self.adam_impl!r} needs mode='perf' on a single rank")
         self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
                                    capturable=self.use_graph,
-                                   impl=("hip" if self.adam_impl == "fused" else self.adam_impl), engine=engine)
+                                   impl=("hip" if self.adam_impl in ("fused", "fused3") else self.adam_impl), engine=engine)
+        self._primed = False          # fused3: the tables of the current step have been sampled from the current params
         self.step_idx = 0
         self.losses: List[float] = []
         self._graph = None
@@ -183,8 +192,18 @@ class SVIRunner:
         self.losses.append(loss)
         return loss
 
-    def _perf_body(self):
+    def invalidate(self):
+        """Tell the runner that params / step counter / seed were changed from outside (fused3 keeps the NEXT step's
+        sample in the engine's tables; it is re-drawn from the current parameters before the next step)."""
+        self._primed = False
+
+    def _perf_body(self, prime: bool = False):
         e = self.e
+        if self.adam_impl == "fused3":         # single rank: K_main -> K_tail -> K_omega
+            o = self.opt
+            e.svi_step_fused(o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, seed=self.seed,
+                             step_dev=self.step_dev, loss_buf=self.loss_hist, prime=prime)
+            return
         if self.adam_impl == "fused":          # single rank: optimiser merged into the last gradient kernel
             o = self.opt
             e.svi_step(o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, eps=None, seed=self.seed, step=0,
@@ -216,7 +235,8 @@ class SVIRunner:
             s = torch.cuda.Stream(device=e.device)
             s.wait_stream(torch.cuda.current_stream(e.device))
             with torch.cuda.stream(s):
-                self._perf_body()                      # warm-up (allocator, lazy init) outside capture
+                self._perf_body(prime=not self._primed)   # warm-up (allocator, lazy init) outside capture
+                self._primed = True
                 torch.cuda.synchronize()
                 # ProcessGroupNCCL's watchdog thread polls the events of the collectives issued before the capture;
                 # under the default "global" capture mode such a query from ANOTHER thread invalidates the capture on
@@ -231,10 +251,11 @@ class SVIRunner:
             self.step_idx += 1
             n_steps -= 1
         for _ in range(n_steps):
-            if self._graph is not None:
+            if self._graph is not None and self._primed:
                 self._graph.replay()
             else:
-                self._perf_body()
+                self._perf_body(prime=not self._primed)
+                self._primed = True
         self.step_idx += n_steps
         if sync:
             torch.cuda.synchronize(e.device)
@@ -277,6 +298,7 @@ class SVIRunner:
         self.opt.load_state_dict(dict(m=sd["m"], v=sd["v"], t=sd["t"]))
         self.step_idx, self.seed = int(sd["step_idx"]), int(sd["seed"])
         losses = torch.as_tensor(sd["losses"], dtype=torch.float64)
+        self._primed = False
         if self.mode == "perf":
             self.step_dev.fill_(self.step_idx)
             n = max(2 * self.step_idx, 1024)
