@@ -163,7 +163,7 @@ def cpu_baseline(args, mode, device=None):
                 else make_velocity_spec(nsample, args.genes, mode, 1, 1, seed=0, device="cpu"))
         kw = {}
         for k, v in spec.__dict__.items():
-            if k == "truth":
+            if k in ("truth", "S_csr", "U_csr"):
                 continue
             kw[k] = v.contiguous() if isinstance(v, torch.Tensor) else v
         return spec, orc.Problem(**kw)

@@ -71,7 +71,7 @@ def problem_from_spec(spec, dtype=torch.float64) -> orc.Problem:
     """The oracle's view of a product ModelSpec (CPU, `dtype`)."""
     kw = {}
     for k, v in spec.__dict__.items():
-        if k == "truth":
+        if k in ("truth", "S_csr", "U_csr"):
             continue
         kw[k] = v.detach().cpu().to(dtype) if (isinstance(v, torch.Tensor) and v.is_floating_point()) else v
     kw["condition_on"] = {k: v.detach().cpu().to(dtype) for k, v in spec.condition_on.items()}

@@ -29,7 +29,7 @@ class OracleShardEngine:
         self.c0, self.c1 = shard_bounds(spec.Nc, rank, world_size)
         self.Nc_local = self.c1 - self.c0
         sl = slice(self.c0, self.c1)
-        kw = {k: v for k, v in spec.__dict__.items() if k != "truth"}
+        kw = {k: v for k, v in spec.__dict__.items() if k not in ("truth", "S_csr", "U_csr")}
         for k in ("S", "U", "Db", "D"):
             kw[k] = kw[k][:, sl].double() if kw[k] is not None else None
         for k in ("count_factor", "phixy_prior"):

@@ -112,7 +112,7 @@ def test_medium_problem_against_oracle(mode, monkeypatch):
     eps = draw_eps(spec, g)
     eng.elbo_grad(eps=eng.pack_eps(eps))
     torch.cuda.synchronize()
-    kw = {k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in spec.__dict__.items() if k != "truth"}
+    kw = {k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in spec.__dict__.items() if k not in ("truth", "S_csr", "U_csr")}
     kw["condition_on"] = {k: v.double() for k, v in spec.condition_on.items()}
     p = orc.Problem(**kw)
     par = {n: v.detach().cpu().double() for n, v in eng.named().items()}
@@ -212,7 +212,7 @@ def test_baseline_config_10k_x_500_against_oracle(mode):
     eps = draw_eps(spec, g)
     eng.elbo_grad(eps=eng.pack_eps(eps))
     torch.cuda.synchronize()
-    kw = {k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in spec.__dict__.items() if k != "truth"}
+    kw = {k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in spec.__dict__.items() if k not in ("truth", "S_csr", "U_csr")}
     kw["condition_on"] = {k: v.double() for k, v in spec.condition_on.items()}
     p = orc.Problem(**kw)
     par = {n: v.detach().cpu().double() for n, v in eng.named().items()}
@@ -247,7 +247,7 @@ def test_trajectory_at_3k_x_200_stays_within_float32_spread_of_the_oracle(mode):
     opt = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / 1000), "betas": (0.80, 0.99)}
     run = SVIRunner(eng, opt, mode="parity", seed=11)
     losses = np.array([run.step() for _ in range(n)])
-    kw = {k: (v.double().cpu() if isinstance(v, torch.Tensor) else v) for k, v in spec.__dict__.items() if k != "truth"}
+    kw = {k: (v.double().cpu() if isinstance(v, torch.Tensor) else v) for k, v in spec.__dict__.items() if k not in ("truth", "S_csr", "U_csr")}
     kw["condition_on"] = {k: v.double().cpu() for k, v in spec.condition_on.items()}
     p64 = orc.Problem(**kw)
     l64, par64 = orc.fit(p64, opt, n, seed=11)
