@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""pmc summary (profiles/summarize.py output of the --pmc FETCH_SIZE / WRITE_SIZE passes) -> latest_traffic.json, keyed by
+the kernel names bench.py reports.  usage: pmc_to_traffic.py <pmc.txt> <out.json> <tag>"""
+import json
+import re
+import sys
+
+KIND = {0: "phase", 1: "vfull", 2: "vu"}
+NOISE = {0: "nb", 1: "poisson", 2: "lognormal"}
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+vals = {}
+pat = re.compile(r"(?:void )?vc_main_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>.*\| (FETCH_SIZE|WRITE_SIZE) \| (\d+) \| ([\d.]+)")
+for line in open(src):
+    m = pat.match(line)
+    if m:
+        h, nb, kind, noise, gpl = (int(x) for x in m.groups()[:5])
+        name = f"vc_main_kernel<{h},{nb},{KIND[kind]}_{NOISE[noise]},gpl{gpl}>"
+        vals.setdefault(name, {})[m.group(6) + "_KiB"] = float(m.group(8))
+for v in vals.values():
+    if "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
+        v["traffic_bytes"] = int((2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024)
+out = {"_comment": "HBM traffic per launch of the likelihood kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and "
+                   f"--pmc WRITE_SIZE runs of the driver's bench command, {tag}). Unit: FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 "
+                   "FETCH_SIZE counts 128-B requests at 64 B for wide (16 B/lane) streaming reads, so the read side is doubled "
+                   "(MI355X_MICROARCH.md, HBM section). bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.",
+       "workload": "50000x2000", "kernels": vals}
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(vals))

@@ -60,7 +60,7 @@ def test_create_validates_and_reports_errors():
     assert lay.header == 4 and lay.n_local == 20
     # mean-field velocity, NB, Nx=1, Hw=1: nu (2*30) + logbeta (2*10) + loggamma (2*10) + nuw (2*3) + shape_inv 10
     assert lay.n_global == 60 + 20 + 20 + 6 + 10 and lay.total == 4 + lay.n_global + 20
-    assert lay.eps_total == 10 + 10 + 30 + 3 + 20
+    assert lay.eps_n_global == 10 + 10 + 30 + 3 + 1 and lay.eps_total == lay.eps_n_global + 20    # global block padded to even
     # call-order errors come back as codes + messages, never as crashes
     assert lib.vc_elbo_grad(h, None, None, 0, 0, None, None, None, 1, None) == mod.VC_ERR_STATE
     assert b"before vc_finalize" in lib.vc_last_error(h)

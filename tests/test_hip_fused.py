@@ -2,7 +2,8 @@
 the unfused kernel sequence it replaces (K_pre -> K_main -> K_post -> K_fin -> ClippedAdam, adam_impl="hip" / "fused"):
 same Philox stream, same arithmetic statement by statement, so the trajectories must coincide -- parameters and
 optimiser moments to float32 rounding of a few reassociated sums (observed: bit-identical in most configurations), losses
-to 1e-9 relative (the fp64 loss assembly adds its terms in a different order).  Every model / guide / noise /
+to 2e-7 relative (the float32 prior / guide terms are grouped per role instead of per thread before they enter the
+fp64 loss assembly).  Every model / guide / noise /
 conditioning combination of the step fixtures, plus medium sizes with ragged tiles and several gene blocks."""
 import numpy as np
 import pytest
@@ -42,7 +43,7 @@ def test_fused_step_equals_unfused_sequence(case):
     for use_graph in (False, True):
         got = _run(spec, "fused3", n, use_graph)
         assert got["sd"] == n and ref["sd"] == n and got["status"][0]
-        assert len(got["l"]) == n and np.allclose(got["l"], ref["l"], rtol=1e-9, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
+        assert len(got["l"]) == n and np.allclose(got["l"], ref["l"], rtol=2e-7, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
         _same(got["p"], ref["p"], f"{case}: params")
         _same(got["m"], ref["m"], f"{case}: exp_avg")
         _same(got["v"], ref["v"], f"{case}: exp_avg_sq", rtol=1e-4)
@@ -60,10 +61,17 @@ def test_fused_step_medium_sizes(mode, ncond, cw, monkeypatch):
     if cw:
         monkeypatch.setenv("VC_CELLS_PER_WAVE", cw)
     spec = make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5)
+    # two steps: nothing but reassociation can differ yet -> tight; twelve steps: the optimiser has amplified that rounding
+    # where gradients pass through zero (same yardstick as the float32-vs-float64 trajectory tests) -> loose
+    ref, got = _run(spec, "hip", 2, False), _run(spec, "fused3", 2, False)
+    assert np.allclose(got["l"], ref["l"], rtol=2e-7, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
+    _same(got["p"], ref["p"], "params after 2 steps", rtol=2e-6, atol=2e-7)
+    _same(got["m"], ref["m"], "exp_avg after 2 steps", rtol=1e-5, atol=1e-6)
+    _same(got["g"][4:], ref["g"][4:], "gradient of step 2", rtol=1e-5, atol=1e-5)
     ref, got = _run(spec, "hip", 12, False), _run(spec, "fused3", 12, True)
-    assert np.allclose(got["l"], ref["l"], rtol=1e-8, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
-    _same(got["p"], ref["p"], "params", rtol=1e-4, atol=1e-5)
-    _same(got["m"], ref["m"], "exp_avg", rtol=1e-4, atol=1e-5)
+    assert np.allclose(got["l"], ref["l"], rtol=1e-6, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
+    _same(got["p"], ref["p"], "params", rtol=1e-3, atol=1e-4)
+    _same(got["m"], ref["m"], "exp_avg", rtol=2e-3, atol=2e-3)
 
 
 def test_fused_phase_medium_and_resume_mid_run():
@@ -74,8 +82,8 @@ def test_fused_phase_medium_and_resume_mid_run():
     from velocycle_amd.workloads import make_phase_spec
     spec = make_phase_spec(3000, 200, seed=5)
     ref, got = _run(spec, "hip", 12, False), _run(spec, "fused3", 12, True)
-    assert np.allclose(got["l"], ref["l"], rtol=1e-8, atol=0)
-    _same(got["p"], ref["p"], "params", rtol=1e-4, atol=1e-5)
+    assert np.allclose(got["l"], ref["l"], rtol=1e-6, atol=0)
+    _same(got["p"], ref["p"], "params", rtol=1e-3, atol=1e-4)
     e1 = HipEngine(spec)
     r1 = SVIRunner(e1, OPT, mode="perf", seed=7)
     assert r1.adam_impl == "fused3"

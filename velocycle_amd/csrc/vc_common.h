@@ -41,7 +41,9 @@ struct VcDims {
   long long eoff[VC_E_COUNT];   // eps offsets
   long long eps_n_global;
   int nb_pre_gene, nb_pre_cell, nb_post_gene, nb_post_cell, n_main_wg;
-  int nlpf;               // fused pipeline: loss slots per half of LPF = nb_post_gene + nb_post_cell + 1
+  int nb_tail_cell;       // fused pipeline: cell blocks of K_tail (256 cells each)
+  int nlpf;               // fused pipeline: loss slots per half of LPF = nb_post_gene + nb_tail_cell + 1
+  float lgamma_alpha;     // lgamma(gamma_alpha) of the shape_inv prior, evaluated once on the host
 };
 
 struct VcBufs {
@@ -71,7 +73,9 @@ struct VcBufs {
   double const_loss;                        // step-invariant part of the loss
   long long* status;                        // [0] number of steps with a non-finite loss, [1] 1 + index of the first one
   // fused single-rank pipeline (vc_svi_step_fused)
-  long long* step_ctr;                      // non-null: K_main advances this device step counter (block 0)
+  long long* step_ctr;                      // non-null: K_main advances this device step counter (block 0) ...
+  float* step_size;                         // ... and leaves the ClippedAdam step size of the new step here (fp64 math, once)
+  double adam_lr0, adam_lrd_l, adam_b1l, adam_b2l;
   double* LPF;                              // [2][nlpf] prior / guide loss terms of the samples of step s in half s & 1
   double* LPP;                              // [nb_post_gene] r-only likelihood terms of the gene blocks (K_tail)
   float* NWS;                               // [4][VC_MAX_NW * (VC_MAX_RANK + 2)] snapshot of the nu_omega parameters, moments, value
@@ -119,6 +123,25 @@ __device__ __forceinline__ double vc_wave_sum_d(double v) {
   return v;
 }
 
+// the same sum with DPP row operations on the two halves of the double (3 VALU per step instead of two LDS-crossbar
+// permutes with their latency): the total lands in LANE 63 only
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double vc_dpp_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double vc_wave_sum_d63(double v) {
+  v += vc_dpp_d<0x111, 0xf>(v);   // row_shr:1
+  v += vc_dpp_d<0x112, 0xf>(v);   // row_shr:2
+  v += vc_dpp_d<0x114, 0xf>(v);   // row_shr:4
+  v += vc_dpp_d<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds its row sum
+  v += vc_dpp_d<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3 (other rows add 0)
+  v += vc_dpp_d<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
+  return v;
+}
+
 // block sum in double for <=1024 threads; result valid in thread 0
 __device__ __forceinline__ double vc_block_sum_d(double v, double* sm /* [16] */) {
   v = vc_wave_sum_d(v);
@@ -161,6 +184,19 @@ __device__ __forceinline__ float vc_philox_normal(uint64_t seed, long long step,
   // hardware log2 / sin / cos (v_log_f32, v_sin_f32, v_cos_f32 take revolutions): plenty for a noise draw
   const float rad = sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(u1));
   return rad * ((idx & 1) ? __builtin_amdgcn_sinf(u2) : __builtin_amdgcn_cosf(u2));
+}
+
+// both normals of one Philox block (the even / odd index of a pair: cos and sin branch of the same Box-Muller draw):
+// n0 == vc_philox_normal(seed, step, 2 * blk), n1 == vc_philox_normal(seed, step, 2 * blk + 1), at the cost of one
+__device__ __forceinline__ void vc_philox_normal2(uint64_t seed, long long step, uint64_t blk, float& n0, float& n1) {
+  uint32_t o[4];
+  vc_philox((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)step, (uint32_t)((uint64_t)step >> 32),
+            (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(u1));
+  n0 = rad * __builtin_amdgcn_cosf(u2);
+  n1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
 // eps value `li` (local index in this rank's eps vector, global index gi for the counter RNG)

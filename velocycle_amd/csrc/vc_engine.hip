@@ -190,6 +190,7 @@ static void build_layout(vc_engine* e) {
   adde(VC_E_NU, (long long)d.Ng * d.Nh);
   if (lrmn) adde(VC_E_LOGBETA, d.Ng);
   if (vel && !lrmn) adde(VC_E_NUOMEGA, d.NW);
+  if (eo & 1) eo++;       // phi_xy pairs start at an even index: (x, y) of a cell are the two normals of ONE Philox block
   L.eps_n_global = eo;
   adde(VC_E_PHIXY, 2LL * d.Nc);
   L.eps_total = eo;
@@ -661,8 +662,10 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.dbg, (size_t)d.n_main_wg * 32 + 3 * 4096 * 8));   // + per-block stamps of K_pre / K_post / K_fin
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
-  TRY(e->dalloc(&b.PW, (size_t)d.nb_post_cell * std::max(1, d.NW)));
-  d.nlpf = d.nb_post_gene + d.nb_post_cell + 1;
+  TRY(e->dalloc(&b.PW, (size_t)((d.Nc + 255) / 256) * std::max(1, d.NW)));      // K_post: 1024-cell blocks; K_tail: 256
+  d.nb_tail_cell = (d.Nc + 255) / 256;
+  d.nlpf = d.nb_post_gene + d.nb_tail_cell + 1;
+  d.lgamma_alpha = lgammaf(d.gamma_alpha);
   TRY(e->dalloc(&b.LPF, 2 * (size_t)d.nlpf));
   HIPCHK(e, hipMemset(b.LPF, 0, 2 * sizeof(double) * d.nlpf));
   TRY(e->dalloc(&b.LPP, (size_t)d.nb_post_gene));
@@ -670,6 +673,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.NWS, 4 * (size_t)VC_MAX_NW * (VC_MAX_RANK + 2)));
   HIPCHK(e, hipMemset(b.NWS, 0, 4 * sizeof(float) * VC_MAX_NW * (VC_MAX_RANK + 2)));
   b.step_ctr = nullptr;
+  TRY(e->dalloc(&b.step_size, 1));
+  HIPCHK(e, hipMemset(b.step_size, 0, sizeof(float)));
   TRY(e->dalloc(&b.status, 2));
   HIPCHK(e, hipMemset(b.status, 0, 2 * sizeof(long long)));
 
@@ -864,6 +869,7 @@ extern "C" int vc_svi_step_fused(vc_engine* e, float* params, uint64_t seed, int
   }
   VcBufs b2 = e->b;
   b2.step_ctr = (long long*)step_dev;
+  b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l;
   if (e->timing) {
     if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
     auto& pr = e->ev_pool[e->ev_used++];

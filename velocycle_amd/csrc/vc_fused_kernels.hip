@@ -104,7 +104,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       off[0] = (int)(d.poff[VC_P_NU_LOCS] + jj); off[1] = (int)(d.poff[VC_P_NU_USCALES] + jj); nown = 2;
       in[1] = b.sd_nu[jj]; in[2] = b.mu_nu[jj];
       if (!boot && !CND(VC_SITE_NU)) { in[0] = b.lat[VC_SITE_NU][jj]; in[3] = b.eps_used[d.eoff[VC_E_NU] + jj]; }
-      e0 = vc_philox_normal(seed, s, d.eoff[VC_E_NU] + jj);
+      if (!CND(VC_SITE_NU)) e0 = vc_philox_normal(seed, s, d.eoff[VC_E_NU] + jj);   // a hidden site's draw is never used
     } else if (r_dnu) {
       jj = (long long)(role - Nh) * d.Ng + g;
       off[0] = (int)(d.poff[VC_P_DNU_LOCS] + jj); nown = 1;
@@ -276,8 +276,8 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
         }
     }
     if (role == 12) {
-      const double tot = vc_wave_sum_d(loss_post);
-      if (lane == 0) b.LPP[gblock] = tot;
+      const double tot = vc_wave_sum_d63(loss_post);
+      if (lane == 63) b.LPP[gblock] = tot;
     }
   }
 
@@ -294,12 +294,14 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     float* GT = b.GT + g;
     if (r_nu) {
       const float e = e0;
-      b.eps_used[d.eoff[VC_E_NU] + jj] = e;
-      const float u = pp[1];
-      const float xg = pp[0] + expf(u) * e;
       float x;
       if (CND(VC_SITE_NU)) x = b.cnd[VC_SITE_NU][jj];
-      else { x = xg; logq += -0.5f * e * e - u - 0.5f * VC_LOG_2PI; }
+      else {
+        b.eps_used[d.eoff[VC_E_NU] + jj] = e;
+        const float u = pp[1];
+        x = pp[0] + expf(u) * e;
+        logq += -0.5f * e * e - u - 0.5f * VC_LOG_2PI;
+      }
       logp += vc_normal_lp(x, in[2], in[1]);
       b.lat[VC_SITE_NU][jj] = x;
       GT[role * NP] = x;
@@ -310,8 +312,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       GT[role * NP] = x;
     } else if (r_si) {
       const float si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : expf(pp[0]);
-      logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) - d.gamma_beta * si -
-              lgammaf(d.gamma_alpha);
+      logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) - d.gamma_beta * si - d.lgamma_alpha;
       b.lat[VC_SITE_SHAPE_INV][g] = si;
       GT[(K + 2) * NP] = 1.0f / si;
     } else if (role == 12 && boot && !nb) {
@@ -388,8 +389,8 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   // prior / guide terms of the step-s sample: fp64 block sum in fixed order
   {
     const double lt = live ? -(double)rw * ((double)logp - (double)logq) : 0.0;
-    const double ws = vc_wave_sum_d(lt);
-    if (lane == 0) sm_ls[wave] = ws;
+    const double ws = vc_wave_sum_d63(lt);
+    if (lane == 63) sm_ls[wave] = ws;
     __syncthreads();
     if (threadIdx.x == 0) {
       double t = 0.0;
@@ -400,70 +401,78 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_tail, cell block: 1024 cells
+// K_tail, cell block: 256 cells on the first 4 waves of the (1024-thread) block -- one wave per SIMD: the per-cell chain
+// (Philox, Adam, atan2, sincos) is instruction-bound, 16 waves on one CU would serialise it four deep
 // ---------------------------------------------------------------------------------------------
+#define VC_TC 256
 __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs& b, float* __restrict__ P,
                                                    float* __restrict__ G, float* __restrict__ Mm, float* __restrict__ Vv,
                                                    int header, int cblock, long long s, uint64_t seed, const VcOpt o,
                                                    int boot) {
-  __shared__ float sm_w[16][VC_MAX_NW];
-  __shared__ double sm_lc[16];
-  const int c = cblock * 1024 + threadIdx.x;
+  __shared__ float sm_w[VC_TC / 64][VC_MAX_NW];
+  __shared__ double sm_lc[VC_TC / 64];
+  if (threadIdx.x >= VC_TC) return;        // waves 4..15 of the block have nothing to do
+  const int c = cblock * VC_TC + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool vel = d.model == VC_MODEL_VELOCITY;
   const bool in_range = c < d.Nc;
   const bool cxy = CND(VC_SITE_PHIXY);
   float A[3] = {0.f, 0.f, 0.f};
-  float phi = 0.f;
   float dx01[2] = {0.f, 0.f};
   float2 pp = make_float2(0.f, 0.f), pm = pp, pv = pp, pxy = pp;
+  float2 sc_old = make_float2(0.f, 1.f);          // sin, cos of the phase of the step being finished (cell record)
   float ex = 0.f, ey = 0.f;
   double loss = 0.0;
   const long long poff = d.poff[VC_P_PHIXY_LOCS] + 2LL * c;
+  const float2* ctr = reinterpret_cast<const float2*>(b.CT + (size_t)(in_range ? c : 0) * d.ctw);
   if (in_range) {
-    pp = *reinterpret_cast<const float2*>(P + poff);
     pxy = *reinterpret_cast<const float2*>(b.pxy + 2 * (size_t)c);
-    const long long gi = d.eoff[VC_E_PHIXY] + 2LL * (d.cell_offset + c);
-    ex = vc_philox_normal(seed, s, gi);
-    ey = vc_philox_normal(seed, s, gi + 1);
+    if (!cxy) {
+      pp = *reinterpret_cast<const float2*>(P + poff);
+      // (x, y) of a cell are the two normals of one Philox block (the eps layout starts phi_xy at an even index)
+      const long long gi = d.eoff[VC_E_PHIXY] + 2LL * (d.cell_offset + c);
+      vc_philox_normal2(seed, s, (uint64_t)gi >> 1, ex, ey);
+    }
     if (!boot) {
       float2 xy = make_float2(1.f, 0.f);
       float om = 0.f, dom = 0.f;
-      phi = b.lat_phi[c];
-      pm = *reinterpret_cast<const float2*>(Mm + (poff - header));
-      pv = *reinterpret_cast<const float2*>(Vv + (poff - header));
       if (vel) {
+        sc_old = make_float2(ctr[0].x, ctr[1].x);
         dx01[0] = b.Dm[c];
         if (d.Nx > 1) dx01[1] = b.Dm[(size_t)d.Nc + c];
       }
       if (!cxy) {
+        pm = *reinterpret_cast<const float2*>(Mm + (poff - header));
+        pv = *reinterpret_cast<const float2*>(Vv + (poff - header));
         xy = *reinterpret_cast<const float2*>(b.lat[VC_SITE_PHIXY] + 2 * (size_t)c);
         if (d.kind == VC_KIND_VFULL) { om = b.lat_omega[c]; dom = b.lat_domega[c]; }
       }
       for (int gb = 0; gb < d.nGB; ++gb)
         for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + c];
-      float gx = 0.f, gy = 0.f;
       if (!cxy) {
         float dphi = A[0];
         if (d.kind == VC_KIND_VFULL) dphi += om * A[1] + A[2] * dom;
         const float x = xy.x, y = xy.y;
         const float inv = 1.0f / (x * x + y * y);
-        gx = -(dphi * (-y * inv) - (x - pxy.x));
-        gy = -(dphi * (x * inv) - (y - pxy.y));
+        const float gx = -(dphi * (-y * inv) - (x - pxy.x));
+        const float gy = -(dphi * (x * inv) - (y - pxy.y));
+        *reinterpret_cast<float2*>(G + poff) = make_float2(gx, gy);
+        pp.x = vc_adam_elem(pp.x, gx, pm.x, pv.x, o.step_size, o.b1, o.b2, o.eps, o.clip);
+        pp.y = vc_adam_elem(pp.y, gy, pm.y, pv.y, o.step_size, o.b1, o.b2, o.eps, o.clip);
+        *reinterpret_cast<float2*>(Mm + (poff - header)) = pm;
+        *reinterpret_cast<float2*>(Vv + (poff - header)) = pv;
+        *reinterpret_cast<float2*>(P + poff) = pp;
+      } else {
+        // conditioned phases: the gradient is zero, so are the moments -- ClippedAdam leaves the parameter where it is
+        *reinterpret_cast<float2*>(G + poff) = make_float2(0.f, 0.f);
       }
-      *reinterpret_cast<float2*>(G + poff) = make_float2(gx, gy);
-      pp.x = vc_adam_elem(pp.x, gx, pm.x, pv.x, o.step_size, o.b1, o.b2, o.eps, o.clip);
-      pp.y = vc_adam_elem(pp.y, gy, pm.y, pv.y, o.step_size, o.b1, o.b2, o.eps, o.clip);
-      *reinterpret_cast<float2*>(Mm + (poff - header)) = pm;
-      *reinterpret_cast<float2*>(Vv + (poff - header)) = pv;
-      *reinterpret_cast<float2*>(P + poff) = pp;
     }
   }
   if (vel && !boot) {
     // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c) at the phases of step s - 1
+    // (their sin / cos are in the cell record; higher harmonics by the angle-addition recurrence, as K_pre built them)
     const float a3 = in_range ? (d.kind == VC_KIND_VFULL ? A[2] : A[0]) : 0.f;
-    float s1, c1;
-    sincosf(phi, &s1, &c1);
+    const float s1 = sc_old.x, c1 = sc_old.y;
     float sk[VC_MAXH], ck[VC_MAXH];
     sk[0] = s1; ck[0] = c1;
     for (int k = 1; k < d.Hw && k < VC_MAXH; ++k) {
@@ -478,20 +487,13 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
         if (lane == 0) sm_w[wave][xq * d.Nhw + h] = t;
       }
     }
-    __syncthreads();
-    if ((int)threadIdx.x < d.NW) {
-      const int j = threadIdx.x;
-      float t = 0.f;
-      for (int w = 0; w < 16; ++w) t += sm_w[w][j];
-      b.PW[(size_t)cblock * d.NW + j] = t;
-    }
   }
   // ---- snapshot of the nu_omega-related parameters, their moments and the nu_omega value of the step being finished:
   // K_omega's blocks all READ this copy while its block 0 stores the updated values (no reader ever races the writer)
   if (vel && cblock == 0) {
     const bool lrmn = d.guide == VC_GUIDE_LRMN;
     const int fin_per = lrmn ? d.R + 2 : 2;
-    for (int tt = threadIdx.x; tt < d.NW * fin_per; tt += 1024) {
+    for (int tt = threadIdx.x; tt < d.NW * fin_per; tt += VC_TC) {
       const long long off = vc_nuw_elem_off(d, lrmn, tt / fin_per, tt % fin_per);
       b.NWS[tt] = P[off];
       b.NWS[VC_NWE + tt] = Mm[off - header];
@@ -501,50 +503,57 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   }
   // ---- phi_xy sample of step s, phase, Fourier basis, cell record (omega is filled by K_omega) -------------------
   if (in_range) {
-    const long long li = d.eoff[VC_E_PHIXY] + 2LL * c;
-    b.eps_used[li] = ex;
-    b.eps_used[li + 1] = ey;
-    float x, y;
     const float px = pxy.x, py = pxy.y;
+    float x, y;
     if (cxy) {
       x = b.cnd[VC_SITE_PHIXY][2 * c]; y = b.cnd[VC_SITE_PHIXY][2 * c + 1];
       loss += 0.5 * ((double)(x - px) * (x - px) + (double)(y - py) * (y - py)) + (double)VC_LOG_2PI;
     } else {
+      const long long li = d.eoff[VC_E_PHIXY] + 2LL * c;
+      *reinterpret_cast<float2*>(b.eps_used + li) = make_float2(ex, ey);
       x = pp.x + ex;
       y = pp.y + ey;
       loss += 0.5 * ((double)(x - px) * (x - px) + (double)(y - py) * (y - py)) - 0.5 * ((double)ex * ex + (double)ey * ey);
     }
-    *reinterpret_cast<float2*>(b.lat[VC_SITE_PHIXY] + 2 * (size_t)c) = make_float2(x, y);
-    const float ph = atan2f(y, x);
-    float s1, c1;
-    sincosf(ph, &s1, &c1);
-    float sk[VC_MAXH], ck[VC_MAXH];
-    sk[0] = s1; ck[0] = c1;
-    for (int k = 1; k < d.H && k < VC_MAXH; ++k) {
-      sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
-      ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
-    }
-    float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
-    for (int k = 0; k < d.H; ++k) { ct[2 * k] = make_float2(sk[k], sk[k]); ct[2 * k + 1] = make_float2(ck[k], ck[k]); }
-    if (boot) {              // step-invariant entries of the record
-      for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
-        const float v = b.Dbm[(size_t)q * d.Nc + c];
-        ct[2 * d.H + q] = make_float2(v, v);
+    if (!cxy || boot) {          // conditioned phases never change: their record is written once
+      *reinterpret_cast<float2*>(b.lat[VC_SITE_PHIXY] + 2 * (size_t)c) = make_float2(x, y);
+      const float ph = atan2f(y, x);
+      float s1, c1;
+      sincosf(ph, &s1, &c1);
+      float sk[VC_MAXH], ck[VC_MAXH];
+      sk[0] = s1; ck[0] = c1;
+      for (int k = 1; k < d.H && k < VC_MAXH; ++k) {
+        sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
+        ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
       }
-      const int nbk = d.with_dnu ? d.Nb : 0;
-      if (!vel) ct[2 * d.H + nbk] = make_float2(0.f, 0.f);
-      ct[2 * d.H + nbk + 1] = make_float2(b.cf[c], b.cf[c]);
-      if (!vel) { b.lat_omega[c] = 0.f; b.lat_domega[c] = 0.f; }
+      float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
+      for (int k = 0; k < d.H; ++k) { ct[2 * k] = make_float2(sk[k], sk[k]); ct[2 * k + 1] = make_float2(ck[k], ck[k]); }
+      if (boot) {              // step-invariant entries of the record
+        for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
+          const float v = b.Dbm[(size_t)q * d.Nc + c];
+          ct[2 * d.H + q] = make_float2(v, v);
+        }
+        const int nbk = d.with_dnu ? d.Nb : 0;
+        if (!vel) ct[2 * d.H + nbk] = make_float2(0.f, 0.f);
+        ct[2 * d.H + nbk + 1] = make_float2(b.cf[c], b.cf[c]);
+        if (!vel) { b.lat_omega[c] = 0.f; b.lat_domega[c] = 0.f; }
+      }
+      b.lat_phi[c] = ph;
     }
-    b.lat_phi[c] = ph;
   }
   {
-    const double ws = vc_wave_sum_d(loss);
-    if (lane == 0) sm_lc[wave] = ws;
-    __syncthreads();
+    const double ws = vc_wave_sum_d63(loss);
+    if (lane == 63) sm_lc[wave] = ws;
+    __syncthreads();                        // (only the 4 live waves take part; also orders sm_w)
+    if (vel && !boot && (int)threadIdx.x < d.NW) {
+      const int j = threadIdx.x;
+      float t = 0.f;
+      for (int w = 0; w < VC_TC / 64; ++w) t += sm_w[w][j];
+      b.PW[(size_t)cblock * d.NW + j] = t;
+    }
     if (threadIdx.x == 0) {
       double t = 0.0;
-      for (int w = 0; w < 16; ++w) t += sm_lc[w];
+      for (int w = 0; w < VC_TC / 64; ++w) t += sm_lc[w];
       b.LPF[(size_t)(s & 1) * d.nlpf + d.nb_post_gene + cblock] = t;
     }
   }
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(1024) void vc_tail_kernel(const VcDims d, const VcB
   // counter, s = t + 1 is also the 1-based optimiser step of the update applied here)
   const long long s = *step_dev;
   VcOpt o;
-  o.step_size = boot ? 0.f : vc_adam_step_size(s, a.lr0, a.lrd_l, a.b1l, a.b2l);
+  o.step_size = boot ? 0.f : b.step_size[0];       // written by K_main together with the counter
   o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip;
   if ((int)blockIdx.x < d.nb_post_gene) vc_tail_gene_block<MQ>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, boot);
   else vc_tail_cell_block(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, boot);
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(1024) void vc_tail_kernel(const VcDims d, const VcB
 
 void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                     const VcAdamArgs& a, int boot, hipStream_t st) {
-  const dim3 grid(d.nb_post_gene + d.nb_post_cell), block(1024);
+  const dim3 grid(d.nb_post_gene + d.nb_tail_cell), block(1024);
   if (d.nq <= 2) hipLaunchKernelGGL(vc_tail_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
   else if (d.nq <= 6) hipLaunchKernelGGL(vc_tail_kernel<6>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
   else hipLaunchKernelGGL(vc_tail_kernel<VC_MAXQ>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
@@ -599,6 +608,23 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
   const int fin_per = lrmn ? d.R + 2 : 2;
   const int nelem = nw * fin_per;
   const bool cnd = CND(VC_SITE_NUOMEGA);
+  // the standard-normal draws of the nu_omega-related elements: element (j, ce) owns eps index e_idx -- mean-field ce = 1:
+  // nu_omega[j]; LRMN ce = 1..R: eps_W[ce - 1], ce = R + 1: eps_D[Ng + j] -- at step s - 1 (gradient of the finished step)
+  // and at step s (next sample, shared through LDS).  Drawn first: they depend on nothing and hide the loads' latency.
+  __shared__ float s_en[VC_NWE];
+  float e_old0 = 0.f;                       // of this thread's first element (tt = t); further elements redraw below
+  for (int tt = t; tt < nelem; tt += 256) {
+    const int j = tt / fin_per, ce = tt % fin_per;
+    long long e_idx = -1;
+    if (!lrmn) { if (ce == 1) e_idx = d.eoff[VC_E_NUOMEGA] + j; }
+    else if (ce >= 1) e_idx = ce <= d.R ? d.eoff[VC_E_LRMN_W] + (ce - 1) : d.eoff[VC_E_LRMN_D] + (long long)d.Ng + j;
+    float en = 0.f;
+    if (e_idx >= 0) {
+      en = vc_philox_normal(seed, s, e_idx);
+      if (!boot && tt == t) e_old0 = vc_philox_normal(seed, s - 1, e_idx);
+    }
+    s_en[tt] = en;
+  }
   // this block's cells: the basis of the next phase (written by K_tail) is requested now
   const int c = blockIdx.x * 256 + t;
   float s1 = 0.f, c1 = 1.f;
@@ -623,22 +649,22 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     for (int q = 0; q < 2; ++q) {
       const int j = wv + 4 * q;
       if (j < nw)
-        for (int i = lane; i < d.nb_post_cell; i += 64) u[q] += (double)b.PW[(size_t)i * d.NW + j];
+        for (int i = lane; i < d.nb_tail_cell; i += 64) u[q] += (double)b.PW[(size_t)i * d.NW + j];
     }
     if (first) {
-      sl = vc_wave_sum_d(sl);
-      if (lane == 0) sm_lossw[wv] = sl;
+      sl = vc_wave_sum_d63(sl);
+      if (lane == 63) sm_lossw[wv] = sl;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int j = wv + 4 * q;
-      if (j < nw) { const double r = vc_wave_sum_d(u[q]); if (lane == 0) sm_up[j] = (float)r; }
+      if (j < nw) { const double r = vc_wave_sum_d63(u[q]); if (lane == 63) sm_up[j] = (float)r; }
     }
     for (int j = wv + 8; j < nw; j += 4) {
       double r = 0.0;
-      for (int i = lane; i < d.nb_post_cell; i += 64) r += (double)b.PW[(size_t)i * d.NW + j];
-      r = vc_wave_sum_d(r);
-      if (lane == 0) sm_up[j] = (float)r;
+      for (int i = lane; i < d.nb_tail_cell; i += 64) r += (double)b.PW[(size_t)i * d.NW + j];
+      r = vc_wave_sum_d63(r);
+      if (lane == 63) sm_up[j] = (float)r;
     }
   }
   __syncthreads();
@@ -658,7 +684,7 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
   }
   if (!vel) return;
   // ---- gradient + ClippedAdam of the nu_omega-related parameters: one thread per element, every block alike ----------
-  const float step_size = boot ? 0.f : vc_adam_step_size(s, a.lr0, a.lrd_l, a.b1l, a.b2l);
+  const float step_size = boot ? 0.f : b.step_size[0];
   for (int tt = t; tt < nelem; tt += 256) {
     const int j = tt / fin_per, ce = tt % fin_per;
     const long long i = (long long)d.Ng + j;
@@ -670,19 +696,26 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
         const float x = b.NWS[3 * VC_NWE + j], sd = b.sd_w[j];
         gx = sm_up[j] - d.root_w * (x - b.mu_w[j]) / (sd * sd);
       }
+      // eps of the finished step for this element (first element of the thread: drawn up front)
+      float eo = e_old0;
+      if (tt != t) {
+        long long e_idx = -1;
+        if (!lrmn) { if (ce == 1) e_idx = d.eoff[VC_E_NUOMEGA] + j; }
+        else if (ce >= 1) e_idx = ce <= d.R ? d.eoff[VC_E_LRMN_W] + (ce - 1) : d.eoff[VC_E_LRMN_D] + i;
+        eo = e_idx >= 0 ? vc_philox_normal(seed, s - 1, e_idx) : 0.f;
+      }
       float gv;
       if (!lrmn) {
         if (ce == 0) gv = -gx;
-        else gv = cnd ? 0.f : -gx * expf(p) * vc_philox_normal(seed, s - 1, d.eoff[VC_E_NUOMEGA] + j) - d.root_w;
+        else gv = cnd ? 0.f : -gx * expf(p) * eo - d.root_w;
       } else {
         if (ce == 0) gv = -gx;
         else if (ce <= d.R) {
           const float w = expf(p);
-          const float ew = vc_philox_normal(seed, s - 1, d.eoff[VC_E_LRMN_W] + (ce - 1));
-          gv = (w > 0.f) ? -gx * ew * w : 0.f;
+          gv = (w > 0.f) ? -gx * eo * w : 0.f;
         } else {
           const float dg = expf(p);
-          gv = -gx * vc_philox_normal(seed, s - 1, d.eoff[VC_E_LRMN_D] + i) / (2.f * sqrtf(dg)) * dg;
+          gv = -gx * eo / (2.f * sqrtf(dg)) * dg;
         }
       }
       float mm = b.NWS[VC_NWE + tt], vv = b.NWS[2 * VC_NWE + tt];
@@ -698,16 +731,17 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     const float* np = s_np + j * fin_per;
     float val, lq = 0.f;
     const long long i = (long long)d.Ng + j;
+    const float* en = s_en + j * fin_per;
     if (!lrmn) {
-      const float e = vc_philox_normal(seed, s, d.eoff[VC_E_NUOMEGA] + j);
+      const float e = en[1];
       if (first) b.eps_used[d.eoff[VC_E_NUOMEGA] + j] = e;
       const float u = np[1];
       val = np[0] + expf(u) * e;
       lq = -0.5f * e * e - u - 0.5f * VC_LOG_2PI;
     } else {
       float delta = 0.f;
-      for (int k = 0; k < d.R; ++k) delta += expf(np[1 + k]) * vc_philox_normal(seed, s, d.eoff[VC_E_LRMN_W] + k);
-      const float ed = vc_philox_normal(seed, s, d.eoff[VC_E_LRMN_D] + i);
+      for (int k = 0; k < d.R; ++k) delta += expf(np[1 + k]) * en[1 + k];
+      const float ed = en[d.R + 1];
       if (first) b.eps_used[d.eoff[VC_E_LRMN_D] + i] = ed;
       delta += sqrtf(expf(np[d.R + 1])) * ed;
       val = np[0] + delta;
@@ -729,9 +763,11 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
   }
   // ---- omega_c and d omega / d phi of step s into the cell records ---------------------------------------------------
   if (c < d.Nc) {
+    // harmonics by the angle-addition recurrence; fully unrolled (compile-time indices keep sk / ck in registers)
     float sk[VC_MAXH], ck[VC_MAXH];
     sk[0] = s1; ck[0] = c1;
-    for (int k = 1; k < d.Hw && k < VC_MAXH; ++k) {
+#pragma unroll
+    for (int k = 1; k < VC_MAXH; ++k) {
       sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
       ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
     }
@@ -739,10 +775,12 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     for (int xq = 0; xq < d.Nx; ++xq) {
       const float* nwp = s_nuw + xq * d.Nhw;
       float om = nwp[0], dd = 0.f;
-      for (int k = 0; k < d.Hw; ++k) {
-        om += nwp[2 * k + 1] * sk[k] + nwp[2 * k + 2] * ck[k];
-        dd += (float)(k + 1) * (nwp[2 * k + 1] * ck[k] - nwp[2 * k + 2] * sk[k]);
-      }
+#pragma unroll
+      for (int k = 0; k < VC_MAXH; ++k)
+        if (k < d.Hw) {
+          om += nwp[2 * k + 1] * sk[k] + nwp[2 * k + 2] * ck[k];
+          dd += (float)(k + 1) * (nwp[2 * k + 1] * ck[k] - nwp[2 * k + 2] * sk[k]);
+        }
       const float dx = b.Dm[(size_t)xq * d.Nc + c];
       omega += dx * om;
       domega += dx * dd;

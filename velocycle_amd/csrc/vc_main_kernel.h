@@ -44,6 +44,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef VC_LB_SINGLE
 #define VC_LB_SINGLE 2    // minimum waves per SIMD the one-matrix kernels (8 genes per lane) are compiled for
 #endif
+#ifndef VC_SWAP_REDUCE
+#define VC_SWAP_REDUCE 0  // 1: the per-cell sums of TWO consecutive cells share one 64-lane reduction (v_permlane32_swap)
+#endif
 #ifndef VC_RCP_MERGE
 #define VC_RCP_MERGE 0    // 1: one reciprocal of t_U * zp instead of rcp(t_U) and rcp(zp) (S+U negative-binomial kernel)
 #endif
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   VC_STAMP(1);
   float keep0 = 0.f, keep1 = 0.f, keep2 = 0.f;
   // one cell against the lane's genes: sv/uv = the counts, rec = the cell record, i = staging lane of the cell
-  auto cell = [&](const v2f* sv, const v2f* uv, const VcCellRec<H, NB>& rec, const int i) __attribute__((always_inline)) {
+  auto cell = [&](const v2f* sv, const v2f* uv, const VcCellRec<H, NB>& rec, float& p0, float& p1, float& p2) __attribute__((always_inline)) {
     v2f A1 = v2(0.f), A2 = v2(0.f), A3 = v2(0.f);
 #ifdef VC_STREAM_ONLY        // measurement aid: the loads and one fma per pair, nothing else (results are meaningless)
 #pragma unroll
@@ -338,18 +341,46 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       if (FULL) A2 = v2_fma(w, e2, A2);
       if (HAS_U) A3 = v2_fma(w, dd, A3);
     }
-    // per-cell sums over the genes of this wave
-    if (KIND == VC_KIND_PHASE) {
-      const float t0 = vc_wave_sum(A1.x + A1.y);
-      keep0 = (lane == i) ? t0 : keep0;
-    } else if (KIND == VC_KIND_VU) {
-      const float t0 = vc_wave_sum(A3.x + A3.y);
-      keep0 = (lane == i) ? t0 : keep0;
-    } else {
-      const float t0 = vc_wave_sum(A1.x + A1.y), t1 = vc_wave_sum(A2.x + A2.y), t2 = vc_wave_sum(A3.x + A3.y);
-      keep0 = (lane == i) ? t0 : keep0;
+    // per-lane partials of the per-cell sums over the genes of this wave
+    if (KIND == VC_KIND_PHASE) { p0 = A1.x + A1.y; }
+    else if (KIND == VC_KIND_VU) { p0 = A3.x + A3.y; }
+    else { p0 = A1.x + A1.y; p1 = A2.x + A2.y; p2 = A3.x + A3.y; }
+  };
+  // 64-lane sums of one cell's partials, staged in lane i of keep0..2
+  auto stage1 = [&](float p0, float p1, float p2, const int i) __attribute__((always_inline)) {
+    const float t0 = vc_wave_sum(p0);
+    keep0 = (lane == i) ? t0 : keep0;
+    if (NCO == 3) {
+      const float t1 = vc_wave_sum(p1), t2 = vc_wave_sum(p2);
       keep1 = (lane == i) ? t1 : keep1;
       keep2 = (lane == i) ? t2 : keep2;
+    }
+  };
+  // the same for the cells i and i + 1 together: v_permlane32_swap puts cell i's lane pairs (l, l + 32) into lanes 0..31
+  // and cell i + 1's into lanes 32..63, one add folds them, then ONE 32-lane DPP reduction serves both cells
+  // (7 VALU instead of 12 per pair and row)
+  auto pair_sum = [&](float x0, float x1, float& t0, float& t1) __attribute__((always_inline)) {
+    // inline asm: hipcc 7.2 maps BOTH results of __builtin_amdgcn_permlane32_swap to the first register (x0 + x0 comes
+    // out); a VALU write needs a wait state before the swap reads it, and the compiler does not look into asm statements
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(x1));
+    float v = x0 + x1;
+    v += vc_dpp<0x111, 0xf>(v);
+    v += vc_dpp<0x112, 0xf>(v);
+    v += vc_dpp<0x114, 0xf>(v);
+    v += vc_dpp<0x118, 0xf>(v);
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v));
+    t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  };
+  auto stage2 = [&](const float* pa, const float* pb, const int i) __attribute__((always_inline)) {
+    float t0, t1;
+    pair_sum(pa[0], pb[0], t0, t1);
+    keep0 = (lane == i) ? t0 : ((lane == i + 1) ? t1 : keep0);
+    if (NCO == 3) {
+      pair_sum(pa[1], pb[1], t0, t1);
+      keep1 = (lane == i) ? t0 : ((lane == i + 1) ? t1 : keep1);
+      pair_sum(pa[2], pb[2], t0, t1);
+      keep2 = (lane == i) ? t0 : ((lane == i + 1) ? t1 : keep2);
     }
   };
   auto flush = [&](long long cb, int n) {      // coalesced store of the staged per-cell sums of the last n <= 64 cells
@@ -370,6 +401,36 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 #pragma unroll
         for (int j = 0; j < PF; ++j) fetch(j, j);
       }
+      auto unpack = [&](int j, v2f* sv, v2f* uv) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q4 = 0; q4 < NV4; ++q4) {
+          sv[2 * q4] = HAS_S ? v2f{s_bf[j][q4].x, s_bf[j][q4].y} : v2(0.f);
+          sv[2 * q4 + 1] = HAS_S ? v2f{s_bf[j][q4].z, s_bf[j][q4].w} : v2(0.f);
+          uv[2 * q4] = HAS_U ? v2f{u_bf[j][q4].x, u_bf[j][q4].y} : v2(0.f);
+          uv[2 * q4 + 1] = HAS_U ? v2f{u_bf[j][q4].z, u_bf[j][q4].w} : v2(0.f);
+        }
+      };
+      if (VC_SWAP_REDUCE && NBUF == 2) {
+        // two cells per trip; their per-cell sums are reduced together
+        for (int i0 = 0; i0 < ncell; i0 += 2) {
+          float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f};
+          v2f sv[NP], uv[NP];
+          fetch(1, i0 + 1);
+          unpack(0, sv, uv);
+          cell(sv, uv, rec_bf[0], pa[0], pa[1], pa[2]);
+          if (i0 + 1 < ncell) {
+            fetch(0, i0 + 2);
+            unpack(1, sv, uv);
+            cell(sv, uv, rec_bf[1], pb[0], pb[1], pb[2]);
+            stage2(pa, pb, i0 & 63);
+            const int i = i0 + 1;
+            if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);
+          } else {
+            stage1(pa[0], pa[1], pa[2], i0 & 63);
+            flush(cbeg + (i0 & ~63), (i0 & 63) + 1);
+          }
+        }
+      } else
       for (int i0 = 0; i0 < ncell; i0 += NBUF) {
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
@@ -377,14 +438,10 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           if (i >= ncell) break;
           fetch((j + PF) % NBUF, i + PF);
           v2f sv[NP], uv[NP];
-#pragma unroll
-          for (int q4 = 0; q4 < NV4; ++q4) {
-            sv[2 * q4] = HAS_S ? v2f{s_bf[j][q4].x, s_bf[j][q4].y} : v2(0.f);
-            sv[2 * q4 + 1] = HAS_S ? v2f{s_bf[j][q4].z, s_bf[j][q4].w} : v2(0.f);
-            uv[2 * q4] = HAS_U ? v2f{u_bf[j][q4].x, u_bf[j][q4].y} : v2(0.f);
-            uv[2 * q4 + 1] = HAS_U ? v2f{u_bf[j][q4].z, u_bf[j][q4].w} : v2(0.f);
-          }
-          cell(sv, uv, rec_bf[j], i & 63);
+          unpack(j, sv, uv);
+          float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+          cell(sv, uv, rec_bf[j], p0, p1, p2);
+          stage1(p0, p1, p2, i & 63);
           if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);
         }
       }
@@ -452,7 +509,12 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   if (threadIdx.x == 0) b.LO[blockIdx.x] = (sm_ll[0] + sm_ll[1]) + (sm_ll[2] + sm_ll[3]);
   // fused pipeline (vc_svi_step_fused): nothing in this launch reads the device step counter, so it is advanced here;
   // the two launches that follow read s = t + 1 (= the 1-based optimiser step, = the index of the next sample)
-  if (b.step_ctr && blockIdx.x == 0 && threadIdx.x == 0) *b.step_ctr += 1;
+  if (b.step_ctr && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long s = *b.step_ctr + 1;
+    *b.step_ctr = s;
+    // lr0 lrd^s sqrt(1 - b2^s) / (1 - b1^s) in fp64, once per step instead of once per thread of the next launch
+    b.step_size[0] = vc_adam_step_size(s, b.adam_lr0, b.adam_lrd_l, b.adam_b1l, b.adam_b2l);
+  }
   VC_STAMP(3);
 #ifdef VC_DBG_TIMES
   if ((threadIdx.x & 63) == 0) {

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
               else {
                 si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
                 logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) -
-                        d.gamma_beta * si - lgammaf(d.gamma_alpha);
+                        d.gamma_beta * si - d.lgamma_alpha;
                 b.lat[VC_SITE_SHAPE_INV][g] = si;
               }
             }

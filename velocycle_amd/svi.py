@@ -131,7 +131,10 @@ class SVIRunner:
         # "torch": PyTorch ops; "hip": one kernel after the gradient; "fused": merged with the last gradient kernel
         # (4 launches per step); "fused3": the three-launch step of vc_svi_step_fused (reductions + chain rule + optimiser +
         # the NEXT step's guide sample in one kernel) -- the single-rank default
-        self.adam_impl = adam_impl or (("hip" if self.do_reduce else "fused3") if mode == "perf" else "torch")
+        # (VC_ADAM_IMPL overrides the single-rank perf default for A/B measurements, e.g. the unfused "fused" sequence)
+        import os
+        self.adam_impl = adam_impl or (("hip" if self.do_reduce else os.environ.get("VC_ADAM_IMPL", "fused3"))
+                                       if mode == "perf" else "torch")
         if self.adam_impl in ("fused", "fused3") and (self.do_reduce or mode != "perf"):
             raise ValueError(f"adam_impl={self.adam_impl!r} needs mode='perf' on a single rank")
         self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
