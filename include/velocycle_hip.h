@@ -243,6 +243,13 @@ int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64_t seed, in
 int vc_svi_step_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad, double* loss_dev,
                       int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr, double lrd, double beta1,
                       double beta2, double adam_eps, double clip_norm, int prime, void* hip_stream);
+/* n_steps of the above, back to back (the body of `for step in range(num_steps): svi.step(...)`,
+ * velocity_inference_model.py:118-121, with verbose=False): 3 * n_steps asynchronous launches on hip_stream from one
+ * call, no host round trip in between -- measured faster than replaying the same launches from a hipGraph (ROCm 7.2:
+ * ~2 us per kernel node, profiles/r02_step_overhead.md).  loss_slots >= n_steps keeps every loss of the run. */
+int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad, double* loss_dev,
+                     int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr, double lrd, double beta1,
+                     double beta2, double adam_eps, double clip_norm, int prime, int64_t n_steps, void* hip_stream);
 
 /* One draw of the guide pushed through the deterministic part of the model (what
  * `Predictive(model, guide=guide, num_samples=1)` evaluates for the latent and deterministic sites;

@@ -49,6 +49,7 @@ for n_ranks, nc in ((8, 6250), (4, 12500), (2, 25000), (1, 50000)):
     spec = make_velocity_spec(nc, 2000, mode, 1, 1, seed=0, device=dev)
     row = {"ranks": n_ranks, "cells": nc}
     variants = [("unfused_4_launches", dict(adam_impl="fused", use_graph=True)),
+                ("unfused_4_launches_eager", dict(adam_impl="fused", use_graph=False)),
                 ("fused_3_launches", dict(adam_impl="fused3", use_graph=True)),
                 ("fused_3_launches_eager", dict(adam_impl="fused3", use_graph=False))]
     if with_nccl:

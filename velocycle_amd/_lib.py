@@ -82,6 +82,9 @@ EXPORTS = {
     "vc_svi_step_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_int, C.c_void_p]),
+    "vc_svi_run_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, C.c_int, C.c_int64, C.c_void_p]),
     "vc_clipped_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

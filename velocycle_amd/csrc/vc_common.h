@@ -39,7 +39,7 @@ struct VcDims {
   float gamma_alpha, gamma_beta, sigma_ln_s, sigma_ln_u, rho_mean, rho_std, rho_scale;
   long long poff[VC_P_COUNT];   // parameter offsets (floats) in the flat buffers, -1 if absent
   long long eoff[VC_E_COUNT];   // eps offsets
-  long long eps_n_global;
+  long long eps_n_global, eps_total;
   int nb_pre_gene, nb_pre_cell, nb_post_gene, nb_post_cell, n_main_wg;
   int nb_tail_cell;       // fused pipeline: cell blocks of K_tail (256 cells each)
   int nlpf;               // fused pipeline: loss slots per half of LPF = nb_post_gene + nb_tail_cell + 1
@@ -79,6 +79,7 @@ struct VcBufs {
   double* LPF;                              // [2][nlpf] prior / guide loss terms of the samples of step s in half s & 1
   double* LPP;                              // [nb_post_gene] r-only likelihood terms of the gene blocks (K_tail)
   float* NWS;                               // [4][VC_MAX_NW * (VC_MAX_RANK + 2)] snapshot of the nu_omega parameters, moments, value
+  float* EPS;                               // [3][eps_total] ring of standard-normal draws: slot (step % 3) holds the draws of `step`
 #ifdef VC_DBG_TIMES
   unsigned long long* dbg;                  // measurement aid: 4 wall-clock stamps per wave of K_main
 #endif
@@ -87,8 +88,12 @@ struct VcBufs {
 #ifdef __HIPCC__
 #ifdef VC_DBG_TIMES      // measurement aid: per-block wall-clock stamps of the small kernels (kid 0 pre, 1 post, 2 fin)
 #define VC_KSTAMP(kid, k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) b.dbg[(size_t)d.n_main_wg * 32 + ((size_t)(kid) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+// per-WAVE stamps of the fused kernels (kid 0 K_tail, 1 K_omega), 8 slots per wave, behind the regions above
+#define VC_WSTAMP(kid, k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) b.dbg[(size_t)d.n_main_wg * 32 + 3 * 4096 * 8 + (((size_t)(kid) * 4096 + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); } while (0)
+#define VC_DBG_WORDS(nwg) ((size_t)(nwg) * 32 + 3 * 4096 * 8 + 2 * 4096 * 16 * 8)
 #else
 #define VC_KSTAMP(kid, k) do {} while (0)
+#define VC_WSTAMP(kid, k) do {} while (0)
 #endif
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions with DPP row operations; the total lands in lane 63.

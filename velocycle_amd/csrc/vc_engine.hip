@@ -197,6 +197,7 @@ static void build_layout(vc_engine* e) {
   for (int i = 0; i < VC_P_COUNT; ++i) d.poff[i] = L.offset[i];
   for (int i = 0; i < VC_E_COUNT; ++i) d.eoff[i] = L.eps_offset[i];
   d.eps_n_global = L.eps_n_global;
+  d.eps_total = L.eps_total;
 }
 
 extern "C" int vc_abi_version(void) { return VC_ABI_VERSION; }
@@ -270,7 +271,7 @@ extern "C" void vc_destroy(vc_engine* e) {
 #ifdef VC_DBG_TIMES
   if (e->b.dbg && getenv("VC_DBG_TIMES_OUT")) {
     (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h((size_t)e->d.n_main_wg * 32 + 3 * 4096 * 8);
+    std::vector<unsigned long long> h(VC_DBG_WORDS(e->d.n_main_wg));
     (void)hipMemcpy(h.data(), e->b.dbg, h.size() * 8, hipMemcpyDeviceToHost);
     FILE* f = fopen(getenv("VC_DBG_TIMES_OUT"), "wb");
     if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
@@ -659,7 +660,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.CO, (size_t)d.nGB * 3 * d.Nc));
   TRY(e->dalloc(&b.LO, (size_t)d.n_main_wg));
 #ifdef VC_DBG_TIMES
-  TRY(e->dalloc(&b.dbg, (size_t)d.n_main_wg * 32 + 3 * 4096 * 8));   // + per-block stamps of K_pre / K_post / K_fin
+  TRY(e->dalloc(&b.dbg, VC_DBG_WORDS(d.n_main_wg)));   // + per-block stamps of K_pre / K_post / K_fin, per-wave of K_tail / K_omega
+  HIPCHK(e, hipMemset(b.dbg, 0, VC_DBG_WORDS(d.n_main_wg) * 8));
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
   TRY(e->dalloc(&b.PW, (size_t)((d.Nc + 255) / 256) * std::max(1, d.NW)));      // K_post: 1024-cell blocks; K_tail: 256
@@ -672,6 +674,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   HIPCHK(e, hipMemset(b.LPP, 0, sizeof(double) * d.nb_post_gene));
   TRY(e->dalloc(&b.NWS, 4 * (size_t)VC_MAX_NW * (VC_MAX_RANK + 2)));
   HIPCHK(e, hipMemset(b.NWS, 0, 4 * sizeof(float) * VC_MAX_NW * (VC_MAX_RANK + 2)));
+  TRY(e->dalloc(&b.EPS, 3 * (size_t)e->layout.eps_total));
+  HIPCHK(e, hipMemset(b.EPS, 0, 3 * sizeof(float) * e->layout.eps_total));
   b.step_ctr = nullptr;
   TRY(e->dalloc(&b.step_size, 1));
   HIPCHK(e, hipMemset(b.step_size, 0, sizeof(float)));
@@ -842,19 +846,20 @@ extern "C" int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64
   return VC_OK;
 }
 
-extern "C" int vc_svi_step_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad,
-                                 double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
-                                 double lrd, double beta1, double beta2, double adam_eps, double clip_norm, int prime,
-                                 void* hip_stream) {
+extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad,
+                                double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
+                                double lrd, double beta1, double beta2, double adam_eps, double clip_norm, int prime,
+                                int64_t n_steps, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
-  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_step_fused before vc_finalize");
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_run_fused before vc_finalize");
   if (e->cfg.world_size != 1)
-    return e->fail(VC_ERR_STATE, "vc_svi_step_fused applies the optimiser inside the gradient kernels: single rank only "
+    return e->fail(VC_ERR_STATE, "vc_svi_run_fused applies the optimiser inside the gradient kernels: single rank only "
                                  "(use vc_elbo_grad + all-reduce + vc_clipped_adam when cells are sharded)");
   if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev)
-    return e->fail(VC_ERR_ARG, "vc_svi_step_fused: null buffer (the device step counter is required)");
+    return e->fail(VC_ERR_ARG, "vc_svi_run_fused: null buffer (the device step counter is required)");
+  if (n_steps < 0) return e->fail(VC_ERR_ARG, "vc_svi_run_fused: negative n_steps");
   if (!(lr > 0.0) || !(lrd > 0.0) || !(beta1 > 0.0 && beta1 < 1.0) || !(beta2 > 0.0 && beta2 < 1.0))
-    return e->fail(VC_ERR_ARG, "vc_svi_step_fused: lr, lrd must be positive and the betas inside (0, 1)");
+    return e->fail(VC_ERR_ARG, "vc_svi_run_fused: lr, lrd must be positive and the betas inside (0, 1)");
   hipStream_t st = (hipStream_t)hip_stream;
   VcAdamArgs a;
   a.m = exp_avg; a.v = exp_avg_sq;
@@ -863,27 +868,37 @@ extern "C" int vc_svi_step_fused(vc_engine* e, float* params, uint64_t seed, int
   a.header = (int)e->layout.header;
   const long long* sd = (const long long*)step_dev;
   const int with_hist = e->hist_each_step ? 1 : 0;
-  if (prime) {       // sample the step *step_dev from the parameters as they are: tables, site values, prior terms
+  if (prime && n_steps > 0) {   // sample the step *step_dev from the parameters as they are: tables, site values, prior terms
     vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 1, st);
     vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 1, with_hist, st);
   }
   VcBufs b2 = e->b;
   b2.step_ctr = (long long*)step_dev;
   b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l;
-  if (e->timing) {
-    if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
-    auto& pr = e->ev_pool[e->ev_used++];
-    HIPCHK(e, hipEventRecord(pr.first, st));
-    e->main_fn(e->d, b2, st);
-    HIPCHK(e, hipEventRecord(pr.second, st));
-  } else {
-    e->main_fn(e->d, b2, st);
+  for (int64_t i = 0; i < n_steps; ++i) {
+    if (e->timing) {
+      if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
+      auto& pr = e->ev_pool[e->ev_used++];
+      HIPCHK(e, hipEventRecord(pr.first, st));
+      e->main_fn(e->d, b2, st);
+      HIPCHK(e, hipEventRecord(pr.second, st));
+    } else {
+      e->main_fn(e->d, b2, st);
+    }
+    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, st);
+    vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
   }
-  vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, st);
-  vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
   return VC_OK;
+}
+
+extern "C" int vc_svi_step_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad,
+                                 double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
+                                 double lrd, double beta1, double beta2, double adam_eps, double clip_norm, int prime,
+                                 void* hip_stream) {
+  return vc_svi_run_fused(e, params, seed, step_dev, grad, loss_dev, loss_slots, exp_avg, exp_avg_sq, lr, lrd, beta1, beta2,
+                          adam_eps, clip_norm, prime, 1, hip_stream);
 }
 
 extern "C" int vc_sample_guide(vc_engine* e, const float* params, const float* eps, uint64_t seed, int64_t step,

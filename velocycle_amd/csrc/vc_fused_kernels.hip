@@ -15,7 +15,10 @@
 //
 // The arithmetic of every piece is the one of vc_small_kernels.hip (K_pre / K_post / K_fin / ClippedAdam), statement by
 // statement; tests/test_hip_fused.py holds the two paths against each other.  eps comes from the Philox stream only
-// (seed, step, index): the host-eps parity path stays on the unfused kernels.
+// (seed, step, index): the host-eps parity path stays on the unfused kernels.  No Philox draw sits on the critical path:
+// extra blocks of K_omega(t) draw the whole eps vector of step t + 2 into a three-slot ring (EPS[step % 3]) while the few
+// blocks of the nu_omega chain run; K_tail / K_omega read the draws of the step being finished (for the scale gradients)
+// and of the next sample from that ring -- slots that no block of the same launch writes.
 // Reference semantics restated: velocity_inference_guide.py:9-141, phase_inference_guide.py:10-56, priors of
 // velocity_inference_model.py:322-353,383 / phase_inference_model.py:360-366,392, pyro ClippedAdam.
 #include "vc_common.h"
@@ -51,9 +54,15 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   __shared__ float sm_ws[2][64][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = gblock * 64 + lane;
-  const int role = wave;
+  // waves 12..15 -> roles 12, 14, 15, 13: the heaviest role (13: log gamma / log beta or the LRMN core) sits on the SIMD
+  // (wave % 4 == 3) whose other waves hold no nu[h] role, so that its serial chain does not share an issue port with them
+  const int role = wave < 12 ? wave : (wave == 12 ? 12 : (wave == 15 ? 13 : wave + 1));
   const bool vel = d.model == VC_MODEL_VELOCITY;
   const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+  // the draws of the finished step (s - 1) and of the next sample (s): boot draws them itself (the ring is empty)
+  const float* __restrict__ eps_new = b.EPS + (size_t)(s % 3) * d.eps_total;
+  const float* __restrict__ eps_old = b.EPS + (size_t)((s + 2) % 3) * d.eps_total;
+  auto draw_new = [&](long long idx) { return boot ? vc_philox_normal(seed, s, idx) : eps_new[idx]; };
   const bool nb = d.noise == VC_NOISE_NB;
   const int K = d.K, Nh = d.Nh;
   const float rw = d.root_w;
@@ -63,20 +72,20 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   const bool r_nu = role < Nh;
   const bool r_dnu = !r_nu && role < Nh + d.Nb && d.with_dnu;
   const bool r_si = role == 12 && nb;
-  const bool r_mf = role == 13 && vel && !lrmn;
+  const bool r_mf = (role == 13 || role == 14) && vel && !lrmn;      // mean-field: role 13 log gamma, role 14 log beta
   const bool r_core = role == 13 && lrmn;
   const bool r_cov = (role == 14 || role == 15) && lrmn;
   const int kbase = (role - 14) * VC_COVW;            // first cov_factor column of a cov role
 
-  // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k draws, readlane
-  // broadcasts while every lane is active (the eps_used copy is not used: another block may already hold step s there)
+  VC_WSTAMP(0, 0);
+  // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k fetches, readlane
+  // broadcasts while every lane is active
   float ew_old[VC_MAX_RANK], ew_new[VC_MAX_RANK];
   {
     float mine_old = 0.f, mine_new = 0.f;
     if (r_cov && lane < d.R) {
-      if (!boot) mine_old = vc_philox_normal(seed, s - 1, d.eoff[VC_E_LRMN_W] + lane);
-      mine_new = vc_philox_normal(seed, s, d.eoff[VC_E_LRMN_W] + lane);
-      if (gblock == 0 && role == 14) b.eps_used[d.eoff[VC_E_LRMN_W] + lane] = mine_new;
+      if (!boot) mine_old = eps_old[d.eoff[VC_E_LRMN_W] + lane];
+      mine_new = draw_new(d.eoff[VC_E_LRMN_W] + lane);
     }
 #pragma unroll
     for (int k = 0; k < VC_MAX_RANK; ++k) {
@@ -103,8 +112,8 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       jj = (long long)g * Nh + role;
       off[0] = (int)(d.poff[VC_P_NU_LOCS] + jj); off[1] = (int)(d.poff[VC_P_NU_USCALES] + jj); nown = 2;
       in[1] = b.sd_nu[jj]; in[2] = b.mu_nu[jj];
-      if (!boot && !CND(VC_SITE_NU)) { in[0] = b.lat[VC_SITE_NU][jj]; in[3] = b.eps_used[d.eoff[VC_E_NU] + jj]; }
-      if (!CND(VC_SITE_NU)) e0 = vc_philox_normal(seed, s, d.eoff[VC_E_NU] + jj);   // a hidden site's draw is never used
+      if (!boot && !CND(VC_SITE_NU)) { in[0] = b.lat[VC_SITE_NU][jj]; in[3] = eps_old[d.eoff[VC_E_NU] + jj]; }
+      if (!CND(VC_SITE_NU)) e0 = draw_new(d.eoff[VC_E_NU] + jj);   // a hidden site's draw is never used
     } else if (r_dnu) {
       jj = (long long)(role - Nh) * d.Ng + g;
       off[0] = (int)(d.poff[VC_P_DNU_LOCS] + jj); nown = 1;
@@ -125,20 +134,24 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
         if (!CND(VC_SITE_LOGBETA)) in[4] = b.lat[VC_SITE_LOGBETA][g];
       }
       if (r_mf) {
-        off[0] = (int)(d.poff[VC_P_LOGGAMMA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGGAMMA_USCALES] + g);
-        off[2] = (int)(d.poff[VC_P_LOGBETA_LOCS] + g); off[3] = (int)(d.poff[VC_P_LOGBETA_USCALES] + g); nown = 4;
-        if (!boot) { in[7] = b.eps_used[d.eoff[VC_E_LOGGAMMA] + g]; in[8] = b.eps_used[d.eoff[VC_E_LOGBETA] + g]; }
-        e0 = vc_philox_normal(seed, s, d.eoff[VC_E_LOGGAMMA] + g);
-        e1 = vc_philox_normal(seed, s, d.eoff[VC_E_LOGBETA] + g);
+        if (role == 13) {
+          off[0] = (int)(d.poff[VC_P_LOGGAMMA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGGAMMA_USCALES] + g); nown = 2;
+          if (!boot) in[7] = eps_old[d.eoff[VC_E_LOGGAMMA] + g];
+          e0 = draw_new(d.eoff[VC_E_LOGGAMMA] + g);
+        } else {
+          off[0] = (int)(d.poff[VC_P_LOGBETA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGBETA_USCALES] + g); nown = 2;
+          if (!boot) in[7] = eps_old[d.eoff[VC_E_LOGBETA] + g];
+          e0 = draw_new(d.eoff[VC_E_LOGBETA] + g);
+        }
       } else {
         if (!boot) { in[7] = b.lat_delta[g]; in[8] = b.lat_sgam[g]; }
         if (r_core) {
           off[0] = (int)(d.poff[VC_P_LOGBETA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGBETA_USCALES] + g);
           off[2] = (int)(d.poff[VC_P_RHO_REAL_LOC] + g); off[3] = (int)(d.poff[VC_P_LRMN_LOC] + g);
           off[4] = (int)(d.poff[VC_P_LRMN_UCOV_DIAG] + g); nown = 5;
-          if (!boot) { in[9] = b.eps_used[d.eoff[VC_E_LOGBETA] + g]; in[10] = b.eps_used[d.eoff[VC_E_LRMN_D] + g]; }
-          e0 = vc_philox_normal(seed, s, d.eoff[VC_E_LRMN_D] + g);
-          e1 = vc_philox_normal(seed, s, d.eoff[VC_E_LOGBETA] + g);
+          if (!boot) { in[9] = eps_old[d.eoff[VC_E_LOGBETA] + g]; in[10] = eps_old[d.eoff[VC_E_LRMN_D] + g]; }
+          e0 = draw_new(d.eoff[VC_E_LRMN_D] + g);
+          e1 = draw_new(d.eoff[VC_E_LOGBETA] + g);
         } else {
 #pragma unroll
           for (int k = 0; k < VC_COVW; ++k)
@@ -156,6 +169,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       }
   }
 
+  VC_WSTAMP(0, 1);
   double loss_post = 0.0;
   if (!boot) {
     // ---- second-stage reduction of K_main's gene-level partials (as K_post) ------------------------------------
@@ -181,7 +195,9 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     }
 #pragma unroll
     for (int q = 0; q < MQ; ++q) sm[wave][q][lane] = acc[q];
+    VC_WSTAMP(0, 2);
     __syncthreads();
+    VC_WSTAMP(0, 3);
     auto T = [&](int q) {
       float t = 0.f;
 #pragma unroll
@@ -222,12 +238,15 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
         if (!CND(VC_SITE_LOGGAMMA)) g_lg = U_lg - rw * (in[1] - in[3]) / (in[2] * in[2]);
         if (!CND(VC_SITE_LOGBETA)) g_lb = U_lb - rw * (in[4] - in[6]) / (in[5] * in[5]);
         if (r_mf) {
-          const float eg = in[7], eb = in[8];
-          const bool cg = CND(VC_SITE_LOGGAMMA), cb = CND(VC_SITE_LOGBETA);
-          gg[0] = -g_lg;
-          gg[1] = cg ? 0.f : -g_lg * expf(pp[1]) * eg - rw;
-          gg[2] = -g_lb;
-          gg[3] = cb ? 0.f : -g_lb * expf(pp[3]) * eb - rw;
+          if (role == 13) {
+            const bool cg = CND(VC_SITE_LOGGAMMA);
+            gg[0] = -g_lg;
+            gg[1] = cg ? 0.f : -g_lg * expf(pp[1]) * in[7] - rw;
+          } else {
+            const bool cb = CND(VC_SITE_LOGBETA);
+            gg[0] = -g_lb;
+            gg[1] = cb ? 0.f : -g_lb * expf(pp[1]) * in[7] - rw;
+          }
         } else {
           const bool cb = CND(VC_SITE_LOGBETA);
           const float A = g_lb;
@@ -281,6 +300,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     }
   }
 
+  VC_WSTAMP(0, 4);
   // ---- the guide sample of step s from the fresh parameters (statement by statement vc_pre_kernel) ---------------
   float logp = 0.f, logq = 0.f;
   if (g < d.Ng_pad && !live) {
@@ -297,7 +317,6 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       float x;
       if (CND(VC_SITE_NU)) x = b.cnd[VC_SITE_NU][jj];
       else {
-        b.eps_used[d.eoff[VC_E_NU] + jj] = e;
         const float u = pp[1];
         x = pp[0] + expf(u) * e;
         logq += -0.5f * e * e - u - 0.5f * VC_LOG_2PI;
@@ -317,22 +336,24 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       GT[(K + 2) * NP] = 1.0f / si;
     } else if (role == 12 && boot && !nb) {
       GT[(K + 2) * NP] = 1.0f;
-    } else if (r_mf) {
-      const float eg = e0, eb = e1;
-      b.eps_used[d.eoff[VC_E_LOGGAMMA] + g] = eg;
-      b.eps_used[d.eoff[VC_E_LOGBETA] + g] = eb;
-      const float ug = pp[1], ub = pp[3];
+    } else if (r_mf && role == 13) {
+      const float eg = e0;
+      const float ug = pp[1];
       const float lg_guide = pp[0] + expf(ug) * eg;
-      const float lb_guide = pp[2] + expf(ub) * eb;
       if (!CND(VC_SITE_LOGGAMMA)) logq += -0.5f * eg * eg - ug - 0.5f * VC_LOG_2PI;
-      if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - ub - 0.5f * VC_LOG_2PI;
       const float lg = CND(VC_SITE_LOGGAMMA) ? b.cnd[VC_SITE_LOGGAMMA][g] : lg_guide;
-      const float lbv = CND(VC_SITE_LOGBETA) ? b.cnd[VC_SITE_LOGBETA][g] : lb_guide;
-      logp += vc_normal_lp(lg, in[3], in[2]) + vc_normal_lp(lbv, in[6], in[5]);
+      logp += vc_normal_lp(lg, in[3], in[2]);
       b.lat[VC_SITE_LOGGAMMA][g] = lg;
+      GT[(K + 1) * NP] = expf(lg);
+    } else if (r_mf) {
+      const float eb = e0;
+      const float ub = pp[1];
+      const float lb_guide = pp[0] + expf(ub) * eb;
+      if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - ub - 0.5f * VC_LOG_2PI;
+      const float lbv = CND(VC_SITE_LOGBETA) ? b.cnd[VC_SITE_LOGBETA][g] : lb_guide;
+      logp += vc_normal_lp(lbv, in[6], in[5]);
       b.lat[VC_SITE_LOGBETA][g] = lbv;
       GT[K * NP] = lbv;
-      GT[(K + 1) * NP] = expf(lg);
     } else if (r_cov) {
       // LowRankMultivariateNormal.rsample, low-rank part: sum_k W[g,k] eps_W[k] and sum_k W[g,k]^2 -> role 13
       float dW = 0.f, w2 = 0.f;
@@ -351,8 +372,6 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   if (live && r_core) {
     float* GT = b.GT + g;
     const float ed = e0, eb = e1;
-    b.eps_used[d.eoff[VC_E_LRMN_D] + g] = ed;
-    b.eps_used[d.eoff[VC_E_LOGBETA] + g] = eb;
     // columns 0..3 summed by role 14, 4..7 by role 15: for rank <= 5 (the reference's default) the same order of
     // additions as the sequential loop of vc_pre_kernel
     float delta = sm_ws[0][lane][0];
@@ -386,6 +405,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     b.GT[(size_t)K * NP + g] = 0.f;
     b.GT[(size_t)(K + 1) * NP + g] = 1.f;
   }
+  VC_WSTAMP(0, 5);
   // prior / guide terms of the step-s sample: fp64 block sum in fixed order
   {
     const double lt = live ? -(double)rw * ((double)logp - (double)logq) : 0.0;
@@ -398,6 +418,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       b.LPF[(size_t)(s & 1) * d.nlpf + gblock] = t;
     }
   }
+  VC_WSTAMP(0, 6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -412,6 +433,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   __shared__ float sm_w[VC_TC / 64][VC_MAX_NW];
   __shared__ double sm_lc[VC_TC / 64];
   if (threadIdx.x >= VC_TC) return;        // waves 4..15 of the block have nothing to do
+  VC_WSTAMP(0, 0);
   const int c = cblock * VC_TC + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool vel = d.model == VC_MODEL_VELOCITY;
@@ -429,9 +451,14 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
     pxy = *reinterpret_cast<const float2*>(b.pxy + 2 * (size_t)c);
     if (!cxy) {
       pp = *reinterpret_cast<const float2*>(P + poff);
-      // (x, y) of a cell are the two normals of one Philox block (the eps layout starts phi_xy at an even index)
-      const long long gi = d.eoff[VC_E_PHIXY] + 2LL * (d.cell_offset + c);
-      vc_philox_normal2(seed, s, (uint64_t)gi >> 1, ex, ey);
+      // single rank: local index == global index of the stream; boot draws directly ((x, y) of a cell are the two
+      // normals of one Philox block: the eps layout starts phi_xy at an even index)
+      const long long gi = d.eoff[VC_E_PHIXY] + 2LL * c;
+      if (boot) vc_philox_normal2(seed, s, (uint64_t)gi >> 1, ex, ey);
+      else {
+        const float2 e2 = *reinterpret_cast<const float2*>(b.EPS + (size_t)(s % 3) * d.eps_total + gi);
+        ex = e2.x; ey = e2.y;
+      }
     }
     if (!boot) {
       float2 xy = make_float2(1.f, 0.f);
@@ -468,6 +495,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
       }
     }
   }
+  VC_WSTAMP(0, 3);
   if (vel && !boot) {
     // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c) at the phases of step s - 1
     // (their sin / cos are in the cell record; higher harmonics by the angle-addition recurrence, as K_pre built them)
@@ -501,6 +529,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
     }
     if ((int)threadIdx.x < d.NW) b.NWS[3 * VC_NWE + threadIdx.x] = b.lat[VC_SITE_NUOMEGA][threadIdx.x];
   }
+  VC_WSTAMP(0, 4);
   // ---- phi_xy sample of step s, phase, Fourier basis, cell record (omega is filled by K_omega) -------------------
   if (in_range) {
     const float px = pxy.x, py = pxy.y;
@@ -509,8 +538,6 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
       x = b.cnd[VC_SITE_PHIXY][2 * c]; y = b.cnd[VC_SITE_PHIXY][2 * c + 1];
       loss += 0.5 * ((double)(x - px) * (x - px) + (double)(y - py) * (y - py)) + (double)VC_LOG_2PI;
     } else {
-      const long long li = d.eoff[VC_E_PHIXY] + 2LL * c;
-      *reinterpret_cast<float2*>(b.eps_used + li) = make_float2(ex, ey);
       x = pp.x + ex;
       y = pp.y + ey;
       loss += 0.5 * ((double)(x - px) * (x - px) + (double)(y - py) * (y - py)) - 0.5 * ((double)ex * ex + (double)ey * ey);
@@ -541,6 +568,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
       b.lat_phi[c] = ph;
     }
   }
+  VC_WSTAMP(0, 5);
   {
     const double ws = vc_wave_sum_d63(loss);
     if (lane == 63) sm_lc[wave] = ws;
@@ -557,6 +585,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
       b.LPF[(size_t)(s & 1) * d.nlpf + d.nb_post_gene + cblock] = t;
     }
   }
+  VC_WSTAMP(0, 6);
 }
 
 template <int MQ>
@@ -582,78 +611,112 @@ void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_omega: nu_omega (gradient, optimiser, next sample) redundantly per block, omega_c into the cell records,
-// the loss of the finished step (block 0), negative-binomial histogram terms of the next step (extra blocks)
+// K_omega: blocks [0, nb_cell): nu_omega (gradient, optimiser, next sample) redundantly per block, then omega_c into the
+// cell records of the block's 256 cells -- the only chain the next K_main waits for.  Off that chain, in blocks of their
+// own: the loss of the finished step (one block), the negative-binomial histogram terms for shape_inv of the next step
+// (one wave per task), and the Philox draws of the step after next into the eps ring.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBufs& b, float* __restrict__ G, long long s,
+                                                    double* __restrict__ loss_dev, long long loss_slots) {
+  __shared__ double sm_lossw[4];
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  double sl = 0.0;
+  const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
+#pragma unroll 4
+  for (int i = t; i < d.nlpf; i += 256) sl += lpf[i];
+#pragma unroll 4
+  for (int i = t; i < d.nb_post_gene; i += 256) sl += b.LPP[i];
+#pragma unroll 4
+  for (int i = t; i < d.n_main_wg; i += 256) sl -= (double)b.LO[i];
+  sl = vc_wave_sum_d63(sl);
+  if (lane == 63) sm_lossw[wv] = sl;
+  __syncthreads();
+  if (t == 0) {
+    const double loss = ((sm_lossw[0] + sm_lossw[1]) + (sm_lossw[2] + sm_lossw[3])) + b.const_loss;
+    const long long step = s - 1;
+    if (loss_dev) loss_dev[loss_slots > 1 ? (step % loss_slots) : 0] = loss;
+    if (!isfinite(loss)) {
+      b.status[0] += 1;
+      if (b.status[1] == 0) b.status[1] = step + 1;
+    }
+    const float hi = (float)loss;
+    G[0] = hi;
+    G[1] = (float)(loss - (double)hi);
+    G[2] = 0.f;
+    G[3] = 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
                                                        float* __restrict__ G, const long long* __restrict__ step_dev,
                                                        uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
-                                                       long long loss_slots, int boot, int nb_cell) {
-  __shared__ double sm_lossw[4];
+                                                       long long loss_slots, int boot, int nb_cell, int nb_hist) {
   __shared__ float sm_up[VC_MAX_NW];
   __shared__ float s_np[VC_NWE];
   __shared__ float s_nuw[VC_MAX_NW];
   __shared__ double sm_lq[VC_MAX_NW];
   const long long s = *step_dev;
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  VC_WSTAMP(1, 0);
   if ((int)blockIdx.x >= nb_cell) {
-    const int task = (blockIdx.x - nb_cell) * 4 + wv;
-    if (task < b.n_tasks) vc_hist_wave(d, b, P, 0, task, lane);
+    int xb = blockIdx.x - nb_cell;
+    if (xb == 0) {                                   // the loss of the finished step
+      if (!boot) vc_omega_loss_block(d, b, G, s, loss_dev, loss_slots);
+      return;
+    }
+    xb -= 1;
+    if (xb < nb_hist) {                              // histogram terms of shape_inv(s), one wave per task
+      const int task = xb * 4 + wv;
+      if (task < b.n_tasks) vc_hist_wave(d, b, P, 0, task, lane);
+      return;
+    }
+    xb -= nb_hist;
+    // eps ring: the draws of step s + 1 (and, when booting, of step s) -- one Philox block = two consecutive indices.
+    // Three slots: this launch reads the slots of s - 1 and s and writes the slot of s + 1.
+    const long long pair = (long long)xb * 256 + t;
+    if (2 * pair < d.eps_total) {
+      float n0, n1;
+      vc_philox_normal2(seed, s + 1, (uint64_t)pair, n0, n1);
+      *reinterpret_cast<float2*>(b.EPS + (size_t)((s + 1) % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
+      if (boot) {
+        vc_philox_normal2(seed, s, (uint64_t)pair, n0, n1);
+        *reinterpret_cast<float2*>(b.EPS + (size_t)(s % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
+      }
+    }
     return;
   }
   const bool vel = d.model == VC_MODEL_VELOCITY;
-  const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
+  if (!vel) return;
+  const bool lrmn = d.guide == VC_GUIDE_LRMN;
   const bool first = blockIdx.x == 0;
-  const int nw = vel ? d.NW : 0;
+  const int nw = d.NW;
   const int fin_per = lrmn ? d.R + 2 : 2;
   const int nelem = nw * fin_per;
   const bool cnd = CND(VC_SITE_NUOMEGA);
-  // the standard-normal draws of the nu_omega-related elements: element (j, ce) owns eps index e_idx -- mean-field ce = 1:
-  // nu_omega[j]; LRMN ce = 1..R: eps_W[ce - 1], ce = R + 1: eps_D[Ng + j] -- at step s - 1 (gradient of the finished step)
-  // and at step s (next sample, shared through LDS).  Drawn first: they depend on nothing and hide the loads' latency.
-  __shared__ float s_en[VC_NWE];
-  float e_old0 = 0.f;                       // of this thread's first element (tt = t); further elements redraw below
-  for (int tt = t; tt < nelem; tt += 256) {
-    const int j = tt / fin_per, ce = tt % fin_per;
-    long long e_idx = -1;
-    if (!lrmn) { if (ce == 1) e_idx = d.eoff[VC_E_NUOMEGA] + j; }
-    else if (ce >= 1) e_idx = ce <= d.R ? d.eoff[VC_E_LRMN_W] + (ce - 1) : d.eoff[VC_E_LRMN_D] + (long long)d.Ng + j;
-    float en = 0.f;
-    if (e_idx >= 0) {
-      en = vc_philox_normal(seed, s, e_idx);
-      if (!boot && tt == t) e_old0 = vc_philox_normal(seed, s - 1, e_idx);
-    }
-    s_en[tt] = en;
-  }
+  // eps index of element (j, ce): mean-field ce = 1: nu_omega[j]; LRMN ce = 1..R: eps_W[ce - 1], ce = R + 1: eps_D[Ng + j]
+  auto eps_index = [&](int j, int ce) -> long long {
+    if (!lrmn) return ce == 1 ? d.eoff[VC_E_NUOMEGA] + j : -1;
+    if (ce == 0) return -1;
+    return ce <= d.R ? d.eoff[VC_E_LRMN_W] + (ce - 1) : d.eoff[VC_E_LRMN_D] + (long long)d.Ng + j;
+  };
+  const float* __restrict__ eps_new = b.EPS + (size_t)(s % 3) * d.eps_total;
+  const float* __restrict__ eps_old = b.EPS + (size_t)((s + 2) % 3) * d.eps_total;
   // this block's cells: the basis of the next phase (written by K_tail) is requested now
   const int c = blockIdx.x * 256 + t;
   float s1 = 0.f, c1 = 1.f;
-  if (vel && c < d.Nc) {
+  if (c < d.Nc) {
     const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)c * d.ctw);
     s1 = ct[0].x; c1 = ct[1].x;
   }
-  // ---- reductions: per-coefficient sums of the cell blocks' partials (every block), loss terms (block 0) -----------
+  VC_WSTAMP(1, 1);
+  // ---- per-coefficient sums of the cell blocks' partials of d loglik / d nu_omega: every block, fixed order -------------
   if (!boot) {
-    double sl = 0.0;
-    if (first) {
-      const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
-#pragma unroll 4
-      for (int i = t; i < d.nlpf; i += 256) sl += lpf[i];
-#pragma unroll 4
-      for (int i = t; i < d.nb_post_gene; i += 256) sl += b.LPP[i];
-#pragma unroll 4
-      for (int i = t; i < d.n_main_wg; i += 256) sl -= (double)b.LO[i];
-    }
     double u[2] = {0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int j = wv + 4 * q;
       if (j < nw)
         for (int i = lane; i < d.nb_tail_cell; i += 64) u[q] += (double)b.PW[(size_t)i * d.NW + j];
-    }
-    if (first) {
-      sl = vc_wave_sum_d63(sl);
-      if (lane == 63) sm_lossw[wv] = sl;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -668,26 +731,11 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     }
   }
   __syncthreads();
-  if (first && t == 0 && !boot) {
-    const double loss = ((sm_lossw[0] + sm_lossw[1]) + (sm_lossw[2] + sm_lossw[3])) + b.const_loss;
-    const long long step = s - 1;
-    if (loss_dev) loss_dev[loss_slots > 1 ? (step % loss_slots) : 0] = loss;
-    if (!isfinite(loss)) {
-      b.status[0] += 1;
-      if (b.status[1] == 0) b.status[1] = step + 1;
-    }
-    const float hi = (float)loss;
-    G[0] = hi;
-    G[1] = (float)(loss - (double)hi);
-    G[2] = 0.f;
-    G[3] = 0.f;
-  }
-  if (!vel) return;
+  VC_WSTAMP(1, 2);
   // ---- gradient + ClippedAdam of the nu_omega-related parameters: one thread per element, every block alike ----------
   const float step_size = boot ? 0.f : b.step_size[0];
   for (int tt = t; tt < nelem; tt += 256) {
     const int j = tt / fin_per, ce = tt % fin_per;
-    const long long i = (long long)d.Ng + j;
     const long long off = vc_nuw_elem_off(d, lrmn, j, ce);
     float p = b.NWS[tt];                       // the snapshot K_tail took: block 0 overwrites P / m / v below
     if (!boot) {
@@ -696,14 +744,8 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
         const float x = b.NWS[3 * VC_NWE + j], sd = b.sd_w[j];
         gx = sm_up[j] - d.root_w * (x - b.mu_w[j]) / (sd * sd);
       }
-      // eps of the finished step for this element (first element of the thread: drawn up front)
-      float eo = e_old0;
-      if (tt != t) {
-        long long e_idx = -1;
-        if (!lrmn) { if (ce == 1) e_idx = d.eoff[VC_E_NUOMEGA] + j; }
-        else if (ce >= 1) e_idx = ce <= d.R ? d.eoff[VC_E_LRMN_W] + (ce - 1) : d.eoff[VC_E_LRMN_D] + i;
-        eo = e_idx >= 0 ? vc_philox_normal(seed, s - 1, e_idx) : 0.f;
-      }
+      const long long ei = eps_index(j, ce);
+      const float eo = ei >= 0 ? eps_old[ei] : 0.f;          // eps of the finished step for this element
       float gv;
       if (!lrmn) {
         if (ce == 0) gv = -gx;
@@ -725,24 +767,23 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     s_np[tt] = p;
   }
   __syncthreads();
+  VC_WSTAMP(1, 3);
   // ---- the nu_omega sample of step s ------------------------------------------------------------------------------
   if (t < VC_MAX_NW) sm_lq[t] = 0.0;
   for (int j = t; j < nw; j += 256) {
     const float* np = s_np + j * fin_per;
     float val, lq = 0.f;
     const long long i = (long long)d.Ng + j;
-    const float* en = s_en + j * fin_per;
+    auto en = [&](int ce) { const long long ei = eps_index(j, ce); return boot ? vc_philox_normal(seed, s, ei) : eps_new[ei]; };
     if (!lrmn) {
-      const float e = en[1];
-      if (first) b.eps_used[d.eoff[VC_E_NUOMEGA] + j] = e;
+      const float e = en(1);
       const float u = np[1];
       val = np[0] + expf(u) * e;
       lq = -0.5f * e * e - u - 0.5f * VC_LOG_2PI;
     } else {
       float delta = 0.f;
-      for (int k = 0; k < d.R; ++k) delta += expf(np[1 + k]) * en[1 + k];
-      const float ed = en[d.R + 1];
-      if (first) b.eps_used[d.eoff[VC_E_LRMN_D] + i] = ed;
+      for (int k = 0; k < d.R; ++k) delta += expf(np[1 + k]) * en(1 + k);
+      const float ed = en(d.R + 1);
       delta += sqrtf(expf(np[d.R + 1])) * ed;
       val = np[0] + delta;
       if (first) b.lat_delta[i] = delta;
@@ -756,6 +797,7 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     s_nuw[j] = x;
   }
   __syncthreads();
+  VC_WSTAMP(1, 4);
   if (first && t == 0) {
     double tot = 0.0;
     for (int j = 0; j < nw; ++j) tot += sm_lq[j];
@@ -791,12 +833,14 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     b.lat_omega[c] = omega;
     b.lat_domega[c] = domega;
   }
+  VC_WSTAMP(1, 5);
 }
 
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st) {
-  const int nb_cell = d.model == VC_MODEL_VELOCITY ? (d.Nc + 255) / 256 : 1;
+  const int nb_cell = d.model == VC_MODEL_VELOCITY ? (d.Nc + 255) / 256 : 0;
   const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
-  hipLaunchKernelGGL(vc_omega_kernel, dim3(nb_cell + nb_hist), dim3(256), 0, st, d, b, params, grad, step_dev, seed, a,
-                     loss_dev, loss_slots, boot, nb_cell);
+  const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
+  hipLaunchKernelGGL(vc_omega_kernel, dim3(nb_cell + 1 + nb_hist + nb_eps), dim3(256), 0, st, d, b, params, grad, step_dev,
+                     seed, a, loss_dev, loss_slots, boot, nb_cell, nb_hist);
 }

@@ -242,14 +242,17 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
                 if (!CND(VC_SITE_LOGBETA)) logq += -0.5f * eb * eb - ub - 0.5f * VC_LOG_2PI;
               } else {
                 // LowRankMultivariateNormal.rsample: X = loc + W eps_W + sqrt(cov_diag) eps_D
-                float delta = 0.f, w2 = 0.f;
+                // columns 0..3 and 4..7 are summed separately and then added: the association the fused step uses
+                // (vc_fused_kernels.hip splits the cov_factor row over two roles), so both paths draw bit-identical samples
+                float delta = 0.f, w2 = 0.f, delta_hi = 0.f, w2_hi = 0.f;
 #pragma unroll
                 for (int k = 0; k < VC_MAX_RANK; ++k)
                   if (k < d.R) {
                     const float w = expf(P[d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + k]);
-                    delta += w * ew_all[k];
-                    w2 += w * w;
+                    if (k < 4) { delta += w * ew_all[k]; w2 += w * w; }
+                    else { delta_hi += w * ew_all[k]; w2_hi += w * w; }
                   }
+                if (d.R > 4) { delta += delta_hi; w2 += w2_hi; }
                 const float dg = expf(P[d.poff[VC_P_LRMN_UCOV_DIAG] + g]);
                 const float ed = vc_eps(eps_in, b.eps_used, seed, step, d.eoff[VC_E_LRMN_D] + g, d.eoff[VC_E_LRMN_D] + g);
                 delta += sqrtf(dg) * ed;

@@ -267,15 +267,17 @@ class HipEngine:
             C.c_void_p(self.grad.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()),
             C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, self._stream()))
 
-    def svi_step_fused(self, m, v, lr, lrd, b1, b2, adam_eps, clip, seed, step_dev, loss_buf=None, prime=False):
-        """One whole SVI step in three launches (vc_svi_step_fused): K_main -> K_tail -> K_omega; `prime` draws the
-        sample of the current step first (first call / after params were changed from outside)."""
+    def svi_step_fused(self, m, v, lr, lrd, b1, b2, adam_eps, clip, seed, step_dev, loss_buf=None, prime=False,
+                       n_steps=1):
+        """n_steps whole SVI steps, three launches each (vc_svi_run_fused): K_main -> K_tail -> K_omega, enqueued back to
+        back from one call; `prime` draws the sample of the current step first (first call / after params were changed
+        from outside)."""
         lb = self.loss_dev if loss_buf is None else loss_buf
-        self._check(self.lib.vc_svi_step_fused(
+        self._check(self.lib.vc_svi_run_fused(
             self._h, C.c_void_p(self.params.data_ptr()), C.c_uint64(seed), C.c_void_p(step_dev.data_ptr()),
             C.c_void_p(self.grad.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()),
             C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, int(bool(prime)),
-            self._stream()))
+            C.c_int64(n_steps), self._stream()))
 
     def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
         """Fused HIP ClippedAdam on flat float32 buffers (same stream); optionally files the (all-reduced) loss

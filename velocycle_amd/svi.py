@@ -121,7 +121,11 @@ class SVIRunner:
         self.seed = 0 if seed is None else int(seed)
         # force_reduce: issue the all-reduce even with one rank (exercises the RCCL-in-graph path on one GPU)
         self.do_reduce = self.world > 1 or force_reduce
-        self.use_graph = (mode == "perf") if use_graph is None else use_graph
+        # perf mode: N > 1 replays the step (RCCL all-reduce included) from a hipGraph -- the host side of a collective
+        # is expensive; a single rank enqueues plain launches from one C call per run_perf (vc_svi_run_fused): measured
+        # ~6 us per step faster than graph replay at every size (profiles/r02_step_overhead.md)
+        single = not (engine.world_size > 1 or force_reduce)
+        self.use_graph = (mode == "perf" and not single) if use_graph is None else use_graph
         if self.do_reduce and self.use_graph:
             import torch.distributed as dist
             if dist.get_backend(process_group) != "nccl":
@@ -200,12 +204,12 @@ class SVIRunner:
         sample in the engine's tables; it is re-drawn from the current parameters before the next step)."""
         self._primed = False
 
-    def _perf_body(self, prime: bool = False):
+    def _perf_body(self, prime: bool = False, n_steps: int = 1):
         e = self.e
         if self.adam_impl == "fused3":         # single rank: K_main -> K_tail -> K_omega
             o = self.opt
             e.svi_step_fused(o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, seed=self.seed,
-                             step_dev=self.step_dev, loss_buf=self.loss_hist, prime=prime)
+                             step_dev=self.step_dev, loss_buf=self.loss_hist, prime=prime, n_steps=n_steps)
             return
         if self.adam_impl == "fused":          # single rank: optimiser merged into the last gradient kernel
             o = self.opt
@@ -253,12 +257,16 @@ class SVIRunner:
             self._graph = g
             self.step_idx += 1
             n_steps -= 1
-        for _ in range(n_steps):
-            if self._graph is not None and self._primed:
-                self._graph.replay()
-            else:
-                self._perf_body(prime=not self._primed)
-                self._primed = True
+        if self._graph is None and self.adam_impl == "fused3":
+            self._perf_body(prime=not self._primed, n_steps=n_steps)      # every launch of the run from one C call
+            self._primed = True
+        else:
+            for _ in range(n_steps):
+                if self._graph is not None and self._primed:
+                    self._graph.replay()
+                else:
+                    self._perf_body(prime=not self._primed)
+                    self._primed = True
         self.step_idx += n_steps
         if sync:
             torch.cuda.synchronize(e.device)
