@@ -156,12 +156,13 @@ typedef struct vc_layout {
 
 typedef struct vc_stats {
   int64_t algorithmic_bytes;      /* count-matrix bytes one step must read in the reference's fp32 storage */
-  int64_t streamed_bytes;         /* bytes the main kernel actually streams (padded layout) */
+  int64_t streamed_bytes;         /* bytes the main kernel actually streams (padded layout, uint16 or float32 elements) */
   int64_t main_grid, main_block;  /* launch geometry of the likelihood kernel */
   int32_t main_kind;              /* 0 phase(S) 1 velocity(S+U) 2 velocity, S-term hoisted (U only) */
   int32_t hist_on_device;         /* 1: the per-gene count histograms were built on the device during the re-layout */
   char main_kernel_name[96];
   int64_t setup_transient_bytes;  /* device memory vc_finalize held only while it ran (histogram tables, owned uploads) */
+  int64_t count_storage_bytes;    /* bytes per count element in HBM: 2 (uint16: every count an integer <= 65535) or 4 */
 } vc_stats;
 
 /* lifecycle ------------------------------------------------------------------------------- */

@@ -9,13 +9,14 @@ KIND = {0: "phase", 1: "vfull", 2: "vu"}
 NOISE = {0: "nb", 1: "poisson", 2: "lognormal"}
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 vals = {}
-pat = re.compile(r"(?:void )?vc_main_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>.*\| (FETCH_SIZE|WRITE_SIZE) \| (\d+) \| ([\d.]+)")
+pat = re.compile(r"(?:void )?vc_main_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>.*\| (FETCH_SIZE|WRITE_SIZE) \| (\d+) \| ([\d.]+)")
 for line in open(src):
     m = pat.match(line)
     if m:
         h, nb, kind, noise, gpl = (int(x) for x in m.groups()[:5])
-        name = f"vc_main_kernel<{h},{nb},{KIND[kind]}_{NOISE[noise]},gpl{gpl}>"
-        vals.setdefault(name, {})[m.group(6) + "_KiB"] = float(m.group(8))
+        c16 = int(m.group(6) or 0)
+        name = f"vc_main_kernel<{h},{nb},{KIND[kind]}_{NOISE[noise]},gpl{gpl}{',u16' if c16 else ''}>"
+        vals.setdefault(name, {})[m.group(7) + "_KiB"] = float(m.group(9))
 for v in vals.values():
     if "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
         v["traffic_bytes"] = int((2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024)

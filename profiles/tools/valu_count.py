@@ -20,9 +20,11 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "velocycle_amd", "csrc")
 TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
-# (translation unit, H, NB, KIND, NOISE, GPL, cells per loop trip) -- the instantiations bench.py runs
-KERNELS = [("vc_main_vfull_nb.hip", 1, 0, 1, 0, 8), ("vc_main_vu_nb.hip", 1, 0, 2, 0, 8), ("vc_main_phase_nb.hip", 1, 0, 0, 0, 8),
-           ("vc_main_vfull_nb.hip", 1, 2, 1, 0, 8), ("vc_main_vfull_nb.hip", 1, 2, 1, 0, 4), ("vc_main_vu_nb.hip", 1, 2, 2, 0, 8)]
+# (translation unit, H, NB, KIND, NOISE, GPL, C16) -- the instantiations bench.py runs, float32 and uint16 count storage
+KERNELS = [("vc_main_vfull_nb_u16.hip", 1, 0, 1, 0, 8, 1), ("vc_main_vu_nb_u16.hip", 1, 0, 2, 0, 8, 1),
+           ("vc_main_phase_nb_u16.hip", 1, 0, 0, 0, 8, 1),
+           ("vc_main_vfull_nb.hip", 1, 0, 1, 0, 8, 0), ("vc_main_vu_nb.hip", 1, 0, 2, 0, 8, 0), ("vc_main_phase_nb.hip", 1, 0, 0, 0, 8, 0),
+           ("vc_main_vfull_nb_u16.hip", 1, 2, 1, 0, 8, 1), ("vc_main_vu_nb_u16.hip", 1, 2, 2, 0, 8, 1)]
 KIND_NAME = {0: "phase", 1: "vfull", 2: "vu"}
 NOISE_NAME = {0: "nb", 1: "poisson", 2: "lognormal"}
 ISSUE_NS = {"valu": 2.28, "trans": 4.3}     # profiles/r01_d_kmain_bound.md section 2b (valu_rate.hip on MI355X)
@@ -57,8 +59,8 @@ def main_loop(body):
     return best
 
 
-def count(tu, H, NB, KIND, NOISE, GPL):
-    sym = f"_Z14vc_main_kernelILi{H}ELi{NB}ELi{KIND}ELi{NOISE}ELi{GPL}EEv6VcDims6VcBufs"
+def count(tu, H, NB, KIND, NOISE, GPL, C16):
+    sym = f"_Z14vc_main_kernelILi{H}ELi{NB}ELi{KIND}ELi{NOISE}ELi{GPL}ELi{C16}EEv6VcDims6VcBufs"
     body = kernel_body(device_asm(tu), sym)
     a, b = main_loop(body)
     ops = [l.split()[0] for l in body[a:b + 1] if l.startswith("\t") and not l.strip().startswith((";", "."))]
@@ -73,7 +75,8 @@ def count(tu, H, NB, KIND, NOISE, GPL):
            "salu_per_cell_iter": len([o for o in ops if o.startswith("s_")]) / cells,
            "genes_per_lane": GPL,
            "issue_ns_per_cell_iter": ((len(valu) - len(trans)) * ISSUE_NS["valu"] + len(trans) * ISSUE_NS["trans"]) / cells}
-    return f"vc_main_kernel<{H},{NB},{KIND_NAME[KIND]}_{NOISE_NAME[NOISE]},gpl{GPL}>", res
+    res["count_storage"] = "u16" if C16 else "f32"
+    return f"vc_main_kernel<{H},{NB},{KIND_NAME[KIND]}_{NOISE_NAME[NOISE]},gpl{GPL}{',u16' if C16 else ''}>", res
 
 
 def main():

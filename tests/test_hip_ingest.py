@@ -86,7 +86,10 @@ def test_device_histograms_full_size(monkeypatch):
     dev.close()
     host = _host_checker(spec, monkeypatch)
     assert _hist_equal(hd, host.histogram())
-    assert transient <= 2 * (2000 * 2048 * 4 + (1 << 22) * 8) + 64        # histogram tables + overflow lists, no matrix copy
+    # histogram tables + overflow lists (+ the float32 layout while its uint16 copy is made): never a copy of the matrix
+    # in the caller's layout, never a byte of it back on the host
+    blocked_f32 = 2 * 4 * 2048 * 50000
+    assert transient <= 2 * (2000 * 2048 * 4 + (1 << 22) * 8) + 64 + blocked_f32
     host.close()
 
 
@@ -155,3 +158,40 @@ def test_invalid_counts_are_refused(bad):
     spec.U[3, 5] = bad
     with pytest.raises(ValueError, match="finite and >= 0"):
         _mk(spec)
+
+
+@pytest.mark.parametrize("mode", ["vjoint", "vcond", "phase"])
+def test_uint16_count_storage_equals_float32(mode, monkeypatch):
+    """Counts that are integers <= 65535 are stored as uint16 in HBM (half the bytes K_main streams); VC_COUNT_STORAGE=f32
+    keeps the reference's float32.  Same arithmetic on the same values: loss and every gradient agree to float32 rounding
+    of re-scheduled FMAs (observed bit-identical); a matrix with one count > 65535 falls back to float32 by itself."""
+    from velocycle_amd.rng import draw_eps
+    from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
+    spec = make_phase_spec(2500, 300, seed=3) if mode == "phase" else make_velocity_spec(2500, 300, mode, 2, 1, seed=3)
+    g = torch.Generator().manual_seed(0)
+    first = draw_eps(spec, g)
+    eps = draw_eps(spec, g)
+    res = {}
+    for storage in ("u16", "f32"):
+        if storage == "f32":
+            monkeypatch.setenv("VC_COUNT_STORAGE", "f32")
+        e = _mk(spec)
+        assert e.stats["count_storage"] == storage and ("u16" in e.stats["main_kernel"]) == (storage == "u16")
+        e.init_params(first.get("_cov_factor_draw"))
+        e.elbo_grad(eps=e.pack_eps(eps))
+        torch.cuda.synchronize()
+        res[storage] = (e.loss(), e.grad.clone().cpu(), e.stats["streamed_bytes"])
+        e.close()
+    monkeypatch.delenv("VC_COUNT_STORAGE")
+    assert res["u16"][2] * 2 == res["f32"][2]
+    assert abs(res["u16"][0] - res["f32"][0]) <= 1e-9 * abs(res["f32"][0])
+    a, b = torch.nan_to_num(res["u16"][1][4:]).double(), torch.nan_to_num(res["f32"][1][4:]).double()
+    assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1.0)
+    # one huge count: the whole rank falls back to float32 storage, results unchanged in kind
+    import copy
+    big = copy.copy(spec)
+    big.S = spec.S.contiguous().clone()
+    big.S[1, 7] = 70000.0
+    e = _mk(big)
+    assert e.stats["count_storage"] == "f32"
+    e.close()

@@ -20,7 +20,7 @@ def test_profile_tool_compiles(src, tmp_path):
     assert out.stat().st_size > 0
 
 
-@pytest.mark.parametrize("flag", ["-DVC_STREAM_ONLY", "-DVC_DBG_TIMES", "-DVC_DBG_HALF_BYTES", "-DVC_PF=2", "-DVC_EPI_ROWS=1"])
+@pytest.mark.parametrize("flag", ["-DVC_STREAM_ONLY", "-DVC_DBG_TIMES", "-DVC_PF=2", "-DVC_EPI_ROWS=1"])
 def test_measurement_aid_builds(flag, tmp_path):
     """One translation unit of the likelihood kernel per macro (the full library takes too long for the CPU suite)."""
     src = os.path.join(ROOT, "velocycle_amd", "csrc", "vc_main_vu_poisson.hip")

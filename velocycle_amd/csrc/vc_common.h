@@ -21,6 +21,7 @@
 struct VcDims {
   int Ng, Ng_pad, nGB;
   int gpl, gbw;           // genes per lane of the likelihood kernel (4 or 8), genes per gene block = 64*gpl
+  int c16;                // 1: the blocked counts are uint16 (every count an integer <= 65535), 0: float32
   int Nc;                 // cells on this rank
   long long cell_offset;  // global index of the first local cell
   int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
@@ -48,7 +49,7 @@ struct VcDims {
 
 struct VcBufs {
   // immutable inputs
-  const float *S, *U;                       // blocked counts [nGB][Nc][gbw]
+  const float *S, *U;                       // blocked counts [nGB][Nc][gbw], float32 or (d.c16) uint16
   const float *cf, *Dm, *Dbm, *pxy;         // (Nc), (Nx,Nc), (Nb,Nc), (Nc,2)
   const float *mu_nu, *sd_nu, *mu_g, *sd_g, *mu_b, *sd_b, *mu_w, *sd_w, *sd_dnu;
   const float *cnd[VC_SITE_COUNT];          // conditioned values per site (or nullptr)
@@ -297,8 +298,9 @@ __device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, c
 
 // launchers implemented in the .hip translation units -----------------------------------------
 typedef void (*vc_main_launch_fn)(const VcDims& d, const VcBufs& b, hipStream_t st);
-vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, const char** name,
+vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, int c16, const char** name,
                                       const void** kernel);
+void vc_launch_counts_to_u16(const float* src, unsigned short* dst, long long n, hipStream_t st);
 
 void vc_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* out2, hipStream_t st);
 // re-layout of one count matrix into [gene block][cell][gbw] (+ log(k+1) for Lognormal noise); with tab != nullptr the

@@ -90,6 +90,10 @@ struct vc_engine {
     err = buf;
     return code;
   }
+  void dfree(const void* p) {           // release one tracked allocation before vc_destroy
+    for (size_t i = 0; i < allocs.size(); ++i)
+      if (allocs[i] == p) { (void)hipFree(allocs[i]); allocs.erase(allocs.begin() + i); return; }
+  }
   template <class T>
   int dalloc(T** out, size_t n) {
     void* p = nullptr;
@@ -507,7 +511,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   {
     const void* k8 = nullptr;
     hipFuncAttributes fa;
-    if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, nullptr, &k8) && k8 &&
+    if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
         hipFuncGetAttributes(&fa, k8) == hipSuccess && fa.localSizeBytes == 0)
       d.gpl = 8;
   }
@@ -516,10 +520,11 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   d.nGB = (d.Ng + d.gbw - 1) / d.gbw;
   d.Ng_pad = d.nGB * d.gbw;
   const void* main_kernel = nullptr;
-  e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, &e->main_name, &main_kernel);
+  d.c16 = 0;
+  e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, 0, &e->main_name, &main_kernel);
   if (!e->main_fn) return e->fail(VC_ERR_UNSUPPORTED, "no likelihood kernel for H=%d Nb=%d kind=%d noise=%d", d.H, d.Nb, d.kind, d.noise);
   if (d.kind == VC_KIND_VU) {
-    e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, nullptr, nullptr);
+    e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, 0, nullptr, nullptr);
     if (!e->phase_fn) return e->fail(VC_ERR_UNSUPPORTED, "no S-only kernel for the hoisted term");
   }
   // HBM layout of the counts: [gene block][cell][gbw], zero padded in genes; the per-gene count histograms are built on
@@ -551,9 +556,9 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     ovf_n = nullptr; bad = nullptr;
   };
   TRY(tmalloc((void**)&ovf_n, 2 * sizeof(unsigned)));
-  TRY(tmalloc((void**)&bad, 2 * sizeof(int)));
+  TRY(tmalloc((void**)&bad, 4 * sizeof(int)));
   HIPCHK(e, hipMemsetAsync(ovf_n, 0, 2 * sizeof(unsigned), st));
-  HIPCHK(e, hipMemsetAsync(bad, 0, 2 * sizeof(int), st));
+  HIPCHK(e, hipMemsetAsync(bad, 0, 4 * sizeof(int), st));
   {
     const size_t blocked = (size_t)d.nGB * d.Nc * d.gbw;
     const float** dstp[2] = {&b.S, &b.U};
@@ -587,10 +592,41 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     }
   }
   {
-    int hbad[2] = {0, 0};
+    int hbad[4] = {0, 0, 0, 0};
     HIPCHK(e, hipMemcpy(hbad, bad, sizeof hbad, hipMemcpyDeviceToHost));
     if (hbad[1]) { free_transients(); return e->fail(VC_ERR_ARG, "vc_set_counts_csr: gene index outside [0, Ng)"); }
     if (hbad[0]) { free_transients(); return e->fail(VC_ERR_ARG, "count matrices must be finite and >= 0 (NaN / Inf / negative value found)"); }
+    // Count storage: when every count of this rank's matrices is an integer <= 65535 (checked by the pass above) the
+    // blocked layout is narrowed to uint16 -- half the bytes K_main streams per step; exact.  VC_COUNT_STORAGE=f32 keeps
+    // the reference's float32 (A/B measurements, tests); Lognormal noise stores log(k + 1) and stays float32.
+    const char* cs_env = getenv("VC_COUNT_STORAGE");
+    const bool want16 = !(cs_env && strcmp(cs_env, "f32") == 0) && d.noise != VC_NOISE_LOGNORMAL && !hbad[2];
+    if (want16) {
+      const void* k16 = nullptr;
+      const char* nm = nullptr;
+      hipFuncAttributes fa;
+      vc_main_launch_fn f16 = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, 1, &nm, &k16);
+      vc_main_launch_fn p16 = d.kind == VC_KIND_VU ? vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, 1, nullptr, nullptr) : nullptr;
+      if (f16 && k16 && (d.kind != VC_KIND_VU || p16) && hipFuncGetAttributes(&fa, k16) == hipSuccess && fa.localSizeBytes == 0) {
+        const size_t blocked = (size_t)d.nGB * d.Nc * d.gbw;
+        const float** dstp[2] = {&b.S, &b.U};
+        for (int m = 0; m < 2; ++m) {
+          if (!*dstp[m]) continue;
+          unsigned short* p16buf = nullptr;
+          int rc = e->dalloc(&p16buf, blocked);
+          if (rc != VC_OK) { free_transients(); return rc; }
+          vc_launch_counts_to_u16(*dstp[m], p16buf, (long long)blocked, st);
+          HIPCHK(e, hipStreamSynchronize(st));
+          transient += blocked * sizeof(float);      // the float32 layout lives until its uint16 copy exists
+          e->dfree(*dstp[m]);
+          *dstp[m] = reinterpret_cast<const float*>(p16buf);
+        }
+        d.c16 = 1;
+        e->main_fn = f16;
+        main_kernel = k16;
+        if (p16) e->phase_fn = p16;
+      }
+    }
   }
   // tiling: one balanced round.  The grid is sized to the workgroups the chip holds at once for
   // this kernel (occupancy x 256 CUs); each wave gets an equal share of the cells of its gene block,
@@ -989,13 +1025,15 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   const VcDims& d = e->d;
   const int nmat = d.kind == VC_KIND_VFULL ? 2 : 1;
   out->algorithmic_bytes = (int64_t)nmat * 4 * d.Ng * (int64_t)d.Nc;
-  out->streamed_bytes = (int64_t)nmat * 4 * d.Ng_pad * (int64_t)d.Nc;
+  out->streamed_bytes = (int64_t)nmat * (d.c16 ? 2 : 4) * d.Ng_pad * (int64_t)d.Nc;
+  out->count_storage_bytes = d.c16 ? 2 : 4;
   out->main_grid = d.n_main_wg;
   out->main_block = 256;
   out->main_kind = d.kind;
   out->hist_on_device = e->hist_on_device;
   out->setup_transient_bytes = (int64_t)e->setup_transient_bytes;
-  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d>", d.H, d.Nb, e->main_name, d.gpl);
+  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.Nb, e->main_name, d.gpl,
+           d.c16 ? ",u16" : "");
   return VC_OK;
 }
 

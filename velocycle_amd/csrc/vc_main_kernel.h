@@ -139,7 +139,10 @@ __device__ __forceinline__ void vc_obs_lognormal(v2f y, v2f eta, float inv_s2, v
 // GPL = genes per lane (4 or 8): 8 amortises the per-cell work (DPP reductions, staging, loop) over twice
 // the genes and is faster whenever its accumulators still fit 2 waves per SIMD (launch bound) -- the host
 // picks GPL per (kind, K); the HBM layout [gene block][cell][64*GPL] follows it.
-template <int H, int NB, int KIND, int NOISE, int GPL>
+// C16: the counts are stored as uint16 (every count of the matrix is an integer <= 65535: decided by vc_finalize from the
+// histograms) -- half the HBM bytes of the reference's float32 storage, one v_cvt_f32_u32 with a WORD_n source select per
+// element; C16 = 0 reads the float32 layout (Lognormal noise stores log(k+1); non-integer or huge counts).
+template <int H, int NB, int KIND, int NOISE, int GPL, int C16>
 __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB_SINGLE) : 1)) void vc_main_kernel(const VcDims d, const VcBufs b) {
   constexpr int GBW = 64 * GPL;
   constexpr int NH = 2 * H + 1;
@@ -173,27 +176,32 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   if (cbeg > d.Nc) cbeg = d.Nc;
   if (cend > d.Nc) cend = d.Nc;
   const int ncell = (int)(cend - cbeg);
-  const size_t blk_base = ((size_t)gb * d.Nc) * GBW + gl;
-  const float* Sp = HAS_S ? b.S + blk_base : nullptr;
-  const float* Up = HAS_U ? b.U + blk_base : nullptr;
+  const size_t blk_base = ((size_t)gb * d.Nc) * GBW + gl;       // in count elements (4 or 2 bytes each)
+  constexpr int ESZ = C16 ? 2 : 4;
+  const char* Sp = HAS_S ? reinterpret_cast<const char*>(b.S) + blk_base * ESZ : nullptr;
+  const char* Up = HAS_U ? reinterpret_cast<const char*>(b.U) + blk_base * ESZ : nullptr;
   constexpr int NP = GPL / 2;           // packed pairs per lane
-  constexpr int NV4 = GPL / 4;          // dwordx4 loads per lane per matrix per cell
+  constexpr int NV4 = GPL / 4;          // float4 groups of the lane's genes (gene table loads, epilogue stores)
+  constexpr int NDW = GPL * ESZ / 4;    // dwords per lane per matrix per cell: 8 / 4 (float32), 4 / 2 (uint16)
   constexpr int PF = FULL ? VC_PF : VC_PF_SINGLE, NBUF = PF + 1;
-  float4 s_bf[NBUF][NV4], u_bf[NBUF][NV4];
+  uint32_t s_bf[NBUF][NDW], u_bf[NBUF][NDW];
   VcCellRec<H, NB> rec_bf[NBUF];
+  auto load_counts = [&](const char* p, uint32_t* w) __attribute__((always_inline)) {
+    if (NDW >= 4) {
+#pragma unroll
+      for (int q = 0; q < NDW / 4; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + 16 * q);
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+      }
+    } else {
+      const uint2 v = *reinterpret_cast<const uint2*>(p);
+      w[0] = v.x; w[1] = v.y;
+    }
+  };
   auto fetch = [&](int j, int i) {
     const long long cn = cbeg + (i < ncell ? i : (ncell > 0 ? ncell - 1 : 0));
-#pragma unroll
-    for (int q4 = 0; q4 < NV4; ++q4) {
-#ifdef VC_DBG_HALF_BYTES      // measurement aid: what a 2-byte count storage could gain (loads half the bytes, results meaningless)
-      if (q4 > 0) { s_bf[j][q4] = s_bf[j][0]; u_bf[j][q4] = u_bf[j][0]; continue; }
-      if (HAS_S) s_bf[j][q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cn * (GBW / 2) - gl / 2 + 4 * q4);
-      if (HAS_U) u_bf[j][q4] = *reinterpret_cast<const float4*>(Up + (size_t)cn * (GBW / 2) - gl / 2 + 4 * q4);
-      continue;
-#endif
-      if (HAS_S) s_bf[j][q4] = *reinterpret_cast<const float4*>(Sp + (size_t)cn * GBW + 4 * q4);
-      if (HAS_U) u_bf[j][q4] = *reinterpret_cast<const float4*>(Up + (size_t)cn * GBW + 4 * q4);
-    }
+    if (HAS_S) load_counts(Sp + (size_t)cn * GBW * ESZ, s_bf[j]);
+    if (HAS_U) load_counts(Up + (size_t)cn * GBW * ESZ, u_bf[j]);
     rec_bf[j] = vc_load_cell<H, NB>(b.CT + (size_t)cn * d.ctw);
   };
   if (VC_EARLY_FETCH && ncell > 0) {
@@ -402,12 +410,14 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         for (int j = 0; j < PF; ++j) fetch(j, j);
       }
       auto unpack = [&](int j, v2f* sv, v2f* uv) __attribute__((always_inline)) {
+        auto pair_of = [&](const uint32_t* w, int p) -> v2f {      // genes 2p, 2p + 1 of the lane
+          if (C16) return v2f{(float)(w[p] & 0xffffu), (float)(w[p] >> 16)};
+          return v2f{__builtin_bit_cast(float, w[2 * p]), __builtin_bit_cast(float, w[2 * p + 1])};
+        };
 #pragma unroll
-        for (int q4 = 0; q4 < NV4; ++q4) {
-          sv[2 * q4] = HAS_S ? v2f{s_bf[j][q4].x, s_bf[j][q4].y} : v2(0.f);
-          sv[2 * q4 + 1] = HAS_S ? v2f{s_bf[j][q4].z, s_bf[j][q4].w} : v2(0.f);
-          uv[2 * q4] = HAS_U ? v2f{u_bf[j][q4].x, u_bf[j][q4].y} : v2(0.f);
-          uv[2 * q4 + 1] = HAS_U ? v2f{u_bf[j][q4].z, u_bf[j][q4].w} : v2(0.f);
+        for (int p = 0; p < NP; ++p) {
+          sv[p] = HAS_S ? pair_of(s_bf[j], p) : v2(0.f);
+          uv[p] = HAS_U ? pair_of(u_bf[j], p) : v2(0.f);
         }
       };
       if (VC_SWAP_REDUCE && NBUF == 2) {
@@ -526,34 +536,36 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 #endif
 }
 
-template <int H, int NB, int KIND, int NOISE, int GPL>
+template <int H, int NB, int KIND, int NOISE, int GPL, int C16>
 static void vc_main_launch(const VcDims& d, const VcBufs& b, hipStream_t st) {
-  hipLaunchKernelGGL((vc_main_kernel<H, NB, KIND, NOISE, GPL>), dim3(d.n_main_wg), dim3(256), 0, st, d, b);
+  hipLaunchKernelGGL((vc_main_kernel<H, NB, KIND, NOISE, GPL, C16>), dim3(d.n_main_wg), dim3(256), 0, st, d, b);
 }
 
-struct VcMainEntry { int H, NB, kind, noise, gpl; vc_main_launch_fn fn; const void* kernel; };
+struct VcMainEntry { int H, NB, kind, noise, gpl, c16; vc_main_launch_fn fn; const void* kernel; };
 
 // Explicit kernel instantiations are needed in both compilation passes; the launcher table is host-only.
-#define VC_INST_K(KIND, NOISE, H, NB)                                                        \
-  template __global__ void vc_main_kernel<H, NB, KIND, NOISE, 4>(const VcDims, const VcBufs); \
-  template __global__ void vc_main_kernel<H, NB, KIND, NOISE, 8>(const VcDims, const VcBufs);
-#define VC_INST_KROW(KIND, NOISE, H)                                                   \
-  VC_INST_K(KIND, NOISE, H, 0) VC_INST_K(KIND, NOISE, H, 1) VC_INST_K(KIND, NOISE, H, 2) \
-  VC_INST_K(KIND, NOISE, H, 3) VC_INST_K(KIND, NOISE, H, 4)
-#define VC_ENT(KIND, NOISE, H, NB)                                                                    \
-  {H, NB, KIND, NOISE, 4, &vc_main_launch<H, NB, KIND, NOISE, 4>, (const void*)&vc_main_kernel<H, NB, KIND, NOISE, 4>}, \
-  {H, NB, KIND, NOISE, 8, &vc_main_launch<H, NB, KIND, NOISE, 8>, (const void*)&vc_main_kernel<H, NB, KIND, NOISE, 8>}
-#define VC_ENT_ROW(KIND, NOISE, H)                                                          \
-  VC_ENT(KIND, NOISE, H, 0), VC_ENT(KIND, NOISE, H, 1), VC_ENT(KIND, NOISE, H, 2), VC_ENT(KIND, NOISE, H, 3), \
-  VC_ENT(KIND, NOISE, H, 4)
+// The uint16 variants exist for the count noise models only (Lognormal stores log(k + 1)).
+#define VC_INST_1(KIND, NOISE, H, NB, GPL, C16) \
+  template __global__ void vc_main_kernel<H, NB, KIND, NOISE, GPL, C16>(const VcDims, const VcBufs);
+#define VC_ENT_1(KIND, NOISE, H, NB, GPL, C16)                                   \
+  {H, NB, KIND, NOISE, GPL, C16, &vc_main_launch<H, NB, KIND, NOISE, GPL, C16>, \
+   (const void*)&vc_main_kernel<H, NB, KIND, NOISE, GPL, C16>},
+#define VC_FOR_NB(M, KIND, NOISE, H, GPL, C16)                                                                  \
+  M(KIND, NOISE, H, 0, GPL, C16) M(KIND, NOISE, H, 1, GPL, C16) M(KIND, NOISE, H, 2, GPL, C16) M(KIND, NOISE, H, 3, GPL, C16) \
+  M(KIND, NOISE, H, 4, GPL, C16)
+#define VC_FOR_H(M, KIND, NOISE, GPL, C16) \
+  VC_FOR_NB(M, KIND, NOISE, 1, GPL, C16) VC_FOR_NB(M, KIND, NOISE, 2, GPL, C16) VC_FOR_NB(M, KIND, NOISE, 3, GPL, C16)
+#define VC_FOR_ALL_F32(M, KIND, NOISE) VC_FOR_H(M, KIND, NOISE, 4, 0) VC_FOR_H(M, KIND, NOISE, 8, 0)
+#define VC_FOR_ALL_U16(M, KIND, NOISE) VC_FOR_H(M, KIND, NOISE, 4, 1) VC_FOR_H(M, KIND, NOISE, 8, 1)
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define VC_DEFINE_TABLE(NAME, KIND, NOISE) \
-  VC_INST_KROW(KIND, NOISE, 1) VC_INST_KROW(KIND, NOISE, 2) VC_INST_KROW(KIND, NOISE, 3)
+#define VC_DEFINE_TABLE(NAME, KIND, NOISE) VC_FOR_ALL_F32(VC_INST_1, KIND, NOISE)
+#define VC_DEFINE_TABLE_U16(NAME, KIND, NOISE) VC_FOR_ALL_U16(VC_INST_1, KIND, NOISE)
 #else
-#define VC_DEFINE_TABLE(NAME, KIND, NOISE)                                                   \
-  VC_INST_KROW(KIND, NOISE, 1) VC_INST_KROW(KIND, NOISE, 2) VC_INST_KROW(KIND, NOISE, 3)      \
-  extern const VcMainEntry NAME[30] = {VC_ENT_ROW(KIND, NOISE, 1), VC_ENT_ROW(KIND, NOISE, 2), \
-                                       VC_ENT_ROW(KIND, NOISE, 3)};
+#define VC_DEFINE_TABLE(NAME, KIND, NOISE)      \
+  VC_FOR_ALL_F32(VC_INST_1, KIND, NOISE)        \
+  extern const VcMainEntry NAME[30] = {VC_FOR_ALL_F32(VC_ENT_1, KIND, NOISE)};
+#define VC_DEFINE_TABLE_U16(NAME, KIND, NOISE)  \
+  VC_FOR_ALL_U16(VC_INST_1, KIND, NOISE)        \
+  extern const VcMainEntry NAME[30] = {VC_FOR_ALL_U16(VC_ENT_1, KIND, NOISE)};
 #endif
-

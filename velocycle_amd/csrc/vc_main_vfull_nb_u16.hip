@@ -1,0 +1,3 @@
+// Instantiations of the likelihood kernel on uint16 count storage: kind=vfull, noise=nb, H in 1..3, NB in 0..4.
+#include "vc_main_kernel.h"
+VC_DEFINE_TABLE_U16(vc_tab_vfull_nb_u16, VC_KIND_VFULL, VC_NOISE_NB)

@@ -1,0 +1,3 @@
+// Instantiations of the likelihood kernel on uint16 count storage: kind=vu, noise=poisson, H in 1..3, NB in 0..4.
+#include "vc_main_kernel.h"
+VC_DEFINE_TABLE_U16(vc_tab_vu_poisson_u16, VC_KIND_VU, VC_NOISE_POISSON)

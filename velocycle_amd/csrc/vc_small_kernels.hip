@@ -38,13 +38,14 @@ struct VcHistDev {
   int* ovf_gene;
   unsigned* ovf_n;          // entries appended (may exceed ovf_cap: then the host falls back to its own pass)
   unsigned ovf_cap;
-  int* bad;                 // [0] invalid count value seen, [1] invalid CSR index seen
+  int* bad;                 // [0] invalid count value seen, [1] invalid CSR index seen, [2] a count that uint16 cannot hold
 };
 
 __device__ __forceinline__ void vc_hist_put(const VcHistDev& h, int g, float v) {
-  if (!h.tab) return;
-  if (!(v >= 0.f && v <= 3.0e38f)) { *h.bad = 1; return; }
+  if (!(v >= 0.f && v <= 3.0e38f)) { h.bad[0] = 1; return; }
   if (v == 0.f) return;
+  if (v > 65535.f || (float)(int)v != v) h.bad[2] = 1;
+  if (!h.tab) return;
   if (v < (float)VC_HIST_CAP && (float)(int)v == v) atomicAdd(&h.tab[(size_t)g * VC_HIST_CAP + (int)v], 1u);
   else {
     const unsigned i = atomicAdd(h.ovf_n, 1u);
@@ -71,6 +72,19 @@ __global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __re
     }
     dst[i] = v;
   }
+}
+
+// float32 blocked counts -> uint16 (called only when every count is an integer <= 65535: exact)
+__global__ void vc_counts_to_u16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, long long n) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    ushort4 o;
+    o.x = (unsigned short)v.x; o.y = (unsigned short)v.y; o.z = (unsigned short)v.z; o.w = (unsigned short)v.w;
+    *reinterpret_cast<ushort4*>(dst + i) = o;
+  }
+}
+void vc_launch_counts_to_u16(const float* src, unsigned short* dst, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(vc_counts_to_u16_kernel, dim3(4096), dim3(256), 0, st, src, dst, n);      // n is a multiple of 256
 }
 
 // CSR (cells x genes, canonical: no duplicate entries) -> the blocked layout, one wave per cell; dst is pre-zeroed.
