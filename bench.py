@@ -142,6 +142,12 @@ def kernel_roofline(engine, run, steps):
             "kernel": st["main_kernel"], "kernel_avg_us": round(avg_s * 1e6, 2), "launches": int(n),
             "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"]),
             "streamed_bytes_per_launch": int(st["streamed_bytes"]),
+            "count_storage": st["count_storage"],
+            "streamed_GBs": round(st["streamed_bytes"] / avg_s / 1e9, 1),
+            "note": "achieved / frac price the ALGORITHMIC bytes (the reference's float32 count matrices read once, SURVEY 8d) "
+                    "against the 8 TB/s HBM spec; with count_storage u16 the kernel streams half of them (streamed_*), "
+                    "so frac is an efficiency against the float32 roofline, and the binding resource is the VALU issue "
+                    "rate (valu.frac ~ 1)",
             "method": "hipEvents recorded by the library on the launch stream around that kernel only, over eager SVI "
                       "steps run right after the timed region"}
 

@@ -20,6 +20,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "velocycle_amd", "csrc")
 TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
+TRANS_SLOW = re.compile(r"^v_(exp|log|sin|cos)_")
 # (translation unit, H, NB, KIND, NOISE, GPL, C16) -- the instantiations bench.py runs, float32 and uint16 count storage
 KERNELS = [("vc_main_vfull_nb_u16.hip", 1, 0, 1, 0, 8, 1), ("vc_main_vu_nb_u16.hip", 1, 0, 2, 0, 8, 1),
            ("vc_main_phase_nb_u16.hip", 1, 0, 0, 0, 8, 1),
@@ -27,7 +28,9 @@ KERNELS = [("vc_main_vfull_nb_u16.hip", 1, 0, 1, 0, 8, 1), ("vc_main_vu_nb_u16.h
            ("vc_main_vfull_nb_u16.hip", 1, 2, 1, 0, 8, 1), ("vc_main_vu_nb_u16.hip", 1, 2, 2, 0, 8, 1)]
 KIND_NAME = {0: "phase", 1: "vfull", 2: "vu"}
 NOISE_NAME = {0: "nb", 1: "poisson", 2: "lognormal"}
-ISSUE_NS = {"valu": 2.28, "trans": 4.3}     # profiles/r01_d_kmain_bound.md section 2b (valu_rate.hip on MI355X)
+# ns per wave64 instruction and SIMD at TWO waves per SIMD (the occupancy K_main runs at), every CU busy:
+# profiles/tools/valu_rate.hip on MI355X, profiles/r02_valu_rate.txt
+ISSUE_NS = {"plain": 1.69, "packed": 2.59, "exp_log": 3.63, "rcp": 2.86}
 
 
 def device_asm(tu, cache={}):
@@ -70,11 +73,16 @@ def count(tu, H, NB, KIND, NOISE, GPL, C16):
     vmem = [o for o in ops if o.startswith(("global_load", "buffer_load"))]
     cells = 2                                                    # NBUF = VC_PF + 1 cells per loop trip
     meta = {l.split()[0]: l.split()[1] for l in device_asm(tu) if False}
+    slow = [o for o in trans if TRANS_SLOW.match(o)]
+    plain = len(valu) - len(trans) - len(pk)
     res = {"valu_per_cell_iter": len(valu) / cells, "trans_per_cell_iter": len(trans) / cells,
-           "packed_per_cell_iter": len(pk) / cells, "vmem_loads_per_cell_iter": len(vmem) / cells,
+           "packed_per_cell_iter": len(pk) / cells, "plain_per_cell_iter": plain / cells,
+           "exp_log_per_cell_iter": len(slow) / cells, "rcp_per_cell_iter": (len(trans) - len(slow)) / cells,
+           "vmem_loads_per_cell_iter": len(vmem) / cells,
            "salu_per_cell_iter": len([o for o in ops if o.startswith("s_")]) / cells,
            "genes_per_lane": GPL,
-           "issue_ns_per_cell_iter": ((len(valu) - len(trans)) * ISSUE_NS["valu"] + len(trans) * ISSUE_NS["trans"]) / cells}
+           "issue_ns_per_cell_iter": (plain * ISSUE_NS["plain"] + len(pk) * ISSUE_NS["packed"] + len(slow) * ISSUE_NS["exp_log"]
+                                      + (len(trans) - len(slow)) * ISSUE_NS["rcp"]) / cells}
     res["count_storage"] = "u16" if C16 else "f32"
     return f"vc_main_kernel<{H},{NB},{KIND_NAME[KIND]}_{NOISE_NAME[NOISE]},gpl{GPL}{',u16' if C16 else ''}>", res
 
@@ -82,7 +90,8 @@ def count(tu, H, NB, KIND, NOISE, GPL, C16):
 def main():
     out = {"issue_ns": ISSUE_NS,
            "note": "static counts of the cell loop in the gfx950 assembly (profiles/tools/valu_count.py); per wave64 "
-                   "instruction issue costs measured on MI355X (profiles/tools/valu_rate.hip, r01_d_kmain_bound.md 2b); "
+                   "instruction issue costs measured on MI355X at 2 waves per SIMD (profiles/tools/valu_rate.hip, "
+                   "profiles/r02_valu_rate.txt); "
                    "arithmetic bound of a launch = issue_ns_per_cell_iter x (gene blocks x cells) / (CUs x 4 SIMDs)",
            "kernels": {}}
     for k in KERNELS:

@@ -48,8 +48,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define VC_SWAP_REDUCE 0  // 1: the per-cell sums of TWO consecutive cells share one 64-lane reduction (v_permlane32_swap)
 #endif
 #ifndef VC_RCP_MERGE
-#define VC_RCP_MERGE 0    // 1: one reciprocal of t_U * zp instead of rcp(t_U) and rcp(zp) (S+U negative-binomial kernel)
-#endif
+#define VC_RCP_MERGE 1    // one reciprocal of t_U * zp instead of rcp(t_U) and rcp(zp) (negative-binomial U likelihood): -2
+#endif                    // transcendentals, +2 packed multiplies per gene pair; measured -2.5 % (S+U) / -5.6 % (U only) on
+                          // uint16 counts, where the kernel is VALU-issue bound (profiles/r02_kmain.md); 0 restores the two rcp
 
 // Cell record as stored in the cell table: every value duplicated {x, x}, so that a scalar load
 // delivers it as an SGPR pair that v_pk_*_f32 consume directly as a packed operand (no per-cell
