@@ -282,6 +282,18 @@ def make_preprocess():
         out["vel_" + k] = getattr(mv, k).numpy()
     out["vel_model_type"] = np.array(mv.model_type)
     out["design"] = Db.numpy()
+    # dense layers with NON-integer values (e.g. pre-normalised data): the reference's `.A` branch fails for an ndarray, its
+    # `except` branch keeps the floats in the phase container (preprocessing.py:141-147) while the velocity container casts
+    # to int64 in both branches (:243-252)
+    ad2 = AnnDataLite(ad.layers["spliced"] * 0.5 + 0.25, ad.layers["unspliced"] * 0.75)
+    ad2.obs["batch"] = list(ad.obs["batch"])
+    mp2 = vc.preprocessing.preprocess_for_phase_estimation(ad2, cyc, ph, Db, n_harmonics=1)
+    mv2 = vc.preprocessing.preprocess_for_velocity_estimation(ad2, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=1,
+                                                              count_factor=mp2.count_factor, ω_n_harmonics=1)
+    for k in ("S", "U", "logS", "count_factor"):
+        out["nonint_phase_" + k] = getattr(mp2, k).numpy()
+    for k in ("S", "U", "logU"):
+        out["nonint_vel_" + k] = getattr(mv2, k).numpy()
     np.savez_compressed(os.path.join(OUT, "ref_preprocess.npz"), **out)
     print("[preprocess] ok")
 

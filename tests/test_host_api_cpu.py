@@ -156,3 +156,23 @@ def test_sparse_layers_give_the_same_containers_as_dense(normalize):
             x, y = getattr(dense, f), getattr(sparse, f)
             if isinstance(x, torch.Tensor):
                 assert torch.equal(x, y), f
+
+
+def test_dense_non_integer_layers_follow_the_reference_branches():
+    """Dense ndarray layers with non-integer values: the reference's phase preprocessing keeps them as floats (its
+    `.A` attempt fails for an ndarray -> `except` branch, preprocessing.py:141-147), its velocity preprocessing casts to
+    int64 in both branches (:243-252).  Pinned by the reference's own output on such layers."""
+    z, ad, cyc, ph = _inputs()
+    ad2 = AnnDataLite(z["S"] * 0.5 + 0.25, z["U"] * 0.75)
+    ad2.obs["batch"] = list(z["batch"])
+    Db = P.make_design_matrix(ad2, ids="batch")
+    mp2 = P.preprocess_for_phase_estimation(ad2, cyc, ph, Db, n_harmonics=1)
+    for k in ("S", "U", "logS", "count_factor"):
+        assert np.allclose(getattr(mp2, k).numpy(), z["nonint_phase_" + k], rtol=1e-6, atol=1e-6), k
+    assert (mp2.S.numpy() != np.floor(mp2.S.numpy())).any()                 # the halves survived
+    spd = C.AngularSpeed.trivial_prior(["b0", "b1"], harmonics=1)
+    mv2 = P.preprocess_for_velocity_estimation(ad2, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=1,
+                                               count_factor=mp2.count_factor, ω_n_harmonics=1)
+    for k in ("S", "U", "logU"):
+        assert np.allclose(getattr(mv2, k).numpy(), z["nonint_vel_" + k], rtol=1e-6, atol=1e-6), k
+    assert (mv2.S.numpy() == np.floor(mv2.S.numpy())).all()                 # truncated, as the reference does

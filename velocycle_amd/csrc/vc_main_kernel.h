@@ -44,6 +44,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef VC_LB_SINGLE
 #define VC_LB_SINGLE 2    // minimum waves per SIMD the one-matrix kernels (8 genes per lane) are compiled for
 #endif
+#ifndef VC_LDS_REDUCE
+#define VC_LDS_REDUCE 1   // S+U kernel (3 per-cell sums): through an LDS tile of 16 cells (lane t adds up the 64 lanes' partials
+#endif                    // of one (cell, row)) instead of three 64-lane DPP trees per cell: -1.6 % measured; the one-sum kernels
+                          // keep the DPP tree (the tile costs them +5 %), profiles/r02_kmain.md
 #ifndef VC_SWAP_REDUCE
 #define VC_SWAP_REDUCE 0  // 1: the per-cell sums of TWO consecutive cells share one 64-lane reduction (v_permlane32_swap)
 #endif
@@ -245,7 +249,11 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   }
 
   constexpr int RPP = NQ < VC_EPI_ROWS ? NQ : VC_EPI_ROWS;           // output rows staged per epilogue pass
-  __shared__ float4 lds4[(VC_WAVES * RPP * GBW + VC_WAVES + 3) / 4];  // staging area of the 4-wave combine
+  constexpr int TILE_C = 16, TILE_S = 68;                            // LDS reduction tile: cells, padded row stride (floats)
+  constexpr bool LDSR = VC_LDS_REDUCE && FULL;
+  constexpr int TILE_F = LDSR ? VC_WAVES * TILE_C * NCO * TILE_S : 0;
+  constexpr int EPI_F = VC_WAVES * RPP * GBW + VC_WAVES;
+  __shared__ float4 lds4[((EPI_F > TILE_F ? EPI_F : TILE_F) + 3) / 4];   // epilogue staging (4-wave combine) / reduction tiles
 
 #ifdef VC_DBG_TIMES
   asm volatile("" ::"v"(nu[0][0]), "v"(rr[0]));   // stamp 1 sits behind the latents' loads
@@ -392,6 +400,28 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       keep2 = (lane == i) ? t0 : ((lane == i + 1) ? t1 : keep2);
     }
   };
+  // LDS variant: the lane partials of cell slot ci go into this wave's tile [ci][row][lane] (conflict-free writes) ...
+  float* tile = reinterpret_cast<float*>(lds4) + (size_t)wave * TILE_C * NCO * TILE_S;
+  auto tile_put = [&](float p0, float p1, float p2, const int ci) __attribute__((always_inline)) {
+    tile[(ci * NCO + 0) * TILE_S + lane] = p0;
+    if (NCO == 3) { tile[(ci * NCO + 1) * TILE_S + lane] = p1; tile[(ci * NCO + 2) * TILE_S + lane] = p2; }
+  };
+  // ... and once the tile holds n <= 16 cells, lane t = row * 16 + cell adds up the 64 partials of its (cell, row) and stores
+  // the sum (DS operations of one wave execute in order: no barrier; the row stride of 68 floats spreads the 48 readers
+  // over the banks)
+  auto tile_flush = [&](long long cb, int n) __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int c = lane & (TILE_C - 1), row = lane >> 4;
+    if (row < NCO) {
+      const float4* src = reinterpret_cast<const float4*>(tile + (c * NCO + row) * TILE_S);
+      float4 acc = src[0];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) { const float4 v = src[q]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      const float t = (acc.x + acc.y) + (acc.z + acc.w);
+      if (c < n) b.CO[((size_t)gb * NCO + row) * d.Nc + cb + c] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   auto flush = [&](long long cb, int n) {      // coalesced store of the staged per-cell sums of the last n <= 64 cells
     if (lane < n) {
       float* co = b.CO + ((size_t)gb * NCO) * d.Nc + cb + lane;
@@ -452,8 +482,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           unpack(j, sv, uv);
           float p0 = 0.f, p1 = 0.f, p2 = 0.f;
           cell(sv, uv, rec_bf[j], p0, p1, p2);
-          stage1(p0, p1, p2, i & 63);
-          if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);
+          if (LDSR) {
+            tile_put(p0, p1, p2, i & (TILE_C - 1));
+            if ((i & (TILE_C - 1)) == TILE_C - 1 || i + 1 == ncell) tile_flush(cbeg + (i & ~(TILE_C - 1)), (i & (TILE_C - 1)) + 1);
+          } else {
+            stage1(p0, p1, p2, i & 63);
+            if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);
+          }
         }
       }
     }
@@ -472,6 +507,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   }
   // RPP output rows are staged per pass (one barrier pair per pass instead of per row: the epilogue of the last
   // workgroups is on the kernel's critical path)
+  if (LDSR) __syncthreads();                                       // the reduction tiles and the epilogue staging share the LDS
   float* sm = reinterpret_cast<float*>(lds4);                      // [VC_WAVES][RPP][GBW]
   float* sm_ll = sm + VC_WAVES * RPP * GBW;
   {

@@ -241,17 +241,25 @@ class SVIRunner:
         if self.use_graph and self._graph is None:
             s = torch.cuda.Stream(device=e.device)
             s.wait_stream(torch.cuda.current_stream(e.device))
+            g = None
             with torch.cuda.stream(s):
-                self._perf_body(prime=not self._primed)   # warm-up (allocator, lazy init) outside capture
+                self._perf_body(prime=not self._primed)   # warm-up (allocator, lazy init, communicator) outside capture
                 self._primed = True
                 torch.cuda.synchronize()
                 # ProcessGroupNCCL's watchdog thread polls the events of the collectives issued before the capture;
                 # under the default "global" capture mode such a query from ANOTHER thread invalidates the capture on
                 # ROCm (hipErrorStreamCaptureUnsafe).  "thread_local" restricts the check to the capturing thread, which
                 # issues only capturable work here -- deterministic, no waiting for the watchdog to go idle.
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local" if self.do_reduce else "global"):
-                    self._perf_body()
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local" if self.do_reduce else "global"):
+                        self._perf_body()
+                except Exception as ex:                  # capture refused (driver / RCCL build): plain launches, same results
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the SVI step failed ({type(ex).__name__}: {ex}); using eager launches")
+                    g = None
+                    self.use_graph = False
+                    torch.cuda.synchronize()
             torch.cuda.current_stream(e.device).wait_stream(s)
             # the warm-up pass was one real step (capture only records)
             self._graph = g
