@@ -66,24 +66,44 @@ def count(tu, H, NB, KIND, NOISE, GPL, C16):
     sym = f"_Z14vc_main_kernelILi{H}ELi{NB}ELi{KIND}ELi{NOISE}ELi{GPL}ELi{C16}EEv6VcDims6VcBufs"
     body = kernel_body(device_asm(tu), sym)
     a, b = main_loop(body)
-    ops = [l.split()[0] for l in body[a:b + 1] if l.startswith("\t") and not l.strip().startswith((";", "."))]
-    valu = [o for o in ops if o.startswith("v_")]
-    trans = [o for o in valu if TRANS.match(o)]
-    pk = [o for o in valu if o.startswith("v_pk_")]
-    vmem = [o for o in ops if o.startswith(("global_load", "buffer_load"))]
+    # basic blocks of the loop; the blocks that flush staged per-cell sums run once per 16 cells (LDS tile: they hold the
+    # ds_read_b128 column sums) or once per 64 cells (DPP staging: a global_store inside the loop) and are weighted so
+    blocks, cur = [], []
+    for l in body[a:b + 1]:
+        if l.startswith(".LBB") and cur:
+            blocks.append(cur); cur = []
+        cur.append(l)
+        if re.match(r"\s+s_c?branch", l):
+            blocks.append(cur); cur = []
+    if cur:
+        blocks.append(cur)
+    ops, weights = [], []
+    for blk in blocks:
+        ins = [l.split()[0] for l in blk if l.startswith("\t") and not l.strip().startswith((";", "."))]
+        w = 1.0
+        if any(o.startswith("ds_read_b128") for o in ins):
+            w = 1.0 / 16
+        elif any(o.startswith("global_store") for o in ins):
+            w = 1.0 / 64
+        ops += ins
+        weights += [w] * len(ins)
+    wsum = lambda pred: sum(w for o, w in zip(ops, weights) if pred(o))
+    isv = lambda o: o.startswith("v_")
+    n_valu = wsum(isv)
+    n_trans = wsum(lambda o: isv(o) and bool(TRANS.match(o)))
+    n_slow = wsum(lambda o: isv(o) and bool(TRANS_SLOW.match(o)))
+    n_pk = wsum(lambda o: o.startswith("v_pk_"))
+    n_plain = n_valu - n_trans - n_pk
     cells = 2                                                    # NBUF = VC_PF + 1 cells per loop trip
-    meta = {l.split()[0]: l.split()[1] for l in device_asm(tu) if False}
-    slow = [o for o in trans if TRANS_SLOW.match(o)]
-    plain = len(valu) - len(trans) - len(pk)
-    res = {"valu_per_cell_iter": len(valu) / cells, "trans_per_cell_iter": len(trans) / cells,
-           "packed_per_cell_iter": len(pk) / cells, "plain_per_cell_iter": plain / cells,
-           "exp_log_per_cell_iter": len(slow) / cells, "rcp_per_cell_iter": (len(trans) - len(slow)) / cells,
-           "vmem_loads_per_cell_iter": len(vmem) / cells,
-           "salu_per_cell_iter": len([o for o in ops if o.startswith("s_")]) / cells,
+    res = {"valu_per_cell_iter": round(n_valu / cells, 2), "trans_per_cell_iter": round(n_trans / cells, 2),
+           "packed_per_cell_iter": round(n_pk / cells, 2), "plain_per_cell_iter": round(n_plain / cells, 2),
+           "exp_log_per_cell_iter": round(n_slow / cells, 2), "rcp_per_cell_iter": round((n_trans - n_slow) / cells, 2),
+           "vmem_loads_per_cell_iter": round(wsum(lambda o: o.startswith(("global_load", "buffer_load"))) / cells, 2),
+           "lds_per_cell_iter": round(wsum(lambda o: o.startswith("ds_")) / cells, 2),
+           "salu_per_cell_iter": round(wsum(lambda o: o.startswith("s_")) / cells, 2),
            "genes_per_lane": GPL,
-           "issue_ns_per_cell_iter": (plain * ISSUE_NS["plain"] + len(pk) * ISSUE_NS["packed"] + len(slow) * ISSUE_NS["exp_log"]
-                                      + (len(trans) - len(slow)) * ISSUE_NS["rcp"]) / cells}
-    res["count_storage"] = "u16" if C16 else "f32"
+           "issue_ns_per_cell_iter": round((n_plain * ISSUE_NS["plain"] + n_pk * ISSUE_NS["packed"] + n_slow * ISSUE_NS["exp_log"]
+                                            + (n_trans - n_slow) * ISSUE_NS["rcp"]) / cells, 2)}
     return f"vc_main_kernel<{H},{NB},{KIND_NAME[KIND]}_{NOISE_NAME[NOISE]},gpl{GPL}{',u16' if C16 else ''}>", res
 
 

@@ -233,7 +233,8 @@ class SVIRunner:
         if n_steps <= 0:          # nothing to do: in particular no graph warm-up pass, which is one real step
             return
         if self.loss_hist is None or self.loss_hist.shape[0] < self.step_idx + n_steps:
-            new = torch.zeros(max(2 * (self.step_idx + n_steps), 1024), dtype=torch.float64, device=e.device)
+            # (a captured graph holds the ring's address: start large enough that a long run does not have to re-capture)
+            new = torch.zeros(max(2 * (self.step_idx + n_steps), 16384), dtype=torch.float64, device=e.device)
             if self.loss_hist is not None:
                 new[: self.loss_hist.shape[0]] = self.loss_hist
             self.loss_hist = new
@@ -320,7 +321,7 @@ class SVIRunner:
         self._primed = False
         if self.mode == "perf":
             self.step_dev.fill_(self.step_idx)
-            n = max(2 * self.step_idx, 1024)
+            n = max(2 * self.step_idx, 16384)
             if self.loss_hist is None or self.loss_hist.shape[0] < n:
                 self.loss_hist = torch.zeros(n, dtype=torch.float64, device=e.device)
                 self._graph = None          # the captured graph holds the old ring's address
