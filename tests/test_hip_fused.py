@@ -134,3 +134,26 @@ def test_fused_long_run_tracks_the_unfused_sequence():
     assert l2[-200:].mean() < l2[400:600].mean()
     for v in out.values():
         v[2].close()
+
+
+@pytest.mark.parametrize("H,Nb", [(1, 0), (2, 1), (3, 2), (2, 4), (3, 0)])
+def test_fused_step_sweep_over_the_kernel_set(H, Nb):
+    """Fused vs unfused on small ragged problems over harmonics / batches / guides / noise models / conditioning patterns
+    (the generator of tests/test_hip_sweep.py): 6 steps each; identical samples -> parameters to float32 rounding."""
+    from tests.helpers import spec_from_problem
+    from tests.test_hip_sweep import _problem
+    cases = [("phase", "meanfield", "NegativeBinomial", 0, 0, []),
+             ("phase", "meanfield", "Poisson", 0, 0, []),
+             ("velocity", "meanfield", "NegativeBinomial", 1, 2, []),
+             ("velocity", "lrmn", "NegativeBinomial", min(H, 2), 2, []),
+             ("velocity", "lrmn", "NegativeBinomial", 0, 1, ["ϕxy", "ν", "shape_inv"] + (["Δν"] if Nb else [])),
+             ("velocity", "meanfield", "Lognormal", 1, 1, ["νω"]),
+             ("velocity", "meanfield", "Poisson", 2, 3, ["logγg"])]
+    for i, (kind, guide, noise, Hw, Nx, cond) in enumerate(cases):
+        p = _problem(kind, guide, noise, H, Hw, Nb, Nx, cond, Nc=150 + 31 * i, Ng=70 + 3 * i, seed=100 * H + 10 * Nb + i)
+        spec = spec_from_problem(p)
+        ref, got = _run(spec, "hip", 6, False, seed=3), _run(spec, "fused3", 6, False, seed=3)
+        tag = f"H={H} Nb={Nb} case {i} {kind}/{guide}/{noise}/cond={cond}"
+        assert got["status"][0] and np.allclose(got["l"], ref["l"], rtol=2e-6, atol=0), (tag, got["l"], ref["l"])
+        _same(got["p"], ref["p"], tag + ": params", rtol=2e-4, atol=2e-5)
+        _same(got["m"], ref["m"], tag + ": exp_avg", rtol=2e-3, atol=2e-4)
