@@ -20,10 +20,12 @@ def test_profile_tool_compiles(src, tmp_path):
     assert out.stat().st_size > 0
 
 
-@pytest.mark.parametrize("flag", ["-DVC_STREAM_ONLY", "-DVC_DBG_TIMES", "-DVC_PF=2", "-DVC_EPI_ROWS=1"])
+@pytest.mark.parametrize("flag", ["-DVC_STREAM_ONLY", "-DVC_DBG_TIMES", "-DVC_PF=2", "-DVC_EPI_ROWS=1", "-DVC_RCP_MERGE=0",
+                                  "-DVC_SWAP_REDUCE=1", "-DVC_LDS_REDUCE=0", "-DVC_LB_SINGLE=3"])
 def test_measurement_aid_builds(flag, tmp_path):
     """One translation unit of the likelihood kernel per macro (the full library takes too long for the CPU suite)."""
-    src = os.path.join(ROOT, "velocycle_amd", "csrc", "vc_main_vu_poisson.hip")
+    src = os.path.join(ROOT, "velocycle_amd", "csrc", "vc_main_vfull_poisson_u16.hip" if "REDUCE" in flag or "RCP" in flag
+                       else "vc_main_vu_poisson.hip")
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", flag, "-c", src, "-o", str(tmp_path / "k.o")],
                        capture_output=True, text=True, cwd=os.path.dirname(src))
     assert r.returncode == 0, r.stderr[-2000:]
