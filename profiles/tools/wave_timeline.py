@@ -17,11 +17,13 @@ spec = make_velocity_spec(NC, 2000, mode, 1, 1, seed=0, device=dev)
 eng = HipEngine(spec, device=dev)
 run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=0, use_graph=False)
 run.run_perf(20, sync=True)
+grid = int(eng.stats["main_grid"])
+print("kernel", eng.stats["main_kernel"], "grid", grid)
 del run
 eng.close() if hasattr(eng, "close") else None
 del eng
 import gc; gc.collect()
-raw = np.fromfile("/tmp/vc_times.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+raw = np.fromfile("/tmp/vc_times.bin", dtype=np.uint64)[: grid * 32].reshape(-1, 8).astype(np.int64)   # the small kernels' stamps follow
 raw = raw[raw[:, 0] > 0]
 t = raw[:, :4]
 z = t[:, 0].min()

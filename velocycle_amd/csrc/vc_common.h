@@ -33,7 +33,10 @@ struct VcDims {
   int nq;                 // per-gene accumulator rows the likelihood kernel emits
   int nco;                // per-cell accumulator rows
   int n_chunks;           // cell chunks = workgroups per gene block
-  int cw;                 // cells per wave (multiple of 64)
+  int cw;                 // cells per wave (the widest pass)
+  int pass_wgs;           // workgroups per dispatch pass of the likelihood kernel (= CUs): workgroup w runs in pass w / pass_wgs
+  int pass_cw[4];         // cells per wave of the workgroups of pass 0..3 (later passes: as pass 3); all equal to cw unless the
+                          // passes take unequal shares of the cells (vc_engine.hip, tiling)
   int hist_has_S, hist_has_U;
   int nmat_r;             // matrices whose NB constant r*log r is evaluated per step
   float root_w;           // 1 on rank 0, 0 elsewhere: weight of replicated prior / entropy terms
