@@ -95,10 +95,11 @@ def median(xs):
     return ys[n // 2] if n % 2 else 0.5 * (ys[n // 2 - 1] + ys[n // 2])
 
 
-def valu_bound(engine, kernel_avg_s):
-    """The kernel's own arithmetic bound: static VALU count of the cell loop (profiles/valu_model.json, written by
-    profiles/tools/valu_count.py from the gfx950 assembly) x measured issue cost per wave64 instruction, times the
-    cell iterations one SIMD executes (gene blocks x cells / (CUs x 4 SIMDs))."""
+def valu_bound(engine, kernel_avg_s, clock_mhz=None):
+    """The arithmetic floor of the kernel's cell loop: what a SIMD needs for the loop's instruction mix ALONE (static VALU
+    count of the code object, profiles/tools/valu_count.py; cost of that mix measured on the GPU at the launch's waves per
+    SIMD without loads or cross-lane work, profiles/tools/valu_rate.hip), times the cell iterations one SIMD executes
+    (gene blocks x cells / (CUs x 4 SIMDs)), at the clock this process reads."""
     try:
         vm = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
         ent = vm["kernels"][engine.stats["main_kernel"]]
@@ -107,12 +108,17 @@ def valu_bound(engine, kernel_avg_s):
     ncu = torch.cuda.get_device_properties(engine.device).multi_processor_count
     gbw = 64 * ent["genes_per_lane"]
     iters = ((engine.spec.Ng + gbw - 1) // gbw) * engine.Nc_local / (ncu * 4.0)
-    bound_us = ent["issue_ns_per_cell_iter"] * iters * 1e-3
+    waves = max(1, -(-int(engine.stats["main_grid"]) // ncu))          # 256-thread workgroups: one wave per SIMD each
+    key = min(ent["floor_ns_per_cell_iter"], key=lambda w: (abs(int(w) - waves), int(w)))
+    scale = (vm["mix_clock_ghz"] * 1e3 / clock_mhz) if clock_mhz else 1.0
+    bound_us = ent["floor_ns_per_cell_iter"][key] * scale * iters * 1e-3
     return {"bound_us": round(bound_us, 1), "frac": round(bound_us / (kernel_avg_s * 1e6), 4),
             "valu_per_cell_iter": ent["valu_per_cell_iter"], "transcendental_per_cell_iter": ent["trans_per_cell_iter"],
-            "issue_ns": vm["issue_ns"], "cell_iters_per_simd": round(iters, 1),
-            "source": "profiles/valu_model.json (static count of the cell loop in the code object; issue costs measured "
-                      "with profiles/tools/valu_rate.hip)"}
+            "waves_per_simd": waves, "floor_ns_per_cell_iter": ent["floor_ns_per_cell_iter"][key],
+            "floor_measured_at_mhz": vm["mix_clock_ghz"] * 1e3, "priced_at_mhz": clock_mhz,
+            "cell_iters_per_simd": round(iters, 1),
+            "source": "profiles/valu_model.json: static instruction count of the cell loop x the cost of that instruction mix "
+                      "alone on one SIMD (profiles/tools/valu_rate.hip, no loads, no cross-lane work)"}
 
 
 def kernel_roofline(engine, run, steps):
@@ -126,6 +132,7 @@ def kernel_roofline(engine, run, steps):
     engine.set_timing(False)
     run._graph, run.use_graph = saved_graph, saved_flag
     avg_s = ms / max(n, 1) * 1e-3
+    clock_mhz = engine.device_clock_mhz()                  # shader clock right after those launches
     st = engine.stats
     achieved = st["algorithmic_bytes"] / avg_s / 1e9
     traffic, traffic_src = None, None
@@ -138,7 +145,7 @@ def kernel_roofline(engine, run, steps):
         pass
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "valu": valu_bound(engine, avg_s),
+            "valu": valu_bound(engine, avg_s, clock_mhz),
             "kernel": st["main_kernel"], "kernel_avg_us": round(avg_s * 1e6, 2), "launches": int(n),
             "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"]),
             "streamed_bytes_per_launch": int(st["streamed_bytes"]),
@@ -146,8 +153,8 @@ def kernel_roofline(engine, run, steps):
             "streamed_GBs": round(st["streamed_bytes"] / avg_s / 1e9, 1),
             "note": "achieved / frac price the ALGORITHMIC bytes (the reference's float32 count matrices read once, SURVEY 8d) "
                     "against the 8 TB/s HBM spec; with count_storage u16 the kernel streams half of them (streamed_*), "
-                    "so frac is an efficiency against the float32 roofline, and the binding resource is the VALU issue "
-                    "rate (valu.frac ~ 1)",
+                    "so frac is an efficiency against the float32 roofline; the nearer ceiling is the arithmetic floor of "
+                    "the cell loop (valu: the loop's instruction mix alone on one SIMD, measured)",
             "method": "hipEvents recorded by the library on the launch stream around that kernel only, over eager SVI "
                       "steps run right after the timed region"}
 

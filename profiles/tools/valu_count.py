@@ -4,9 +4,11 @@
 For every requested instantiation of vc_main_kernel the main loop (the largest innermost loop of the kernel: two cells
 per trip, the rotating register buffers) is located in `hipcc --cuda-device-only -S` output and its VALU instructions
 are counted: all `v_*` (one issue slot per wave64 instruction; packed-math ops retire two genes per slot) and, among
-them, the transcendentals (v_exp/v_log/v_rcp/v_rsq/v_sqrt/v_sin/v_cos: quarter rate).  With the issue costs measured by
-profiles/tools/valu_rate.hip (ns per wave64 instruction and SIMD) this gives the kernel's arithmetic bound that
-bench.py reports next to the HBM roofline (`roofline.valu`).  Runs without a GPU.
+them, the transcendentals (v_exp/v_log/v_rcp/v_rsq/v_sqrt/v_sin/v_cos: quarter rate).  profiles/tools/valu_rate.hip
+measures on the GPU what a SIMD needs for exactly that instruction MIX and nothing else (no loads, no cross-lane work,
+16 independent chains) at 1..8 waves per SIMD; its output (profiles/r02_valu_rate.txt) is folded in here, scaled by
+the instruction count of each instantiation: the arithmetic floor of the cell loop that bench.py reports next to the
+HBM roofline (`roofline.valu`).  The counting runs without a GPU.
 
   python profiles/tools/valu_count.py            -> writes profiles/valu_model.json
 """
@@ -28,9 +30,27 @@ KERNELS = [("vc_main_vfull_nb_u16.hip", 1, 0, 1, 0, 8, 1), ("vc_main_vu_nb_u16.h
            ("vc_main_vfull_nb_u16.hip", 1, 2, 1, 0, 8, 1), ("vc_main_vu_nb_u16.hip", 1, 2, 2, 0, 8, 1)]
 KIND_NAME = {0: "phase", 1: "vfull", 2: "vu"}
 NOISE_NAME = {0: "nb", 1: "poisson", 2: "lognormal"}
-# ns per wave64 instruction and SIMD at TWO waves per SIMD (the occupancy K_main runs at), every CU busy:
-# profiles/tools/valu_rate.hip on MI355X, profiles/r02_valu_rate.txt
-ISSUE_NS = {"plain": 1.69, "packed": 2.59, "exp_log": 3.63, "rcp": 2.86}
+MIX_OF_KIND = {0: "mix phase (S only)", 1: "mix vfull (S+U)", 2: "mix vu (U only)"}
+
+
+def mix_table(path=os.path.join(ROOT, "profiles", "r02_valu_rate.txt")):
+    """{mix name: {"instr": instructions per cell iteration of the mix, "ns": {waves per SIMD: ns per cell iteration}}},
+    and the shader clock of the run (ticks per ns of the one-wave rows, where the stamping wave is the only one)."""
+    mixes, clocks = {}, []
+    for line in open(path):
+        line = line.strip()
+        if not line.startswith("{"):
+            continue
+        r = json.loads(line)
+        if r["waves_per_simd"] == 1 and r["what"].startswith("mix"):
+            clocks.append(r["ticks_per_ns"])
+        if "ns_per_cell_iter" in r:
+            m = mixes.setdefault(r["what"], {"instr": r["instr_per_cell_iter"], "ns": {}})
+            m["ns"][str(r["waves_per_simd"])] = r["ns_per_cell_iter"]
+    return mixes, round(sorted(clocks)[len(clocks) // 2], 3)
+
+
+MIXES, MIX_CLOCK_GHZ = mix_table()
 
 
 def device_asm(tu, cache={}):
@@ -101,18 +121,20 @@ def count(tu, H, NB, KIND, NOISE, GPL, C16):
            "vmem_loads_per_cell_iter": round(wsum(lambda o: o.startswith(("global_load", "buffer_load"))) / cells, 2),
            "lds_per_cell_iter": round(wsum(lambda o: o.startswith("ds_")) / cells, 2),
            "salu_per_cell_iter": round(wsum(lambda o: o.startswith("s_")) / cells, 2),
-           "genes_per_lane": GPL,
-           "issue_ns_per_cell_iter": round((n_plain * ISSUE_NS["plain"] + n_pk * ISSUE_NS["packed"] + n_slow * ISSUE_NS["exp_log"]
-                                            + (n_trans - n_slow) * ISSUE_NS["rcp"]) / cells, 2)}
+           "genes_per_lane": GPL}
+    mix = MIXES[MIX_OF_KIND[KIND]]
+    res["mix"] = MIX_OF_KIND[KIND]
+    res["floor_ns_per_cell_iter"] = {w: round(ns * res["valu_per_cell_iter"] / mix["instr"], 1) for w, ns in mix["ns"].items()}
     return f"vc_main_kernel<{H},{NB},{KIND_NAME[KIND]}_{NOISE_NAME[NOISE]},gpl{GPL}{',u16' if C16 else ''}>", res
 
 
 def main():
-    out = {"issue_ns": ISSUE_NS,
-           "note": "static counts of the cell loop in the gfx950 assembly (profiles/tools/valu_count.py); per wave64 "
-                   "instruction issue costs measured on MI355X at 2 waves per SIMD (profiles/tools/valu_rate.hip, "
-                   "profiles/r02_valu_rate.txt); "
-                   "arithmetic bound of a launch = issue_ns_per_cell_iter x (gene blocks x cells) / (CUs x 4 SIMDs)",
+    out = {"mix_clock_ghz": MIX_CLOCK_GHZ, "mixes": MIXES,
+           "note": "static counts of the cell loop in the gfx950 assembly (profiles/tools/valu_count.py); "
+                   "floor_ns_per_cell_iter[w] = what a SIMD needs at w waves for the kernel's instruction mix alone, measured "
+                   "on MI355X (profiles/tools/valu_rate.hip -> profiles/r02_valu_rate.txt, at mix_clock_ghz) and scaled by "
+                   "valu_per_cell_iter / the mix's instruction count; arithmetic floor of a launch = floor_ns_per_cell_iter"
+                   "[waves per SIMD of the launch] x (gene blocks x cells) / (CUs x 4 SIMDs) x mix_clock / clock",
            "kernels": {}}
     for k in KERNELS:
         name, res = count(*k)

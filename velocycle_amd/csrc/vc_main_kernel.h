@@ -222,8 +222,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   };
   auto fetch = [&](int j, int i) {
     const long long cn = cbeg + (i < ncell ? i : (ncell > 0 ? ncell - 1 : 0));
-    if (HAS_S) load_counts(Sp + (size_t)cn * GBW * ESZ, s_bf[j]);
-    if (HAS_U) load_counts(Up + (size_t)cn * GBW * ESZ, u_bf[j]);
+#ifdef VC_NO_LOADS           // measurement aid: only the first cells are fetched, the loop re-uses them (results are meaningless):
+    if (i >= NBUF) { asm volatile("" : "+v"(s_bf[j][0]), "+v"(u_bf[j][0])); } else      // what the memory stalls cost, profiles/r02_kmain.md
+#endif
+    {
+      if (HAS_S) load_counts(Sp + (size_t)cn * GBW * ESZ, s_bf[j]);
+      if (HAS_U) load_counts(Up + (size_t)cn * GBW * ESZ, u_bf[j]);
+    }
     rec_bf[j] = vc_load_cell<H, NB>(b.CT + (size_t)cn * d.ctw);
   };
   if (VC_EARLY_FETCH && ncell > 0) {
