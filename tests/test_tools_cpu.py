@@ -21,7 +21,7 @@ def test_profile_tool_compiles(src, tmp_path):
 
 
 @pytest.mark.parametrize("flag", ["-DVC_STREAM_ONLY", "-DVC_DBG_TIMES", "-DVC_PF=2", "-DVC_EPI_ROWS=1", "-DVC_RCP_MERGE=0",
-                                  "-DVC_SWAP_REDUCE=1", "-DVC_LDS_REDUCE=0", "-DVC_LB_SINGLE=3"])
+                                  "-DVC_SWAP_REDUCE=1", "-DVC_LDS_REDUCE=0", "-DVC_LB_SINGLE=3", "-DVC_NO_LOADS"])
 def test_measurement_aid_builds(flag, tmp_path):
     """One translation unit of the likelihood kernel per macro (the full library takes too long for the CPU suite)."""
     src = os.path.join(ROOT, "velocycle_amd", "csrc", "vc_main_vfull_poisson_u16.hip" if "REDUCE" in flag or "RCP" in flag
@@ -29,3 +29,21 @@ def test_measurement_aid_builds(flag, tmp_path):
     r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", flag, "-c", src, "-o", str(tmp_path / "k.o")],
                        capture_output=True, text=True, cwd=os.path.dirname(src))
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_valu_model_is_what_bench_reads():
+    """profiles/valu_model.json (written by profiles/tools/valu_count.py from the code objects and the GPU run of
+    valu_rate.hip) carries, for the kernels bench.py runs, the measured floor of the instruction mix per occupancy."""
+    import json
+    vm = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
+    assert 1.5 < vm["mix_clock_ghz"] < 3.0
+    for name in ("vc_main_kernel<1,0,vfull_nb,gpl8,u16>", "vc_main_kernel<1,0,vu_nb,gpl8,u16>", "vc_main_kernel<1,0,phase_nb,gpl8,u16>"):
+        ent = vm["kernels"][name]
+        floor = ent["floor_ns_per_cell_iter"]
+        assert {"2", "3"} <= set(floor) and ent["genes_per_lane"] == 8
+        mix = vm["mixes"][ent["mix"]]
+        # the mix the GPU tool ran is the kernel's own: instruction counts within 2 %
+        assert abs(mix["instr"] - ent["valu_per_cell_iter"]) <= 0.02 * ent["valu_per_cell_iter"] + 2
+        # more waves never cost more per instruction, and the floor sits between 1.9 and 2.4 ns per instruction
+        assert floor["3"] <= floor["2"] * 1.01
+        assert 1.9 < floor["2"] / ent["valu_per_cell_iter"] < 2.4
