@@ -163,6 +163,8 @@ typedef struct vc_stats {
   char main_kernel_name[96];
   int64_t setup_transient_bytes;  /* device memory vc_finalize held only while it ran (histogram tables, owned uploads) */
   int64_t count_storage_bytes;    /* bytes per count element in HBM: 2 (uint16: every count an integer <= 65535) or 4 */
+  int32_t pass_cells[4];          /* cells per wave of the likelihood kernel's workgroups in dispatch pass 0..3 (all equal:
+                                     balanced tiling; falling: the older passes take larger shares) */
 } vc_stats;
 
 /* lifecycle ------------------------------------------------------------------------------- */

@@ -1,0 +1,68 @@
+"""GPU: the likelihood kernel's cell tiling with unequal shares per dispatch pass (vc_engine.hip).
+
+The shares only move the boundaries between the waves' cell ranges: every cell still belongs to exactly one wave of every
+gene block.  At a size where the grid spans all passes and the shares are in force (30 000 cells x 128 genes: 512 / 768
+workgroups, >= 12 cells per wave) one ELBO + gradient evaluation is compared with the float64 oracle, and the same
+evaluation under other shares (equal, strongly skewed, three and four entries) with the default: per-cell gradients to
+float32 rounding of the per-cell sums, gene-level gradients and the loss to the rounding of a re-associated sum."""
+import os
+
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _evaluate(spec, eps_seed, shares):
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.rng import draw_eps
+    old = os.environ.get("VC_PASS_SHARES")
+    try:
+        if shares is None:
+            os.environ.pop("VC_PASS_SHARES", None)
+        else:
+            os.environ["VC_PASS_SHARES"] = shares
+        eng = HipEngine(spec)          # the tiling is fixed at vc_finalize
+    finally:
+        if old is None:
+            os.environ.pop("VC_PASS_SHARES", None)
+        else:
+            os.environ["VC_PASS_SHARES"] = old
+    g = torch.Generator().manual_seed(eps_seed)
+    first = draw_eps(spec, g)
+    eng.init_params(first.get("_cov_factor_draw"))
+    eps = draw_eps(spec, g)
+    eng.elbo_grad(eps=eng.pack_eps(eps))
+    torch.cuda.synchronize()
+    return eng, eps
+
+
+@pytest.mark.parametrize("mode", ["vjoint", "vcond", "phase"])
+def test_pass_shares_leave_the_result_alone(mode):
+    from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
+    if mode == "phase":
+        spec = make_phase_spec(40000, 128, seed=21)
+    else:
+        spec = make_velocity_spec(40000, 128, mode, 1, 1, seed=21)
+    ref, eps = _evaluate(spec, 5, None)
+    st = ref.stats
+    assert st["main_grid"] > 256, st                      # more than one dispatch pass
+    pc = st["pass_cells"]
+    assert pc[0] > pc[1] and abs(pc[0] - 2 * pc[1]) <= 2, pc    # default: every pass half the cells of the one before
+    H.assert_step_matches_oracle(ref, spec, eps)
+    g_ref = {k: v.double().cpu().clone() for k, v in ref.named(ref.grad).items()}
+    loss_ref = float(ref.loss())
+    for shares in ("1:1", "0.85:0.15", "0.5:0.3:0.2", "4:3:2:1"):
+        eng, _ = _evaluate(spec, 5, shares)
+        pcs = eng.stats["pass_cells"]
+        assert (pcs[0] == pcs[1]) == (shares == "1:1") and pcs != pc, (shares, pcs)
+        assert abs(float(eng.loss()) - loss_ref) <= 2e-6 * abs(loss_ref), (shares, float(eng.loss()), loss_ref)
+        for name, got in eng.named(eng.grad).items():
+            want = g_ref[name]
+            fin = torch.isfinite(want)
+            err = (got.double().cpu()[fin] - want[fin]).abs().max()
+            assert err <= 2e-5 * max(float(want[fin].abs().max()), 1e-3), (shares, name, float(err))
+        eng.close()
+    ref.close()

@@ -58,7 +58,8 @@ class vc_stats(C.Structure):
     _fields_ = [("algorithmic_bytes", C.c_int64), ("streamed_bytes", C.c_int64),
                 ("main_grid", C.c_int64), ("main_block", C.c_int64), ("main_kind", C.c_int32),
                 ("hist_on_device", C.c_int32), ("main_kernel_name", C.c_char * 96),
-                ("setup_transient_bytes", C.c_int64), ("count_storage_bytes", C.c_int64)]
+                ("setup_transient_bytes", C.c_int64), ("count_storage_bytes", C.c_int64),
+                ("pass_cells", C.c_int32 * 4)]
 
 
 EXPORTS = {

@@ -1090,6 +1090,7 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   out->main_kind = d.kind;
   out->hist_on_device = e->hist_on_device;
   out->setup_transient_bytes = (int64_t)e->setup_transient_bytes;
+  for (int p = 0; p < 4; ++p) out->pass_cells[p] = d.pass_cw[p];
   snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.Nb, e->main_name, d.gpl,
            d.c16 ? ",u16" : "");
   return VC_OK;

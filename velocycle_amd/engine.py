@@ -171,7 +171,8 @@ class HipEngine:
                           main_grid=st.main_grid, main_block=st.main_block, main_kind=st.main_kind,
                           main_kernel=st.main_kernel_name.decode(), hist_on_device=bool(st.hist_on_device),
                           setup_transient_bytes=st.setup_transient_bytes,
-                          count_storage="u16" if st.count_storage_bytes == 2 else "f32")
+                          count_storage="u16" if st.count_storage_bytes == 2 else "f32",
+                          pass_cells=[int(x) for x in st.pass_cells])
 
     # ------------------------------------------------------------------------------------------
     def param_shape(self, name):
