@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--cells", type=int, default=50000)
     ap.add_argument("--genes", type=int, default=2000)
     ap.add_argument("--mode", default="vjoint", choices=["vjoint", "vcond", "vcond_mf", "phase"])
+    ap.add_argument("--conditions", type=int, default=1,
+                    help="velocity modes: samples / conditions (Nx = Nb = this; > 1 adds the per-batch offsets Δν); the cells "
+                         "are split evenly over them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-modes", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -173,7 +176,7 @@ def cpu_baseline(args, mode, device=None):
 
     def problem(nsample):
         spec = (make_phase_spec(nsample, args.genes, seed=0, device="cpu") if mode == "phase"
-                else make_velocity_spec(nsample, args.genes, mode, 1, 1, seed=0, device="cpu"))
+                else make_velocity_spec(nsample // args.conditions, args.genes, mode, args.conditions, 1, seed=0, device="cpu"))
         kw = {}
         for k, v in spec.__dict__.items():
             if k in ("truth", "S_csr", "U_csr"):
@@ -321,7 +324,7 @@ def main():
         if mode == "phase":
             spec = make_phase_spec(args.cells, args.genes, seed=0, device=device)
         else:
-            spec = make_velocity_spec(args.cells, args.genes, mode, 1, 1, seed=0, device=device)
+            spec = make_velocity_spec(args.cells // args.conditions, args.genes, mode, args.conditions, 1, seed=0, device=device)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
         eng = HipEngine(spec, device=device, rank=rank, world_size=world)
@@ -375,8 +378,9 @@ def main():
                                   "vcond": "tutorial flow: LRMN guide conditioned on phixy, nu, shape_inv",
                                   "vcond_mf": "mean-field guide conditioned on phixy, nu, shape_inv",
                                   "phase": "spliced matrix only, mean-field guide, nothing conditioned"}[args.mode]
-                               + ", NegativeBinomial noise, H=1, Hw=1",
-                   "cells": args.cells, "genes": args.genes, "mode": args.mode,
+                               + ", NegativeBinomial noise, H=1, Hw=1"
+                               + (f", {args.conditions} samples (Nx = Nb = {args.conditions}, per-batch offsets)" if args.conditions > 1 and args.mode != "phase" else ""),
+                   "cells": args.cells, "genes": args.genes, "mode": args.mode, "conditions": args.conditions,
                    "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
                    "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + (("gloo (test hook) " if one_device else "RCCL ") + "all-reduce -> " if (dist_on or solo_group) else "")
                             + f"ClippedAdam ({run.adam_impl}), " + ("hipGraph replay" if run.use_graph else "eager launches")

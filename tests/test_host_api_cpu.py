@@ -176,3 +176,28 @@ def test_dense_non_integer_layers_follow_the_reference_branches():
     for k in ("S", "U", "logU"):
         assert np.allclose(getattr(mv2, k).numpy(), z["nonint_vel_" + k], rtol=1e-6, atol=1e-6), k
     assert (mv2.S.numpy() == np.floor(mv2.S.numpy())).all()                 # truncated, as the reference does
+
+
+def test_gene_selection_copies_only_the_layers_that_are_read():
+    """adata[:, genes].copy() (preprocessing.py:20-63 filter_shared_genes): the stand-in selects a layer when it is first
+    read, so the float64 logS / logU a phase preprocess left on the object are not copied for a velocity preprocess that
+    never looks at them; values, order and independence from the parent are those of an eager copy."""
+    rng = np.random.default_rng(0)
+    S, U = rng.poisson(2.0, (50, 12)).astype(np.float32), rng.poisson(1.0, (50, 12)).astype(np.float32)
+    ad = AnnDataLite(S, U)
+    ad.layers["logS"] = np.log(S.astype(np.float64) + 1)
+    genes = list(ad.var.index)
+    keep = [genes[7], genes[2], genes[9]]
+    sub = ad[:, keep].copy()
+    assert list(sub.var.index) == keep and sub.shape == (50, 3)
+    assert not dict.__contains__(sub.layers, "logS") and "logS" in sub.layers          # present, not materialised
+    assert np.array_equal(sub.layers["unspliced"], U[:, [7, 2, 9]]) and np.array_equal(sub.X, S[:, [7, 2, 9]])
+    sub.layers["unspliced"][0, 0] = -1.0
+    assert ad.layers["unspliced"][0, 7] == U[0, 7]                                     # a copy, not a view
+    sub.layers["new"] = np.zeros((50, 3))
+    assert set(sub.layers.keys()) == {"spliced", "unspliced", "logS", "new"} and len(sub.layers) == 4
+    assert np.array_equal(sub.layers["logS"], ad.layers["logS"][:, [7, 2, 9]])
+    again = sub.copy()
+    assert again is sub                                                               # already owns its data
+    rows = ad[[3, 1], keep]
+    assert np.array_equal(rows.layers["spliced"], S[np.ix_([3, 1], [7, 2, 9])])

@@ -508,11 +508,13 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // per-gene state (latents + accumulators) fits 2 waves per SIMD without scratch, which the code object itself
   // tells (private segment size 0); else 4.
   d.gpl = 4;
+  size_t max_scratch = 0;      // VC_MAX_SCRATCH (bytes per lane, measurement aid): accept an 8-genes-per-lane kernel that spills this little
+  if (const char* env = getenv("VC_MAX_SCRATCH")) max_scratch = (size_t)atoi(env);
   {
     const void* k8 = nullptr;
     hipFuncAttributes fa;
     if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
-        hipFuncGetAttributes(&fa, k8) == hipSuccess && fa.localSizeBytes == 0)
+        hipFuncGetAttributes(&fa, k8) == hipSuccess && fa.localSizeBytes <= max_scratch)
       d.gpl = 8;
   }
   if (const char* env = getenv("VC_GPL")) { if (atoi(env) == 4 || atoi(env) == 8) d.gpl = atoi(env); }
@@ -607,7 +609,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       hipFuncAttributes fa;
       vc_main_launch_fn f16 = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, 1, &nm, &k16);
       vc_main_launch_fn p16 = d.kind == VC_KIND_VU ? vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, 1, nullptr, nullptr) : nullptr;
-      if (f16 && k16 && (d.kind != VC_KIND_VU || p16) && hipFuncGetAttributes(&fa, k16) == hipSuccess && fa.localSizeBytes == 0) {
+      if (f16 && k16 && (d.kind != VC_KIND_VU || p16) && hipFuncGetAttributes(&fa, k16) == hipSuccess && fa.localSizeBytes <= max_scratch) {
         const size_t blocked = (size_t)d.nGB * d.Nc * d.gbw;
         const float** dstp[2] = {&b.S, &b.U};
         for (int m = 0; m < 2; ++m) {

@@ -76,9 +76,13 @@ class _FitBase:
     def fit(self, optimizer, loss=None, num_steps=1000, intermediate_output_step_size=100, store_output=False,
             verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None, process_group=None):
         self._warn_sizes()
+        import time
+        t_start = time.perf_counter()
         if self.engine is None:
             self._make_engine(device, process_group)
         eng = self.engine
+        torch.cuda.synchronize(eng.device)
+        t_engine = time.perf_counter()
         args = optim_args_of(optimizer)
         exact = mode == "parity" or self.early_exit or store_output
         if mode == "parity":
@@ -119,14 +123,20 @@ class _FitBase:
                 elif step > 200 and self.early_exit:
                     early = True
         self.losses = losses
+        torch.cuda.synchronize(eng.device)
+        t_svi = time.perf_counter()
         ok, first_bad, n_bad = eng.status()                                     # device-side latch of the C ABI
         if not ok or not np.all(np.isfinite(np.asarray(losses, dtype=np.float64))):   # pyro.util.warn_if_nan(loss, "loss")
             import warnings
             warnings.warn("Encountered NaN/Inf: loss" + ("" if ok else f" (first at step {first_bad}, {n_bad} steps)"),
                           UserWarning)
         self._extract()
+        t_extract = time.perf_counter()
         if self.get_posterior:
             self._posterior()
+        # wall seconds of the stages of this call (not in the reference; profiles/tools/fit_wall_time.py prints them)
+        self.timings = {"engine_setup": t_engine - t_start, "svi_steps": t_svi - t_engine, "extract": t_extract - t_svi,
+                        "posterior": time.perf_counter() - t_extract}
         if store_output:
             return intermediate_output
 
