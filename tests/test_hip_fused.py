@@ -157,3 +157,28 @@ def test_fused_step_sweep_over_the_kernel_set(H, Nb):
         assert got["status"][0] and np.allclose(got["l"], ref["l"], rtol=2e-6, atol=0), (tag, got["l"], ref["l"])
         _same(got["p"], ref["p"], tag + ": params", rtol=2e-4, atol=2e-5)
         _same(got["m"], ref["m"], tag + ": exp_avg", rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("mode", ["vjoint", "vcond"])
+def test_step_with_loss_equals_the_device_ring(mode):
+    """SVIRunner.step_with_loss: the loss of every step reaches the host through the pinned ring the device writes into
+    (no synchronise, no copy) -- the same steps, the same losses as run_perf, bit for bit, and the two can be mixed."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    from velocycle_amd.workloads import make_velocity_spec
+    spec = make_velocity_spec(3000, 256, mode, 1, 1, seed=4)
+    ea, eb = HipEngine(spec), HipEngine(spec)
+    a = SVIRunner(ea, OPT, mode="perf", seed=11)
+    b = SVIRunner(eb, OPT, mode="perf", seed=11)
+    a.run_perf(40)
+    la = a.perf_losses()
+    b.run_perf(5)                                   # the ring starts on the device ...
+    lb = b.perf_losses()
+    lb += [b.step_with_loss() for _ in range(25)]   # ... moves to pinned host memory ...
+    assert not b.loss_hist.is_cuda and b.loss_hist.is_pinned()
+    b.run_perf(10)                                  # ... and run_perf keeps filling it
+    lb += b.perf_losses()[30:]
+    assert len(lb) == 40 and lb == la
+    assert b.perf_losses() == la
+    assert torch.equal(ea.params, eb.params)
+    ea.close(); eb.close()

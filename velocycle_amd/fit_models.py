@@ -111,8 +111,7 @@ class _FitBase:
                 if mode == "parity":
                     l = run.step()
                 else:
-                    run.run_perf(1)
-                    l = run.perf_losses()[-1]
+                    l = run.step_with_loss()
                 losses.append(l)
                 if store_output and step % intermediate_output_step_size == 0:
                     logging.info("Elbo loss: {}".format(l))

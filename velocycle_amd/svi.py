@@ -280,6 +280,42 @@ class SVIRunner:
         if sync:
             torch.cuda.synchronize(e.device)
 
+    _SENTINEL = -0x0007_2174_5EED_0001          # an int64 bit pattern no loss takes (a NaN with this payload)
+
+    def step_with_loss(self) -> float:
+        """One perf-mode step that hands its loss to the host, as `svi.step()` does (velocity_inference_model.py:118-121),
+        without a stream synchronise or a device-to-host copy: the loss ring is moved to pinned host memory, which the
+        device writes directly (K_omega's loss block), and the host spins on the slot of this step.  Single-rank fused
+        path only; every other configuration runs the step and copies the loss back."""
+        e = self.e
+        if self.mode != "perf" or self.adam_impl != "fused3" or self._graph is not None or self.use_graph:
+            self.run_perf(1, sync=False)
+            return float(self.loss_hist[self.step_idx - 1].item())
+        import numpy as np
+        ring = self.loss_hist
+        if ring is None or ring.is_cuda or ring.shape[0] < self.step_idx + 1:
+            n = max(2 * (self.step_idx + 1), 16384)
+            new = torch.zeros(n, dtype=torch.float64).pin_memory()
+            if ring is not None:
+                torch.cuda.synchronize(e.device)
+                new[: min(ring.shape[0], n)] = ring[: min(ring.shape[0], n)].cpu()
+            self.loss_hist = ring = new
+            self._ring_i64 = ring.numpy().view(np.int64)
+        slots, i64 = self._ring_i64, self._ring_i64
+        k = self.step_idx % ring.shape[0]
+        i64[k] = self._SENTINEL
+        self._perf_body(prime=not self._primed, n_steps=1)
+        self._primed = True
+        self.step_idx += 1
+        spins = 0
+        while i64[k] == self._SENTINEL:
+            spins += 1
+            if spins > 2_000_000:                       # a step takes ~0.1 ms: something failed -- surface the error
+                torch.cuda.synchronize(e.device)
+                if i64[k] == self._SENTINEL:
+                    raise RuntimeError("the device never wrote the loss of this step")
+        return float(ring[k])
+
     def perf_losses(self) -> List[float]:
         torch.cuda.synchronize(self.e.device)
         if self.loss_hist is None:
