@@ -182,3 +182,18 @@ def test_step_with_loss_equals_the_device_ring(mode):
     assert b.perf_losses() == la
     assert torch.equal(ea.params, eb.params)
     ea.close(); eb.close()
+
+
+@pytest.mark.parametrize("mode", ["vjoint", "vcond"])
+def test_fused_step_with_large_shard_cell_blocks(mode, monkeypatch):
+    """K_tail's cell blocks take 1024 instead of 256 cells on shards above 160 000 cells (all 16 waves of the block busy);
+    forced here at a small size: same steps as the unfused sequence."""
+    from velocycle_amd.workloads import make_velocity_spec
+    monkeypatch.setenv("VC_TAIL_TC", "1024")
+    spec = make_velocity_spec(2600, 200, mode, 2, 1, seed=9)
+    a = _run(spec, "fused3", 6, False)
+    monkeypatch.delenv("VC_TAIL_TC")
+    b = _run(spec, "fused", 6, False)
+    assert a["sd"] == b["sd"] == 6 and a["status"][0] and b["status"][0]
+    assert np.allclose(a["l"], b["l"], rtol=2e-7, atol=0)
+    _same(a["p"], b["p"], "params", rtol=2e-4, atol=2e-5)

@@ -45,7 +45,8 @@ struct VcDims {
   long long eoff[VC_E_COUNT];   // eps offsets
   long long eps_n_global, eps_total;
   int nb_pre_gene, nb_pre_cell, nb_post_gene, nb_post_cell, n_main_wg;
-  int nb_tail_cell;       // fused pipeline: cell blocks of K_tail (256 cells each)
+  int nb_tail_cell;       // fused pipeline: cell blocks of K_tail (tail_tc cells each)
+  int tail_tc;            // cells per cell block of K_tail: 256 (one wave per SIMD, shortest chain) or 1024 (large shards)
   int nlpf;               // fused pipeline: loss slots per half of LPF = nb_post_gene + nb_tail_cell + 1
   float lgamma_alpha;     // lgamma(gamma_alpha) of the shape_inv prior, evaluated once on the host
 };

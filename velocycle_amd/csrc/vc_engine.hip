@@ -761,7 +761,12 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
   TRY(e->dalloc(&b.PW, (size_t)((d.Nc + 255) / 256) * std::max(1, d.NW)));      // K_post: 1024-cell blocks; K_tail: 256
-  d.nb_tail_cell = (d.Nc + 255) / 256;
+  // K_tail's cell blocks: 256 cells on 4 of the block's 16 waves keep the per-cell chain shortest, but a block still takes a
+  // 1024-thread slot when it is placed (2 per CU): beyond ~2 rounds of them the placement is what costs (400 000 cells:
+  // K_tail 68 us), and 1024 cells per block -- every wave busy, a quarter of the blocks -- is faster (measured threshold)
+  d.tail_tc = d.Nc > 160000 ? 1024 : 256;
+  if (const char* env = getenv("VC_TAIL_TC")) { if (atoi(env) == 256 || atoi(env) == 1024) d.tail_tc = atoi(env); }
+  d.nb_tail_cell = (d.Nc + d.tail_tc - 1) / d.tail_tc;
   d.nlpf = d.nb_post_gene + d.nb_tail_cell + 1;
   d.lgamma_alpha = lgammaf(d.gamma_alpha);
   TRY(e->dalloc(&b.LPF, 2 * (size_t)d.nlpf));

@@ -422,17 +422,19 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_tail, cell block: 256 cells on the first 4 waves of the (1024-thread) block -- one wave per SIMD: the per-cell chain
-// (Philox, Adam, atan2, sincos) is instruction-bound, 16 waves on one CU would serialise it four deep
+// K_tail, cell block: d.tail_tc cells.  256 cells on the first 4 waves of the (1024-thread) block -- one wave per SIMD: the
+// per-cell chain (Philox, Adam, atan2, sincos) is instruction-bound, 16 waves on one CU would serialise it four deep; large
+// shards (vc_engine.hip) use all 16 waves, 1024 cells per block, because the number of blocks to place then dominates
 // ---------------------------------------------------------------------------------------------
-#define VC_TC 256
+#define VC_TC_MAX 1024
 __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs& b, float* __restrict__ P,
                                                    float* __restrict__ G, float* __restrict__ Mm, float* __restrict__ Vv,
                                                    int header, int cblock, long long s, uint64_t seed, const VcOpt o,
                                                    int boot) {
-  __shared__ float sm_w[VC_TC / 64][VC_MAX_NW];
-  __shared__ double sm_lc[VC_TC / 64];
-  if (threadIdx.x >= VC_TC) return;        // waves 4..15 of the block have nothing to do
+  __shared__ float sm_w[VC_TC_MAX / 64][VC_MAX_NW];
+  __shared__ double sm_lc[VC_TC_MAX / 64];
+  const int VC_TC = d.tail_tc;
+  if ((int)threadIdx.x >= VC_TC) return;   // 256-cell blocks: waves 4..15 of the block have nothing to do
   VC_WSTAMP(0, 0);
   const int c = cblock * VC_TC + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -572,7 +574,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   {
     const double ws = vc_wave_sum_d63(loss);
     if (lane == 63) sm_lc[wave] = ws;
-    __syncthreads();                        // (only the 4 live waves take part; also orders sm_w)
+    __syncthreads();                        // (only the live waves take part; also orders sm_w)
     if (vel && !boot && (int)threadIdx.x < d.NW) {
       const int j = threadIdx.x;
       float t = 0.f;
