@@ -301,7 +301,7 @@ class SVIRunner:
                 new[: min(ring.shape[0], n)] = ring[: min(ring.shape[0], n)].cpu()
             self.loss_hist = ring = new
             self._ring_i64 = ring.numpy().view(np.int64)
-        slots, i64 = self._ring_i64, self._ring_i64
+        i64 = self._ring_i64
         k = self.step_idx % ring.shape[0]
         i64[k] = self._SENTINEL
         self._perf_body(prime=not self._primed, n_steps=1)
