@@ -66,3 +66,29 @@ def test_pass_shares_leave_the_result_alone(mode):
             assert err <= 2e-5 * max(float(want[fin].abs().max()), 1e-3), (shares, name, float(err))
         eng.close()
     ref.close()
+
+
+def test_pass_shares_with_gene_blocks_that_do_not_divide_the_cus(monkeypatch):
+    """1 100 genes = 3 gene blocks: the boundary between two dispatch passes then falls inside a row of chunks (chunk c of
+    gene block gb runs in pass (3 c + gb) / CUs), so the gene blocks have different numbers of chunks per pass.  One
+    evaluation against the float64 oracle, and against the balanced tiling selected the old way (VC_CELLS_PER_WAVE), which
+    does not go through the share arithmetic at all."""
+    from velocycle_amd.workloads import make_velocity_spec
+    spec = make_velocity_spec(9000, 1100, "vjoint", 1, 1, seed=23)
+    ref, eps = _evaluate(spec, 6, None)
+    pc = ref.stats["pass_cells"]
+    assert ref.stats["main_grid"] > 256 and pc[0] > pc[1] >= 8, (ref.stats["main_grid"], pc)
+    H.assert_step_matches_oracle(ref, spec, eps)
+    g_ref = {k: v.double().cpu().clone() for k, v in ref.named(ref.grad).items()}
+    loss_ref = float(ref.loss())
+    monkeypatch.setenv("VC_CELLS_PER_WAVE", "14")
+    old, _ = _evaluate(spec, 6, None)
+    monkeypatch.delenv("VC_CELLS_PER_WAVE")
+    assert len(set(old.stats["pass_cells"])) == 1
+    assert abs(float(old.loss()) - loss_ref) <= 2e-6 * abs(loss_ref)
+    for name, got in old.named(old.grad).items():
+        want = g_ref[name]
+        fin = torch.isfinite(want)
+        err = (got.double().cpu()[fin] - want[fin]).abs().max()
+        assert err <= 2e-5 * max(float(want[fin].abs().max()), 1e-3), (name, float(err))
+    old.close(); ref.close()
