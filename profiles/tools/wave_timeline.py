@@ -16,7 +16,7 @@ NC = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
 spec = make_velocity_spec(NC, 2000, mode, 1, 1, seed=0, device=dev)
 eng = HipEngine(spec, device=dev)
 run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=0, use_graph=False)
-run.run_perf(20, sync=True)
+run.run_perf(int(os.environ.get("VC_TIMELINE_STEPS", "600")), sync=True)      # long enough for the clocks to settle (the first ~30 ms run slower)
 grid = int(eng.stats["main_grid"])
 print("kernel", eng.stats["main_kernel"], "grid", grid)
 del run
@@ -35,6 +35,11 @@ for k, nm in enumerate(["entry", "latents loaded", "loop end", "epilogue end"]):
     v = us[:, k]
     print(f"{nm:16s} min {v.min():7.2f} p10 {np.percentile(v,10):7.2f} med {np.median(v):7.2f} p90 {np.percentile(v,90):7.2f} max {v.max():7.2f}")
 d = us[:, 2] - us[:, 1]
+if raw[:, 6].max() > 0:      # shader-clock ticks of the cell loop / its duration on the constant-rate clock (nominally 10 ns per tick)
+    clk = raw[:, 6] / np.maximum(t[:, 2] - t[:, 1], 1) / 10.0
+    sel = d > 0.5 * np.median(d)
+    print("shader clock inside the cell loop (GHz, against the nominal 100 MHz constant clock): med %.3f p10 %.3f p90 %.3f" %
+          (np.median(clk[sel]), np.percentile(clk[sel], 10), np.percentile(clk[sel], 90)))
 print("loop duration    min %.2f med %.2f p90 %.2f max %.2f" % (d.min(), np.median(d), np.percentile(d, 90), d.max()))
 wg = np.arange(len(us)) // 4
 nGB = int(sys.argv[2]) if len(sys.argv) > 2 else 4

@@ -281,6 +281,9 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   asm volatile("" ::"v"(nu[0][0]), "v"(rr[0]));   // stamp 1 sits behind the latents' loads
 #endif
   VC_STAMP(1);
+#ifdef VC_DBG_TIMES
+  const unsigned long long dbg_m1 = __builtin_readcyclecounter();      // shader-clock ticks at the start of the cell loop
+#endif
   float keep0 = 0.f, keep1 = 0.f, keep2 = 0.f;
   // one cell against the lane's genes: sv/uv = the counts, rec = the cell record, i = staging lane of the cell
   auto cell = [&](const v2f* sv, const v2f* uv, const VcCellRec<H, NB>& rec, float& p0, float& p1, float& p2) __attribute__((always_inline)) {
@@ -517,6 +520,12 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   }
 
   VC_STAMP(2);
+#ifdef VC_DBG_TIMES
+  if ((threadIdx.x & 63) == 0) {      // ticks spent in the cell loop: with stamps 1 and 2 the clock the loop ran at
+    unsigned long long* o = b.dbg + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    o[6] = __builtin_readcyclecounter() - dbg_m1;
+  }
+#endif
   // ---- combine the 4 waves' gene-level partials through LDS, one store per workgroup ----------
   // d loglik / d r (NB): -sum_c [log(r+mu) + (r+k)/(r+mu)] = -ln2 * sum log2 t - n_obs - (sum_c a)/r
   v2f gr[NP];
