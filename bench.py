@@ -61,8 +61,8 @@ def parse():
     ap.add_argument("--cpu-sample-cells", type=int, default=10000)
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed regions of --steps steps each, the median is reported; 0 = max(9, ceil(1000 / steps)): "
-                         "short regions are repeated until ~1000 steps are timed (memory / fabric clocks take ~30 ms of "
-                         "GPU work to ramp, a 20-step region is 4 ms)")
+                         "short regions are repeated until ~1000 steps are timed (the sustained clock under this load takes ~30 ms "
+                         "of GPU work to ramp, a 20-step region is 3 ms)")
     ap.add_argument("--roofline-launches", type=int, default=100)
     return ap.parse_args()
 
@@ -379,8 +379,10 @@ def main():
                   "synchronize on both sides, max over ranks); repeat_ms_per_step lists all of them in order",
         "device_clock_mhz": {"before_timed_region": round(clock_before, 1), "after_timed_region": round(clock_after, 1),
                              "method": "shader clock: s_memtime ticks per 200 us of s_memrealtime, one wave "
-                                       "(vc_device_clock_mhz); memory / fabric clocks are not observable from a kernel -- "
-                                       "their ramp shows in the first entries of repeat_ms_per_step"},
+                                       "(vc_device_clock_mhz) -- the clock of a LIGHT kernel; the sustained clock inside the "
+                                       "likelihood kernel is lower (2.29-2.36 GHz at steady state, 1.6-1.7 GHz during the first "
+                                       "~30 ms of a fresh process: profiles/r02_wave_timeline_u16.txt), and that ramp shows in "
+                                       "the first entries of repeat_ms_per_step"},
         "setup_s": setup,
         "config": {"workload": f"synthetic {args.cells} cells x {args.genes} genes " + ("phase_inference" if args.mode == "phase" else "velocity_inference") + ", "
                                + {"vjoint": "mean-field guide, nothing conditioned (every gradient)",
