@@ -78,7 +78,51 @@ static void one_case(int Ng, int Nc, bool gene_major, bool spiky, unsigned seed)
   CHECK(covered == (long long)val_h.size());
 }
 
+// The cell tiling of the likelihood kernel: for every gene block the waves' ranges [first, first + cw) clamped to Nc, taken in
+// the order (chunk, wave), tile [0, Nc) exactly -- no gap, no overlap -- whatever the shares, the number of gene blocks
+// (also when it does not divide the CUs), the occupancy; and the grid never exceeds the resident slots when shares apply.
+static void tiling_case(long long Nc, int nGB, int n_cu, int bpc, const double* share, int min_cw, long long cw_override) {
+  const int waves = 4;
+  const VcTiling t = vc_tile_cells(Nc, nGB, n_cu, bpc, waves, cw_override, share, min_cw);
+  CHECK(t.n_chunks >= 1 && t.cw >= 1);
+  bool unequal = false;
+  for (int p = 1; p < 4; ++p) unequal |= t.pass_cw[p] != t.pass_cw[0];
+  if (unequal) CHECK((long long)nGB * t.n_chunks <= (long long)bpc * n_cu);
+  for (int p = 0; p < 4; ++p) CHECK(t.pass_cw[p] >= 1 && t.pass_cw[p] <= t.cw);
+  for (int gb = 0; gb < nGB; ++gb) {
+    long long next = 0;                    // first cell nobody has taken yet
+    for (int chunk = 0; chunk < t.n_chunks; ++chunk)
+      for (int w = 0; w < waves; ++w) {
+        int cw = 0;
+        long long b = vc_wave_first_cell(chunk, gb, w, nGB, n_cu, t.pass_cw, waves, &cw);
+        long long e = b + cw;
+        CHECK(cw >= 1);
+        if (b > Nc) b = Nc;
+        if (e > Nc) e = Nc;
+        if (b < Nc) CHECK(b == next);
+        if (e > next) next = e;
+      }
+    CHECK(next == Nc);
+  }
+}
+
 int main() {
+  {
+    const double half[4] = {1.0, 0.5, 0.25, 0.125}, flat[4] = {1, 1, 1, 1}, odd[4] = {0.5, 0.3, 0.2, 0.2}, steep[4] = {0.85, 0.15, 0.15, 0.15};
+    std::mt19937 rng(11);
+    for (int it = 0; it < 400; ++it) {
+      const long long Nc = 1 + (long long)(rng() % 200000) * (it % 7 == 0 ? 13 : 1);
+      const int nGB = 1 + (int)(rng() % 9), n_cu = (it % 5 == 0) ? 1 + (int)(rng() % 300) : 256, bpc = 1 + (int)(rng() % 5);
+      const double* sh[] = {half, flat, odd, steep, nullptr};
+      tiling_case(Nc, nGB, n_cu, bpc, sh[rng() % 5], (it % 3 == 0) ? 1 : 12, (it % 11 == 0) ? 1 + (long long)(rng() % 300) : 0);
+    }
+    tiling_case(50000, 4, 256, 2, half, 12, 0);
+    tiling_case(50000, 4, 256, 3, half, 12, 0);
+    tiling_case(9000, 3, 256, 2, half, 12, 0);
+    tiling_case(1, 1, 256, 2, half, 12, 0);
+    const VcTiling t = vc_tile_cells(50000, 4, 256, 2, 4, 0, half, 12);
+    CHECK(t.n_chunks == 128 && t.pass_cw[0] == 131 && t.pass_cw[1] == 66);
+  }
   one_case(7, 33, false, false, 1);
   one_case(7, 33, true, true, 2);
   one_case(64, 301, false, true, 3);

@@ -644,74 +644,29 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     const char* env = getenv("VC_BLOCKS_PER_CU");
     if (env && atoi(env) > 0) blocks_per_cu = atoi(env);
-    long long slots = (long long)blocks_per_cu * n_cu;
-    long long chunks = slots / d.nGB;
-    if (chunks < 1) chunks = 1;
-    long long cw = (d.Nc + VC_WAVES * chunks - 1) / (VC_WAVES * chunks);
-    if (cw < 8) cw = 8;       // keep the per-gene prologue/epilogue amortised (measured: 8 beats 16 for Nc <= 6250, r01)
-    env = getenv("VC_CELLS_PER_WAVE");
-    if (env && atoi(env) > 0) cw = atoi(env);
-    d.cw = (int)cw;
-    const long long per_wg = (long long)VC_WAVES * d.cw;
-    d.n_chunks = (int)((d.Nc + per_wg - 1) / per_wg);
-    d.pass_wgs = n_cu;
-    for (int p = 0; p < 4; ++p) d.pass_cw[p] = d.cw;
     // Unequal shares per dispatch pass.  The workgroups of pass p (the p-th one on every CU) are older than those of pass
     // p + 1 and the SIMD arbiter issues the oldest ready wave first: with equal shares the first pass ends its cells at
     // ~60 % of the kernel and the last pass then runs alone, one wave per SIMD (profiles/tools/wave_timeline.py).  Measured
     // (profiles/r02_pass_shares.md): shares falling by 1/2 per pass (2 passes 0.67 : 0.33, 3 passes 0.57 : 0.29 : 0.14) cut the
-    // kernel by 6-8 %; that is the default for a full multi-pass grid.  VC_PASS_SHARES="a:b[:c[:d]]" overrides ("1:1" = the
-    // balanced tiling above).  The tiling stays a pure function of (Nc, Ng, occupancy, CUs): results are reproducible.
-    {
-      const int P = blocks_per_cu > 4 ? 4 : blocks_per_cu;
-      double share[4] = {1.0, 0.5, 0.25, 0.125};
-      bool want = blocks_per_cu <= 4;           // (no instantiation in use exceeds 3 workgroups per CU)
-      if (const char* se = getenv("VC_PASS_SHARES")) {
-        int n = sscanf(se, "%lf%*[,:]%lf%*[,:]%lf%*[,:]%lf", &share[0], &share[1], &share[2], &share[3]);
-        want = want && n >= 2;
-        for (int p = (n > 0 ? n : 1); p < 4; ++p) share[p] = share[p - 1] * (n >= 2 ? share[n - 1] / share[n - 2] : 1.0);
-        for (int p = 0; p < 4; ++p) if (!(share[p] > 0)) want = false;
-      }
-      const long long full = (long long)P * n_cu;
-      const char* mce = getenv("VC_PASS_MIN_CW");
-      const int min_cw = mce && atoi(mce) > 0 ? atoi(mce) : 12;   // below that the passes' fixed prologue / epilogue dominate (measured at the 6 250-cell shard)
-      if (want && P >= 2 && (long long)d.nGB * d.n_chunks > (long long)(P - 1) * n_cu && d.cw >= min_cw && !(env && atoi(env) > 0)) {
-        // chunks of gene block gb in pass p: [first(p, gb), first(p + 1, gb)), first(p, gb) = ceil((p n_cu - gb) / nGB)
-        auto first = [&](int p, int gb) -> long long {
-          const long long x = (long long)p * n_cu - gb;
-          return x > 0 ? (x + d.nGB - 1) / d.nGB : 0;
-        };
-        const long long n_ch = full / d.nGB;                   // chunks per gene block of the full grid
-        double ssum = 0;
-        for (int p = 0; p < P; ++p) ssum += share[p];
-        int pcw[4];
-        for (int p = 0; p < 4; ++p) {
-          const int q = p < P ? p : P - 1;
-          const double per_pass_chunks = (double)n_ch / P;
-          pcw[p] = (int)ceil(share[q] / ssum * d.Nc / (VC_WAVES * per_pass_chunks));
-          if (pcw[p] < 8) pcw[p] = 8;
-        }
-        auto covered = [&](int gb) -> long long {
-          long long c = 0;
-          for (int p = 0; p < P; ++p) {
-            long long lo = first(p, gb), hi = (p == P - 1) ? n_ch : first(p + 1, gb);
-            if (hi > n_ch) hi = n_ch;
-            if (hi > lo) c += (hi - lo) * VC_WAVES * pcw[p];
-          }
-          return c;
-        };
-        for (int it = 0; it < 100000; ++it) {                  // widen every pass by one cell until every gene block is covered
-          long long mn = covered(0);
-          for (int gb = 1; gb < d.nGB; ++gb) { const long long c = covered(gb); if (c < mn) mn = c; }
-          if (mn >= d.Nc) break;
-          for (int p = 0; p < 4; ++p) ++pcw[p];
-        }
-        int mx = 0;
-        for (int p = 0; p < 4; ++p) { d.pass_cw[p] = pcw[p]; if (pcw[p] > mx) mx = pcw[p]; }
-        d.cw = mx;
-        d.n_chunks = (int)n_ch;
-      }
+    // kernel by 5-9 %; that is the default for a full multi-pass grid.  VC_PASS_SHARES="a:b[:c[:d]]" overrides ("1:1" = the
+    // balanced tiling).  The tiling (vc_host_logic.h, also what the kernel evaluates per wave) stays a pure function of
+    // (Nc, Ng, occupancy, CUs): results are reproducible.
+    double share[4] = {1.0, 0.5, 0.25, 0.125};
+    bool want = true;
+    if (const char* se = getenv("VC_PASS_SHARES")) {
+      int n = sscanf(se, "%lf%*[,:]%lf%*[,:]%lf%*[,:]%lf", &share[0], &share[1], &share[2], &share[3]);
+      want = n >= 2;
+      for (int p = (n > 0 ? n : 1); p < 4; ++p) share[p] = share[p - 1] * (n >= 2 ? share[n - 1] / share[n - 2] : 1.0);
     }
+    const char* cwe = getenv("VC_CELLS_PER_WAVE");
+    const char* mce = getenv("VC_PASS_MIN_CW");
+    // below 12 cells per wave the passes' fixed prologue / epilogue dominate (measured at the 6 250-cell shard)
+    const VcTiling t = vc_tile_cells(d.Nc, d.nGB, n_cu, blocks_per_cu, VC_WAVES, cwe && atoi(cwe) > 0 ? atoi(cwe) : 0,
+                                     want ? share : nullptr, mce && atoi(mce) > 0 ? atoi(mce) : 12);
+    d.cw = t.cw;
+    d.n_chunks = t.n_chunks;
+    d.pass_wgs = n_cu;
+    for (int p = 0; p < 4; ++p) d.pass_cw[p] = t.pass_cw[p];
     d.n_main_wg = d.nGB * d.n_chunks;
   }
   d.nb_pre_gene = d.Ng_pad / 64;       // 64 genes per block, the sites of a gene spread over its 4 waves

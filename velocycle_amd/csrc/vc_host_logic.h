@@ -10,6 +10,12 @@
 #include <utility>
 #include <vector>
 
+#if defined(__HIPCC__)
+#define VC_HD __host__ __device__
+#else
+#define VC_HD
+#endif
+
 #define VC_HIST_CAP 2048          // counts 1 .. VC_HIST_CAP-1 have a dense per-gene bin; everything else is "overflow"
 
 // a count the negative binomial / Poisson likelihood accepts: finite and >= 0
@@ -117,4 +123,85 @@ static inline void vc_build_hist_tasks(const std::vector<int>& ptr, int Ng, std:
         task.insert(task.end(), {g, m, beg, std::min(end, beg + 64)});
   }
   tptr.push_back((int)task.size() / 4);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Cell tiling of the likelihood kernel.  Workgroup (chunk, gene block gb) has the linear index
+// chunk * nGB + gb and runs in dispatch pass index / pass_wgs (pass_wgs = CUs: the dispatcher places one workgroup per CU
+// per pass); the waves of pass p take pass_cw[p] consecutive cells each (passes >= 3: pass_cw[3]).  Chunks of one gene
+// block are contiguous per pass: first chunk of pass p = ceil((p * pass_wgs - gb) / nGB).
+// ---------------------------------------------------------------------------------------------
+// first cell and cells-per-wave of wave `wave` (0..waves-1) of workgroup (chunk, gb); the caller clamps to the cell count
+VC_HD static inline long long vc_wave_first_cell(int chunk, int gb, int wave, int nGB, int pass_wgs, const int* pass_cw,
+                                                 int waves, int* my_cw) {
+  long long cbeg = 0;
+  int cw = pass_cw[0];
+  int c_lo = 0;
+  for (int p = 0; p < 4; ++p) {
+    const long long nxt = (long long)(p + 1) * pass_wgs - gb;
+    const int c_hi = (p == 3) ? 0x7fffffff : (nxt > 0 ? (int)((nxt + nGB - 1) / nGB) : 0);
+    if (chunk >= c_hi) cbeg += (long long)(c_hi - c_lo) * (waves * pass_cw[p]);
+    else if (chunk >= c_lo) { cbeg += (long long)(chunk - c_lo) * (waves * pass_cw[p]); cw = pass_cw[p]; }
+    c_lo = c_hi;
+  }
+  *my_cw = cw;
+  return cbeg + (long long)wave * cw;
+}
+
+struct VcTiling { int n_chunks, cw, pass_cw[4]; };
+
+// Balanced tiling (every wave `cw` cells) or, when `share` is given, cells per wave proportional to share[p] in pass p,
+// widened until every gene block covers all Nc cells.  slots = workgroups resident at once (occupancy x CUs).
+static inline VcTiling vc_tile_cells(long long Nc, int nGB, int n_cu, int blocks_per_cu, int waves, long long cw_override,
+                                     const double* share, int min_cw) {
+  VcTiling t;
+  const long long slots = (long long)blocks_per_cu * n_cu;
+  long long chunks = slots / nGB;
+  if (chunks < 1) chunks = 1;
+  long long cw = (Nc + waves * chunks - 1) / (waves * chunks);
+  if (cw < 8) cw = 8;       // keep the per-gene prologue/epilogue amortised (measured: 8 beats 16 for Nc <= 6250, r01)
+  if (cw_override > 0) cw = cw_override;
+  t.cw = (int)cw;
+  const long long per_wg = (long long)waves * t.cw;
+  t.n_chunks = (int)((Nc + per_wg - 1) / per_wg);
+  for (int p = 0; p < 4; ++p) t.pass_cw[p] = t.cw;
+  const int P = blocks_per_cu > 4 ? 4 : blocks_per_cu;
+  if (!share || blocks_per_cu > 4 || P < 2 || cw_override > 0 || t.cw < min_cw ||
+      (long long)nGB * t.n_chunks <= (long long)(P - 1) * n_cu)
+    return t;
+  for (int p = 0; p < P; ++p) if (!(share[p] > 0.0)) return t;
+  auto first = [&](int p, int gb) -> long long {
+    const long long x = (long long)p * n_cu - gb;
+    return x > 0 ? (x + nGB - 1) / nGB : 0;
+  };
+  const long long n_ch = (long long)P * n_cu / nGB;              // chunks per gene block of the full grid
+  double ssum = 0;
+  for (int p = 0; p < P; ++p) ssum += share[p];
+  int pcw[4];
+  for (int p = 0; p < 4; ++p) {
+    const int q = p < P ? p : P - 1;
+    pcw[p] = (int)std::ceil(share[q] / ssum * (double)Nc / (waves * ((double)n_ch / P)));
+    if (pcw[p] < 8) pcw[p] = 8;
+  }
+  auto covered = [&](int gb) -> long long {
+    long long c = 0;
+    for (int p = 0; p < P; ++p) {
+      long long lo = first(p, gb), hi = (p == P - 1) ? n_ch : first(p + 1, gb);
+      if (hi > n_ch) hi = n_ch;
+      if (hi > lo) c += (hi - lo) * waves * pcw[p];
+    }
+    return c;
+  };
+  for (int it = 0; it < 1000000; ++it) {                         // widen every pass by one cell until every gene block is covered
+    long long mn = covered(0);
+    for (int gb = 1; gb < nGB; ++gb) { const long long c = covered(gb); if (c < mn) mn = c; }
+    if (mn >= Nc) break;
+    for (int p = 0; p < 4; ++p) ++pcw[p];
+  }
+  int mx = 0;
+  for (int p = 0; p < 4; ++p) { t.pass_cw[p] = pcw[p]; if (pcw[p] > mx) mx = pcw[p]; }
+  t.cw = mx;
+  t.n_chunks = (int)n_ch;
+  return t;
 }

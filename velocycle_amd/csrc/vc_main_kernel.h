@@ -22,6 +22,7 @@
 // at 95 % of their arithmetic (profiles/r01_d_kmain_bound.md).
 #pragma once
 #include "vc_common.h"
+#include "vc_host_logic.h"   // vc_wave_first_cell: the cell tiling, shared with the host (and its CPU sanitizer test)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -178,22 +179,9 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // runs in parallel with the loads of the per-gene latents below -------------------------------------------------
   // The workgroups of one dispatch pass (pass_wgs = one per CU) are co-resident with those of the other passes on every
   // CU, and the SIMD arbiter serves the oldest wave first; the passes may therefore take unequal shares of the cells
-  // (pass_cw[p] cells per wave in pass p), so that the waves of a SIMD end together.  Chunks c of gene block gb belong to
-  // pass (c nGB + gb) / pass_wgs: contiguous in c, first chunk of pass p = ceil((p pass_wgs - gb) / nGB).
-  long long cbeg = 0;
-  int my_cw = d.pass_cw[0];
-  {
-    int c_lo = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int nxt = (p + 1) * d.pass_wgs - gb;
-      const int c_hi = (p == 3) ? 0x7fffffff : (nxt > 0 ? (nxt + d.nGB - 1) / d.nGB : 0);
-      if (chunk >= c_hi) cbeg += (long long)(c_hi - c_lo) * (VC_WAVES * d.pass_cw[p]);
-      else if (chunk >= c_lo) { cbeg += (long long)(chunk - c_lo) * (VC_WAVES * d.pass_cw[p]); my_cw = d.pass_cw[p]; }
-      c_lo = c_hi;
-    }
-  }
-  cbeg += (long long)wave * my_cw;
+  // (pass_cw[p] cells per wave in pass p), so that the waves of a SIMD end together (vc_host_logic.h: vc_tile_cells).
+  int my_cw;
+  long long cbeg = vc_wave_first_cell(chunk, gb, wave, d.nGB, d.pass_wgs, d.pass_cw, VC_WAVES, &my_cw);
   long long cend = cbeg + my_cw;
   if (cbeg > d.Nc) cbeg = d.Nc;
   if (cend > d.Nc) cend = d.Nc;
