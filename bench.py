@@ -282,6 +282,28 @@ def device_identity(device):
             "cus": pr.multi_processor_count, "hbm_gb": round(pr.total_memory / 2 ** 30, 1)}
 
 
+def self_launch(n: int) -> int:
+    import socket
+    import subprocess
+    with socket.socket() as so:                       # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    sys.stderr.write(proc.stderr)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if ln not in js:
+            sys.stderr.write(ln + "\n")               # anything else the ranks printed goes to stderr: stdout is ONE JSON line
+    if js:
+        print(js[-1])
+    return proc.returncode if (proc.returncode != 0 or js) else 1
+
+
 def main():
     args = parse()
     if args.repeats <= 0:
@@ -294,7 +316,10 @@ def main():
     if args.gpus != world and dist_on:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and not dist_on:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+        # `python bench.py --gpus N` as written: this process has made NO GPU call yet (importing torch does not initialise
+        # HIP), so it may start the launcher as a CHILD process -- one rank per GPU over RCCL -- and relay rank 0's JSON line
+        # and the exit code.  Never os.exec*: a process that touched the GPU must not be replaced (Environment notes).
+        sys.exit(self_launch(args.gpus))
     # test hook (tests/test_hip_multiproc.py): VC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and exchanges through
     # gloo, so that the N > 1 path can be exercised end to end on a 1-GPU box.  Never set in a measured run.
     one_device = os.environ.get("VC_BENCH_ONE_DEVICE", "0") == "1"

@@ -120,3 +120,28 @@ def assert_trajectory_within_float32_spread(spec, opt, n, seed, losses, named_pa
         scale = max(np.abs(want[fin]).max(), 1e-2)
         err, spread = np.abs(got[fin] - want[fin]).max(), np.abs(ref32[fin] - want[fin]).max()
         assert err <= max(1e-3 * scale, 4 * spread), (k, err, spread, scale)
+
+
+def philox_eps_list(spec, params_flat, seed, n):
+    """The standard-normal draws the performance path uses at steps 0..n-1 (Philox4x32-10 keyed by (seed, step, index)),
+    rebuilt INDEPENDENTLY of the run under test: a second engine's sampling kernel at (seed, t), read back through
+    vc_read_site(eps).  Returned as the oracle's per-site eps dicts (float64, CPU)."""
+    from velocycle_amd.engine import HipEngine
+    eng = HipEngine(spec)
+    eng.params.copy_(params_flat.to(eng.device))
+    shapes = {"ν": (spec.Ng, spec.Nh), "νω": (spec.Nx, spec.Nhw), "ϕxy": (spec.Nc, 2)}
+    out = []
+    for t in range(n):
+        eng.sample_guide(eps=None, seed=seed, step=t)
+        flat = eng.read_site("eps")
+        out.append({k: flat[o:o + s].double().reshape(shapes.get(k, (s,))) for k, (o, s) in eng.eps_slices.items()})
+    eng.close()
+    return out
+
+
+def oracle_replay(spec, opt, par0_named, eps_list, dtype=torch.float64):
+    """orc.fit on explicit initial parameters and eps draws: (losses, final unconstrained params)."""
+    p = problem_from_spec(spec, dtype)
+    par0 = {k: v.detach().cpu().to(dtype).clone() for k, v in par0_named.items()}
+    eps = [{k: v.to(dtype) for k, v in e.items()} for e in eps_list]
+    return orc.fit(p, opt, len(eps), eps_list=eps, params=par0)

@@ -47,3 +47,18 @@ def test_two_process_bench_matches_single_process():
     for a, b in zip(j1["loss_first_last"], j2["loss_first_last"]):
         assert abs(a - b) <= 1e-6 * abs(a), (j1["loss_first_last"], j2["loss_first_last"])
     assert j1["loss_first_last"][1] < j1["loss_first_last"][0]
+
+
+def test_bench_gpus_2_launches_itself():
+    """`python bench.py --gpus 2 ...` as the driver writes it for N = 1 (no launcher in front): the parent, which has made no
+    GPU call, starts torch.distributed.run as a child, relays rank 0's ONE JSON line on stdout and the exit code."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2", *SIZE], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    out_lines = [l for l in two.stdout.splitlines() if l.strip()]
+    assert len(out_lines) == 1, two.stdout[-2000:]
+    j = json.loads(out_lines[0])
+    assert j["n_gpus"] == 2 and j["distributed"]["world_size"] == 2 and j["steps"] == 30

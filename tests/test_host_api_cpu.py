@@ -201,3 +201,31 @@ def test_gene_selection_copies_only_the_layers_that_are_read():
     assert again is sub                                                               # already owns its data
     rows = ad[[3, 1], keep]
     assert np.array_equal(rows.layers["spliced"], S[np.ix_([3, 1], [7, 2, 9])])
+
+
+def test_csr_side_channel_is_dropped_when_the_dense_counts_were_replaced_or_edited():
+    """ADVICE r2 (engine.py:94): the CSR copy of a sparse layer may feed the engine only while it provably describes the
+    same data as the dense S / U fields of the container, which users edit with `_replace` or in place."""
+    import scipy.sparse as sp
+    from velocycle_amd import containers as C, preprocessing as P
+    from velocycle_amd.anndata_lite import AnnDataLite
+    from velocycle_amd.spec import spec_from_metaparams
+    rng = np.random.default_rng(0)
+    S = rng.poisson(1.0, size=(60, 12)).astype(np.float32)
+    U = rng.poisson(0.5, size=(60, 12)).astype(np.float32)
+    ad = AnnDataLite(sp.csr_matrix(S), sp.csr_matrix(U))
+    cyc = C.Cycle.from_array(np.zeros((3, 12)), np.ones((3, 12)), list(ad.var.index))
+    ph = C.Phases.from_array(np.ones((2, 60)), cell_names=list(ad.obs.index))
+    mp = P.preprocess_for_phase_estimation(ad, cyc, ph, torch.ones(60, 1), n_harmonics=1, with_delta_nu=False)
+    assert mp.S_csr is not None and P.csr_is_current(mp.S_csr, mp.S)
+    assert spec_from_metaparams(mp, "phase").S_csr is mp.S_csr
+    # same-shape replacement (subsampled / permuted / normalised counts): the stale CSR must not be used
+    mp2 = mp._replace(S=mp.S.flip(1).contiguous())
+    assert spec_from_metaparams(mp2, "phase").S_csr is None
+    # other fields replaced (what fit() itself does for count_factor): still current
+    mp3 = mp._replace(count_factor=mp.count_factor * 0)
+    assert spec_from_metaparams(mp3, "phase").S_csr is mp.S_csr
+    # in-place edit of the dense tensor: version counter moves, CSR dropped
+    mp.S.mul_(2.0)
+    assert not P.csr_is_current(mp.S_csr, mp.S)
+    assert spec_from_metaparams(mp, "phase").S_csr is None

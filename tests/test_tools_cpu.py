@@ -20,15 +20,37 @@ def test_profile_tool_compiles(src, tmp_path):
     assert out.stat().st_size > 0
 
 
-@pytest.mark.parametrize("flag", ["-DVC_STREAM_ONLY", "-DVC_DBG_TIMES", "-DVC_PF=2", "-DVC_EPI_ROWS=1", "-DVC_RCP_MERGE=0",
-                                  "-DVC_SWAP_REDUCE=1", "-DVC_LDS_REDUCE=0", "-DVC_LB_SINGLE=3", "-DVC_NO_LOADS"])
+@pytest.mark.parametrize("flag", ["-DVC_STREAM_ONLY", "-DVC_DBG_TIMES", "-DVC_PF=1", "-DVC_EPI_ROWS=1", "-DVC_RCP_MERGE=0",
+                                  "-DVC_SWAP_REDUCE=1 -DVC_ASM_LOADS=0", "-DVC_LDS_REDUCE=0", "-DVC_LB_SINGLE=3",
+                                  "-DVC_NO_LOADS -DVC_ASM_LOADS=0", "-DVC_ASM_LOADS=0", "-DVC_ISSUE_PIN=0"])
 def test_measurement_aid_builds(flag, tmp_path):
     """One translation unit of the likelihood kernel per macro (the full library takes too long for the CPU suite)."""
     src = os.path.join(ROOT, "velocycle_amd", "csrc", "vc_main_vfull_poisson_u16.hip" if "REDUCE" in flag or "RCP" in flag
                        else "vc_main_vu_poisson.hip")
-    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", flag, "-c", src, "-o", str(tmp_path / "k.o")],
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", *flag.split(), "-c", src, "-o", str(tmp_path / "k.o")],
                        capture_output=True, text=True, cwd=os.path.dirname(src))
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("tu", ["vc_main_vfull_nb_u16.hip", "vc_main_vu_nb_u16.hip", "vc_main_phase_nb.hip"])
+def test_asm_count_loads_are_never_touched_in_flight(tu):
+    """The likelihood kernel issues its count loads from inline asm with hand-placed waits (VC_ASM_LOADS).  hipcc does not
+    model such loads, so the emitted code object is audited (profiles/tools/check_asm_loads.py): in every instantiation the
+    engine can select (no scratch -- vc_finalize refuses the others) no instruction touches a destination tuple between its
+    load and the wait that retires it, around the loop's back edge too; every loop wait leaves the same number of
+    operations outstanding; a vmcnt(0) drain retires every tuple before the epilogue."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_loads", os.path.join(ROOT, "profiles", "tools", "check_asm_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.report_tu(tu)
+    assert rep, "no vc_main_kernel instantiation found"
+    selectable = [r for r in rep if r["scratch"] == 0]
+    assert len(selectable) >= 15                                   # every 4-genes-per-lane kernel + the small 8-genes-per-lane ones
+    for r in selectable:
+        assert r["asm_loads"] > 0 and not r["problems"], r
+    h1 = [r for r in selectable if "ILi1ELi0E" in r["name"] and "ELi8ELi" in r["name"]]
+    assert h1, "the benchmark instantiation (H = 1, no batches, 8 genes per lane) must stay scratch-free"
 
 
 def test_valu_model_is_what_bench_reads():

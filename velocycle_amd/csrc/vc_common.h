@@ -7,6 +7,9 @@
 #include "../../include/velocycle_hip.h"
 
 #define VC_WAVES 4          // waves per workgroup of the likelihood kernel
+#ifndef VC_ASM_LOADS
+#define VC_ASM_LOADS 1      // likelihood kernel: count loads issued from inline asm with hand-placed waits (vc_main_kernel.h)
+#endif
 #define VC_MAXH 3
 #define VC_MAXNB 4
 #define VC_MAX_NW 64        // max Nx*Nhw (angular-speed coefficients)

@@ -510,6 +510,9 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   d.gpl = 4;
   size_t max_scratch = 0;      // VC_MAX_SCRATCH (bytes per lane, measurement aid): accept an 8-genes-per-lane kernel that spills this little
   if (const char* env = getenv("VC_MAX_SCRATCH")) max_scratch = (size_t)atoi(env);
+#if VC_ASM_LOADS
+  max_scratch = 0;             // asm-issued count loads: a spilled destination tuple would be stored before its data has landed
+#endif
   {
     const void* k8 = nullptr;
     hipFuncAttributes fa;

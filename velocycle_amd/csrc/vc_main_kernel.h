@@ -21,6 +21,7 @@
 // the S+U kernel sits within 10 % of both that memory-side bound and its own arithmetic bound, the one-matrix kernels
 // at 95 % of their arithmetic (profiles/r01_d_kmain_bound.md).
 #pragma once
+#include <type_traits>
 #include "vc_common.h"
 #include "vc_host_logic.h"   // vc_wave_first_cell: the cell tiling, shared with the host (and its CPU sanitizer test)
 
@@ -36,11 +37,20 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef VC_EPI_ROWS
 #define VC_EPI_ROWS 6     // output rows staged per epilogue pass (LDS: 4 waves x rows x 64*GPL floats)
 #endif
+#ifndef VC_ASM_LOADS
+#define VC_ASM_LOADS 1    // the count loads are issued from inline asm (global_load_dwordx4 with an SGPR base) and waited for with
+#endif                    // hand-placed `s_waitcnt vmcnt(k)`, k = the loads of the cells fetched AFTER the one about to be
+                          // processed: hipcc's own wait insertion drains the queue (`vmcnt(0)`) once per loop trip as soon as
+                          // more than one cell is in flight (the exits of the unrolled loop join its latch), which is what kept
+                          // the loop at one cell of prefetch; profiles/r03_kmain.md.  0 = the compiler-counted loads of round 2.
 #ifndef VC_PF
-#define VC_PF 1           // register path: cells in flight ahead of the one being processed
+#define VC_PF (VC_ASM_LOADS ? 2 : 1)   // register path: cells in flight ahead of the one being processed
 #endif
 #ifndef VC_PF_SINGLE
 #define VC_PF_SINGLE VC_PF   // the same for the one-matrix kernels (phase, U-only): half the bytes in flight per cell
+#endif
+#ifndef VC_ISSUE_PIN
+#define VC_ISSUE_PIN 1    // sched_barrier behind the issue of the next cell's loads (asm path): keeps them at the top of the cell
 #endif
 #ifndef VC_LB_SINGLE
 #define VC_LB_SINGLE 2    // minimum waves per SIMD the one-matrix kernels (8 genes per lane) are compiled for
@@ -142,6 +152,49 @@ __device__ __forceinline__ void vc_obs_lognormal(v2f y, v2f eta, float inv_s2, v
   ll = v2_fma(e * (-0.5f * VC_LOG2E), a, ll);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Count loads with hand-placed waits (VC_ASM_LOADS).  An asm load is invisible to hipcc's s_waitcnt bookkeeping
+// (cdna_hip_programming.md section 5.7): the destination tuple counts as written at the end of the statement, so
+//   * every consumer sits behind a wait statement that names the tuple "+v" (pins the order), and
+//   * a drain statement naming every tuple closes the loop (a load landing after the registers were re-used would corrupt
+//     the epilogue), and
+//   * tests/test_tools_cpu.py checks the code object: no instruction touches a tuple between its load and its wait, no scratch.
+// Address form: SGPR base (wave-uniform row of the blocked layout) + 32-bit VGPR lane offset; `s_nop 4` covers a base that was
+// produced by v_readfirstlane (VALU write of an SGPR -> VMEM read: 5 wait states).
+// ---------------------------------------------------------------------------------------------
+static_assert(!(VC_SWAP_REDUCE && VC_ASM_LOADS), "VC_SWAP_REDUCE pairs cells without the asm path's waits: build it with -DVC_ASM_LOADS=0");
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+
+template <int NDW> struct VcCnt;                  // the count registers of one (cell, matrix) of a lane: NDW dwords
+template <> struct VcCnt<2> { v2u a; };
+template <> struct VcCnt<4> { v4u a; };
+template <> struct VcCnt<8> { v4u a, b; };
+
+__device__ __forceinline__ void vc_issue(VcCnt<2>& c, uint32_t voff, const char* sbase) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(c.a) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void vc_issue(VcCnt<4>& c, uint32_t voff, const char* sbase) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(c.a) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void vc_issue(VcCnt<8>& c, uint32_t voff, const char* sbase) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+               : "=&v"(c.a), "=&v"(c.b) : "v"(voff), "s"(sbase) : "memory");
+}
+// wait until at most N vector-memory operations of this wave are outstanding; the tuples named are readable afterwards
+template <int N> __device__ __forceinline__ void vc_wait(VcCnt<2>& c) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(c.a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void vc_wait(VcCnt<4>& c) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(c.a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void vc_wait(VcCnt<8>& c) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(c.a), "+v"(c.b) : "n"(N)); }
+template <int N> __device__ __forceinline__ void vc_wait(VcCnt<2>& c, VcCnt<2>& e) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(c.a), "+v"(e.a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void vc_wait(VcCnt<4>& c, VcCnt<4>& e) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(c.a), "+v"(e.a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void vc_wait(VcCnt<8>& c, VcCnt<8>& e) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(c.a), "+v"(c.b), "+v"(e.a), "+v"(e.b) : "n"(N));
+}
+template <int NDW> __device__ __forceinline__ uint32_t vc_cnt_dword(const VcCnt<NDW>& c, int k);
+template <> __device__ __forceinline__ uint32_t vc_cnt_dword<2>(const VcCnt<2>& c, int k) { return c.a[k]; }
+template <> __device__ __forceinline__ uint32_t vc_cnt_dword<4>(const VcCnt<4>& c, int k) { return c.a[k]; }
+template <> __device__ __forceinline__ uint32_t vc_cnt_dword<8>(const VcCnt<8>& c, int k) { return k < 4 ? c.a[k] : c.b[k - 4]; }
+
 // GPL = genes per lane (4 or 8): 8 amortises the per-cell work (DPP reductions, staging, loop) over twice
 // the genes and is faster whenever its accumulators still fit 2 waves per SIMD (launch bound) -- the host
 // picks GPL per (kind, K); the HBM layout [gene block][cell][64*GPL] follows it.
@@ -193,8 +246,14 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   constexpr int NP = GPL / 2;           // packed pairs per lane
   constexpr int NV4 = GPL / 4;          // float4 groups of the lane's genes (gene table loads, epilogue stores)
   constexpr int NDW = GPL * ESZ / 4;    // dwords per lane per matrix per cell: 8 / 4 (float32), 4 / 2 (uint16)
-  constexpr int PF = FULL ? VC_PF : VC_PF_SINGLE, NBUF = PF + 1;
-  uint32_t s_bf[NBUF][NDW], u_bf[NBUF][NDW];
+  constexpr bool ASM = VC_ASM_LOADS != 0;
+  // cells in flight ahead of the one being processed.  The S+U kernel at 8 genes per lane has room for a third count buffer
+  // (8 more VGPRs) only up to K = 3 coefficients per gene (H = 1, no batch offsets: 248 VGPRs); beyond that the third buffer
+  // spills, and a spilled asm-load tuple is not just slow but wrong, so those instantiations keep one cell ahead
+  constexpr int PF = FULL ? ((GPL == 8 && K > 3 && VC_PF > 1) ? 1 : VC_PF) : VC_PF_SINGLE, NBUF = PF + 1;
+  constexpr int LPF = (HAS_S + HAS_U) * (NDW == 8 ? 2 : 1);   // vector-memory instructions per fetched cell (asm path)
+  uint32_t s_bf[ASM ? 1 : NBUF][NDW], u_bf[ASM ? 1 : NBUF][NDW];
+  VcCnt<NDW> s_q[ASM ? NBUF : 1], u_q[ASM ? NBUF : 1];        // asm path: the count registers as load tuples
   VcCellRec<H, NB> rec_bf[NBUF];
   auto load_counts = [&](const char* p, uint32_t* w) __attribute__((always_inline)) {
     if (NDW >= 4) {
@@ -208,8 +267,19 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       w[0] = v.x; w[1] = v.y;
     }
   };
-  auto fetch = [&](int j, int i) {
+  // asm path: wave-uniform base of this wave's gene block (SGPR pair) + the lane's byte offset inside a row (VGPR)
+  const char* Sb = HAS_S ? reinterpret_cast<const char*>(b.S) + ((size_t)gb * d.Nc) * GBW * ESZ : nullptr;
+  const char* Ub = HAS_U ? reinterpret_cast<const char*>(b.U) + ((size_t)gb * d.Nc) * GBW * ESZ : nullptr;
+  const uint32_t lane_off = (uint32_t)gl * ESZ;
+  auto fetch = [&](int j, int i) __attribute__((always_inline)) {
     const long long cn = cbeg + (i < ncell ? i : (ncell > 0 ? ncell - 1 : 0));
+    if (ASM) {
+      // the "s" operand needs a PROVABLY wave-uniform value (else hipcc hands the asm a VGPR pair and the assembler rejects
+      // it): the cell index goes through readfirstlane, which folds away wherever the compiler already knows it is uniform
+      const size_t row = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)cn) * (GBW * ESZ);
+      if (HAS_S) vc_issue(s_q[j], lane_off, Sb + row);
+      if (HAS_U) vc_issue(u_q[j], lane_off, Ub + row);
+    } else
 #ifdef VC_NO_LOADS           // measurement aid: only the first cells are fetched, the loop re-uses them (results are meaningless):
     if (i >= NBUF) { asm volatile("" : "+v"(s_bf[j][0]), "+v"(u_bf[j][0])); } else      // what the memory stalls cost, profiles/r02_kmain.md
 #endif
@@ -218,6 +288,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       if (HAS_U) load_counts(Up + (size_t)cn * GBW * ESZ, u_bf[j]);
     }
     rec_bf[j] = vc_load_cell<H, NB>(b.CT + (size_t)cn * d.ctw);
+  };
+  // asm path: the counts of buffer j are readable once at most `pend` younger fetches are outstanding
+  auto wait_counts = [&](int j, auto pend) __attribute__((always_inline)) {
+    constexpr int N = decltype(pend)::value * LPF;
+    if (HAS_S && HAS_U) vc_wait<N>(s_q[j], u_q[j]);
+    else if (HAS_S) vc_wait<N>(s_q[j]);
+    else vc_wait<N>(u_q[j]);
   };
   if (VC_EARLY_FETCH && ncell > 0) {
 #pragma unroll
@@ -454,14 +531,25 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         for (int j = 0; j < PF; ++j) fetch(j, j);
       }
       auto unpack = [&](int j, v2f* sv, v2f* uv) __attribute__((always_inline)) {
-        auto pair_of = [&](const uint32_t* w, int p) -> v2f {      // genes 2p, 2p + 1 of the lane
-          if (C16) return v2f{(float)(w[p] & 0xffffu), (float)(w[p] >> 16)};
-          return v2f{__builtin_bit_cast(float, w[2 * p]), __builtin_bit_cast(float, w[2 * p + 1])};
+        auto pair_w = [&](uint32_t lo, uint32_t hi) -> v2f {      // genes 2p, 2p + 1 of the lane
+          if (C16) return v2f{(float)(lo & 0xffffu), (float)(lo >> 16)};
+          return v2f{__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};
+        };
+        auto pair_of = [&](const uint32_t* w, int p) -> v2f {
+          return C16 ? pair_w(w[p], 0u) : pair_w(w[2 * p], w[2 * p + 1]);
+        };
+        auto pair_q = [&](const VcCnt<NDW>& c, int p) -> v2f {
+          return C16 ? pair_w(vc_cnt_dword<NDW>(c, p), 0u) : pair_w(vc_cnt_dword<NDW>(c, 2 * p), vc_cnt_dword<NDW>(c, 2 * p + 1));
         };
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          sv[p] = HAS_S ? pair_of(s_bf[j], p) : v2(0.f);
-          uv[p] = HAS_U ? pair_of(u_bf[j], p) : v2(0.f);
+          if (ASM) {
+            sv[p] = HAS_S ? pair_q(s_q[j], p) : v2(0.f);
+            uv[p] = HAS_U ? pair_q(u_q[j], p) : v2(0.f);
+          } else {
+            sv[p] = HAS_S ? pair_of(s_bf[j], p) : v2(0.f);
+            uv[p] = HAS_U ? pair_of(u_bf[j], p) : v2(0.f);
+          }
         }
       };
       if (VC_SWAP_REDUCE && NBUF == 2) {
@@ -491,6 +579,10 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           const int i = i0 + j;
           if (i >= ncell) break;
           fetch((j + PF) % NBUF, i + PF);
+          if (ASM) {
+            if (VC_ISSUE_PIN) __builtin_amdgcn_sched_barrier(0);
+            wait_counts(j, std::integral_constant<int, PF>());       // the PF cells fetched after this one stay in flight
+          }
           v2f sv[NP], uv[NP];
           unpack(j, sv, uv);
           float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -503,6 +595,12 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
             if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);
           }
         }
+      }
+      if (ASM) {
+        // the last PF fetches (re-fetches of the last cell) are still in flight: nothing may re-use their registers before
+        // they have landed
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) wait_counts(j, std::integral_constant<int, 0>());
       }
     }
   }

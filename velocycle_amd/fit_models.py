@@ -81,6 +81,12 @@ class _FitBase:
         if self.engine is None:
             self._make_engine(device, process_group)
         eng = self.engine
+        eng.clear_status()           # the engine is kept across fit() calls: the NaN / Inf latch must describe THIS fit only
+        if eng.stats["count_storage"] != "u16" and self.spec.noisemodel != "Lognormal":
+            import warnings
+            warnings.warn("velocycle_amd: this rank's count matrices hold a non-integer value or a count > 65535, so they are "
+                          "kept as float32 in HBM (twice the bytes per step of the uint16 layout; results are unaffected)",
+                          RuntimeWarning)
         torch.cuda.synchronize(eng.device)
         t_engine = time.perf_counter()
         args = optim_args_of(optimizer)
@@ -135,7 +141,7 @@ class _FitBase:
             self._posterior()
         # wall seconds of the stages of this call (not in the reference; profiles/tools/fit_wall_time.py prints them)
         self.timings = {"engine_setup": t_engine - t_start, "svi_steps": t_svi - t_engine, "extract": t_extract - t_svi,
-                        "posterior": time.perf_counter() - t_extract}
+                        "posterior": time.perf_counter() - t_extract, "count_storage": eng.stats["count_storage"]}
         if store_output:
             return intermediate_output
 

@@ -42,16 +42,38 @@ def _dense(x):
     return np.asarray(x)
 
 
-def _csr_counts(layer):
+def _csr_counts(layer, dense=None):
     """scipy sparse layer -> canonical float32 CSR (cells x genes) with the reference's int64 truncation applied, or None
     for dense layers.  Carried in the container next to the dense S / U (which the reference's contract requires) so
-    that the engine can ingest the sparse form directly (vc_set_counts_csr) without uploading the dense matrices."""
+    that the engine can ingest the sparse form directly (vc_set_counts_csr) without uploading the dense matrices.
+    `dense` = the container's dense tensor of the same layer: the CSR copy is tagged with it (`csr_is_current`), so that
+    a container whose S / U were replaced or edited afterwards never runs on stale CSR counts."""
     if not (hasattr(layer, "tocsr") and hasattr(layer, "toarray")):
         return None
     m = layer.tocsr().astype(np.int64).astype(np.float32)
     m.sum_duplicates()
     m.eliminate_zeros()
+    if dense is not None:
+        tag_csr(m, dense)
     return m
+
+
+def tag_csr(csr, dense):
+    """Record which dense tensor (object identity + in-place version counter) `csr` was derived from."""
+    import weakref
+    csr._vc_dense_ref = weakref.ref(dense)
+    csr._vc_dense_version = dense._version
+    return csr
+
+
+def csr_is_current(csr, dense) -> bool:
+    """True iff `csr` provably describes the same data as `dense`: `dense` is the very tensor object the CSR copy was
+    built next to in `preprocess_for_*` and it has not been written in place since.  `mp._replace(S=...)`, in-place
+    normalisation / subsampling / permutation of S all make this False, and the engine then reads the dense tensor."""
+    ref = getattr(csr, "_vc_dense_ref", None)
+    if csr is None or ref is None or dense is None:
+        return False
+    return ref() is dense and getattr(csr, "_vc_dense_version", -1) == dense._version
 
 
 def _container(fields: dict):
@@ -143,6 +165,7 @@ def preprocess_for_phase_estimation(anndata, cycle_obj, phase_obj, design_mtx, n
     count_factor = torch.log(s_umi / torch.mean(s_umi))
     anndata.layers["logS"], anndata.layers["logU"] = logS, logU
     design_mtx = torch.as_tensor(design_mtx)
+    S_t, U_t = S.T.to(device), U.T.to(device)                    # float32 views with strides (1, Ng), as `S.T.float()`
     fields = dict(
         Ng=len(cycle_obj), Nc=len(phase_obj), Nb=design_mtx.shape[-1],
         Db=design_mtx.T[:, None, :].float().to(device),
@@ -156,13 +179,13 @@ def preprocess_for_phase_estimation(anndata, cycle_obj, phase_obj, design_mtx, n
         kwargsζ=dict(num_harmonics=n_harmonics), σgc=torch.tensor(0.5).to(device),
         with_delta_nu=with_delta_nu, μΔν=_t(μΔν, device), σΔν=_t(σΔν, device),
         count_factor=count_factor[None, None, :].to(device),
-        S=S.T.to(device), U=U.T.to(device),                      # float32 views with strides (1, Ng), as `S.T.float()`
+        S=S_t, U=U_t,
         condition=np.array(list(condition_on.keys())),
         logS=torch.from_numpy(logS.astype(np.float32)).T.to(device),
         logU=torch.from_numpy(logU.astype(np.float32)).T.to(device),
         beta0=torch.tensor(beta0).to(device), beta1=torch.tensor(beta1).to(device),
-        S_csr=None if normalize else _csr_counts(anndata.layers["spliced"]),
-        U_csr=None if normalize else _csr_counts(anndata.layers["unspliced"]))
+        S_csr=None if normalize else _csr_counts(anndata.layers["spliced"], S_t),
+        U_csr=None if normalize else _csr_counts(anndata.layers["unspliced"], U_t))
     return _container(fields)
 
 
@@ -194,6 +217,7 @@ def preprocess_for_velocity_estimation(anndata, cycle_obj, phase_obj, speed_obj,
     ng = len(cycle_obj)
     cdm, bdm = torch.as_tensor(condition_design_mtx), torch.as_tensor(batch_design_mtx)
     rep = lambda v: torch.as_tensor(v).detach().clone().float().repeat([ng, 1]).to(device)
+    S_t, U_t = S.T.to(device), U.T.to(device)
     fields = dict(
         Ng=ng, Nc=len(phase_obj), Nhω=(ω_n_harmonics * 2) + 1, Nb=bdm.shape[-1], Nx=cdm.shape[-1],
         D=cdm.T[:, None, None, :].clone().detach().to(device),
@@ -213,12 +237,12 @@ def preprocess_for_velocity_estimation(anndata, cycle_obj, phase_obj, speed_obj,
         kwargsζ=dict(num_harmonics=n_harmonics), kwargsζ_dϕ=dict(num_harmonics=n_harmonics),
         kwargsζω=dict(num_harmonics=ω_n_harmonics),
         σₛgc=torch.tensor(0.1, device=device), σᵤgc=torch.tensor(0.1, device=device),
-        S=S.T.to(device), U=U.T.to(device),
+        S=S_t, U=U_t,
         logS=torch.from_numpy(logS.astype(np.float32)).T.to(device),
         logU=torch.from_numpy(logU.astype(np.float32)).T.to(device),
         condition=np.array(list(condition_on.keys())), device=device, model_type=model_type,
         rho_mean=torch.as_tensor(rho_mean).to(device), rho_std=torch.as_tensor(rho_std).to(device),
         rho_scale=torch.as_tensor(rho_scale).to(device), rho_rank=torch.as_tensor(rho_rank).to(device),
-        S_csr=None if normalize else _csr_counts(anndata.layers[lay[0]]),
-        U_csr=None if normalize else _csr_counts(anndata.layers[lay[1]]))
+        S_csr=None if normalize else _csr_counts(anndata.layers[lay[0]], S_t),
+        U_csr=None if normalize else _csr_counts(anndata.layers[lay[1]], U_t))
     return _container(fields)

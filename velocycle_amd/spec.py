@@ -68,6 +68,12 @@ def spec_from_metaparams(mp, kind: str, condition_on=None) -> ModelSpec:
     """Squeeze a reference-style MetaparContainer into canonical shapes (float32, no copies of S/U)."""
     condition_on = dict(condition_on or {})
     f = lambda t: torch.as_tensor(t).detach().float()
+
+    def current_csr(csr, dense):
+        # the CSR side channel is used only while it provably describes the same data as the dense field the reference's
+        # contract exposes (and users edit with `_replace` / in place): preprocessing tags it with that tensor
+        from .preprocessing import csr_is_current
+        return csr if (csr is not None and csr_is_current(csr, dense)) else None
     Ng, Nc = int(mp.Ng), int(mp.Nc)
     common = dict(
         kind=kind, noisemodel=mp.noisemodel, with_delta_nu=bool(mp.with_delta_nu),
@@ -77,7 +83,7 @@ def spec_from_metaparams(mp, kind: str, condition_on=None) -> ModelSpec:
         phixy_prior=f(mp.φxy_prior).reshape(Nc, 2), mu_dnu=float(mp.μΔν),
         gamma_alpha=float(mp.gamma_alpha), gamma_beta=float(mp.gamma_beta),
         condition_on={k: f(v) for k, v in condition_on.items()},
-        S_csr=getattr(mp, "S_csr", None))
+        S_csr=current_csr(getattr(mp, "S_csr", None), mp.S))
     if kind == "phase":
         sd = f(mp.σΔν)
         return ModelSpec(guide="meanfield", H=int(mp.num_harmonics_S),
@@ -93,4 +99,4 @@ def spec_from_metaparams(mp, kind: str, condition_on=None) -> ModelSpec:
         mu_nuw=f(mp.μνω).reshape(Nx, -1), sd_nuw=f(mp.σνω).reshape(Nx, -1),
         sd_dnu=0.01, sigma_ln_s=float(mp.σsgc), sigma_ln_u=float(mp.σugc),
         rho_mean=float(mp.rho_mean), rho_std=float(mp.rho_std), rho_scale=float(mp.rho_scale),
-        rho_rank=int(mp.rho_rank), U_csr=getattr(mp, "U_csr", None), **common)
+        rho_rank=int(mp.rho_rank), U_csr=current_csr(getattr(mp, "U_csr", None), mp.U), **common)
