@@ -355,12 +355,16 @@ def main():
         eng = HipEngine(spec, device=device, rank=rank, world_size=world)
         torch.cuda.synchronize(device)
         t2 = time.perf_counter()
-        # N > 1: the whole step, RCCL all-reduce included, is replayed from one hipGraph (capture is per rank; RCCL
-        # supports captured collectives, exercised with a 1-rank group in tests/test_hip_svi.py and A/B-timed against
-        # eager launches at N = 1 with VC_BENCH_NCCL_GROUP=1, profiles/r02_*).  VC_BENCH_DIST_GRAPH=0 falls back to eager.
+        # N > 1: the fused step cut at its one exchange (K_main -> phase A -> sum over ranks -> phase B).  On the nccl backend
+        # the engine owns the exchange (its own RCCL communicator): every launch and every all-reduce of a timed region is
+        # enqueued from one C call, no Python and no graph in the loop.  VC_EXCHANGE=torch routes the sum through
+        # torch.distributed.all_reduce between the two phases; VC_BENCH_DIST_GRAPH=1 additionally replays that sequence from a
+        # hipGraph (opt-in: it has only ever run on a 1-rank RCCL group); VC_ADAM_IMPL_DIST=hip is round 2's five-kernel step.
         graph = None
-        if args.no_graph or (dist_on and (one_device or os.environ.get("VC_BENCH_DIST_GRAPH", "1") != "1")):
+        if args.no_graph or one_device:
             graph = False
+        elif dist_on or solo_group:
+            graph = os.environ.get("VC_BENCH_DIST_GRAPH", "0") == "1"
         run = SVIRunner(eng, optim, mode="perf", seed=0, use_graph=graph, force_reduce=solo_group)
         return spec, eng, run, {"synthetic_data_s": round(t1 - t0, 3), "engine_setup_s": round(t2 - t1, 3)}
 
@@ -418,7 +422,8 @@ def main():
                                + (f", {args.conditions} samples (Nx = Nb = {args.conditions}, per-batch offsets)" if args.conditions > 1 and args.mode != "phase" else ""),
                    "cells": args.cells, "genes": args.genes, "mode": args.mode, "conditions": args.conditions,
                    "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
-                   "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + (("gloo (test hook) " if one_device else "RCCL ") + "all-reduce -> " if (dist_on or solo_group) else "")
+                   "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + (("gloo (test hook) " if one_device else "RCCL ") + "all-reduce"
+                                                                            + (f" [{run.exchange}]" if run.exchange else "") + " -> " if (dist_on or solo_group) else "")
                             + f"ClippedAdam ({run.adam_impl}), " + ("hipGraph replay" if run.use_graph else "eager launches")
                             + "; losses stay in a device ring and are read back ONCE after the timed region "
                               "(with_loss_readback_each_step gives the rate with a host read-back after every step)")},
@@ -437,7 +442,8 @@ def main():
         dist.all_gather_object(ids, me)
         out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ids,
                               "distinct_devices": len({(i["uuid"], i["local_rank"]) for i in ids}),
-                              "step_launch": "hipGraph replay (RCCL all-reduce captured)" if run.use_graph else "eager"}
+                              "step_launch": "hipGraph replay (RCCL all-reduce captured)" if run.use_graph else "eager",
+                              "step_kind": run.adam_impl, "exchange": run.exchange}
     else:
         out["device"] = device_identity(device)
     extra = {}

@@ -254,6 +254,42 @@ int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_d
                      int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr, double lrd, double beta1,
                      double beta2, double adam_eps, double clip_norm, int prime, int64_t n_steps, void* hip_stream);
 
+/* --- cells sharded over ranks: the fused step cut at its one exchange ------------------------------
+ * The per-step sequence of a rank is  K_main -> phase A -> [sum of the exchange buffer over all ranks] -> phase B  (three
+ * launches + the exchange; the single-rank step of vc_svi_run_fused is the same code with nothing to sum).  It replaces, for
+ * `svi.step` under a process group (velocity_inference_model.py:118-121 has no multi-GPU form: SURVEY.md F1), the
+ * five-kernel sequence vc_elbo_grad + all-reduce + vc_clipped_adam.
+ *
+ * Exchange buffer `xbuf`: DEVICE float[vc_exchange_size], caller-owned like params / grad, zero-initialised once.
+ *   [0, header + n_global)                         gradient partials of the replicated parameters, offsets of `grad`
+ *   [pw_off, pw_off + pw_cap * Nx * Nhw)           per-cell-block partials of d loglik / d nu_omega (rows beyond a rank's
+ *                                                  own cell blocks are zero), pw_cap = ceil(ceil(Nc_global / world) / 256)
+ *   [loss_off, loss_off + 2 * (1 + ceil(Ng/64)))   (hi, lo) float pairs of the rank's loss terms
+ * Every element is additive over ranks; replicated prior / entropy terms are contributed by rank 0 only.  After the sum
+ * every rank holds the complete gradient and applies the identical update: parameters stay replicated bit for bit.
+ *
+ * phase = VC_PHASE_A : K_main + phase A of ONE step (n_steps must be 1); the caller then sums xbuf over the ranks
+ *                      (e.g. torch.distributed.all_reduce -- any backend) on the same stream and calls
+ * phase = VC_PHASE_B : phase B of that step (optimiser on the summed gradient, next guide sample, loss of the step into
+ *                      loss_dev[t % loss_slots], step_dev = t + 1 was already set by phase A's K_main).
+ * phase = VC_PHASE_AB: n_steps whole steps enqueued from this one call, the exchange made by the engine's own communicator
+ *                      (vc_comm_init_rccl: ncclAllReduce on hip_stream between the two phases; world_size 1 needs none).
+ * prime: as vc_svi_run_fused (sampling is rank-local: no exchange).  Same arguments otherwise. */
+#define VC_PHASE_A 1
+#define VC_PHASE_B 2
+#define VC_PHASE_AB 3
+int vc_exchange_size(const vc_engine* e, int64_t* n_floats);
+int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad, float* xbuf,
+                       double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr, double lrd,
+                       double beta1, double beta2, double adam_eps, double clip_norm, int prime, int phase,
+                       int64_t n_steps, void* hip_stream);
+/* The engine's own communicator for VC_PHASE_AB: RCCL, loaded at run time from `rccl_path` (the librccl.so the process
+ * already uses, e.g. the one bundled with PyTorch -- the library itself does not link RCCL).  Rank 0 creates the 128-byte
+ * unique id (vc_comm_rccl_unique_id), the host side broadcasts it (any transport), every rank of the engine's world_size
+ * calls vc_comm_init_rccl with it (collective).  vc_destroy releases the communicator. */
+int vc_comm_rccl_unique_id(const char* rccl_path, void* id_out_128_bytes);
+int vc_comm_init_rccl(vc_engine* e, const char* rccl_path, const void* id_128_bytes);
+
 /* One draw of the guide pushed through the deterministic part of the model (what
  * `Predictive(model, guide=guide, num_samples=1)` evaluates for the latent and deterministic sites;
  * velocity_inference_model.py:279-291, phase_inference_model.py:274-302): runs the sampling kernel only, no

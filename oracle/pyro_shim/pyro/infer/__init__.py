@@ -1,4 +1,4 @@
-"""`pyro.infer` subset: Trace_ELBO(num_particles=1), SVI, Predictive, config_enumerate (no-op)."""
+"""`pyro.infer` subset: Trace_ELBO(num_particles=K), SVI, Predictive, config_enumerate (no-op)."""
 import torch
 from ..runtime import run_traced, _Wrapped
 from . import autoguide  # noqa: F401
@@ -12,9 +12,7 @@ def config_enumerate(fn=None, **kw):
 
 class Trace_ELBO:
     def __init__(self, num_particles=1, max_plate_nesting=float("inf"), **kw):
-        if num_particles != 1:
-            raise NotImplementedError("shim supports num_particles=1")
-        self.num_particles = num_particles
+        self.num_particles = int(num_particles)
         self.max_plate_nesting = max_plate_nesting
 
     def _guess_max_plate_nesting(self, model, guide, args, kwargs):
@@ -37,9 +35,16 @@ class Trace_ELBO:
         return -elbo, params, mt, gt
 
     def loss_and_grads(self, model, guide, *args, **kwargs):
-        loss, params, _, _ = self.differentiable_loss_and_params(model, guide, *args, **kwargs)
-        loss.backward()
-        return loss.item(), params
+        # pyro-ppl 1.8.6 Trace_ELBO.loss_and_grads (vectorize_particles=False): the particles are drawn one after the other
+        # (num_particles sequential guide + replayed-model executions), loss = mean of the particles' losses, and every
+        # particle's surrogate / num_particles is back-propagated, i.e. the gradients are the mean over particles
+        loss, params = 0.0, {}
+        for _ in range(self.num_particles):
+            lp, pp, _, _ = self.differentiable_loss_and_params(model, guide, *args, **kwargs)
+            (lp / self.num_particles).backward()
+            loss += lp.item() / self.num_particles
+            params.update(pp)
+        return loss, params
 
 
 TraceEnum_ELBO = Trace_ELBO

@@ -443,22 +443,30 @@ class ClippedAdam:
 
 
 def fit(p: Problem, optim_args: dict, num_steps: int, seed: Optional[int] = None,
-        eps_list=None, params=None, warmup_draw: bool = True):
+        eps_list=None, params=None, warmup_draw: bool = True, num_particles: int = 1):
     """The SVI loop of `XFitModel.fit` with verbose=False, early_exit=False.  With `seed`, eps is
     drawn from a torch CPU generator in the reference's order, including (warmup_draw) the extra
-    guide pass Trace_ELBO makes before its first step.  Returns (losses, final unconstrained params)."""
+    guide pass Trace_ELBO makes before its first step.  num_particles = K: `Trace_ELBO(num_particles=K)` -- K guide
+    draws per step, one after the other, loss and gradients averaged over them before the optimiser step (the `loss=`
+    argument of fit(), velocity_inference_model.py:79,111); eps_list then holds num_steps * K draws.
+    Returns (losses, final unconstrained params)."""
     gen = None
     if seed is not None:
         gen = torch.Generator().manual_seed(seed)
     opt = ClippedAdam(optim_args)
     losses = []
     first = draw_eps(p, gen) if (eps_list is None and warmup_draw) else None
+    K = int(num_particles)
     for i in range(num_steps):
-        eps = eps_list[i] if eps_list is not None else draw_eps(p, gen)
-        if params is None:
-            src = first if first is not None else eps
-            params = init_params(p, src.get("_cov_factor_draw"))
-        loss, grads, _, _ = loss_and_grads(p, params, eps)
+        loss, grads = 0.0, None
+        for k in range(K):
+            eps = eps_list[i * K + k] if eps_list is not None else draw_eps(p, gen)
+            if params is None:
+                src = first if first is not None else eps
+                params = init_params(p, src.get("_cov_factor_draw"))
+            lk, gk, _, _ = loss_and_grads(p, params, eps)
+            loss += lk / K
+            grads = {n: g / K for n, g in gk.items()} if grads is None else {n: grads[n] + g / K for n, g in gk.items()}
         losses.append(loss)
         params = opt.step(params, grads)
     return losses, params

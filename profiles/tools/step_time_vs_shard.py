@@ -5,8 +5,10 @@ measured on ONE MI355X: what a rank spends per step before any inter-GPU latency
   python profiles/tools/step_time_vs_shard.py [mode] [--nccl]
 
 Columns: the unfused single-rank step (K_pre, K_main, K_post, K_fin+Adam: 4 launches, round 1), the fused step
-(K_main, K_tail, K_omega: 3 launches), both replayed from a hipGraph; with --nccl also the multi-rank launch sequence
-(vc_elbo_grad + RCCL all-reduce on a 1-rank group + optimiser kernel), graph and eager.  K_main's own duration
+(K_main, K_tail, K_omega: 3 launches), both replayed from a hipGraph; with --nccl also the multi-rank launch sequences on a
+1-rank RCCL group: round 2's (vc_elbo_grad + all-reduce + optimiser kernel: 5 launches + the collective) and round 3's
+sharded fused step (K_main -> phase A -> all-reduce -> phase B: 3 launches + the collective), graph and eager, and the
+sharded step with NO exchange between its phases (what the two extra seams cost by themselves).  K_main's own duration
 (hipEvents, eager) is printed next to them, so that `step - K_main` = the fixed per-step cost.
 """
 import json
@@ -54,7 +56,11 @@ for n_ranks, nc in ((8, 6250), (4, 12500), (2, 25000), (1, 50000)):
                 ("fused_3_launches_eager", dict(adam_impl="fused3", use_graph=False))]
     if with_nccl:
         variants += [("multirank_seq_graph", dict(adam_impl="hip", use_graph=True, force_reduce=True)),
-                     ("multirank_seq_eager", dict(adam_impl="hip", use_graph=False, force_reduce=True))]
+                     ("multirank_seq_eager", dict(adam_impl="hip", use_graph=False, force_reduce=True)),
+                     ("sharded_fused_graph", dict(adam_impl="sharded", use_graph=True, force_reduce=True, exchange="torch")),
+                     ("sharded_fused_eager", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="torch")),
+                     ("sharded_fused_engine_rccl", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="engine")),
+                     ("sharded_fused_no_exchange", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="none"))]
     for name, kw in variants:
         eng = HipEngine(spec, device=dev)
         run = SVIRunner(eng, OPT, mode="perf", seed=0, **kw)

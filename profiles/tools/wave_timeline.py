@@ -41,6 +41,10 @@ if raw[:, 6].max() > 0:      # shader-clock ticks of the cell loop / its duratio
     print("shader clock inside the cell loop (GHz, against the nominal 100 MHz constant clock): med %.3f p10 %.3f p90 %.3f" %
           (np.median(clk[sel]), np.percentile(clk[sel], 10), np.percentile(clk[sel], 90)))
 print("loop duration    min %.2f med %.2f p90 %.2f max %.2f" % (d.min(), np.median(d), np.percentile(d, 90), d.max()))
+if raw[:, 6].max() > 0:      # the same loop in SHADER cycles (what a removed stall shows up in, whatever clock the chip then holds)
+    cyc = raw[:, 6].astype(np.float64)
+    print("cell loop shader cycles per wave: med %.0f p10 %.0f p90 %.0f sum over waves %.4g" %
+          (np.median(cyc), np.percentile(cyc, 10), np.percentile(cyc, 90), cyc.sum()))
 wg = np.arange(len(us)) // 4
 nGB = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 print("by XCC_ID:", {int(x): round(float(np.median(d[xcc == x])), 1) for x in np.unique(xcc)})

@@ -357,7 +357,64 @@ def make_tutorial_flow():
     print(f"[tutorial flow] phase {pf.losses[-1]:.3f} velocity {vf.losses[-1]:.3f}")
 
 
+def make_particles(seed=11, K=3, n=12):
+    """`fit(loss=Trace_ELBO(num_particles=3))` of the reference's own fit drivers (velocity_inference_model.py:79,111 passes
+    the user's ELBO object into SVI): K guide draws per step, loss and gradients averaged.  -> ref_fitK3_<case>.npz"""
+    for name in ("vel_mf_joint", "phase_nb", "vel_lrmn_cond"):
+        c = CASES[name]
+        d, ad, cyc, ph, Db = build_inputs(c["Nc"], c["Ng"], c["H"], c["nb"], seed)
+        Nc = ad.n_obs
+        rs = np.random.RandomState(seed + 1)
+        cond = {}
+        if c["kind"] == "phase":
+            mp = vc.preprocessing.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=c["H"], noisemodel=c["noise"],
+                                                                  with_delta_nu=c["wdn"])
+            FitCls = vc.phase_inference_model.PhaseFitModel
+        else:
+            spd = vc.angularspeed.AngularSpeed.trivial_prior(condition_names=[f"b{i}" for i in range(c["nb"])], harmonics=c["Hw"])
+            if c["Hw"] == 1:
+                spd.stds.loc["nu1_cos"] = [0.05] * c["nb"]
+                spd.stds.loc["nu1_sin"] = [0.05] * c["nb"]
+            cf = torch.tensor(np.log(ad.layers["spliced"].sum(1) / ad.layers["spliced"].sum(1).mean())).float()[None, None, :]
+            for site in c.get("cond", []):
+                if site == "ϕxy":
+                    cond[site] = ph.phi_xy_tensor.T + torch.tensor(0.05 * rs.randn(Nc, 2)).float()
+                elif site == "ν":
+                    cond[site] = cyc.means_tensor.T.unsqueeze(-2) + torch.tensor(0.05 * rs.randn(c["Ng"], 1, 2 * c["H"] + 1)).float()
+                elif site == "shape_inv":
+                    cond[site] = torch.tensor(rs.uniform(0.2, 1.0, (c["Ng"], 1))).float()
+            mp = vc.preprocessing.preprocess_for_velocity_estimation(
+                ad, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=c["H"], ω_n_harmonics=c["Hw"], count_factor=cf,
+                noisemodel=c["noise"], with_delta_nu=c["wdn"], condition_on=cond, model_type=c.get("model_type", "lrmn"))
+            FitCls = vc.velocity_inference_model.VelocityFitModel
+        p64 = orc.problem_from_metaparams(mp, c["kind"], cond, dtype=torch.float64)
+        p32 = p64.to(torch.float32)
+        opt_args = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1 / n), "betas": (0.80, 0.99)}
+        fitm = FitCls(mp, condition_on=cond, num_samples=4, n_per_bin=2)
+        pyro.clear_param_store()
+        torch.manual_seed(seed)
+        fitm.fit(pyro.optim.ClippedAdam(dict(opt_args)), loss=pyro.infer.Trace_ELBO(num_particles=K), num_steps=n, verbose=False)
+        ref_par, _ = ref_params_canonical(p32)
+        o_losses, o_par = orc.fit(p32, opt_args, n, seed=seed, num_particles=K)
+        check(o_losses, fitm.losses, f"{name}: K={K} fit losses", 1e-4, 1e-2)
+        for k in ref_par:
+            check(o_par[k], ref_par[k], f"{name}: K={K} fitted {k}", 2e-3, 2e-3)
+        l64s, par64f = orc.fit(p64, opt_args, n, seed=seed, num_particles=K)
+        fo = problem_arrays(p32)
+        fo.update({"reffit_" + k: v.numpy() for k, v in ref_par.items()})
+        fo.update({"fit64_" + k: v.numpy() for k, v in par64f.items()})
+        fo.update(ref_losses=np.array(fitm.losses), losses64=np.array(l64s), num_steps=np.array(n), seed=np.array(seed),
+                  num_particles=np.array(K))
+        for k, v in opt_args.items():
+            fo["opt_" + k] = np.array(v)
+        np.savez_compressed(os.path.join(OUT, f"ref_fitK{K}_{name}.npz"), **fo)
+        print(f"[fit K={K}] {name}: {n} steps, ref final loss {fitm.losses[-1]:.4f}, oracle {o_losses[-1]:.4f}")
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["--particles"]:
+        make_particles()
+        sys.exit(0)
     make_basis()
     make_tutorial_flow()
     make_preprocess()

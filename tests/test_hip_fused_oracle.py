@@ -7,7 +7,8 @@ fused run, the eps vector of (seed, t) is rebuilt by an independent engine's sam
 phase_inference_model.py:166-170 with pyro's Trace_ELBO and ClippedAdam) is replayed from the same initial parameters on
 exactly those draws.  Bars: loss[t] within 1e-5 relative for the first 5 steps; afterwards float32 and float64 Adam
 trajectories separate by themselves, so the yardstick is the oracle's own float32 replay (x4); fitted parameters within 1e-3
-of each block's max-norm wherever the float32 oracle is."""
+of each block's max-norm wherever the float32 oracle is (tests/helpers.py: assert_params_track_oracle -- single genes that
+cross the relu kink of ElogU may leave the float64 trajectory in ANY float32 run)."""
 import numpy as np
 import pytest
 import torch
@@ -18,7 +19,7 @@ pytestmark = pytest.mark.gpu
 OPT = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / 1000), "betas": (0.80, 0.99)}
 
 
-def _fused_vs_oracle(spec, n, seed, check_params=True):
+def _fused_vs_oracle(spec, n, seed, check_params=True, report=None):
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
     eng = HipEngine(spec)
@@ -39,15 +40,8 @@ def _fused_vs_oracle(spec, n, seed, check_params=True):
     assert rel_hip[:5].max() <= 1e-5, rel_hip[:5]
     assert (rel_hip <= np.maximum(1e-5, 4 * np.maximum.accumulate(rel_32))).all(), (rel_hip.max(), rel_32.max())
     if check_params:
-        for k, g in got.items():
-            want, ref32 = par64[k].numpy(), par32[k].double().numpy()
-            fin = np.isfinite(want)
-            assert np.array_equal(np.isfinite(g), fin), k
-            if not fin.any():
-                continue
-            scale = max(np.abs(want[fin]).max(), 1e-2)
-            err, spread = np.abs(g[fin] - want[fin]).max(), np.abs(ref32[fin] - want[fin]).max()
-            assert err <= max(1e-3 * scale, 4 * spread), (k, err, spread, scale)
+        H.assert_params_track_oracle(got, {k: v.numpy() for k, v in par64.items()}, {k: v.double().numpy() for k, v in par32.items()},
+                                     report=report)
     return rel_hip
 
 
@@ -61,7 +55,7 @@ def test_fused_philox_run_matches_oracle_replay_on_fixtures(case):
 def test_fused_philox_run_matches_oracle_replay_medium(mode, ncond):
     """3001 (x conditions) cells x 300 genes: two gene blocks, ragged cell tiles, Nx = Nb = 2 with per-batch offsets."""
     from velocycle_amd.workloads import make_velocity_spec
-    _fused_vs_oracle(make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5), n=12, seed=77)
+    _fused_vs_oracle(make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5), n=12, seed=77, report=f"{mode} x{ncond}")
 
 
 def test_fused_philox_run_matches_oracle_replay_phase_medium():
@@ -75,7 +69,7 @@ def test_fused_philox_run_matches_oracle_on_a_slice_of_the_benchmark_data(mode):
     the full-size launch, the oracle finishes in seconds."""
     import copy
     from velocycle_amd.workloads import make_velocity_spec
-    full = make_velocity_spec(50000, 2000, mode, 1, 1, seed=0)
+    full = make_velocity_spec(50000, 2000, mode, 1, 1, seed=0, device="cuda")
     n = 2000
     spec = copy.copy(full)
     spec.S, spec.U = full.S[:, :n].contiguous(), full.U[:, :n].contiguous()

@@ -173,7 +173,7 @@ def test_shard_invariance_two_ranks_on_one_gpu():
 
 
 def test_rccl_allreduce_inside_captured_step_single_rank():
-    """The N > 1 step (RCCL all-reduce between the HIP kernels and the optimiser, all inside one hipGraph)
+    """The N > 1 step (RCCL all-reduce between the two phases of the sharded fused step, all inside one hipGraph: opt-in)
     exercised with a 1-rank nccl process group: results equal the plain single-GPU path."""
     import os
     import torch.distributed as dist
@@ -193,7 +193,11 @@ def test_rccl_allreduce_inside_captured_step_single_rank():
             r.run_perf(8)
             outs.append((e.params.clone().cpu(), r.perf_losses()))
             e.close()
-        assert torch.equal(outs[0][0], outs[1][0])
+        # force=True runs the sharded fused step (K_main -> phase A -> all-reduce -> phase B), force=False the single-rank fused
+        # step: the same arithmetic compiled into different kernels (fma contraction may differ by an ulp per step)
+        a, b = outs[0][0].double().numpy(), outs[1][0].double().numpy()
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin) and np.allclose(a[fin], b[fin], rtol=2e-5, atol=2e-6), np.abs(a[fin] - b[fin]).max()
         assert np.allclose(outs[0][1], outs[1][1], rtol=1e-6)      # reduced loss is float hi+lo
     finally:
         dist.destroy_process_group()

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("VC_LIB_PATH") or os.path.join(HERE, "libvelocycle_hip
 
 VC_ABI_VERSION = 1
 VC_OK = 0
+VC_PHASE_A, VC_PHASE_B, VC_PHASE_AB = 1, 2, 3
 VC_ERR_ARG, VC_ERR_HIP, VC_ERR_UNSUPPORTED, VC_ERR_STATE, VC_ERR_NONFINITE = -1, -2, -3, -4, -5
 MODEL = {"phase": 0, "velocity": 1}
 GUIDE = {"meanfield": 0, "lrmn": 1}
@@ -86,6 +87,12 @@ EXPORTS = {
     "vc_svi_run_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_int, C.c_int64, C.c_void_p]),
+    "vc_exchange_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "vc_svi_run_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                                     C.c_double, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "vc_comm_rccl_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "vc_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "vc_clipped_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

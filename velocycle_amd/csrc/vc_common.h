@@ -54,6 +54,15 @@ struct VcDims {
   float lgamma_alpha;     // lgamma(gamma_alpha) of the shape_inv prior, evaluated once on the host
 };
 
+// View of the exchange buffer of the sharded fused step (vc_svi_run_sharded; layout: include/velocycle_hip.h)
+struct VcXb {
+  float* x = nullptr;     // [0, header + n_global): gradient partials at the offsets of the gradient buffer;
+  int pw_off = 0;         //   [pw_off, pw_off + pw_cap * NW): per-cell-block partials of d loglik / d nu_omega;
+  int pw_cap = 0;         //   rows of that region (an upper bound of every rank's cell blocks: ceil(ceil(Nc / world) / 256))
+  int loss_off = 0;       //   [loss_off, loss_off + 2 * (1 + nb_post_gene)): (hi, lo) float pairs of the rank's loss terms
+  float* sis = nullptr;   // [3][Ng_pad] snapshot {parameter, exp_avg, exp_avg_sq} of shape_inv taken by phase A (engine-owned)
+};
+
 struct VcBufs {
   // immutable inputs
   const float *S, *U;                       // blocked counts [nGB][Nc][gbw], float32 or (d.c16) uint16
@@ -278,14 +287,14 @@ __device__ __forceinline__ float vc_adam_step_size(long long t, double lr0, doub
 // latency of the kernel is one pass whatever the spread of a gene's counts; K_post adds the few task sums of
 // a gene in fixed order.
 __device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, const float* __restrict__ P,
-                                             int cond_only, int task, int lane) {
+                                             int cond_only, int task, int lane, float si_given = -1.f) {
   const int g = b.h_task[4 * task], m = b.h_task[4 * task + 1];
   const int beg = b.h_task[4 * task + 2], end = b.h_task[4 * task + 3];
   double hl = 0.0, hd = 0.0;
   if ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U)) {
     float si;
     if (CND(VC_SITE_SHAPE_INV)) si = b.cnd[VC_SITE_SHAPE_INV][g];
-    else si = cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
+    else si = si_given > 0.f ? si_given : (cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]));
     const float r = 1.0f / si;
     const int i = beg + lane;
     if (i < end) {
@@ -343,8 +352,13 @@ struct VcAdamArgs {
 };
 // fused single-rank step (vc_svi_step_fused): K_main(t) -> K_tail(t) -> K_omega(t); boot = 1: sampling only (primes the
 // tables for the step *step_dev)
+// phase: 0 = the whole single-rank launch, 1 = phase A of the sharded step (writes the exchange buffer `xb`)
 void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
-                    const VcAdamArgs& a, int boot, hipStream_t st);
+                    const VcAdamArgs& a, int boot, int phase, const VcXb& xb, hipStream_t st);
+// phase B of the sharded step: optimiser on the summed gradient + next sample (gene blocks) and K_omega's blocks, one launch
+void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                       const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, const VcXb& xb,
+                       hipStream_t st);
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,

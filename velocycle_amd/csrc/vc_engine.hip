@@ -1,6 +1,8 @@
 // Host side of the engine behind the C ABI of include/velocycle_hip.h: configuration, HBM layout,
 // count histograms, workspaces, kernel sequencing.  No exception leaves this file (VC_GUARD_* around every entry
 // point that allocates host memory).
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -21,8 +23,38 @@ thread_local std::string g_create_error;
 
 }  // namespace
 
+// RCCL, bound at run time (vc_comm_init_rccl): the four entry points the sharded step needs.  Declared here instead of
+// including rccl.h so that the library neither links nor requires RCCL (single-GPU use never loads it).
+struct VcNcclId { char internal[128]; };
+typedef void* VcNcclComm;
+struct VcRccl {
+  void* dl = nullptr;
+  int (*GetUniqueId)(VcNcclId*) = nullptr;
+  int (*CommInitRank)(VcNcclComm*, int, VcNcclId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, VcNcclComm, hipStream_t) = nullptr;
+  int (*CommDestroy)(VcNcclComm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load(const char* path, std::string* err) {
+    if (dl) return true;
+    dl = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) { *err = std::string("dlopen(rccl): ") + dlerror(); return false; }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(dl, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(dl, "ncclCommInitRank");
+    AllReduce = (decltype(AllReduce))dlsym(dl, "ncclAllReduce");
+    CommDestroy = (decltype(CommDestroy))dlsym(dl, "ncclCommDestroy");
+    GetErrorString = (decltype(GetErrorString))dlsym(dl, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { *err = "librccl.so lacks the nccl* entry points"; return false; }
+    return true;
+  }
+};
+static VcRccl g_rccl;
+
 struct vc_engine {
   vc_config cfg{};
+  VcNcclComm comm = nullptr;          // the engine's own communicator (vc_comm_init_rccl), or null
+  float* sis = nullptr;               // phase A's snapshot of shape_inv {parameter, exp_avg, exp_avg_sq} [3][Ng_pad]
+  int xb_pw_off = 0, xb_pw_cap = 0, xb_loss_off = 0;
+  long long xb_total = 0;
   VcDims d{};
   VcBufs b{};
   vc_layout layout{};
@@ -281,6 +313,7 @@ extern "C" void vc_destroy(vc_engine* e) {
     if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
   }
 #endif
+  if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
   for (void* p : e->allocs) (void)hipFree(p);
   for (auto& c : e->src) c.release();
   for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -655,6 +688,12 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     // balanced tiling).  The tiling (vc_host_logic.h, also what the kernel evaluates per wave) stays a pure function of
     // (Nc, Ng, occupancy, CUs): results are reproducible.
     double share[4] = {1.0, 0.5, 0.25, 0.125};
+    if (VC_ASM_LOADS && d.kind == VC_KIND_VFULL && blocks_per_cu == 2) {
+      // round 3: with two cells of the S+U kernel's counts in flight (hand-placed waits) the older wave of a SIMD stalls less
+      // and leaves the younger one fewer issue slots: 0.67 : 0.33 ends the passes at 104 / 120 us, 0.75 : 0.25 together
+      // (profiles/r03_kmain.md: 119.4 vs 121.4 us)
+      share[1] = 1.0 / 3.0; share[2] = 1.0 / 9.0; share[3] = 1.0 / 27.0;
+    }
     bool want = true;
     if (const char* se = getenv("VC_PASS_SHARES")) {
       int n = sscanf(se, "%lf%*[,:]%lf%*[,:]%lf%*[,:]%lf", &share[0], &share[1], &share[2], &share[3]);
@@ -727,6 +766,22 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   d.nb_tail_cell = (d.Nc + d.tail_tc - 1) / d.tail_tc;
   d.nlpf = d.nb_post_gene + d.nb_tail_cell + 1;
   d.lgamma_alpha = lgammaf(d.gamma_alpha);
+  {
+    // exchange buffer of the sharded fused step (include/velocycle_hip.h): gradient region, PW rows, loss pairs
+    const long long world = e->cfg.world_size, ncg = e->cfg.Nc_global > 0 ? e->cfg.Nc_global : d.Nc;
+    const long long max_shard = std::max<long long>((ncg + world - 1) / world, d.Nc);
+    e->xb_pw_cap = (int)((max_shard + 255) / 256);
+    long long off = e->layout.header + e->layout.n_global;
+    off = (off + 3) / 4 * 4;
+    e->xb_pw_off = (int)off;
+    off += (long long)e->xb_pw_cap * d.NW;
+    off = (off + 3) / 4 * 4;
+    e->xb_loss_off = (int)off;
+    off += 2LL * (1 + d.nb_post_gene);
+    e->xb_total = (off + 3) / 4 * 4;
+    TRY(e->dalloc(&e->sis, 3 * (size_t)d.Ng_pad));
+    HIPCHK(e, hipMemset(e->sis, 0, 3 * sizeof(float) * d.Ng_pad));
+  }
   TRY(e->dalloc(&b.LPF, 2 * (size_t)d.nlpf));
   HIPCHK(e, hipMemset(b.LPF, 0, 2 * sizeof(double) * d.nlpf));
   TRY(e->dalloc(&b.LPP, (size_t)d.nb_post_gene));
@@ -928,7 +983,7 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
   const long long* sd = (const long long*)step_dev;
   const int with_hist = e->hist_each_step ? 1 : 0;
   if (prime && n_steps > 0) {   // sample the step *step_dev from the parameters as they are: tables, site values, prior terms
-    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 1, st);
+    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 1, 0, VcXb{}, st);
     vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 1, with_hist, st);
   }
   VcBufs b2 = e->b;
@@ -944,8 +999,102 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
     } else {
       e->main_fn(e->d, b2, st);
     }
-    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, st);
+    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 0, VcXb{}, st);
     vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
+extern "C" int vc_exchange_size(const vc_engine* e, int64_t* n_floats) {
+  if (!e || !n_floats) return VC_ERR_ARG;
+  if (!e->finalized) return VC_ERR_STATE;
+  *n_floats = e->xb_total;
+  return VC_OK;
+}
+
+extern "C" int vc_comm_rccl_unique_id(const char* rccl_path, void* id_out) {
+  if (!id_out) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
+  std::string err;
+  if (!g_rccl.load(rccl_path, &err)) { g_create_error = err; return VC_ERR_STATE; }
+  VcNcclId id;
+  const int rc = g_rccl.GetUniqueId(&id);
+  if (rc != 0) { g_create_error = std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed"); return VC_ERR_STATE; }
+  memcpy(id_out, id.internal, sizeof id.internal);
+  return VC_OK;
+  VC_GUARD_END((vc_engine*)nullptr)
+}
+
+extern "C" int vc_comm_init_rccl(vc_engine* e, const char* rccl_path, const void* id_bytes) {
+  if (!e || !id_bytes) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
+  if (e->comm) return e->fail(VC_ERR_STATE, "vc_comm_init_rccl: the engine already has a communicator");
+  std::string err;
+  if (!g_rccl.load(rccl_path, &err)) return e->fail(VC_ERR_STATE, "%s", err.c_str());
+  VcNcclId id;
+  memcpy(id.internal, id_bytes, sizeof id.internal);
+  const int rc = g_rccl.CommInitRank(&e->comm, e->cfg.world_size, id, e->cfg.rank);
+  if (rc != 0) {
+    e->comm = nullptr;
+    return e->fail(VC_ERR_STATE, "ncclCommInitRank(rank %d of %d): %s", e->cfg.rank, e->cfg.world_size,
+                   g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed");
+  }
+  return VC_OK;
+  VC_GUARD_END(e)
+}
+
+extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad, float* xbuf,
+                                  double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
+                                  double lrd, double beta1, double beta2, double adam_eps, double clip_norm, int prime,
+                                  int phase, int64_t n_steps, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_run_sharded before vc_finalize");
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev || !xbuf)
+    return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: null buffer (step counter and exchange buffer are required)");
+  if (phase != VC_PHASE_A && phase != VC_PHASE_B && phase != VC_PHASE_AB) return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: bad phase %d", phase);
+  if (n_steps < 0 || (phase != VC_PHASE_AB && n_steps != 1)) return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: phase A / B take exactly one step");
+  if (phase == VC_PHASE_AB && e->cfg.world_size > 1 && !e->comm)
+    return e->fail(VC_ERR_STATE, "vc_svi_run_sharded(VC_PHASE_AB) on %d ranks needs vc_comm_init_rccl first", e->cfg.world_size);
+  if (!(lr > 0.0) || !(lrd > 0.0) || !(beta1 > 0.0 && beta1 < 1.0) || !(beta2 > 0.0 && beta2 < 1.0))
+    return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: lr, lrd must be positive and the betas inside (0, 1)");
+  hipStream_t st = (hipStream_t)hip_stream;
+  VcAdamArgs a;
+  a.m = exp_avg; a.v = exp_avg_sq;
+  a.lr0 = lr; a.lrd_l = log(lrd); a.b1l = log(beta1); a.b2l = log(beta2);
+  a.b1 = (float)beta1; a.b2 = (float)beta2; a.eps = (float)adam_eps; a.clip = (float)clip_norm;
+  a.header = (int)e->layout.header;
+  const long long* sd = (const long long*)step_dev;
+  const int with_hist = e->hist_each_step ? 1 : 0;
+  VcXb xb;
+  xb.x = xbuf; xb.pw_off = e->xb_pw_off; xb.pw_cap = e->xb_pw_cap; xb.loss_off = e->xb_loss_off; xb.sis = e->sis;
+  if (prime && n_steps > 0 && phase != VC_PHASE_B) {      // sampling is rank-local: the single-rank priming launches
+    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 1, 0, VcXb{}, st);
+    vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 1, with_hist, st);
+  }
+  VcBufs b2 = e->b;
+  b2.step_ctr = (long long*)step_dev;
+  b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l;
+  for (int64_t i = 0; i < n_steps; ++i) {
+    if (phase != VC_PHASE_B) {
+      if (e->timing) {
+        if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
+        auto& pr = e->ev_pool[e->ev_used++];
+        HIPCHK(e, hipEventRecord(pr.first, st));
+        e->main_fn(e->d, b2, st);
+        HIPCHK(e, hipEventRecord(pr.second, st));
+      } else {
+        e->main_fn(e->d, b2, st);
+      }
+      vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 1, xb, st);
+    }
+    if (phase == VC_PHASE_AB && e->comm) {      // (a 1-rank communicator is summed too: the single-GPU measurement of this path)
+      const int rc = g_rccl.AllReduce(xbuf, xbuf, (size_t)e->xb_total, /*ncclFloat32*/ 7, /*ncclSum*/ 0, e->comm, st);
+      if (rc != 0) return e->fail(VC_ERR_STATE, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed");
+    }
+    if (phase != VC_PHASE_A)
+      vc_launch_phase_b(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, with_hist, xb, st);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));

@@ -32,6 +32,24 @@ struct VcOpt { float step_size, b1, b2, eps, clip; };
 
 #define VC_NWE (VC_MAX_NW * (VC_MAX_RANK + 2))      // nu_omega-related parameter elements at most
 
+// ---------------------------------------------------------------------------------------------
+// Cells sharded over ranks (vc_svi_run_sharded): the same step cut at its ONE exchange.
+//   K_main(t) -> K_tail phase A -> [sum of the exchange buffer over ranks] -> K_omega phase B        (3 launches + exchange)
+// Phase A: gene blocks reduce K_main's partials and apply the chain rule, but write the gradient PARTIAL of this rank's cells
+// into the exchange buffer X (same offsets as the gradient buffer) and stop; cell blocks are rank-local and run whole
+// (phi_xy gradient, optimiser, next sample, cell record), their partials of d loglik / d nu_omega go to X's PW rows; one
+// extra block folds the terms of this rank's loss that are complete before the launch (prior / guide terms of the sample,
+// K_main's likelihood partials, the constant) into one (hi, lo) float pair of X, the r-only likelihood terms of the gene
+// blocks follow as one pair each.  Everything in X is additive over ranks; replicated prior terms carry root_w.
+// Phase B (after the sum, one launch: gene blocks and K_omega's blocks do not depend on each other): gene blocks read the
+// SUMMED gradient, apply ClippedAdam and draw the next sample; the nu_omega blocks reduce the summed PW rows (prior weight 1:
+// the sum is complete); the loss block adds up the summed pairs; the histogram blocks re-derive the shape_inv update from a
+// snapshot phase A took (the gene blocks of the same launch are rewriting it).
+// ---------------------------------------------------------------------------------------------
+#define VC_PH_ALL 0
+#define VC_PH_A 1
+#define VC_PH_B 2
+
 // flat offset of element `ce` of angular-speed coefficient j: mean-field {loc, log scale}; LRMN tail row i = Ng + j
 // {loc, R cov_factor entries, cov_diag}
 __device__ __forceinline__ long long vc_nuw_elem_off(const VcDims& d, bool lrmn, int j, int ce) {
@@ -44,11 +62,11 @@ __device__ __forceinline__ long long vc_nuw_elem_off(const VcDims& d, bool lrmn,
 // ---------------------------------------------------------------------------------------------
 // K_tail, gene block: 1024 threads = 16 waves (roles) x 64 genes
 // ---------------------------------------------------------------------------------------------
-template <int MQ>
+template <int MQ, int phase>
 __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs& b, float* __restrict__ P,
                                                    float* __restrict__ G, float* __restrict__ Mm, float* __restrict__ Vv,
                                                    int header, int gblock, long long s, uint64_t seed, const VcOpt o,
-                                                   int boot) {
+                                                   int boot, const VcXb xb) {
   __shared__ float sm[VC_PG_WAVES][MQ][64];
   __shared__ double sm_ls[VC_PG_WAVES];
   __shared__ float sm_ws[2][64][2];
@@ -76,6 +94,9 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   const bool r_core = role == 13 && lrmn;
   const bool r_cov = (role == 14 || role == 15) && lrmn;
   const int kbase = (role - 14) * VC_COVW;            // first cov_factor column of a cov role
+  const bool chain = !boot && phase != VC_PH_B;       // second-stage reduction + chain rule happen in this launch
+  const bool upd = !boot && phase != VC_PH_A;         // ... the optimiser
+  const bool samp = phase != VC_PH_A;                 // ... the next sample
 
   VC_WSTAMP(0, 0);
   // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k fetches, readlane
@@ -84,8 +105,8 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   {
     float mine_old = 0.f, mine_new = 0.f;
     if (r_cov && lane < d.R) {
-      if (!boot) mine_old = eps_old[d.eoff[VC_E_LRMN_W] + lane];
-      mine_new = draw_new(d.eoff[VC_E_LRMN_W] + lane);
+      if (chain) mine_old = eps_old[d.eoff[VC_E_LRMN_W] + lane];
+      if (samp) mine_new = draw_new(d.eoff[VC_E_LRMN_W] + lane);
     }
 #pragma unroll
     for (int k = 0; k < VC_MAX_RANK; ++k) {
@@ -112,23 +133,23 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       jj = (long long)g * Nh + role;
       off[0] = (int)(d.poff[VC_P_NU_LOCS] + jj); off[1] = (int)(d.poff[VC_P_NU_USCALES] + jj); nown = 2;
       in[1] = b.sd_nu[jj]; in[2] = b.mu_nu[jj];
-      if (!boot && !CND(VC_SITE_NU)) { in[0] = b.lat[VC_SITE_NU][jj]; in[3] = eps_old[d.eoff[VC_E_NU] + jj]; }
-      if (!CND(VC_SITE_NU)) e0 = draw_new(d.eoff[VC_E_NU] + jj);   // a hidden site's draw is never used
+      if (chain && !CND(VC_SITE_NU)) { in[0] = b.lat[VC_SITE_NU][jj]; in[3] = eps_old[d.eoff[VC_E_NU] + jj]; }
+      if (samp && !CND(VC_SITE_NU)) e0 = draw_new(d.eoff[VC_E_NU] + jj);   // a hidden site's draw is never used
     } else if (r_dnu) {
       jj = (long long)(role - Nh) * d.Ng + g;
       off[0] = (int)(d.poff[VC_P_DNU_LOCS] + jj); nown = 1;
       in[1] = vel ? 0.01f : b.sd_dnu[jj];
-      if (!boot && !CND(VC_SITE_DNU)) in[0] = b.lat[VC_SITE_DNU][jj];
+      if (chain && !CND(VC_SITE_DNU)) in[0] = b.lat[VC_SITE_DNU][jj];
     } else if (r_si) {
       off[0] = (int)(d.poff[VC_P_SHAPE_INV_ULOCS] + g); nown = 1;
-      if (!boot) {
+      if (chain) {
         in[0] = b.GT[(size_t)(K + 2) * NP + g];
         if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
         for (int t = b.h_tptr[g]; t < b.h_tptr[g + 1]; ++t) { HLg += b.HL[t]; HDg += b.HD[t]; }
       }
     } else if (r_mf || r_core || r_cov) {
       in[2] = b.sd_g[g]; in[3] = b.mu_g[g]; in[5] = b.sd_b[g]; in[6] = b.mu_b[g];
-      if (!boot) {
+      if (chain) {
         in[0] = b.GT[(size_t)(K + 1) * NP + g];
         if (!CND(VC_SITE_LOGGAMMA)) in[1] = b.lat[VC_SITE_LOGGAMMA][g];
         if (!CND(VC_SITE_LOGBETA)) in[4] = b.lat[VC_SITE_LOGBETA][g];
@@ -136,28 +157,27 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       if (r_mf) {
         if (role == 13) {
           off[0] = (int)(d.poff[VC_P_LOGGAMMA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGGAMMA_USCALES] + g); nown = 2;
-          if (!boot) in[7] = eps_old[d.eoff[VC_E_LOGGAMMA] + g];
-          e0 = draw_new(d.eoff[VC_E_LOGGAMMA] + g);
+          if (chain) in[7] = eps_old[d.eoff[VC_E_LOGGAMMA] + g];
+          if (samp) e0 = draw_new(d.eoff[VC_E_LOGGAMMA] + g);
         } else {
           off[0] = (int)(d.poff[VC_P_LOGBETA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGBETA_USCALES] + g); nown = 2;
-          if (!boot) in[7] = eps_old[d.eoff[VC_E_LOGBETA] + g];
-          e0 = draw_new(d.eoff[VC_E_LOGBETA] + g);
+          if (chain) in[7] = eps_old[d.eoff[VC_E_LOGBETA] + g];
+          if (samp) e0 = draw_new(d.eoff[VC_E_LOGBETA] + g);
         }
       } else {
-        if (!boot) { in[7] = b.lat_delta[g]; in[8] = b.lat_sgam[g]; }
+        if (chain) { in[7] = b.lat_delta[g]; in[8] = b.lat_sgam[g]; }
         if (r_core) {
           off[0] = (int)(d.poff[VC_P_LOGBETA_LOCS] + g); off[1] = (int)(d.poff[VC_P_LOGBETA_USCALES] + g);
           off[2] = (int)(d.poff[VC_P_RHO_REAL_LOC] + g); off[3] = (int)(d.poff[VC_P_LRMN_LOC] + g);
           off[4] = (int)(d.poff[VC_P_LRMN_UCOV_DIAG] + g); nown = 5;
-          if (!boot) { in[9] = eps_old[d.eoff[VC_E_LOGBETA] + g]; in[10] = eps_old[d.eoff[VC_E_LRMN_D] + g]; }
-          e0 = draw_new(d.eoff[VC_E_LRMN_D] + g);
-          e1 = draw_new(d.eoff[VC_E_LOGBETA] + g);
+          if (chain) { in[9] = eps_old[d.eoff[VC_E_LOGBETA] + g]; in[10] = eps_old[d.eoff[VC_E_LRMN_D] + g]; }
+          if (samp) { e0 = draw_new(d.eoff[VC_E_LRMN_D] + g); e1 = draw_new(d.eoff[VC_E_LOGBETA] + g); }
         } else {
 #pragma unroll
           for (int k = 0; k < VC_COVW; ++k)
             if (kbase + k < d.R) off[k] = (int)(d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)g * d.R + kbase + k);
           nown = d.R - kbase < 0 ? 0 : (d.R - kbase > VC_COVW ? VC_COVW : d.R - kbase);
-          if (!boot) { in[9] = P[d.poff[VC_P_LOGBETA_USCALES] + g]; in[10] = P[d.poff[VC_P_RHO_REAL_LOC] + g]; }
+          if (chain) { in[9] = P[d.poff[VC_P_LOGBETA_USCALES] + g]; in[10] = P[d.poff[VC_P_RHO_REAL_LOC] + g]; }
         }
       }
     }
@@ -165,13 +185,21 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     for (int k = 0; k < VC_MAXOWN; ++k)
       if (k < nown) {
         pp[k] = P[off[k]];
-        if (!boot) { pm[k] = Mm[off[k] - header]; pv[k] = Vv[off[k] - header]; }
+        if (upd) { pm[k] = Mm[off[k] - header]; pv[k] = Vv[off[k] - header]; }
+        if (upd && phase == VC_PH_B) gg[k] = xb.x[off[k]];          // the gradient summed over ranks
       }
+    // phase A: the histogram blocks of phase B re-derive the shape_inv update while the gene blocks of the same launch
+    // rewrite it -- they read this snapshot {parameter, exp_avg, exp_avg_sq}
+    if (phase == VC_PH_A && r_si) {
+      xb.sis[g] = pp[0];
+      xb.sis[NP + g] = Mm[off[0] - header];
+      xb.sis[2 * NP + g] = Vv[off[0] - header];
+    }
   }
 
   VC_WSTAMP(0, 1);
   double loss_post = 0.0;
-  if (!boot) {
+  if (chain) {
     // ---- second-stage reduction of K_main's gene-level partials (as K_post) ------------------------------------
     constexpr int U = MQ <= 2 ? 16 : (MQ <= 6 ? 8 : 2);     // chunk groups in flight per wave (register budget: 128)
     float acc[MQ];
@@ -282,23 +310,39 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
           }
         }
       }
-      // ---- gradient out, ClippedAdam on the owned parameters ---------------------------------------------------
+      // ---- phase A: this rank's gradient partial into the exchange buffer ----------------------------------------
+      if (phase == VC_PH_A) {
 #pragma unroll
-      for (int k = 0; k < VC_MAXOWN; ++k)
-        if (k < nown) {
-          G[off[k]] = gg[k];
-          const float np = vc_adam_elem(pp[k], gg[k], pm[k], pv[k], o.step_size, o.b1, o.b2, o.eps, o.clip);
-          Mm[off[k] - header] = pm[k];
-          Vv[off[k] - header] = pv[k];
-          P[off[k]] = np;
-          pp[k] = np;
-        }
+        for (int k = 0; k < VC_MAXOWN; ++k)
+          if (k < nown) xb.x[off[k]] = gg[k];
+      }
     }
     if (role == 12) {
       const double tot = vc_wave_sum_d63(loss_post);
-      if (lane == 63) b.LPP[gblock] = tot;
+      if (lane == 63) {
+        b.LPP[gblock] = tot;
+        if (phase == VC_PH_A) {
+          const float hi = (float)tot;
+          xb.x[xb.loss_off + 2 * (1 + gblock)] = hi;
+          xb.x[xb.loss_off + 2 * (1 + gblock) + 1] = (float)(tot - (double)hi);
+        }
+      }
     }
   }
+  // ---- gradient out, ClippedAdam on the owned parameters (phase B: gg is the sum over ranks) -------------------------
+  if (upd && live) {
+#pragma unroll
+    for (int k = 0; k < VC_MAXOWN; ++k)
+      if (k < nown) {
+        G[off[k]] = gg[k];
+        const float np = vc_adam_elem(pp[k], gg[k], pm[k], pv[k], o.step_size, o.b1, o.b2, o.eps, o.clip);
+        Mm[off[k] - header] = pm[k];
+        Vv[off[k] - header] = pv[k];
+        P[off[k]] = np;
+        pp[k] = np;
+      }
+  }
+  if (!samp) return;                    // phase A ends here (uniform per launch: no barrier is skipped by part of a block)
 
   VC_WSTAMP(0, 4);
   // ---- the guide sample of step s from the fresh parameters (statement by statement vc_pre_kernel) ---------------
@@ -427,10 +471,11 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 // shards (vc_engine.hip) use all 16 waves, 1024 cells per block, because the number of blocks to place then dominates
 // ---------------------------------------------------------------------------------------------
 #define VC_TC_MAX 1024
+template <int phase>
 __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs& b, float* __restrict__ P,
                                                    float* __restrict__ G, float* __restrict__ Mm, float* __restrict__ Vv,
                                                    int header, int cblock, long long s, uint64_t seed, const VcOpt o,
-                                                   int boot) {
+                                                   int boot, const VcXb xb) {
   __shared__ float sm_w[VC_TC_MAX / 64][VC_MAX_NW];
   __shared__ double sm_lc[VC_TC_MAX / 64];
   const int VC_TC = d.tail_tc;
@@ -453,10 +498,10 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
     pxy = *reinterpret_cast<const float2*>(b.pxy + 2 * (size_t)c);
     if (!cxy) {
       pp = *reinterpret_cast<const float2*>(P + poff);
-      // single rank: local index == global index of the stream; boot draws directly ((x, y) of a cell are the two
-      // normals of one Philox block: the eps layout starts phi_xy at an even index)
+      // the ring holds this rank's slice of the stream (local index); boot draws directly at the GLOBAL index ((x, y) of a
+      // cell are the two normals of one Philox block: the eps layout starts phi_xy at an even index)
       const long long gi = d.eoff[VC_E_PHIXY] + 2LL * c;
-      if (boot) vc_philox_normal2(seed, s, (uint64_t)gi >> 1, ex, ey);
+      if (boot) vc_philox_normal2(seed, s, (uint64_t)(gi + 2LL * d.cell_offset) >> 1, ex, ey);
       else {
         const float2 e2 = *reinterpret_cast<const float2*>(b.EPS + (size_t)(s % 3) * d.eps_total + gi);
         ex = e2.x; ey = e2.y;
@@ -531,6 +576,18 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
     }
     if ((int)threadIdx.x < d.NW) b.NWS[3 * VC_NWE + threadIdx.x] = b.lat[VC_SITE_NUOMEGA][threadIdx.x];
   }
+  // sharded step: the exchange buffer comes back from the sum holding every rank's contribution; the elements no block of
+  // this rank writes (PW rows beyond this rank's cell blocks, the header, the nu_omega slots of the gradient region) are
+  // cleared here so that they do not re-enter the next sum
+  if (phase == VC_PH_A && cblock == 0) {
+    for (int tt = d.nb_tail_cell * d.NW + (int)threadIdx.x; tt < xb.pw_cap * d.NW; tt += VC_TC) xb.x[xb.pw_off + tt] = 0.f;
+    if (threadIdx.x < 4) xb.x[threadIdx.x] = 0.f;
+    if (vel) {
+      const bool lrmn = d.guide == VC_GUIDE_LRMN;
+      const int fin_per = lrmn ? d.R + 2 : 2;
+      for (int tt = threadIdx.x; tt < d.NW * fin_per; tt += VC_TC) xb.x[vc_nuw_elem_off(d, lrmn, tt / fin_per, tt % fin_per)] = 0.f;
+    }
+  }
   VC_WSTAMP(0, 4);
   // ---- phi_xy sample of step s, phase, Fourier basis, cell record (omega is filled by K_omega) -------------------
   if (in_range) {
@@ -579,7 +636,8 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
       const int j = threadIdx.x;
       float t = 0.f;
       for (int w = 0; w < VC_TC / 64; ++w) t += sm_w[w][j];
-      b.PW[(size_t)cblock * d.NW + j] = t;
+      if (phase == VC_PH_A) xb.x[xb.pw_off + cblock * d.NW + j] = t;
+      else b.PW[(size_t)cblock * d.NW + j] = t;
     }
     if (threadIdx.x == 0) {
       double t = 0.0;
@@ -590,26 +648,59 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   VC_WSTAMP(0, 6);
 }
 
-template <int MQ>
+// Phase A: the part of this rank's loss that is complete before the launch -- prior / guide terms of the sample of the step
+// being finished (LPF, written one step earlier), K_main's likelihood partials, the step-invariant constant -- folded in
+// fixed order into one double and handed to the exchange as a (hi, lo) float pair
+__device__ __forceinline__ void vc_tail_loss_base_block(const VcDims& d, const VcBufs& b, long long s, const VcXb xb) {
+  __shared__ double sm_lb[16];
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  double sl = 0.0;
+  const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
+  for (int i = t; i < d.nlpf; i += 1024) sl += lpf[i];
+  for (int i = t; i < d.n_main_wg; i += 1024) sl -= (double)b.LO[i];
+  sl = vc_wave_sum_d63(sl);
+  if (lane == 63) sm_lb[wv] = sl;
+  __syncthreads();
+  if (t == 0) {
+    double tot = b.const_loss;
+    for (int w = 0; w < 16; ++w) tot += sm_lb[w];
+    const float hi = (float)tot;
+    xb.x[xb.loss_off] = hi;
+    xb.x[xb.loss_off + 1] = (float)(tot - (double)hi);
+  }
+}
+
+template <int MQ, int phase>
 __global__ __launch_bounds__(1024) void vc_tail_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
                                                        float* __restrict__ G, const long long* __restrict__ step_dev,
-                                                       uint64_t seed, const VcAdamArgs a, int boot) {
+                                                       uint64_t seed, const VcAdamArgs a, int boot, const VcXb xb) {
   // s: index of the step whose sample this launch draws (boot: the step about to run; else K_main has advanced the
   // counter, s = t + 1 is also the 1-based optimiser step of the update applied here)
   const long long s = *step_dev;
   VcOpt o;
   o.step_size = boot ? 0.f : b.step_size[0];       // written by K_main together with the counter
   o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip;
-  if ((int)blockIdx.x < d.nb_post_gene) vc_tail_gene_block<MQ>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, boot);
-  else vc_tail_cell_block(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, boot);
+  if ((int)blockIdx.x < d.nb_post_gene) vc_tail_gene_block<MQ, phase>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, boot, xb);
+  else if ((int)blockIdx.x < d.nb_post_gene + d.nb_tail_cell)
+    vc_tail_cell_block<phase>(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, boot, xb);
+  else if (phase == VC_PH_A) vc_tail_loss_base_block(d, b, s, xb);
 }
 
 void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
-                    const VcAdamArgs& a, int boot, hipStream_t st) {
-  const dim3 grid(d.nb_post_gene + d.nb_tail_cell), block(1024);
-  if (d.nq <= 2) hipLaunchKernelGGL(vc_tail_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
-  else if (d.nq <= 6) hipLaunchKernelGGL(vc_tail_kernel<6>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
-  else hipLaunchKernelGGL(vc_tail_kernel<VC_MAXQ>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot);
+                    const VcAdamArgs& a, int boot, int phase, const VcXb& xb, hipStream_t st) {
+  // phase A: + the loss-base block (phase B has its own launch: vc_launch_phase_b)
+  const int nblk = d.nb_post_gene + d.nb_tail_cell + (phase == VC_PH_A ? 1 : 0);
+  const dim3 grid(nblk), block(1024);
+  // the phase is a template parameter: the single-rank kernel carries none of the sharded step's code (or registers)
+#define VC_TAIL_LAUNCH(MQ_)                                                                                                       \
+  do {                                                                                                                            \
+    if (phase == VC_PH_A) hipLaunchKernelGGL((vc_tail_kernel<MQ_, VC_PH_A>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot, xb); \
+    else hipLaunchKernelGGL((vc_tail_kernel<MQ_, VC_PH_ALL>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot, xb); \
+  } while (0)
+  if (d.nq <= 2) VC_TAIL_LAUNCH(2);
+  else if (d.nq <= 6) VC_TAIL_LAUNCH(6);
+  else VC_TAIL_LAUNCH(VC_MAXQ);
+#undef VC_TAIL_LAUNCH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -619,22 +710,28 @@ void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad
 // (one wave per task), and the Philox draws of the step after next into the eps ring.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBufs& b, float* __restrict__ G, long long s,
-                                                    double* __restrict__ loss_dev, long long loss_slots) {
+                                                    double* __restrict__ loss_dev, long long loss_slots, int phase,
+                                                    const VcXb xb) {
   __shared__ double sm_lossw[4];
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   double sl = 0.0;
-  const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
+  if (phase == VC_PH_B) {
+    // the (hi, lo) pairs of every rank's loss terms, summed by the exchange: base + one per gene block, fixed order
+    for (int i = t; i < 1 + d.nb_post_gene; i += 256) sl += (double)xb.x[xb.loss_off + 2 * i] + (double)xb.x[xb.loss_off + 2 * i + 1];
+  } else {
+    const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
 #pragma unroll 4
-  for (int i = t; i < d.nlpf; i += 256) sl += lpf[i];
+    for (int i = t; i < d.nlpf; i += 256) sl += lpf[i];
 #pragma unroll 4
-  for (int i = t; i < d.nb_post_gene; i += 256) sl += b.LPP[i];
+    for (int i = t; i < d.nb_post_gene; i += 256) sl += b.LPP[i];
 #pragma unroll 4
-  for (int i = t; i < d.n_main_wg; i += 256) sl -= (double)b.LO[i];
+    for (int i = t; i < d.n_main_wg; i += 256) sl -= (double)b.LO[i];
+  }
   sl = vc_wave_sum_d63(sl);
   if (lane == 63) sm_lossw[wv] = sl;
   __syncthreads();
   if (t == 0) {
-    const double loss = ((sm_lossw[0] + sm_lossw[1]) + (sm_lossw[2] + sm_lossw[3])) + b.const_loss;
+    const double loss = ((sm_lossw[0] + sm_lossw[1]) + (sm_lossw[2] + sm_lossw[3])) + (phase == VC_PH_B ? 0.0 : b.const_loss);
     const long long step = s - 1;
     if (loss_dev) loss_dev[loss_slots > 1 ? (step % loss_slots) : 0] = loss;
     if (!isfinite(loss)) {
@@ -649,39 +746,54 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
   }
 }
 
-__global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
-                                                       float* __restrict__ G, const long long* __restrict__ step_dev,
-                                                       uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
-                                                       long long loss_slots, int boot, int nb_cell, int nb_hist) {
+// One block of K_omega's grid (256 threads; `oblk` = its index in that grid).  Also called from the 1024-thread launch of
+// phase B, where the waves beyond the fourth have left before the first barrier.
+__device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                               const long long s, uint64_t seed, const VcAdamArgs& a,
+                                               double* __restrict__ loss_dev, long long loss_slots, int boot, int nb_cell,
+                                               int nb_hist, int oblk, int phase, const VcXb xb) {
   __shared__ float sm_up[VC_MAX_NW];
   __shared__ float s_np[VC_NWE];
   __shared__ float s_nuw[VC_MAX_NW];
   __shared__ double sm_lq[VC_MAX_NW];
-  const long long s = *step_dev;
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   VC_WSTAMP(1, 0);
-  if ((int)blockIdx.x >= nb_cell) {
-    int xb = blockIdx.x - nb_cell;
-    if (xb == 0) {                                   // the loss of the finished step
-      if (!boot) vc_omega_loss_block(d, b, G, s, loss_dev, loss_slots);
+  if (oblk >= nb_cell) {
+    int xblk = oblk - nb_cell;
+    if (xblk == 0) {                                 // the loss of the finished step
+      if (!boot) vc_omega_loss_block(d, b, G, s, loss_dev, loss_slots, phase, xb);
       return;
     }
-    xb -= 1;
-    if (xb < nb_hist) {                              // histogram terms of shape_inv(s), one wave per task
-      const int task = xb * 4 + wv;
-      if (task < b.n_tasks) vc_hist_wave(d, b, P, 0, task, lane);
+    xblk -= 1;
+    if (xblk < nb_hist) {                            // histogram terms of shape_inv(s), one wave per task
+      const int task = xblk * 4 + wv;
+      if (task < b.n_tasks) {
+        if (phase == VC_PH_B && !CND(VC_SITE_SHAPE_INV)) {
+          // the gene blocks of this launch are rewriting shape_inv: re-derive its update from phase A's snapshot and the
+          // summed gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
+          const int g = b.h_task[4 * task];
+          const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
+          float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
+          const float np = vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip);
+          vc_hist_wave(d, b, P, 0, task, lane, expf(np));
+        } else {
+          vc_hist_wave(d, b, P, 0, task, lane);
+        }
+      }
       return;
     }
-    xb -= nb_hist;
+    xblk -= nb_hist;
     // eps ring: the draws of step s + 1 (and, when booting, of step s) -- one Philox block = two consecutive indices.
-    // Three slots: this launch reads the slots of s - 1 and s and writes the slot of s + 1.
-    const long long pair = (long long)xb * 256 + t;
+    // Three slots: this launch reads the slots of s - 1 and s and writes the slot of s + 1.  The ring holds this rank's slice
+    // of the stream: replicated sites at their global index, phi_xy shifted by the rank's first cell.
+    const long long pair = (long long)xblk * 256 + t;
     if (2 * pair < d.eps_total) {
+      const uint64_t gpair = (uint64_t)(pair + (2 * pair >= d.eps_n_global ? d.cell_offset : 0));
       float n0, n1;
-      vc_philox_normal2(seed, s + 1, (uint64_t)pair, n0, n1);
+      vc_philox_normal2(seed, s + 1, gpair, n0, n1);
       *reinterpret_cast<float2*>(b.EPS + (size_t)((s + 1) % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
       if (boot) {
-        vc_philox_normal2(seed, s, (uint64_t)pair, n0, n1);
+        vc_philox_normal2(seed, s, gpair, n0, n1);
         *reinterpret_cast<float2*>(b.EPS + (size_t)(s % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
       }
     }
@@ -690,7 +802,11 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
   const bool vel = d.model == VC_MODEL_VELOCITY;
   if (!vel) return;
   const bool lrmn = d.guide == VC_GUIDE_LRMN;
-  const bool first = blockIdx.x == 0;
+  const bool first = oblk == 0;
+  // phase B: the PW rows are the sums over ranks (every rank holds the complete gradient: prior / entropy weight 1)
+  const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : b.PW;
+  const int n_pw = phase == VC_PH_B ? xb.pw_cap : d.nb_tail_cell;
+  const float rw = phase == VC_PH_B ? 1.f : d.root_w;
   const int nw = d.NW;
   const int fin_per = lrmn ? d.R + 2 : 2;
   const int nelem = nw * fin_per;
@@ -704,7 +820,7 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
   const float* __restrict__ eps_new = b.EPS + (size_t)(s % 3) * d.eps_total;
   const float* __restrict__ eps_old = b.EPS + (size_t)((s + 2) % 3) * d.eps_total;
   // this block's cells: the basis of the next phase (written by K_tail) is requested now
-  const int c = blockIdx.x * 256 + t;
+  const int c = oblk * 256 + t;
   float s1 = 0.f, c1 = 1.f;
   if (c < d.Nc) {
     const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)c * d.ctw);
@@ -718,7 +834,7 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     for (int q = 0; q < 2; ++q) {
       const int j = wv + 4 * q;
       if (j < nw)
-        for (int i = lane; i < d.nb_tail_cell; i += 64) u[q] += (double)b.PW[(size_t)i * d.NW + j];
+        for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * d.NW + j];
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -727,7 +843,7 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     }
     for (int j = wv + 8; j < nw; j += 4) {
       double r = 0.0;
-      for (int i = lane; i < d.nb_tail_cell; i += 64) r += (double)b.PW[(size_t)i * d.NW + j];
+      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * d.NW + j];
       r = vc_wave_sum_d63(r);
       if (lane == 63) sm_up[j] = (float)r;
     }
@@ -744,14 +860,14 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
       float gx = 0.f;
       if (!cnd) {
         const float x = b.NWS[3 * VC_NWE + j], sd = b.sd_w[j];
-        gx = sm_up[j] - d.root_w * (x - b.mu_w[j]) / (sd * sd);
+        gx = sm_up[j] - rw * (x - b.mu_w[j]) / (sd * sd);
       }
       const long long ei = eps_index(j, ce);
       const float eo = ei >= 0 ? eps_old[ei] : 0.f;          // eps of the finished step for this element
       float gv;
       if (!lrmn) {
         if (ce == 0) gv = -gx;
-        else gv = cnd ? 0.f : -gx * expf(p) * eo - d.root_w;
+        else gv = cnd ? 0.f : -gx * expf(p) * eo - rw;
       } else {
         if (ce == 0) gv = -gx;
         else if (ce <= d.R) {
@@ -836,6 +952,44 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
     b.lat_domega[c] = domega;
   }
   VC_WSTAMP(1, 5);
+}
+
+__global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
+                                                       float* __restrict__ G, const long long* __restrict__ step_dev,
+                                                       uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
+                                                       long long loss_slots, int boot, int nb_cell, int nb_hist) {
+  vc_omega_block(d, b, P, G, *step_dev, seed, a, loss_dev, loss_slots, boot, nb_cell, nb_hist, blockIdx.x, VC_PH_ALL, VcXb{});
+}
+
+// Phase B of the sharded step in ONE launch: gene blocks (optimiser on the summed gradient + next sample) and K_omega's
+// blocks (which depend on phase A and on the exchange, not on the gene blocks) side by side
+template <int MQ>
+__global__ __launch_bounds__(1024) void vc_phase_b_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
+                                                          float* __restrict__ G, const long long* __restrict__ step_dev,
+                                                          uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
+                                                          long long loss_slots, int nb_cell, int nb_hist, const VcXb xb) {
+  const long long s = *step_dev;
+  if ((int)blockIdx.x < d.nb_post_gene) {
+    VcOpt o;
+    o.step_size = b.step_size[0];
+    o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip;
+    vc_tail_gene_block<MQ, VC_PH_B>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, xb);
+    return;
+  }
+  if (threadIdx.x >= 256) return;          // K_omega's blocks are 256 threads wide: the other waves leave before any barrier
+  vc_omega_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_cell, nb_hist, blockIdx.x - d.nb_post_gene, VC_PH_B, xb);
+}
+
+void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                       const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, const VcXb& xb,
+                       hipStream_t st) {
+  const int nb_cell = d.model == VC_MODEL_VELOCITY ? (d.Nc + 255) / 256 : 0;
+  const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
+  const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
+  const dim3 grid(d.nb_post_gene + nb_cell + 1 + nb_hist + nb_eps), block(1024);
+  // (the gene blocks of phase B neither reduce nor stage rows: the smallest row bound keeps their registers free)
+  hipLaunchKernelGGL(vc_phase_b_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots,
+                     nb_cell, nb_hist, xb);
 }
 
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,

@@ -47,8 +47,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define VC_PF (VC_ASM_LOADS ? 2 : 1)   // register path: cells in flight ahead of the one being processed
 #endif
 #ifndef VC_PF_SINGLE
-#define VC_PF_SINGLE VC_PF   // the same for the one-matrix kernels (phase, U-only): half the bytes in flight per cell
-#endif
+#define VC_PF_SINGLE 1    // the same for the one-matrix kernels (phase, U-only): they stream half the bytes per cell and lose
+#endif                    // 2 us to waits; 2 or 3 cells ahead measured equal or slower (profiles/r03_kmain.md)
 #ifndef VC_ISSUE_PIN
 #define VC_ISSUE_PIN 1    // sched_barrier behind the issue of the next cell's loads (asm path): keeps them at the top of the cell
 #endif
@@ -277,8 +277,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       // the "s" operand needs a PROVABLY wave-uniform value (else hipcc hands the asm a VGPR pair and the assembler rejects
       // it): the cell index goes through readfirstlane, which folds away wherever the compiler already knows it is uniform
       const size_t row = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)cn) * (GBW * ESZ);
-      if (HAS_S) vc_issue(s_q[j], lane_off, Sb + row);
-      if (HAS_U) vc_issue(u_q[j], lane_off, Ub + row);
+#ifdef VC_NO_LOADS           // measurement aid: only the first cells are fetched, the loop re-uses them (results are meaningless)
+      if (i < NBUF)
+#endif
+      {
+        if (HAS_S) vc_issue(s_q[j], lane_off, Sb + row);
+        if (HAS_U) vc_issue(u_q[j], lane_off, Ub + row);
+      }
     } else
 #ifdef VC_NO_LOADS           // measurement aid: only the first cells are fetched, the loop re-uses them (results are meaningless):
     if (i >= NBUF) { asm volatile("" : "+v"(s_bf[j][0]), "+v"(u_bf[j][0])); } else      // what the memory stalls cost, profiles/r02_kmain.md

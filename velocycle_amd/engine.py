@@ -281,6 +281,58 @@ class HipEngine:
             C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, int(bool(prime)),
             C.c_int64(n_steps), self._stream()))
 
+    # ---- cells sharded over ranks: the fused step cut at its one exchange (vc_svi_run_sharded) ----------------------
+    def exchange_size(self) -> int:
+        n = C.c_int64()
+        self._check(self.lib.vc_exchange_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def svi_run_sharded(self, xbuf, m, v, lr, lrd, b1, b2, adam_eps, clip, seed, step_dev, loss_buf=None, prime=False,
+                        phase=_lib.VC_PHASE_AB, n_steps=1):
+        """phase A: K_main + the part of the step before the exchange (writes `xbuf`, which the caller then sums over the
+        ranks); phase B: the part after it; phase AB: n_steps whole steps, the sum made by the engine's own RCCL
+        communicator (`init_rccl_comm`; a single rank needs none)."""
+        lb = self.loss_dev if loss_buf is None else loss_buf
+        self._check(self.lib.vc_svi_run_sharded(
+            self._h, C.c_void_p(self.params.data_ptr()), C.c_uint64(seed), C.c_void_p(step_dev.data_ptr()),
+            C.c_void_p(self.grad.data_ptr()), C.c_void_p(xbuf.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()),
+            C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, int(bool(prime)), int(phase),
+            C.c_int64(n_steps), self._stream()))
+
+    @staticmethod
+    def rccl_path() -> str:
+        """The librccl.so this process already uses (PyTorch's bundled one), so that the engine's communicator and
+        torch.distributed share one RCCL."""
+        import os
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return cand if os.path.exists(cand) else "librccl.so"
+
+    def init_rccl_comm(self, process_group=None) -> bool:
+        """Creates the engine's own RCCL communicator over the ranks of `process_group` (collective).  The 128-byte unique
+        id is made by group rank 0 through the library and broadcast with torch.distributed (any backend).  Returns True
+        when EVERY rank succeeded (agreed by a MIN all-reduce), else False on every rank."""
+        import torch.distributed as dist
+        path = self.rccl_path().encode()
+        ok = 1
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_char * 128)()
+            rc = self.lib.vc_comm_rccl_unique_id(path, buf)
+            ident = [bytes(buf.raw) if rc == _lib.VC_OK else None]
+        src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+        dist.broadcast_object_list(ident, src=src, group=process_group)
+        if ident[0] is None:
+            ok = 0
+        else:
+            ib = (C.c_char * 128).from_buffer_copy(ident[0])
+            rc = self.lib.vc_comm_init_rccl(self._h, path, ib)
+            if rc != _lib.VC_OK:
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32,
+                            device=self.device if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+        return bool(int(flag.item()))
+
     def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
         """Fused HIP ClippedAdam on flat float32 buffers (same stream); optionally files the (all-reduced) loss
         found in `loss_hdr[0:2]` into `loss_ring[(t-1) % len]`."""

@@ -90,6 +90,12 @@ class _FitBase:
         torch.cuda.synchronize(eng.device)
         t_engine = time.perf_counter()
         args = optim_args_of(optimizer)
+        # the user's ELBO object (velocity_inference_model.py:79,111): num_particles = K guide draws per step, averaged
+        particles = int(getattr(loss, "num_particles", 1)) if loss is not None else 1
+        if particles < 1:
+            raise ValueError("loss.num_particles must be >= 1")
+        if loss is not None and getattr(loss, "vectorize_particles", False):
+            raise NotImplementedError("Trace_ELBO(vectorize_particles=True) is not supported by the HIP engine")
         exact = mode == "parity" or self.early_exit or store_output
         if mode == "parity":
             gen_seed = seed
@@ -99,13 +105,18 @@ class _FitBase:
                 gen_seed = broadcast_int(torch.initial_seed() % (2 ** 63), self._pg, eng.device)
             warm = type(self)._default_elbo_fresh if loss is None else bool(getattr(loss, "fresh", True))
             run = SVIRunner(eng, args, mode="parity", seed=gen_seed, warmup_draw=warm,   # seed None -> torch's global RNG
-                            process_group=self._pg)
+                            process_group=self._pg, num_particles=particles)
             if loss is None:
                 type(self)._default_elbo_fresh = False
+            elif hasattr(loss, "fresh"):
+                try:
+                    loss.fresh = False       # the object has made its extra guide pass: a later fit with it will not
+                except Exception:
+                    pass
         else:
             s = int(torch.initial_seed() % (2 ** 63)) if seed is None else int(seed)
             s = broadcast_int(s, self._pg, eng.device)
-            run = SVIRunner(eng, args, mode="perf", seed=s, process_group=self._pg)
+            run = SVIRunner(eng, args, mode="perf", seed=s, process_group=self._pg, num_particles=particles)
         self._runner = run
         losses, intermediate_output = [], []
         if mode == "perf" and not exact:

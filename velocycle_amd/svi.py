@@ -113,19 +113,28 @@ class SVIRunner:
 
     def __init__(self, engine: HipEngine, optim_args: dict, mode: str = "parity", seed: Optional[int] = None,
                  process_group=None, use_graph: Optional[bool] = None, warmup_draw: bool = True,
-                 init: bool = True, adam_impl: Optional[str] = None, force_reduce: bool = False):
+                 init: bool = True, adam_impl: Optional[str] = None, force_reduce: bool = False,
+                 exchange: Optional[str] = None, num_particles: int = 1):
         assert mode in ("parity", "perf")
+        # Trace_ELBO(num_particles=K): K guide draws per step, loss and gradients averaged before the optimiser step.  K > 1
+        # runs the unfused kernel sequence once per particle (the fused steps draw the NEXT step's single sample inside
+        # the optimiser kernel); parity mode draws K host eps sets per step, perf mode uses the Philox streams
+        # (seed, step * K + k)
+        self.K = int(num_particles)
+        if self.K < 1:
+            raise ValueError("num_particles must be >= 1")
         self.e, self.mode = engine, mode
         self.pg = process_group
         self.world = engine.world_size
         self.seed = 0 if seed is None else int(seed)
         # force_reduce: issue the all-reduce even with one rank (exercises the RCCL-in-graph path on one GPU)
         self.do_reduce = self.world > 1 or force_reduce
-        # perf mode: N > 1 replays the step (RCCL all-reduce included) from a hipGraph -- the host side of a collective
-        # is expensive; a single rank enqueues plain launches from one C call per run_perf (vc_svi_run_fused): measured
-        # ~6 us per step faster than graph replay at every size (profiles/r02_step_overhead.md)
-        single = not (engine.world_size > 1 or force_reduce)
-        self.use_graph = (mode == "perf" and not single) if use_graph is None else use_graph
+        # perf mode launches plain kernels by default: a single rank enqueues every launch of a run from one C call
+        # (vc_svi_run_fused; measured ~6 us per step faster than graph replay, profiles/r02_step_overhead.md), and so do N > 1
+        # ranks when the engine owns the exchange (vc_svi_run_sharded, VC_PHASE_AB).  hipGraph replay of the N > 1 step with
+        # a torch.distributed collective inside is OPT-IN (use_graph=True): it has only ever run on a 1-rank RCCL group, and
+        # the ranks agree on the outcome of the capture (MIN all-reduce) before anyone replays.
+        self.use_graph = False if use_graph is None else bool(use_graph)
         if self.do_reduce and self.use_graph:
             import torch.distributed as dist
             if dist.get_backend(process_group) != "nccl":
@@ -134,16 +143,54 @@ class SVIRunner:
                 self.use_graph = False
         # "torch": PyTorch ops; "hip": one kernel after the gradient; "fused": merged with the last gradient kernel
         # (4 launches per step); "fused3": the three-launch step of vc_svi_step_fused (reductions + chain rule + optimiser +
-        # the NEXT step's guide sample in one kernel) -- the single-rank default
-        # (VC_ADAM_IMPL overrides the single-rank perf default for A/B measurements, e.g. the unfused "fused" sequence)
+        # the NEXT step's guide sample in one kernel) -- the single-rank default; "sharded": the same step cut at its one
+        # exchange (K_main -> phase A -> sum over ranks -> phase B: vc_svi_run_sharded) -- the default when cells are sharded
+        # (VC_ADAM_IMPL / VC_ADAM_IMPL_DIST override the perf defaults for A/B measurements, e.g. the unfused "hip" sequence)
         import os
-        self.adam_impl = adam_impl or (("hip" if self.do_reduce else os.environ.get("VC_ADAM_IMPL", "fused3"))
-                                       if mode == "perf" else "torch")
+        if adam_impl is None and self.K > 1 and mode == "perf":
+            adam_impl = "hip"
+        if self.K > 1 and adam_impl in ("fused", "fused3", "sharded"):
+            raise ValueError(f"adam_impl={adam_impl!r} draws one sample per step; num_particles > 1 runs the unfused sequence")
+        if adam_impl is None:
+            if mode != "perf":
+                adam_impl = "torch"
+            elif self.do_reduce:
+                adam_impl = os.environ.get("VC_ADAM_IMPL_DIST", "sharded")
+            else:
+                adam_impl = os.environ.get("VC_ADAM_IMPL", "fused3")
+        self.adam_impl = adam_impl
         if self.adam_impl in ("fused", "fused3") and (self.do_reduce or mode != "perf"):
             raise ValueError(f"adam_impl={self.adam_impl!r} needs mode='perf' on a single rank")
+        if self.adam_impl == "sharded" and mode != "perf":
+            raise ValueError("adam_impl='sharded' needs mode='perf'")
+        # who sums the exchange buffer of the sharded step: "engine" = the library's own RCCL communicator, whole runs enqueued
+        # from one C call (needs the nccl backend and > 1 rank); "torch" = torch.distributed.all_reduce between the two phases
+        # of every step (any backend: gloo in the one-device tests)
+        self.exchange = None
+        self.xbuf = None
+        if self.adam_impl == "sharded":
+            import torch.distributed as dist
+            want = exchange or os.environ.get("VC_EXCHANGE")
+            if want is None:
+                want = "engine" if (self.world > 1 and dist.get_backend(process_group) == "nccl" and not self.use_graph) else "torch"
+            if want == "engine":
+                if not (self.do_reduce and dist.get_backend(process_group) == "nccl"):
+                    raise ValueError("exchange='engine' needs a process group on the nccl (RCCL) backend")
+                if not engine.init_rccl_comm(process_group):
+                    import warnings
+                    warnings.warn("the engine's RCCL communicator could not be created on every rank; the exchange goes "
+                                  "through torch.distributed.all_reduce instead")
+                    want = "torch"
+            elif want == "none":               # measurement aid (profiles/tools/step_time_vs_shard.py): one rank, nothing to sum
+                if self.world > 1:
+                    raise ValueError("exchange='none' is a single-rank measurement aid")
+            elif want != "torch":
+                raise ValueError(f"unknown exchange {want!r}")
+            self.exchange = want
+            self.xbuf = torch.zeros(engine.exchange_size(), dtype=torch.float32, device=engine.device)
         self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
                                    capturable=self.use_graph,
-                                   impl=("hip" if self.adam_impl in ("fused", "fused3") else self.adam_impl), engine=engine)
+                                   impl=("hip" if self.adam_impl in ("fused", "fused3", "sharded") else self.adam_impl), engine=engine)
         self._primed = False          # fused3: the tables of the current step have been sampled from the current params
         self.step_idx = 0
         self.losses: List[float] = []
@@ -185,6 +232,8 @@ class SVIRunner:
     def step(self, eps: Optional[Dict[str, torch.Tensor]] = None) -> float:
         """One SVI step in parity mode; returns the loss like `svi.step` does."""
         e = self.e
+        if self.K > 1:
+            return self._step_particles(eps)
         if eps is None:
             if getattr(self, "_pending", None) is not None:
                 eps, self._pending = self._pending, None
@@ -199,6 +248,45 @@ class SVIRunner:
         self.losses.append(loss)
         return loss
 
+    def _step_particles(self, eps_list=None) -> float:
+        """One parity-mode step of Trace_ELBO(num_particles=K): K guide draws in sequence (pyro draws the particles one after
+        the other), each through the whole ELBO + gradient kernel sequence; the K losses and gradients are averaged, then one
+        all-reduce (cells sharded) and one optimiser step."""
+        e, K = self.e, self.K
+        acc = torch.zeros_like(e.grad)
+        for k in range(K):
+            if eps_list is not None:
+                eps = eps_list[k]
+            elif getattr(self, "_pending", None) is not None:
+                eps, self._pending = self._pending, None
+            else:
+                eps = draw_eps(e.spec, self.gen)
+            e.elbo_grad(eps=e.pack_eps(eps), step=self.step_idx * K + k)
+            acc += e.grad                      # header included: loss hi / lo average like everything else
+        e.grad.copy_(acc / K)
+        self._reduce()
+        loss = float(e.grad[:2].double().sum().item())
+        self._update()
+        self.step_idx += 1
+        self.losses.append(loss)
+        return loss
+
+    def _perf_particles(self, n_steps: int):
+        """perf mode with K particles: per step the unfused kernel sequence on the Philox streams (seed, step * K + k),
+        averaged on the device; losses stay in the device ring."""
+        e, K = self.e, self.K
+        for _ in range(n_steps):
+            acc = torch.zeros_like(e.grad)
+            for k in range(K):
+                e.elbo_grad(eps=None, seed=self.seed, step=self.step_idx * K + k)
+                acc += e.grad
+            e.grad.copy_(acc / K)
+            self._reduce()
+            self.loss_hist[self.step_idx] = e.grad[:2].double().sum()
+            self._update()
+            self.step_idx += 1
+            self.step_dev += 1                 # the device counter mirrors the steps done (checkpoints read it)
+
     def invalidate(self):
         """Tell the runner that params / step counter / seed were changed from outside (fused3 keeps the NEXT step's
         sample in the engine's tables; it is re-drawn from the current parameters before the next step)."""
@@ -206,6 +294,21 @@ class SVIRunner:
 
     def _perf_body(self, prime: bool = False, n_steps: int = 1):
         e = self.e
+        if self.adam_impl == "sharded":        # cells sharded: K_main -> phase A -> sum over ranks -> phase B
+            from . import _lib
+            o = self.opt
+            kw = dict(seed=self.seed, step_dev=self.step_dev, loss_buf=self.loss_hist)
+            if self.exchange in ("engine", "none"):      # every launch and every all-reduce of the run from one C call
+                e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime,
+                                  phase=_lib.VC_PHASE_AB, n_steps=n_steps, **kw)
+                return
+            import torch.distributed as dist
+            for i in range(n_steps):
+                e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime and i == 0,
+                                  phase=_lib.VC_PHASE_A, **kw)
+                dist.all_reduce(self.xbuf, group=self.pg)
+                e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, phase=_lib.VC_PHASE_B, **kw)
+            return
         if self.adam_impl == "fused3":         # single rank: K_main -> K_tail -> K_omega
             o = self.opt
             e.svi_step_fused(o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, seed=self.seed,
@@ -239,6 +342,11 @@ class SVIRunner:
                 new[: self.loss_hist.shape[0]] = self.loss_hist
             self.loss_hist = new
             self._graph = None
+        if self.K > 1:
+            self._perf_particles(n_steps)
+            if sync:
+                torch.cuda.synchronize(e.device)
+            return
         if self.use_graph and self._graph is None:
             s = torch.cuda.Stream(device=e.device)
             s.wait_stream(torch.cuda.current_stream(e.device))
@@ -259,14 +367,23 @@ class SVIRunner:
                     import warnings
                     warnings.warn(f"hipGraph capture of the SVI step failed ({type(ex).__name__}: {ex}); using eager launches")
                     g = None
-                    self.use_graph = False
                     torch.cuda.synchronize()
+                if self.do_reduce and self.world > 1:
+                    # every rank replays or none does: a rank that fell back to eager launches beside ranks that replay a
+                    # captured collective would issue its all-reduces in a different order
+                    import torch.distributed as dist
+                    flag = torch.tensor([0 if g is None else 1], dtype=torch.int32, device=e.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+                    if int(flag.item()) == 0:
+                        g = None
+                if g is None:
+                    self.use_graph = False
             torch.cuda.current_stream(e.device).wait_stream(s)
             # the warm-up pass was one real step (capture only records)
             self._graph = g
             self.step_idx += 1
             n_steps -= 1
-        if self._graph is None and self.adam_impl == "fused3":
+        if self._graph is None and self.adam_impl in ("fused3", "sharded"):
             self._perf_body(prime=not self._primed, n_steps=n_steps)      # every launch of the run from one C call
             self._primed = True
         else:

@@ -14,11 +14,14 @@ from .spec import ModelSpec
 
 
 def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, seed=0, device="cpu",
-                       noisemodel="NegativeBinomial", concentration=5.0) -> ModelSpec:
+                       noisemodel="NegativeBinomial", concentration=5.0, sim=None) -> ModelSpec:
     """mode: "vjoint" (mean-field guide, nothing conditioned), "vcond" (default LRMN guide conditioned
-    on ϕxy, ν, shape_inv [, Δν] like the tutorials), "vcond_mf" (same conditioning, mean-field)."""
+    on ϕxy, ν, shape_inv [, Δν] like the tutorials), "vcond_mf" (same conditioning, mean-field).
+    `sim`: a stored output of `simulate_counts` (the sampling kernels of torch are not bit-reproducible across hosts, so
+    fixtures that must describe the SAME data on every machine carry the simulated counts: tests/golden/oracle_fit_data_*)."""
     omegas = (0.4, 0.3)[:n_conditions]
-    sim = simulate_counts(Nc, Ng, omegas=omegas, seed=seed, device=device)
+    if sim is None:
+        sim = simulate_counts(Nc, Ng, omegas=omegas, seed=seed, device=device)
     S_cm, U_cm = sim["S"], sim["U"]                  # (Nc_total, Ng) cell-major, like AnnData layers
     nct = S_cm.shape[0]
     colsum = S_cm.sum(1)
@@ -56,8 +59,8 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
     return spec
 
 
-def make_phase_spec(Nc=3000, Ng=200, seed=0, device="cpu", noisemodel="NegativeBinomial") -> ModelSpec:
-    v = make_velocity_spec(Nc, Ng, "vjoint", 1, 0, seed, device, noisemodel)
+def make_phase_spec(Nc=3000, Ng=200, seed=0, device="cpu", noisemodel="NegativeBinomial", sim=None) -> ModelSpec:
+    v = make_velocity_spec(Nc, Ng, "vjoint", 1, 0, seed, device, noisemodel, sim=sim)
     spec = ModelSpec(kind="phase", guide="meanfield", noisemodel=noisemodel, with_delta_nu=False, H=1,
                      S=v.S, count_factor=v.count_factor, Db=v.Db, mu_nu=v.mu_nu, sd_nu=v.sd_nu,
                      phixy_prior=v.phixy_prior, sigma_ln_s=0.5)
