@@ -146,18 +146,38 @@ def kernel_roofline(engine, run, steps):
             traffic, traffic_src = int(ent["traffic_bytes"]), "profiles/latest_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per gfx950 note)"
     except Exception:
         pass
+    pipe = (traffic if traffic else st["streamed_bytes"]) / avg_s / 1e9
+    vb = valu_bound(engine, avg_s, clock_mhz)
+    if vb is not None:
+        # the same floor priced at the clock the kernel itself holds inside its cell loop (stamped build,
+        # profiles/tools/wave_timeline.py; profiles/valu_model.json "in_loop_clock_mhz"): the light one-wave probe above
+        # reads the clock of an idle-ish chip, the likelihood kernel runs 5-10 % below it (DVFS give-back)
+        try:
+            ilc = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))["in_loop_clock_mhz"].get(st["main_kernel"])
+        except Exception:
+            ilc = None
+        if ilc:
+            b_us = vb["floor_ns_per_cell_iter"] * (vb["floor_measured_at_mhz"] / ilc) * vb["cell_iters_per_simd"] * 1e-3
+            vb["in_loop_clock_mhz"] = ilc
+            vb["bound_us_at_in_loop_clock"] = round(b_us, 1)
+            vb["frac_at_in_loop_clock"] = round(b_us / (avg_s * 1e6), 4)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "valu": valu_bound(engine, avg_s, clock_mhz),
+            "hbm_pipe_GBs": round(pipe, 1), "hbm_pipe_frac": round(pipe / HBM_PEAK_GBS, 4),
+            "valu": vb,
             "kernel": st["main_kernel"], "kernel_avg_us": round(avg_s * 1e6, 2), "launches": int(n),
             "algorithmic_bytes_per_launch": int(st["algorithmic_bytes"]),
             "streamed_bytes_per_launch": int(st["streamed_bytes"]),
             "count_storage": st["count_storage"],
             "streamed_GBs": round(st["streamed_bytes"] / avg_s / 1e9, 1),
-            "note": "achieved / frac price the ALGORITHMIC bytes (the reference's float32 count matrices read once, SURVEY 8d) "
-                    "against the 8 TB/s HBM spec; with count_storage u16 the kernel streams half of them (streamed_*), "
-                    "so frac is an efficiency against the float32 roofline; the nearer ceiling is the arithmetic floor of "
-                    "the cell loop (valu: the loop's instruction mix alone on one SIMD, measured)",
+            "note": "achieved / frac price the ALGORITHMIC bytes (the reference's float32 count matrices read once, SURVEY 8d: "
+                    "what the task's roofline contract asks for) against the 8 TB/s HBM spec; hbm_pipe_* is what the HBM pipe "
+                    "really carries per launch (PMC traffic when a committed rocprofv3 pass matches this workload, else the "
+                    "streamed bytes of the uint16 / float32 layout) -- with count_storage u16 that is about half of the "
+                    "algorithmic bytes, so frac is an efficiency against the float32 roofline, NOT pipe utilisation; the "
+                    "nearer ceiling is the arithmetic floor of the cell loop (valu: the loop's instruction mix alone on one "
+                    "SIMD, measured; frac = at the clock this process's probe reads, frac_at_in_loop_clock = at the clock the "
+                    "kernel holds inside its loop)",
             "method": "hipEvents recorded by the library on the launch stream around that kernel only, over eager SVI "
                       "steps run right after the timed region"}
 
@@ -456,7 +476,8 @@ def main():
             rf = kernel_roofline(e2, r2, args.roofline_launches)
             extra[m] = {"steps_per_s": round(args.steps / median(ts2), 2), "kernel": rf["kernel"],
                         "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"],
-                        "hbm_frac": rf["frac"], "valu_frac": (rf["valu"] or {}).get("frac")}
+                        "hbm_frac": rf["frac"], "hbm_pipe_frac": rf["hbm_pipe_frac"], "valu_frac": (rf["valu"] or {}).get("frac"),
+                        "valu_frac_at_in_loop_clock": (rf["valu"] or {}).get("frac_at_in_loop_clock")}
             del s2, e2, r2
             torch.cuda.empty_cache()
         out["modes"] = extra

@@ -264,7 +264,8 @@ int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_d
  *   [0, header + n_global)                         gradient partials of the replicated parameters, offsets of `grad`
  *   [pw_off, pw_off + pw_cap * Nx * Nhw)           per-cell-block partials of d loglik / d nu_omega (rows beyond a rank's
  *                                                  own cell blocks are zero), pw_cap = ceil(ceil(Nc_global / world) / 256)
- *   [loss_off, loss_off + 2 * (1 + ceil(Ng/64)))   (hi, lo) float pairs of the rank's loss terms
+ *   [loss_off, loss_off + 4 * (1 + ceil(Ng/64)))   the rank's loss terms, each double as four floats on fixed grids (their
+ *                                                  float32 sum over <= 16 ranks is exact)
  * Every element is additive over ranks; replicated prior / entropy terms are contributed by rank 0 only.  After the sum
  * every rank holds the complete gradient and applies the identical update: parameters stay replicated bit for bit.
  *
@@ -289,6 +290,17 @@ int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, int64_t* step
  * calls vc_comm_init_rccl with it (collective).  vc_destroy releases the communicator. */
 int vc_comm_rccl_unique_id(const char* rccl_path, void* id_out_128_bytes);
 int vc_comm_init_rccl(vc_engine* e, const char* rccl_path, const void* id_128_bytes);
+
+/* The one-shot exchange for VC_PHASE_AB over peer-mapped device memory (SURVEY.md section 5's latency-optimised variant;
+ * velocycle_amd/csrc/vc_p2p_exchange.hip): every rank publishes its exchange buffer in a region of its own HBM and a
+ * step-stamped flag in every peer's region, then reads all N buffers directly and adds them in fixed rank order (identical
+ * bits on every rank, no float atomics).  vc_p2p_alloc creates this rank's region and returns its 64-byte hipIpcMemHandle_t;
+ * the host side gathers the handles of all ranks in rank order (any transport) and hands the world_size x 64 bytes to
+ * vc_p2p_connect (collective in effect: every rank must do it before the first step).  When connected, VC_PHASE_AB uses
+ * this exchange instead of RCCL.  A peer that never publishes is detected by a bounded wait (VC_P2P_TIMEOUT_S, default 2 s):
+ * vc_get_status then returns VC_ERR_STATE.  Opt-in: it has run across processes on one device only. */
+int vc_p2p_alloc(vc_engine* e, void* ipc_handle_out_64_bytes);
+int vc_p2p_connect(vc_engine* e, const void* all_handles_world_x_64_bytes);
 
 /* One draw of the guide pushed through the deterministic part of the model (what
  * `Predictive(model, guide=guide, num_samples=1)` evaluates for the latent and deterministic sites;

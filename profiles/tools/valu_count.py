@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Static VALU count of the likelihood kernel's cell loop, from the device assembly hipcc emits.
 
-For every requested instantiation of vc_main_kernel the main loop (the largest innermost loop of the kernel: two cells
-per trip, the rotating register buffers) is located in `hipcc --cuda-device-only -S` output and its VALU instructions
+For every requested instantiation of vc_main_kernel the main loop (the largest innermost loop of the kernel: two or three
+cells per trip, the rotating register buffers) is located in `hipcc --cuda-device-only -S` output and its VALU instructions
 are counted: all `v_*` (one issue slot per wave64 instruction; packed-math ops retire two genes per slot) and, among
 them, the transcendentals (v_exp/v_log/v_rcp/v_rsq/v_sqrt/v_sin/v_cos: quarter rate).  profiles/tools/valu_rate.hip
 measures on the GPU what a SIMD needs for exactly that instruction MIX and nothing else (no loads, no cross-lane work,
@@ -114,7 +114,11 @@ def count(tu, H, NB, KIND, NOISE, GPL, C16):
     n_slow = wsum(lambda o: isv(o) and bool(TRANS_SLOW.match(o)))
     n_pk = wsum(lambda o: o.startswith("v_pk_"))
     n_plain = n_valu - n_trans - n_pk
-    cells = 2                                                    # NBUF = VC_PF + 1 cells per loop trip
+    # cells per loop trip = NBUF = prefetch depth + 1: the asm-load path has one hand-placed `s_waitcnt vmcnt(k)` per cell
+    # (k > 0: the younger fetches stay in flight); round 2's compiler-counted loop had two cells per trip
+    asm_waits = sum(1 for i, l in enumerate(body[a:b + 1]) if re.match(r"\s+s_waitcnt vmcnt\([1-9]\d*\)\s*$", l)
+                    and ";;#ASMSTART" in body[a + i - 1])
+    cells = asm_waits if asm_waits else 2
     res = {"valu_per_cell_iter": round(n_valu / cells, 2), "trans_per_cell_iter": round(n_trans / cells, 2),
            "packed_per_cell_iter": round(n_pk / cells, 2), "plain_per_cell_iter": round(n_plain / cells, 2),
            "exp_log_per_cell_iter": round(n_slow / cells, 2), "rcp_per_cell_iter": round((n_trans - n_slow) / cells, 2),
@@ -141,6 +145,11 @@ def main():
         out["kernels"][name] = res
         print(name, res)
     path = os.environ.get("VALU_MODEL_OUT", os.path.join(ROOT, "profiles", "valu_model.json"))
+    try:        # measured on the GPU with the stamped build, not derivable here: carried over
+        old = json.load(open(path))
+        out.update({k: v for k, v in old.items() if k.startswith("in_loop_clock")})
+    except Exception:
+        pass
     json.dump(out, open(path, "w"), indent=1)
 
 

@@ -51,10 +51,12 @@ def test_fused_philox_run_matches_oracle_replay_on_fixtures(case):
     _fused_vs_oracle(H.spec_from_fixture(z), n=25, seed=1234)
 
 
-@pytest.mark.parametrize("mode,ncond", [("vjoint", 1), ("vcond", 2), ("vjoint", 2)])
-def test_fused_philox_run_matches_oracle_replay_medium(mode, ncond):
-    """3001 (x conditions) cells x 300 genes: two gene blocks, ragged cell tiles, Nx = Nb = 2 with per-batch offsets."""
+@pytest.mark.parametrize("mode,ncond,gpl", [("vjoint", 1, 8), ("vjoint", 1, 4), ("vcond", 2, 8), ("vjoint", 2, 4)])
+def test_fused_philox_run_matches_oracle_replay_medium(mode, ncond, gpl, monkeypatch):
+    """3001 (x conditions) cells x 300 genes: two gene blocks, ragged cell tiles, Nx = Nb = 2 with per-batch offsets; the
+    8-genes-per-lane kernels (what the full-size benchmark runs; shards this small default to 4) and the 4-genes-per-lane ones."""
     from velocycle_amd.workloads import make_velocity_spec
+    monkeypatch.setenv("VC_GPL", str(gpl))
     _fused_vs_oracle(make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5), n=12, seed=77, report=f"{mode} x{ncond}")
 
 
@@ -64,11 +66,12 @@ def test_fused_philox_run_matches_oracle_replay_phase_medium():
 
 
 @pytest.mark.parametrize("mode", ["vjoint", "vcond"])
-def test_fused_philox_run_matches_oracle_on_a_slice_of_the_benchmark_data(mode):
+def test_fused_philox_run_matches_oracle_on_a_slice_of_the_benchmark_data(mode, monkeypatch):
     """The first 2 000 cells of the 50 000 x 2 000 benchmark workload (bench.py's generator and seed): every gene block of
     the full-size launch, the oracle finishes in seconds."""
     import copy
     from velocycle_amd.workloads import make_velocity_spec
+    monkeypatch.setenv("VC_GPL", "8")            # the kernel of the full-size launch (a 2 000-cell shard alone would take 4)
     full = make_velocity_spec(50000, 2000, mode, 1, 1, seed=0, device="cuda")
     n = 2000
     spec = copy.copy(full)

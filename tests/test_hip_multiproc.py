@@ -62,3 +62,25 @@ def test_bench_gpus_2_launches_itself():
     assert len(out_lines) == 1, two.stdout[-2000:]
     j = json.loads(out_lines[0])
     assert j["n_gpus"] == 2 and j["distributed"]["world_size"] == 2 and j["steps"] == 30
+
+
+def _two_ranks(env_extra, extra_args=()):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_BENCH_ONE_DEVICE="1", **env_extra)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", *SIZE, *extra_args],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return _json_line(r.stdout)
+
+
+def test_two_process_p2p_exchange_equals_the_collective():
+    """VC_EXCHANGE=p2p: the one-shot exchange over peer-mapped device memory (vc_p2p_exchange.hip) between two PROCESSES (both
+    on cuda:0 -- hipIpc works between processes on one device, which is all a 1-GPU box can offer): region export / import,
+    step-stamped flags, double-buffered slots, fixed-rank-order sum, all enqueued from one C call per run.  Same losses as the
+    gloo all-reduce of the same two ranks (two addends: a + b is b + a, bit for bit), no exchange time-out latched."""
+    ref = _two_ranks({"VC_EXCHANGE": "torch"})
+    got = _two_ranks({"VC_EXCHANGE": "p2p", "VC_P2P_TIMEOUT_S": "20"})
+    assert got["distributed"]["exchange"] == "p2p" and ref["distributed"]["exchange"] == "torch"
+    assert got["nonfinite_loss_steps"] == 0
+    for a, b in zip(ref["loss_first_last"], got["loss_first_last"]):
+        assert abs(a - b) <= 1e-9 * abs(a), (ref["loss_first_last"], got["loss_first_last"])

@@ -40,8 +40,9 @@ def _evaluate(spec, eps_seed, shares):
 
 
 @pytest.mark.parametrize("mode", ["vjoint", "vcond", "phase"])
-def test_pass_shares_leave_the_result_alone(mode):
+def test_pass_shares_leave_the_result_alone(mode, monkeypatch):
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
+    monkeypatch.setenv("VC_GPL", "8")          # the multi-pass kernels of the full-size problems (a shard this narrow defaults to 4)
     if mode == "phase":
         spec = make_phase_spec(40000, 128, seed=21)
     else:
@@ -50,7 +51,9 @@ def test_pass_shares_leave_the_result_alone(mode):
     st = ref.stats
     assert st["main_grid"] > 256, st                      # more than one dispatch pass
     pc = st["pass_cells"]
-    assert pc[0] > pc[1] and abs(pc[0] - 2 * pc[1]) <= 2, pc    # default: every pass half the cells of the one before
+    # default: every pass half the cells of the one before; a third for the S+U kernel (two cells of its counts in flight)
+    ratio = 3 if mode == "vjoint" else 2
+    assert pc[0] > pc[1] and abs(pc[0] - ratio * pc[1]) <= ratio, pc
     H.assert_step_matches_oracle(ref, spec, eps)
     g_ref = {k: v.double().cpu().clone() for k, v in ref.named(ref.grad).items()}
     loss_ref = float(ref.loss())

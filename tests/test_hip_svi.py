@@ -98,12 +98,15 @@ def test_hip_adam_equals_torch_ops():
     assert torch.equal(res[1][0], res[2][0]) and res[1][1] == res[2][1]
 
 
+@pytest.mark.parametrize("gpl", [4, 8])
 @pytest.mark.parametrize("mode", ["vjoint", "vcond", "vcond_mf"])
-def test_medium_problem_against_oracle(mode, monkeypatch):
-    """3000 cells x 300 genes (two gene blocks, many cell chunks, ragged tails) vs the float64 oracle."""
+def test_medium_problem_against_oracle(mode, gpl, monkeypatch):
+    """3000 cells x 300 genes (two gene blocks, many cell chunks, ragged tails) vs the float64 oracle, on the 4- and on the
+    8-genes-per-lane kernels (the engine picks 4 by itself for shards this small, 8 for the full-size benchmark)."""
     from velocycle_amd.workloads import make_velocity_spec
     spec = make_velocity_spec(3001, 300, mode, n_conditions=2, Hw=1, seed=5)
     monkeypatch.setenv("VC_CELLS_PER_WAVE", "37")
+    monkeypatch.setenv("VC_GPL", str(gpl))
     eng = _mk(spec)
     g = torch.Generator().manual_seed(0)
     from velocycle_amd.rng import draw_eps

@@ -76,14 +76,14 @@ def _check(p, gpl=None, monkeypatch=None):
 
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 1, 2, 3, 4))))
 def test_phase_kernels(H, Nb, monkeypatch):
-    for noise, gpl in (("NegativeBinomial", None), ("Poisson", 4), ("Lognormal", 8)):
+    for noise, gpl in (("NegativeBinomial", 8), ("Poisson", 4), ("Lognormal", None)):
         p = _problem("phase", "meanfield", noise, H, 0, Nb, 0, [], Nc=70 + 13 * H, Ng=9 + Nb, seed=H * 10 + Nb)
         _check(p, gpl, monkeypatch)
 
 
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 1, 2, 4))))
 def test_velocity_joint_kernels(H, Nb, monkeypatch):
-    for noise, guide, Hw, Nx, gpl in (("NegativeBinomial", "meanfield", 1, 2, None), ("Poisson", "lrmn", 0, 1, 4),
+    for noise, guide, Hw, Nx, gpl in (("NegativeBinomial", "meanfield", 1, 2, 8), ("Poisson", "lrmn", 0, 1, 4),
                                       ("Lognormal", "meanfield", 2, 3, None)):
         p = _problem("velocity", guide, noise, H, Hw, Nb, Nx, [], Nc=90 + 7 * Nb, Ng=7 + H, seed=100 + H * 10 + Nb)
         k = _check(p, gpl, monkeypatch)
@@ -93,7 +93,7 @@ def test_velocity_joint_kernels(H, Nb, monkeypatch):
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 2, 3))))
 def test_velocity_conditioned_kernels(H, Nb, monkeypatch):
     full = ["ϕxy", "ν", "shape_inv"] + (["Δν"] if Nb else [])
-    for noise, guide, Hw, gpl in (("NegativeBinomial", "lrmn", 1, None), ("NegativeBinomial", "meanfield", 3, 4),
+    for noise, guide, Hw, gpl in (("NegativeBinomial", "lrmn", 1, 8), ("NegativeBinomial", "meanfield", 3, 4),
                                   ("Poisson", "lrmn", 0, None), ("Lognormal", "meanfield", 1, None)):
         sites = [s for s in full if not (s == "shape_inv" and noise != "NegativeBinomial")]
         p = _problem("velocity", guide, noise, H, Hw, Nb, 2, sites, Nc=130, Ng=11, seed=200 + H * 10 + Nb)

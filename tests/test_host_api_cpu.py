@@ -217,7 +217,19 @@ def test_csr_side_channel_is_dropped_when_the_dense_counts_were_replaced_or_edit
     cyc = C.Cycle.from_array(np.zeros((3, 12)), np.ones((3, 12)), list(ad.var.index))
     ph = C.Phases.from_array(np.ones((2, 60)), cell_names=list(ad.obs.index))
     mp = P.preprocess_for_phase_estimation(ad, cyc, ph, torch.ones(60, 1), n_harmonics=1, with_delta_nu=False)
-    assert mp.S_csr is not None and P.csr_is_current(mp.S_csr, mp.S)
+    # sparse layers: the dense fields are placeholders until somebody reads them; the engine's spec does not
+    assert isinstance(P.raw_field(mp, "S"), P._Lazy) and not P.raw_field(mp, "S").done
+    sp0 = spec_from_metaparams(mp, "phase")
+    assert sp0.S_csr is mp.S_csr and sp0.S is None and (sp0.Ng, sp0.Nc) == (12, 60)
+    assert not P.raw_field(mp, "S").done and not P.raw_field(mp, "logU").done
+    # reading them gives exactly what the dense-layer path builds
+    mpd = P.preprocess_for_phase_estimation(AnnDataLite(S, U), cyc, ph, torch.ones(60, 1), n_harmonics=1, with_delta_nu=False)
+    for name in ("S", "U", "logS", "logU", "count_factor"):
+        a, b = getattr(mp, name), getattr(mpd, name)
+        assert torch.equal(a, b) and a.stride() == b.stride() and a.dtype == b.dtype, name
+    assert np.array_equal(ad.layers["logS"], AnnDataLite(S, U).layers.get("logS", ad.layers["logS"]))
+    assert ad.layers["logS"].dtype == np.float64 and ad.layers["logS"].shape == (60, 12)
+    assert mp.S_csr is not None and P.csr_is_current(mp.S_csr, mp.S) and P.csr_is_current(mp.S_csr, P.raw_field(mp, "S"))
     assert spec_from_metaparams(mp, "phase").S_csr is mp.S_csr
     # same-shape replacement (subsampled / permuted / normalised counts): the stale CSR must not be used
     mp2 = mp._replace(S=mp.S.flip(1).contiguous())

@@ -91,6 +91,8 @@ EXPORTS = {
     "vc_svi_run_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_double, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "vc_p2p_alloc": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "vc_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vc_comm_rccl_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
     "vc_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "vc_clipped_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,

@@ -19,7 +19,7 @@ class AnnDataLite:
             gene_names = ["G" + str(i).zfill(5) for i in range(ng)]
         if cell_names is None:
             cell_names = ["C" + str(i).zfill(6) for i in range(nc)]
-        self.layers = {"spliced": spliced, "unspliced": unspliced}
+        self.layers = _Layers({"spliced": spliced, "unspliced": unspliced})
         self.var = pd.DataFrame(index=pd.Index(list(gene_names)))
         self.obs = pd.DataFrame(index=pd.Index(list(cell_names))) if obs is None else obs
         self.X = spliced
@@ -40,7 +40,7 @@ class AnnDataLite:
         if isinstance(self.layers, _SelectedLayers):      # a fresh adata[cells, genes]: its layers are copies already
             return self
         out = AnnDataLite.__new__(AnnDataLite)
-        out.layers = {k: (v.copy() if _is_sparse(v) else np.array(v, copy=True)) for k, v in self.layers.items()}
+        out.layers = _Layers({k: (v.copy() if _is_sparse(v) else np.array(v, copy=True)) for k, v in self.layers.items()})
         out.var = self.var.copy()
         out.obs = self.obs.copy()
         out.X = out.layers["spliced"]
@@ -71,15 +71,61 @@ class AnnDataLite:
         pass
 
 
+class _Layers(dict):
+    """`adata.layers`: a dict whose entries may be installed lazily (`set_lazy(key, fn)`: built when first read) -- the
+    float64 logS / logU layers that `preprocess_for_*` leave behind are 800 MB each at 50 000 x 2 000 and are read by plots
+    only."""
+
+    def set_lazy(self, key, fn):
+        dict.__setitem__(self, key, _LazyLayer(fn))
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, _LazyLayer):
+            v = v.fn()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
+class _LazyLayer:
+    def __init__(self, fn):
+        self.fn = fn
+
+
 class _SelectedLayers(dict):
     """Layers of adata[cells, genes]: every layer is selected (= copied) the first time it is read, so that layers nobody
     asks for -- the float64 logS / logU a phase preprocess left behind, 800 MB each at 50 000 x 2 000 -- are never copied."""
 
     def __init__(self, parent, ridx, cidx):
         super().__init__()
-        self._parent, self._ridx, self._cidx = dict(parent), np.asarray(ridx), np.asarray(cidx)
+        # (a snapshot of the parent's entries; lazily installed ones stay lazy until this selection reads them)
+        self._parent = {k: dict.__getitem__(parent, k) if isinstance(parent, dict) else parent[k] for k in parent.keys()}
+        self._ridx, self._cidx = np.asarray(ridx), np.asarray(cidx)
+
+    def set_lazy(self, key, fn):
+        dict.__setitem__(self, key, _LazyLayer(fn))
+
+    def __getitem__(self, k):
+        if dict.__contains__(self, k):
+            v = dict.__getitem__(self, k)
+            if isinstance(v, _LazyLayer):
+                v = v.fn()
+                dict.__setitem__(self, k, v)
+            return v
+        return self.__missing__(k)
 
     def _take(self, v):
+        if isinstance(v, _LazyLayer):
+            v = v.fn()
         if _is_sparse(v):
             return v.tocsr()[self._ridx][:, self._cidx]
         v = np.asarray(v)

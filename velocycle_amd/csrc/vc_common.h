@@ -59,8 +59,17 @@ struct VcXb {
   float* x = nullptr;     // [0, header + n_global): gradient partials at the offsets of the gradient buffer;
   int pw_off = 0;         //   [pw_off, pw_off + pw_cap * NW): per-cell-block partials of d loglik / d nu_omega;
   int pw_cap = 0;         //   rows of that region (an upper bound of every rank's cell blocks: ceil(ceil(Nc / world) / 256))
-  int loss_off = 0;       //   [loss_off, loss_off + 2 * (1 + nb_post_gene)): (hi, lo) float pairs of the rank's loss terms
+  int loss_off = 0;       //   [loss_off, loss_off + 4 * (1 + nb_post_gene)): the rank's loss terms, four floats each
   float* sis = nullptr;   // [3][Ng_pad] snapshot {parameter, exp_avg, exp_avg_sq} of shape_inv taken by phase A (engine-owned)
+};
+
+// Peer-mapped regions of the one-shot exchange (vc_p2p_exchange.hip): region[q] = rank q's region as mapped in THIS process
+#define VC_P2P_MAX_RANKS 16
+struct VcP2p {
+  void* region[VC_P2P_MAX_RANKS];
+  int world = 0, rank = 0;
+  int flag_words = 0;           // 4-byte words in front of the slots (world flags, one 64-byte line each)
+  long long slot_floats = 0;    // floats per slot (= the exchange buffer, padded to 64 bytes)
 };
 
 struct VcBufs {
@@ -361,6 +370,8 @@ void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* g
                        hipStream_t st);
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st);
+void vc_launch_p2p_xchg(const VcP2p& p, long long step, float* out, long long n, long long* status, double timeout_s,
+                        hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
                     double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
                     const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st);

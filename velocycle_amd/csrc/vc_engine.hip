@@ -55,6 +55,12 @@ struct vc_engine {
   float* sis = nullptr;               // phase A's snapshot of shape_inv {parameter, exp_avg, exp_avg_sq} [3][Ng_pad]
   int xb_pw_off = 0, xb_pw_cap = 0, xb_loss_off = 0;
   long long xb_total = 0;
+  // one-shot peer-to-peer exchange (vc_p2p_alloc / vc_p2p_connect, vc_p2p_exchange.hip)
+  VcP2p p2p{};
+  void* p2p_own = nullptr;            // this rank's region (hipMalloc, IPC-exported)
+  bool p2p_connected = false;
+  long long p2p_step = 0;             // steps exchanged so far: slot parity and flag value, identical on every rank
+  double p2p_timeout_s = 2.0;
   VcDims d{};
   VcBufs b{};
   vc_layout layout{};
@@ -314,6 +320,10 @@ extern "C" void vc_destroy(vc_engine* e) {
   }
 #endif
   if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
+  if (e->p2p_connected)
+    for (int q = 0; q < e->p2p.world; ++q)
+      if (q != e->p2p.rank && e->p2p.region[q]) (void)hipIpcCloseMemHandle(e->p2p.region[q]);
+  if (e->p2p_own) (void)hipFree(e->p2p_own);
   for (void* p : e->allocs) (void)hipFree(p);
   for (auto& c : e->src) c.release();
   for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -552,8 +562,34 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
         hipFuncGetAttributes(&fa, k8) == hipSuccess && fa.localSizeBytes <= max_scratch)
       d.gpl = 8;
+    if (d.gpl == 8) {
+      // Small shards (round 3, profiles/r03_small_shard.md): with few cells per wave the per-wave prologue / epilogue of the
+      // 8-genes-per-lane kernel (twice the gene-table loads, twice the rows to combine) outweighs what it saves per cell --
+      // 6 250 cells x 2 000 genes: 22.5 vs 24.7 us (S+U), 16.8 vs 17.8 (U only); 12 500: 35.6 vs 36.8 (S+U) but 26.1 vs 23.7
+      // (U only); 25 000: 61.7 vs 62.9; 50 000: 8 genes per lane wins.  Decided from the cells a wave would get under the
+      // 8-genes-per-lane tiling -- a pure function of (cells, genes, kernel kind, occupancy, CUs), like the tiling itself.
+      int bpc8 = 0, n_cu = 256, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc8, k8, 256, 0) == hipSuccess && bpc8 >= 1 &&
+          hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        const int ngb8 = (d.Ng + 511) / 512;
+        const VcTiling t8 = vc_tile_cells(d.Nc, ngb8, n_cu, bpc8, VC_WAVES, 0, nullptr, 12);
+        const int small_cw = d.kind == VC_KIND_VFULL ? 52 : 10;
+        if (t8.cw <= small_cw) d.gpl = 4;
+      }
+    }
   }
-  if (const char* env = getenv("VC_GPL")) { if (atoi(env) == 4 || atoi(env) == 8) d.gpl = atoi(env); }
+  if (const char* env = getenv("VC_GPL")) {
+    if (atoi(env) == 4) d.gpl = 4;
+    if (atoi(env) == 8) {       // honoured only where the 8-genes-per-lane kernel may run at all (no scratch: see above)
+      const void* k8 = nullptr;
+      hipFuncAttributes fa;
+      if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
+          hipFuncGetAttributes(&fa, k8) == hipSuccess && fa.localSizeBytes <= max_scratch)
+        d.gpl = 8;
+    }
+  }
   d.gbw = 64 * d.gpl;
   d.nGB = (d.Ng + d.gbw - 1) / d.gbw;
   d.Ng_pad = d.nGB * d.gbw;
@@ -777,7 +813,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     off += (long long)e->xb_pw_cap * d.NW;
     off = (off + 3) / 4 * 4;
     e->xb_loss_off = (int)off;
-    off += 2LL * (1 + d.nb_post_gene);
+    off += 4LL * (1 + d.nb_post_gene);      // VC_LOSS_PIECES floats per loss term (vc_fused_kernels.hip)
     e->xb_total = (off + 3) / 4 * 4;
     TRY(e->dalloc(&e->sis, 3 * (size_t)d.Ng_pad));
     HIPCHK(e, hipMemset(e->sis, 0, 3 * sizeof(float) * d.Ng_pad));
@@ -793,8 +829,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   b.step_ctr = nullptr;
   TRY(e->dalloc(&b.step_size, 1));
   HIPCHK(e, hipMemset(b.step_size, 0, sizeof(float)));
-  TRY(e->dalloc(&b.status, 2));
-  HIPCHK(e, hipMemset(b.status, 0, 2 * sizeof(long long)));
+  TRY(e->dalloc(&b.status, 4));       // [0] steps with a non-finite loss, [1] 1 + the first of them, [2] 1 + step of an exchange time-out
+  HIPCHK(e, hipMemset(b.status, 0, 4 * sizeof(long long)));
 
   // histograms + step-invariant constants -----------------------------------------------------
   double lg_S = 0.0, lg_U = 0.0;   // sum lgamma(k+1)
@@ -1045,6 +1081,54 @@ extern "C" int vc_comm_init_rccl(vc_engine* e, const char* rccl_path, const void
   VC_GUARD_END(e)
 }
 
+extern "C" int vc_p2p_alloc(vc_engine* e, void* ipc_handle_out) {
+  if (!e || !ipc_handle_out) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_p2p_alloc before vc_finalize");
+  if (e->p2p_own) return e->fail(VC_ERR_STATE, "vc_p2p_alloc: the region exists already");
+  if (e->cfg.world_size > VC_P2P_MAX_RANKS) return e->fail(VC_ERR_UNSUPPORTED, "peer-to-peer exchange: at most %d ranks", VC_P2P_MAX_RANKS);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C ABI documents a 64-byte handle");
+  VcP2p& p = e->p2p;
+  p.world = e->cfg.world_size; p.rank = e->cfg.rank;
+  p.flag_words = p.world * 16;                                   // one 64-byte line per flag
+  p.slot_floats = (e->xb_total + 15) / 16 * 16;
+  const size_t bytes = ((size_t)p.flag_words + 2 * (size_t)p.slot_floats) * sizeof(float);
+  HIPCHK(e, hipMalloc(&e->p2p_own, bytes));
+  HIPCHK(e, hipMemset(e->p2p_own, 0, bytes));
+  HIPCHK(e, hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  HIPCHK(e, hipIpcGetMemHandle(&h, e->p2p_own));
+  memcpy(ipc_handle_out, &h, sizeof h);
+  if (const char* env = getenv("VC_P2P_TIMEOUT_S")) { if (atof(env) > 0.0) e->p2p_timeout_s = atof(env); }
+  return VC_OK;
+  VC_GUARD_END(e)
+}
+
+extern "C" int vc_p2p_connect(vc_engine* e, const void* all_handles) {
+  if (!e || !all_handles) return VC_ERR_ARG;
+  VC_GUARD_BEGIN
+  if (!e->p2p_own) return e->fail(VC_ERR_STATE, "vc_p2p_connect before vc_p2p_alloc");
+  if (e->p2p_connected) return e->fail(VC_ERR_STATE, "vc_p2p_connect called twice");
+  VcP2p& p = e->p2p;
+  for (int q = 0; q < p.world; ++q) {
+    if (q == p.rank) { p.region[q] = e->p2p_own; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)all_handles + (size_t)q * sizeof h, sizeof h);
+    void* ptr = nullptr;
+    hipError_t er = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (er != hipSuccess) {
+      for (int k = 0; k < q; ++k)
+        if (k != p.rank && p.region[k]) { (void)hipIpcCloseMemHandle(p.region[k]); p.region[k] = nullptr; }
+      return e->fail(VC_ERR_HIP, "hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(er));
+    }
+    p.region[q] = ptr;
+  }
+  e->p2p_connected = true;
+  e->p2p_step = 0;
+  return VC_OK;
+  VC_GUARD_END(e)
+}
+
 extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad, float* xbuf,
                                   double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
                                   double lrd, double beta1, double beta2, double adam_eps, double clip_norm, int prime,
@@ -1055,8 +1139,9 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
     return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: null buffer (step counter and exchange buffer are required)");
   if (phase != VC_PHASE_A && phase != VC_PHASE_B && phase != VC_PHASE_AB) return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: bad phase %d", phase);
   if (n_steps < 0 || (phase != VC_PHASE_AB && n_steps != 1)) return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: phase A / B take exactly one step");
-  if (phase == VC_PHASE_AB && e->cfg.world_size > 1 && !e->comm)
-    return e->fail(VC_ERR_STATE, "vc_svi_run_sharded(VC_PHASE_AB) on %d ranks needs vc_comm_init_rccl first", e->cfg.world_size);
+  if (phase == VC_PHASE_AB && e->cfg.world_size > 1 && !e->comm && !e->p2p_connected)
+    return e->fail(VC_ERR_STATE, "vc_svi_run_sharded(VC_PHASE_AB) on %d ranks needs vc_comm_init_rccl or vc_p2p_connect first", e->cfg.world_size);
+  const bool use_p2p = phase == VC_PHASE_AB && e->p2p_connected;
   if (!(lr > 0.0) || !(lrd > 0.0) || !(beta1 > 0.0 && beta1 < 1.0) || !(beta2 > 0.0 && beta2 < 1.0))
     return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: lr, lrd must be positive and the betas inside (0, 1)");
   hipStream_t st = (hipStream_t)hip_stream;
@@ -1087,9 +1172,15 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
       } else {
         e->main_fn(e->d, b2, st);
       }
-      vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 1, xb, st);
+      VcXb xa = xb;
+      if (use_p2p)        // phase A writes this rank's slot of the step's parity; K_xchg sums every rank's slot into xbuf
+        xa.x = reinterpret_cast<float*>(e->p2p_own) + e->p2p.flag_words + (size_t)(e->p2p_step & 1) * (size_t)e->p2p.slot_floats;
+      vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 1, xa, st);
     }
-    if (phase == VC_PHASE_AB && e->comm) {      // (a 1-rank communicator is summed too: the single-GPU measurement of this path)
+    if (use_p2p) {
+      vc_launch_p2p_xchg(e->p2p, e->p2p_step, xbuf, (long long)e->xb_total, e->b.status, e->p2p_timeout_s, st);
+      e->p2p_step++;
+    } else if (phase == VC_PHASE_AB && e->comm) {      // (a 1-rank communicator is summed too: the single-GPU measurement of this path)
       const int rc = g_rccl.AllReduce(xbuf, xbuf, (size_t)e->xb_total, /*ncclFloat32*/ 7, /*ncclSum*/ 0, e->comm, st);
       if (rc != 0) return e->fail(VC_ERR_STATE, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed");
     }
@@ -1223,9 +1314,12 @@ extern "C" int vc_get_histogram(const vc_engine* e, int64_t* n_entries, int32_t*
 extern "C" int vc_get_status(vc_engine* e, int64_t* first_bad_step, int64_t* n_bad, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_get_status before vc_finalize");
-  long long h[2] = {0, 0};
+  long long h[4] = {0, 0, 0, 0};
   HIPCHK(e, hipStreamSynchronize((hipStream_t)hip_stream));
   HIPCHK(e, hipMemcpy(h, e->b.status, sizeof h, hipMemcpyDeviceToHost));
+  if (h[2] > 0)
+    return e->fail(VC_ERR_STATE, "peer-to-peer exchange: a rank did not publish its buffer of step %lld within %.1f s", h[2] - 1,
+                   e->p2p_timeout_s);
   if (first_bad_step) *first_bad_step = h[1] - 1;
   if (n_bad) *n_bad = h[0];
   if (h[0] > 0)
@@ -1236,7 +1330,7 @@ extern "C" int vc_get_status(vc_engine* e, int64_t* first_bad_step, int64_t* n_b
 extern "C" int vc_clear_status(vc_engine* e, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_clear_status before vc_finalize");
-  HIPCHK(e, hipMemsetAsync(e->b.status, 0, 2 * sizeof(long long), (hipStream_t)hip_stream));
+  HIPCHK(e, hipMemsetAsync(e->b.status, 0, 4 * sizeof(long long), (hipStream_t)hip_stream));
   return VC_OK;
 }
 

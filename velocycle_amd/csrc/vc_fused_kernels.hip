@@ -39,8 +39,8 @@ struct VcOpt { float step_size, b1, b2, eps, clip; };
 // into the exchange buffer X (same offsets as the gradient buffer) and stop; cell blocks are rank-local and run whole
 // (phi_xy gradient, optimiser, next sample, cell record), their partials of d loglik / d nu_omega go to X's PW rows; one
 // extra block folds the terms of this rank's loss that are complete before the launch (prior / guide terms of the sample,
-// K_main's likelihood partials, the constant) into one (hi, lo) float pair of X, the r-only likelihood terms of the gene
-// blocks follow as one pair each.  Everything in X is additive over ranks; replicated prior terms carry root_w.
+// K_main's likelihood partials, the constant) into one double that crosses the exchange as four floats on fixed grids (vc_loss_split),
+// the r-only likelihood terms of the gene blocks follow the same way.  Everything in X is additive over ranks; replicated prior terms carry root_w.
 // Phase B (after the sum, one launch: gene blocks and K_omega's blocks do not depend on each other): gene blocks read the
 // SUMMED gradient, apply ClippedAdam and draw the next sample; the nu_omega blocks reduce the summed PW rows (prior weight 1:
 // the sum is complete); the loss block adds up the summed pairs; the histogram blocks re-derive the shape_inv update from a
@@ -49,6 +49,24 @@ struct VcOpt { float step_size, b1, b2, eps, clip; };
 #define VC_PH_ALL 0
 #define VC_PH_A 1
 #define VC_PH_B 2
+
+// A rank's loss terms cross the exchange as floats and are ADDED there in float32 (RCCL ring / tree, or our own sums).  The
+// terms cancel (likelihood partials and count constants of 1e7..1e9 against a total of 1e6), so a plain (hi, lo) split would
+// lose ulps of the LARGE terms in the cross-rank add (observed: 1e-6 relative on the loss).  Each double therefore travels as
+// four floats on FIXED grids -- multiples of 2^20, 2^1, 2^-17 and the remainder -- with fewer than 2^19 multiples each: the
+// float32 sum of up to 16 ranks' pieces is exact piece by piece (|v| < 2^39), whatever the order of the adds.
+#define VC_LOSS_PIECES 4
+__device__ __forceinline__ void vc_loss_split(double v, float* __restrict__ out) {
+  const double p0 = rint(v * (1.0 / 1048576.0)) * 1048576.0;
+  const double r0 = v - p0;
+  const double p1 = rint(r0 * 0.5) * 2.0;
+  const double r1 = r0 - p1;
+  const double p2 = rint(r1 * 131072.0) * (1.0 / 131072.0);
+  out[0] = (float)p0; out[1] = (float)p1; out[2] = (float)p2; out[3] = (float)(r1 - p2);
+}
+__device__ __forceinline__ double vc_loss_join(const float* __restrict__ in) {
+  return (((double)in[0] + (double)in[1]) + (double)in[2]) + (double)in[3];
+}
 
 // flat offset of element `ce` of angular-speed coefficient j: mean-field {loc, log scale}; LRMN tail row i = Ng + j
 // {loc, R cov_factor entries, cov_diag}
@@ -321,11 +339,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       const double tot = vc_wave_sum_d63(loss_post);
       if (lane == 63) {
         b.LPP[gblock] = tot;
-        if (phase == VC_PH_A) {
-          const float hi = (float)tot;
-          xb.x[xb.loss_off + 2 * (1 + gblock)] = hi;
-          xb.x[xb.loss_off + 2 * (1 + gblock) + 1] = (float)(tot - (double)hi);
-        }
+        if (phase == VC_PH_A) vc_loss_split(tot, xb.x + xb.loss_off + VC_LOSS_PIECES * (1 + gblock));
       }
     }
   }
@@ -650,7 +664,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
 
 // Phase A: the part of this rank's loss that is complete before the launch -- prior / guide terms of the sample of the step
 // being finished (LPF, written one step earlier), K_main's likelihood partials, the step-invariant constant -- folded in
-// fixed order into one double and handed to the exchange as a (hi, lo) float pair
+// fixed order into one double and handed to the exchange (vc_loss_split)
 __device__ __forceinline__ void vc_tail_loss_base_block(const VcDims& d, const VcBufs& b, long long s, const VcXb xb) {
   __shared__ double sm_lb[16];
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
@@ -664,9 +678,7 @@ __device__ __forceinline__ void vc_tail_loss_base_block(const VcDims& d, const V
   if (t == 0) {
     double tot = b.const_loss;
     for (int w = 0; w < 16; ++w) tot += sm_lb[w];
-    const float hi = (float)tot;
-    xb.x[xb.loss_off] = hi;
-    xb.x[xb.loss_off + 1] = (float)(tot - (double)hi);
+    vc_loss_split(tot, xb.x + xb.loss_off);
   }
 }
 
@@ -716,8 +728,8 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   double sl = 0.0;
   if (phase == VC_PH_B) {
-    // the (hi, lo) pairs of every rank's loss terms, summed by the exchange: base + one per gene block, fixed order
-    for (int i = t; i < 1 + d.nb_post_gene; i += 256) sl += (double)xb.x[xb.loss_off + 2 * i] + (double)xb.x[xb.loss_off + 2 * i + 1];
+    // every rank's loss terms, summed piece by piece by the exchange: base + one per gene block, fixed order
+    for (int i = t; i < 1 + d.nb_post_gene; i += 256) sl += vc_loss_join(xb.x + xb.loss_off + VC_LOSS_PIECES * i);
   } else {
     const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
 #pragma unroll 4

@@ -1,0 +1,72 @@
+// One-shot exchange of the sharded step's buffer over peer-mapped device memory ("latency-optimised
+// one-shot variant"): instead of an RCCL ring all-reduce of a ~64 KB buffer (latency-bound: 2 (N - 1) hops),
+// every rank PUBLISHES its buffer in a region of its own HBM that its peers have mapped (hipIpc), and every rank then reads
+// all N buffers directly (xGMI is point to point: N - 1 concurrent reads of 64 KB) and adds them up in FIXED RANK ORDER --
+// the same bits on every rank, no float atomics, replicated parameters stay identical.
+//
+// Region of rank r (one hipMalloc, IPC-exported):  flags[N] (one 64-byte line each) | slot 0 | slot 1     (slots: xb_total floats)
+// Step s (engine-local counter, the same on every rank), slot p = s & 1:
+//   phase A writes its partials into the rank's own slot p                      (vc_svi_run_sharded points the kernels there)
+//   K_xchg, one launch:
+//     block 0 publishes: system-scope release, then flags[r] := s + 1 in EVERY rank's region (remote stores)
+//     every block waits until its own region's flags[q] >= s + 1 for all q        (polling LOCAL memory, bounded)
+//     system-scope acquire, then  out[i] = sum_{q = 0..N-1} slot_p(q)[i]  in rank order, 16-byte loads that bypass the caches
+//   phase B reads `out` (the caller's exchange buffer).
+// Two slots suffice: a rank can start writing slot p again (step s + 2) only after its K_xchg(s + 1) has seen every peer's
+// flag s + 2, which a peer raises after its phase A(s + 1), i.e. after its reads of step s.
+// The kernel boundary in front of K_xchg is what makes phase A's plain stores visible to the peers (end-of-kernel release);
+// the flag stores are system-scope atomics.  The wait is BOUNDED (a peer that died must not hang the device): on time-out the
+// kernel records it in status[2] and the sum proceeds on whatever is there -- vc_get_status reports VC_ERR_STATE.
+// Correctness across processes is tested with two processes on one device (tests/test_hip_p2p.py); across xGMI it cannot be
+// tested or timed on a 1-GPU box: default stays RCCL, this path is opt-in (VC_EXCHANGE=p2p).
+#include "vc_common.h"
+
+#define VC_P2P_FLAG_STRIDE 16      // 64-byte line per flag (in 4-byte words)
+
+__global__ __launch_bounds__(256) void vc_p2p_xchg_kernel(VcP2p p, long long step, float* __restrict__ out, long long n,
+                                                          long long* __restrict__ status, unsigned long long timeout_ticks) {
+  const unsigned want = (unsigned)(step + 1);
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)p.world) {
+    // publish: this rank's slot is complete (kernel boundary) -> raise flag[rank] in every region, the own one included
+    __atomic_thread_fence(__ATOMIC_RELEASE);       // system scope
+    unsigned* f = reinterpret_cast<unsigned*>(p.region[threadIdx.x]) + (size_t)p.rank * VC_P2P_FLAG_STRIDE;
+    __hip_atomic_store(f, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __shared__ int sm_ok;
+  if (threadIdx.x == 0) sm_ok = 1;
+  __syncthreads();
+  if (threadIdx.x < (unsigned)p.world) {
+    const unsigned* f = reinterpret_cast<const unsigned*>(p.region[p.rank]) + (size_t)threadIdx.x * VC_P2P_FLAG_STRIDE;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { sm_ok = 0; break; }
+    }
+  }
+  __syncthreads();
+  if (!sm_ok && threadIdx.x == 0 && status) status[2] = step + 1;          // a peer never arrived
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);         // system scope: nothing of the peers' slots may come from a stale line
+  const size_t slot_off = (size_t)p.flag_words + (size_t)(step & 1) * (size_t)p.slot_floats;
+  const long long n4 = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < p.world; ++q) {
+      const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.region[q]) + slot_off) + i;
+      float4 v;
+      // 16-byte load that bypasses L1 and L2 (sc0 sc1 = system scope): the peer rewrote this slot two steps ago
+      asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+
+void vc_launch_p2p_xchg(const VcP2p& p, long long step, float* out, long long n, long long* status, double timeout_s,
+                        hipStream_t st) {
+  const long long n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(vc_p2p_xchg_kernel, dim3(blocks), dim3(256), 0, st, p, step, out, n, status,
+                     (unsigned long long)(timeout_s * 1e8));       // s_memrealtime: 100 MHz
+}

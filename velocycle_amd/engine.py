@@ -333,6 +333,29 @@ class HipEngine:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
         return bool(int(flag.item()))
 
+    def init_p2p_exchange(self, process_group=None) -> bool:
+        """The one-shot peer-to-peer exchange (vc_p2p_alloc / vc_p2p_connect): this rank's region is created and exported,
+        the 64-byte IPC handles of all ranks are gathered in rank order with torch.distributed (any backend), the peers'
+        regions are mapped.  Returns True when EVERY rank is connected (MIN all-reduce), else False on every rank."""
+        import torch.distributed as dist
+        buf = (C.c_char * 64)()
+        rc = self.lib.vc_p2p_alloc(self._h, buf)
+        mine = bytes(buf.raw) if rc == _lib.VC_OK else None
+        world = dist.get_world_size(process_group)
+        handles = [None] * world
+        dist.all_gather_object(handles, mine, group=process_group)
+        ok = 1
+        if any(h is None for h in handles):
+            ok = 0
+        else:
+            allh = (C.c_char * (64 * world)).from_buffer_copy(b"".join(handles))
+            if self.lib.vc_p2p_connect(self._h, allh) != _lib.VC_OK:
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32,
+                            device=self.device if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+        return bool(int(flag.item()))
+
     def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
         """Fused HIP ClippedAdam on flat float32 buffers (same stream); optionally files the (all-reduced) loss
         found in `loss_hdr[0:2]` into `loss_ring[(t-1) % len]`."""

@@ -58,27 +58,76 @@ def _csr_counts(layer, dense=None):
     return m
 
 
+class _Lazy:
+    """A dense container field of a sparse layer that is built when somebody reads it (`mp.S`, `mp.logU`, ...): the
+    reference's contract wants the dense float32 views in the container, the HIP engine ingests the CSR form and never
+    looks at them -- at 50 000 x 2 000 building them is half the wall time of a whole fit().  Reading the attribute gives
+    the same tensor the eager code built, bit for bit; index access (`mp[i]`) and iteration see this placeholder."""
+    __slots__ = ("fn", "value", "done", "version0", "__weakref__")
+
+    def __init__(self, fn):
+        self.fn, self.value, self.done, self.version0 = fn, None, False, None
+
+    def __call__(self):
+        if not self.done:
+            self.value = self.fn()
+            self.fn = None
+            self.version0 = getattr(self.value, "_version", None)
+            self.done = True
+        return self.value
+
+
+def raw_field(mp, name):
+    """The stored item of a container field: the tensor, or its `_Lazy` placeholder (without building it)."""
+    try:
+        return tuple.__getitem__(mp, mp._fields.index(unicodedata.normalize("NFKC", name)))
+    except (ValueError, AttributeError, TypeError):
+        return getattr(mp, name, None)
+
+
 def tag_csr(csr, dense):
-    """Record which dense tensor (object identity + in-place version counter) `csr` was derived from."""
+    """Record which dense field (tensor or `_Lazy` placeholder: object identity + in-place version counter) `csr`
+    was derived next to."""
     import weakref
     csr._vc_dense_ref = weakref.ref(dense)
-    csr._vc_dense_version = dense._version
+    csr._vc_dense_version = getattr(dense, "_version", None)
     return csr
 
 
 def csr_is_current(csr, dense) -> bool:
-    """True iff `csr` provably describes the same data as `dense`: `dense` is the very tensor object the CSR copy was
-    built next to in `preprocess_for_*` and it has not been written in place since.  `mp._replace(S=...)`, in-place
-    normalisation / subsampling / permutation of S all make this False, and the engine then reads the dense tensor."""
+    """True iff `csr` provably describes the same data as the container's dense field `dense` (the tensor, or the raw
+    `_Lazy` placeholder from `raw_field`): it is the very object the CSR copy was built next to in `preprocess_for_*` and
+    it has not been written in place since.  `mp._replace(S=...)`, in-place normalisation / subsampling / permutation of
+    S all make this False, and the engine then reads the dense tensor."""
     ref = getattr(csr, "_vc_dense_ref", None)
     if csr is None or ref is None or dense is None:
         return False
-    return ref() is dense and getattr(csr, "_vc_dense_version", -1) == dense._version
+    if isinstance(dense, _Lazy):
+        return ref() is dense and (not dense.done or getattr(dense.value, "_version", None) == dense.version0)
+    tagged = ref()
+    if isinstance(tagged, _Lazy):         # the caller handed over the materialised tensor of the tagged placeholder
+        return tagged.done and tagged.value is dense and dense._version == tagged.version0
+    return tagged is dense and getattr(csr, "_vc_dense_version", -1) == dense._version
+
+
+_CONTAINER_CLASSES = {}
 
 
 def _container(fields: dict):
-    names = [unicodedata.normalize("NFKC", k) for k in fields]       # Python normalises identifiers (SURVEY F8)
-    return namedtuple("MetaparContainer", names)(*fields.values())
+    names = tuple(unicodedata.normalize("NFKC", k) for k in fields)       # Python normalises identifiers (SURVEY F8)
+    lazy = tuple(i for i, v in enumerate(fields.values()) if isinstance(v, _Lazy))
+    cls = _CONTAINER_CLASSES.get((names, lazy))
+    if cls is None:
+        base = namedtuple("MetaparContainer", names)
+        ns = {"__slots__": ()}
+        for i in lazy:             # attribute access builds the field; `_replace`, `_make`, pickling carry the placeholder
+            def get(self, _i=i):
+                v = tuple.__getitem__(self, _i)
+                return v() if isinstance(v, _Lazy) else v
+            ns[names[i]] = property(get, doc=f"field {names[i]} (dense view of a sparse layer, built on first read)")
+        cls = type("MetaparContainer", (base,), ns)
+        _CONTAINER_CLASSES[(names, lazy)] = cls
+    return cls(*fields.values())
 
 
 def filter_shared_genes(cycle, data, filter_type="intersection"):
@@ -137,6 +186,58 @@ def _counts_and_log(layer, truncate):
     return torch.from_numpy(s32), l64
 
 
+def _is_sparse_layer(layer):
+    return hasattr(layer, "tocsr") and hasattr(layer, "toarray")
+
+
+class _LayerFields:
+    """The four dense container fields derived from one AnnData layer -- counts (Ng, Nc) float32 view, log counts as
+    float32 (Ng, Nc), the float64 log layer the reference leaves in `anndata.layers` -- built together on first use
+    (sparse layers) or at once (dense layers, as before)."""
+
+    def __init__(self, layer, truncate, device, lazy):
+        self._args, self._res = (layer, truncate, device), None
+        if not lazy:
+            self._build()
+
+    def _build(self):
+        if self._res is None:
+            layer, truncate, device = self._args
+            S, logS = _counts_and_log(layer, truncate)
+            self._res = (S.T.to(device), logS, torch.from_numpy(logS.astype(np.float32)).T.to(device))
+            self._args = None
+        return self._res
+
+    def counts(self):
+        return self._build()[0]
+
+    def log64(self):
+        return self._build()[1]
+
+    def log32(self):
+        return self._build()[2]
+
+    def field(self, which, lazy):
+        fn = {"counts": self.counts, "log32": self.log32, "log64": self.log64}[which]
+        return _Lazy(fn) if lazy else fn()
+
+
+def _set_layer(anndata, key, fields: _LayerFields, lazy):
+    """anndata.layers[key] = the float64 log layer (preprocessing.py:153-154); on an AnnDataLite with sparse input it is
+    installed as a lazy layer (built when read), a real AnnData gets the array."""
+    if lazy and hasattr(anndata.layers, "set_lazy"):
+        anndata.layers.set_lazy(key, fields.log64)
+    else:
+        anndata.layers[key] = fields.log64()
+
+
+def _row_sums_int(layer):
+    """Per-cell UMI totals of a layer with the reference's int64 cast, without forming the dense matrix of a sparse one."""
+    if _is_sparse_layer(layer):      # sum in the layer's own dtype, then the cast (preprocessing.py:149)
+        return np.asarray(layer.sum(1)).reshape(-1).astype(np.int64)
+    return np.asarray(_dense(layer).sum(1)).reshape(-1).astype(np.int64)
+
+
 def _t(x, device=None):
     return torch.as_tensor(x).float() if device is None else torch.as_tensor(x).float().to(device)
 
@@ -153,19 +254,22 @@ def preprocess_for_phase_estimation(anndata, cycle_obj, phase_obj, design_mtx, n
     if normalize:
         if ("S_sz" not in anndata.layers) or ("U_sz" not in anndata.layers):
             normalize_total(anndata)
-        (S, logS), (U, logU) = _counts_and_log(anndata.layers["S_sz"], False), _counts_and_log(anndata.layers["U_sz"], False)
+        lazy = False
+        fS, fU = _LayerFields(anndata.layers["S_sz"], False, device, False), _LayerFields(anndata.layers["U_sz"], False, device, False)
     else:
         # preprocessing.py:141-147: layers with an `.A` attribute (scipy sparse, np.matrix) are cast to int64; a dense
         # ndarray has none, lands in the reference's `except` branch and stays float (non-integer values survive,
         # e.g. pre-normalised data for the Lognormal model)
         trunc = lambda layer: hasattr(layer, "A") or hasattr(layer, "toarray")
-        S, logS = _counts_and_log(anndata.layers["spliced"], trunc(anndata.layers["spliced"]))
-        U, logU = _counts_and_log(anndata.layers["unspliced"], trunc(anndata.layers["unspliced"]))
-    s_umi = torch.tensor(np.asarray(_dense(anndata.layers["spliced"]).sum(1)).reshape(-1).astype(np.int64)).float()
+        lS, lU = anndata.layers["spliced"], anndata.layers["unspliced"]
+        lazy = _is_sparse_layer(lS) and _is_sparse_layer(lU)       # sparse layers: the engine ingests the CSR form
+        fS, fU = _LayerFields(lS, trunc(lS), device, lazy), _LayerFields(lU, trunc(lU), device, lazy)
+    s_umi = torch.tensor(_row_sums_int(anndata.layers["spliced"])).float()
     count_factor = torch.log(s_umi / torch.mean(s_umi))
-    anndata.layers["logS"], anndata.layers["logU"] = logS, logU
+    _set_layer(anndata, "logS", fS, lazy)
+    _set_layer(anndata, "logU", fU, lazy)
     design_mtx = torch.as_tensor(design_mtx)
-    S_t, U_t = S.T.to(device), U.T.to(device)                    # float32 views with strides (1, Ng), as `S.T.float()`
+    S_t, U_t = fS.field("counts", lazy), fU.field("counts", lazy)   # float32 views with strides (1, Ng), as `S.T.float()`
     fields = dict(
         Ng=len(cycle_obj), Nc=len(phase_obj), Nb=design_mtx.shape[-1],
         Db=design_mtx.T[:, None, :].float().to(device),
@@ -181,8 +285,7 @@ def preprocess_for_phase_estimation(anndata, cycle_obj, phase_obj, design_mtx, n
         count_factor=count_factor[None, None, :].to(device),
         S=S_t, U=U_t,
         condition=np.array(list(condition_on.keys())),
-        logS=torch.from_numpy(logS.astype(np.float32)).T.to(device),
-        logU=torch.from_numpy(logU.astype(np.float32)).T.to(device),
+        logS=fS.field("log32", lazy), logU=fU.field("log32", lazy),
         beta0=torch.tensor(beta0).to(device), beta1=torch.tensor(beta1).to(device),
         S_csr=None if normalize else _csr_counts(anndata.layers["spliced"], S_t),
         U_csr=None if normalize else _csr_counts(anndata.layers["unspliced"], U_t))
@@ -205,19 +308,21 @@ def preprocess_for_velocity_estimation(anndata, cycle_obj, phase_obj, speed_obj,
                                        rho_rank=torch.tensor(5)):
     cycle_obj, anndata = filter_shared_genes(cycle_obj, anndata, filter_type=behavior)
     lay = ("S_sz", "U_sz") if normalize else ("spliced", "unspliced")
-    S, logS = _counts_and_log(anndata.layers[lay[0]], True)
-    U, logU = _counts_and_log(anndata.layers[lay[1]], True)
+    lS, lU = anndata.layers[lay[0]], anndata.layers[lay[1]]
+    lazy = (not normalize) and _is_sparse_layer(lS) and _is_sparse_layer(lU)
+    fS, fU = _LayerFields(lS, True, device, lazy), _LayerFields(lU, True, device, lazy)
     if model_type == "lrmn":
         model_fn, guide_fn = velocity_latent_variable_model_LRMN, velocity_latent_variable_guide_LRMN
     elif gene_selection_model == "all":
         model_fn, guide_fn = velocity_latent_variable_model, velocity_latent_variable_guide
     else:
         raise ValueError(f"{gene_selection_model=} is not a valid model")
-    anndata.layers["logS"], anndata.layers["logU"] = logS, logU
+    _set_layer(anndata, "logS", fS, lazy)
+    _set_layer(anndata, "logU", fU, lazy)
     ng = len(cycle_obj)
     cdm, bdm = torch.as_tensor(condition_design_mtx), torch.as_tensor(batch_design_mtx)
     rep = lambda v: torch.as_tensor(v).detach().clone().float().repeat([ng, 1]).to(device)
-    S_t, U_t = S.T.to(device), U.T.to(device)
+    S_t, U_t = fS.field("counts", lazy), fU.field("counts", lazy)
     fields = dict(
         Ng=ng, Nc=len(phase_obj), Nhω=(ω_n_harmonics * 2) + 1, Nb=bdm.shape[-1], Nx=cdm.shape[-1],
         D=cdm.T[:, None, None, :].clone().detach().to(device),
@@ -238,8 +343,7 @@ def preprocess_for_velocity_estimation(anndata, cycle_obj, phase_obj, speed_obj,
         kwargsζω=dict(num_harmonics=ω_n_harmonics),
         σₛgc=torch.tensor(0.1, device=device), σᵤgc=torch.tensor(0.1, device=device),
         S=S_t, U=U_t,
-        logS=torch.from_numpy(logS.astype(np.float32)).T.to(device),
-        logU=torch.from_numpy(logU.astype(np.float32)).T.to(device),
+        logS=fS.field("log32", lazy), logU=fU.field("log32", lazy),
         condition=np.array(list(condition_on.keys())), device=device, model_type=model_type,
         rho_mean=torch.as_tensor(rho_mean).to(device), rho_std=torch.as_tensor(rho_std).to(device),
         rho_scale=torch.as_tensor(rho_scale).to(device), rho_rank=torch.as_tensor(rho_rank).to(device),

@@ -68,22 +68,28 @@ def spec_from_metaparams(mp, kind: str, condition_on=None) -> ModelSpec:
     """Squeeze a reference-style MetaparContainer into canonical shapes (float32, no copies of S/U)."""
     condition_on = dict(condition_on or {})
     f = lambda t: torch.as_tensor(t).detach().float()
-
-    def current_csr(csr, dense):
-        # the CSR side channel is used only while it provably describes the same data as the dense field the reference's
-        # contract exposes (and users edit with `_replace` / in place): preprocessing tags it with that tensor
-        from .preprocessing import csr_is_current
-        return csr if (csr is not None and csr_is_current(csr, dense)) else None
     Ng, Nc = int(mp.Ng), int(mp.Nc)
+    from .preprocessing import csr_is_current, raw_field
+    # The CSR side channel is used only while it provably describes the same data as the dense field the reference's contract
+    # exposes (and users edit with `_replace` / in place): preprocessing tags it with that field.  While it is current the
+    # dense field -- a lazily built view of the sparse layer -- is not even touched.
+    vel = kind == "velocity"
+    S_csr, U_csr = getattr(mp, "S_csr", None), getattr(mp, "U_csr", None) if vel else None
+    use_csr = (S_csr is not None and csr_is_current(S_csr, raw_field(mp, "S"))
+               and (not vel or (U_csr is not None and csr_is_current(U_csr, raw_field(mp, "U")))))
+
+    def dense(t):
+        t = f(t)
+        return t.reshape(Ng, Nc) if tuple(t.shape) != (Ng, Nc) else t
     common = dict(
         kind=kind, noisemodel=mp.noisemodel, with_delta_nu=bool(mp.with_delta_nu),
-        S=f(mp.S).reshape(Ng, Nc) if tuple(mp.S.shape) != (Ng, Nc) else f(mp.S),
+        S=None if use_csr else dense(mp.S),
         count_factor=f(mp.count_factor).reshape(Nc), Db=f(mp.Db).reshape(int(mp.Nb), Nc),
         mu_nu=f(mp.μνg).reshape(Ng, -1), sd_nu=f(mp.σνg).reshape(Ng, -1),
         phixy_prior=f(mp.φxy_prior).reshape(Nc, 2), mu_dnu=float(mp.μΔν),
         gamma_alpha=float(mp.gamma_alpha), gamma_beta=float(mp.gamma_beta),
         condition_on={k: f(v) for k, v in condition_on.items()},
-        S_csr=current_csr(getattr(mp, "S_csr", None), mp.S))
+        S_csr=S_csr if use_csr else None)
     if kind == "phase":
         sd = f(mp.σΔν)
         return ModelSpec(guide="meanfield", H=int(mp.num_harmonics_S),
@@ -92,11 +98,11 @@ def spec_from_metaparams(mp, kind: str, condition_on=None) -> ModelSpec:
     Nx = int(mp.Nx)
     return ModelSpec(
         guide=("lrmn" if mp.model_type == "lrmn" else "meanfield"), H=int(mp.num_harmonics),
-        U=f(mp.U).reshape(Ng, Nc) if tuple(mp.U.shape) != (Ng, Nc) else f(mp.U),
+        U=None if use_csr else dense(mp.U),
         D=f(mp.D).reshape(Nx, Nc), Hw=(int(mp.Nhω) - 1) // 2,
         mu_gamma=f(mp.μγ).reshape(Ng), sd_gamma=f(mp.σγ).reshape(Ng),
         mu_beta=f(mp.μβ).reshape(Ng), sd_beta=f(mp.σβ).reshape(Ng),
         mu_nuw=f(mp.μνω).reshape(Nx, -1), sd_nuw=f(mp.σνω).reshape(Nx, -1),
         sd_dnu=0.01, sigma_ln_s=float(mp.σsgc), sigma_ln_u=float(mp.σugc),
         rho_mean=float(mp.rho_mean), rho_std=float(mp.rho_std), rho_scale=float(mp.rho_scale),
-        rho_rank=int(mp.rho_rank), U_csr=current_csr(getattr(mp, "U_csr", None), mp.U), **common)
+        rho_rank=int(mp.rho_rank), U_csr=U_csr if use_csr else None, **common)

@@ -165,7 +165,8 @@ class SVIRunner:
             raise ValueError("adam_impl='sharded' needs mode='perf'")
         # who sums the exchange buffer of the sharded step: "engine" = the library's own RCCL communicator, whole runs enqueued
         # from one C call (needs the nccl backend and > 1 rank); "torch" = torch.distributed.all_reduce between the two phases
-        # of every step (any backend: gloo in the one-device tests)
+        # of every step (any backend: gloo in the one-device tests); "p2p" = the one-shot exchange over peer-mapped device
+        # memory, also enqueued from one C call (opt-in: VC_EXCHANGE=p2p)
         self.exchange = None
         self.xbuf = None
         if self.adam_impl == "sharded":
@@ -181,6 +182,12 @@ class SVIRunner:
                     warnings.warn("the engine's RCCL communicator could not be created on every rank; the exchange goes "
                                   "through torch.distributed.all_reduce instead")
                     want = "torch"
+            elif want == "p2p":                # one-shot exchange over peer-mapped device memory (opt-in, vc_p2p_exchange.hip)
+                if not self.do_reduce:
+                    raise ValueError("exchange='p2p' needs a process group")
+                if not engine.init_p2p_exchange(process_group):
+                    raise RuntimeError("the peer-to-peer exchange could not be connected on every rank: "
+                                       + engine.lib.vc_last_error(engine._h).decode())
             elif want == "none":               # measurement aid (profiles/tools/step_time_vs_shard.py): one rank, nothing to sum
                 if self.world > 1:
                     raise ValueError("exchange='none' is a single-rank measurement aid")
@@ -298,15 +305,20 @@ class SVIRunner:
             from . import _lib
             o = self.opt
             kw = dict(seed=self.seed, step_dev=self.step_dev, loss_buf=self.loss_hist)
-            if self.exchange in ("engine", "none"):      # every launch and every all-reduce of the run from one C call
+            if self.exchange in ("engine", "p2p", "none"):      # every launch and every all-reduce of the run from one C call
                 e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime,
                                   phase=_lib.VC_PHASE_AB, n_steps=n_steps, **kw)
                 return
+            import os
             import torch.distributed as dist
             for i in range(n_steps):
                 e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime and i == 0,
                                   phase=_lib.VC_PHASE_A, **kw)
+                if os.environ.get("VC_DEBUG_SYNC"):
+                    torch.cuda.synchronize()
                 dist.all_reduce(self.xbuf, group=self.pg)
+                if os.environ.get("VC_DEBUG_SYNC"):
+                    torch.cuda.synchronize()
                 e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, phase=_lib.VC_PHASE_B, **kw)
             return
         if self.adam_impl == "fused3":         # single rank: K_main -> K_tail -> K_omega
