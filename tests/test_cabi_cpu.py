@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     mod, lib = _lib()
     hdr = open(os.path.join(ROOT, "include", "velocycle_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(vc_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(vc_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no prototypes parsed"
     assert declared == set(mod.EXPORTS), declared ^ set(mod.EXPORTS)
     for name in declared:
