@@ -76,5 +76,5 @@ T["sparse_layers"] = sparse
 for name, f in (("phase", pf), ("velocity", vf)):
     tm = getattr(f, "timings", None)
     if tm:
-        T[name + "_stages"] = {k: round(v, 3) for k, v in tm.items()}
+        T[name + "_stages"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tm.items()}
 print(json.dumps(T, ensure_ascii=False))
