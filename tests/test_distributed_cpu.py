@@ -185,3 +185,105 @@ def test_gather_cells_without_process_group_is_identity():
     assert dist_context() == (0, 1, None)
     x = torch.arange(6.).reshape(2, 3)
     assert torch.equal(gather_cells(x, 1, [3]), x) and broadcast_int(7) == 7
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The sharded FUSED step's host loop (SVIRunner adam_impl="sharded", exchange="torch": phase A -> all_reduce of ONE exchange
+# buffer -> phase B) over gloo with a test double that models the device protocol of vc_svi_run_sharded: phase A leaves this
+# rank's gradient partial of the replicated parameters and its loss partial (four floats on fixed grids) in the buffer and
+# updates its own cells' parameters; phase B applies ClippedAdam to the replicated parameters from the SUMMED buffer and files
+# the summed loss.  The product has no such CPU path (HipEngine raises without a GPU); this covers rank / shard / exchange
+# plumbing where a GPU is not available.
+# ---------------------------------------------------------------------------------------------------------------------
+def _split4(v):
+    p0 = np.rint(v / 1048576.0) * 1048576.0
+    r0 = v - p0
+    p1 = np.rint(r0 * 0.5) * 2.0
+    r1 = r0 - p1
+    p2 = np.rint(r1 * 131072.0) / 131072.0
+    return [np.float32(p0), np.float32(p1), np.float32(p2), np.float32(r1 - p2)]
+
+
+class OracleShardedStepEngine(OracleShardEngine):
+    def __init__(self, spec, rank, world_size):
+        super().__init__(spec, rank, world_size)
+        self.pfull = H.problem_from_spec(spec, torch.float64)
+
+    def exchange_size(self):
+        return self.header + self.n_global + 4
+
+    def _eps(self, seed, step):
+        g = torch.Generator().manual_seed(int(seed) * 100003 + int(step))
+        return self.pack_eps(orc.draw_eps(self.pfull, g))
+
+    def svi_run_sharded(self, xbuf, m, v, lr, lrd, b1, b2, adam_eps, clip, seed, step_dev, loss_buf=None, prime=False,
+                        phase=3, n_steps=1):
+        assert phase in (1, 2) and n_steps == 1
+        ng = self.header + self.n_global
+        t = int(step_dev.item()) + (1 if phase == 1 else 0)          # 1-based optimiser step of this SVI step
+        step_size = lr * lrd ** t * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+
+        def adam(sl):
+            g = self.grad[sl].clamp(-clip, clip)
+            mm, vv = m[sl.start - self.header:sl.stop - self.header], v[sl.start - self.header:sl.stop - self.header]
+            mm.mul_(b1).add_(g, alpha=1 - b1)
+            vv.mul_(b2).addcmul_(g, g, value=1 - b2)
+            self.params[sl] -= step_size * mm / (vv.sqrt() + adam_eps)
+        if phase == 1:
+            self.elbo_grad(eps=self._eps(seed, t - 1))
+            xbuf.zero_()
+            xbuf[self.header:ng] = self.grad[self.header:ng]
+            xbuf[ng:ng + 4] = torch.tensor(_split4(float(self.loss_dev[0])))
+            adam(slice(ng, self.total))                               # rank-local parameters: no exchange needed
+            step_dev += 1
+        else:
+            self.grad[self.header:ng] = xbuf[self.header:ng]          # the sum over ranks
+            adam(slice(self.header, ng))
+            loss_buf[(t - 1) % loss_buf.numel()] = float(xbuf[ng:ng + 4].double().sum())
+
+
+def _sharded_worker(rank, world, port, case, n_steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from velocycle_amd.svi import SVIRunner
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
+    eng = OracleShardedStepEngine(H.spec_from_fixture(z), rank, world)
+    run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.97, "betas": (0.8, 0.99)}, mode="perf", seed=5)
+    assert run.adam_impl == "sharded" and run.exchange == "torch" and not run.use_graph and run.xbuf.numel() == eng.exchange_size()
+    run.run_perf(n_steps)
+    q.put((rank, run.perf_losses(), eng.params[eng.header:eng.header + eng.n_global].clone().numpy(),
+           eng.params[eng.header + eng.n_global:].clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["vel_mf_joint", "phase_nb"])
+def test_two_rank_sharded_fused_host_loop_equals_single_process(case):
+    n_steps, world = 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, case, n_steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
+    p64 = H.problem_from_fixture(z)
+    eps_list = []
+    for t in range(n_steps):
+        g = torch.Generator().manual_seed(5 * 100003 + t)
+        eps_list.append(orc.draw_eps(p64, g))
+    losses, par = orc.fit(p64, {"lr": 0.03, "lrd": 0.97, "betas": (0.8, 0.99)}, n_steps, eps_list=eps_list,
+                          params=orc.init_params(p64))
+    for r in res:
+        assert len(r[1]) == n_steps and np.allclose(r[1], losses, rtol=2e-6), (r[1], losses)
+    assert np.array_equal(res[0][2], res[1][2])                           # replicated parameters stay in sync
+    order = [k for k in par if k != "ϕxy_locs"]
+    flat = np.concatenate([par[k].reshape(-1).numpy() for k in order])
+    fin = np.isfinite(flat)
+    assert np.allclose(res[0][2][fin], flat[fin], rtol=1e-4, atol=1e-5)
+    xy = np.concatenate([r[3] for r in res]).reshape(-1, 2)
+    assert np.allclose(xy, par["ϕxy_locs"].numpy(), rtol=1e-4, atol=1e-5)

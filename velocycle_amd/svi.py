@@ -309,16 +309,11 @@ class SVIRunner:
                 e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime,
                                   phase=_lib.VC_PHASE_AB, n_steps=n_steps, **kw)
                 return
-            import os
             import torch.distributed as dist
             for i in range(n_steps):
                 e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime and i == 0,
                                   phase=_lib.VC_PHASE_A, **kw)
-                if os.environ.get("VC_DEBUG_SYNC"):
-                    torch.cuda.synchronize()
                 dist.all_reduce(self.xbuf, group=self.pg)
-                if os.environ.get("VC_DEBUG_SYNC"):
-                    torch.cuda.synchronize()
                 e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, phase=_lib.VC_PHASE_B, **kw)
             return
         if self.adam_impl == "fused3":         # single rank: K_main -> K_tail -> K_omega
@@ -406,7 +401,7 @@ class SVIRunner:
                     self._perf_body(prime=not self._primed)
                     self._primed = True
         self.step_idx += n_steps
-        if sync:
+        if sync and torch.device(e.device).type == "cuda":
             torch.cuda.synchronize(e.device)
 
     _SENTINEL = -0x0007_2174_5EED_0001          # an int64 bit pattern no loss takes (a NaN with this payload)
@@ -446,7 +441,8 @@ class SVIRunner:
         return float(ring[k])
 
     def perf_losses(self) -> List[float]:
-        torch.cuda.synchronize(self.e.device)
+        if torch.device(self.e.device).type == "cuda":
+            torch.cuda.synchronize(self.e.device)
         if self.loss_hist is None:
             return []
         return self.loss_hist[: self.step_idx].cpu().tolist()
