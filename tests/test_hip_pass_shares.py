@@ -51,9 +51,9 @@ def test_pass_shares_leave_the_result_alone(mode, monkeypatch):
     st = ref.stats
     assert st["main_grid"] > 256, st                      # more than one dispatch pass
     pc = st["pass_cells"]
-    # default: every pass half the cells of the one before; a third for the S+U kernel (two cells of its counts in flight)
-    ratio = 3 if mode == "vjoint" else 2
-    assert pc[0] > pc[1] and abs(pc[0] - ratio * pc[1]) <= ratio, pc
+    # defaults (round 3): the two-pass S+U kernel 0.75 : 0.25, the three-pass one-matrix kernels 0.62 : 0.26 : 0.12
+    r = 1.0 / 3.0 if mode == "vjoint" else 0.42
+    assert pc[0] > pc[1] and abs(pc[1] - r * pc[0]) <= 2, pc
     H.assert_step_matches_oracle(ref, spec, eps)
     g_ref = {k: v.double().cpu().clone() for k, v in ref.named(ref.grad).items()}
     loss_ref = float(ref.loss())

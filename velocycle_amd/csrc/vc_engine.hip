@@ -729,6 +729,10 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       // and leaves the younger one fewer issue slots: 0.67 : 0.33 ends the passes at 104 / 120 us, 0.75 : 0.25 together
       // (profiles/r03_kmain.md: 119.4 vs 121.4 us)
       share[1] = 1.0 / 3.0; share[2] = 1.0 / 9.0; share[3] = 1.0 / 27.0;
+    } else if (VC_ASM_LOADS && d.kind != VC_KIND_VFULL && blocks_per_cu == 3) {
+      // the three-pass one-matrix kernels: 0.62 : 0.26 : 0.12 instead of 0.57 : 0.29 : 0.14 (the third pass ended 12 us after
+      // the first): phase 58.3 -> 56.2-56.9 us, U only 70.6 -> 70.0-70.1 us (profiles/r03_kmain.md section 3)
+      share[1] = 0.42; share[2] = 0.19; share[3] = 0.09;
     }
     bool want = true;
     if (const char* se = getenv("VC_PASS_SHARES")) {
