@@ -274,3 +274,33 @@ def test_trajectory_at_3k_x_200_stays_within_float32_spread_of_the_oracle(mode):
         err, spread = np.abs(got[fin] - want[fin]).max(), np.abs(ref32[fin] - want[fin]).max()
         assert err <= max(1e-3 * scale, 4 * spread), (k, err, spread, scale)
     eng.close()
+
+
+def test_engine_owned_rccl_exchange_single_rank():
+    """The sharded fused step with the exchange made by the ENGINE'S OWN RCCL communicator (vc_comm_rccl_unique_id ->
+    broadcast -> vc_comm_init_rccl; ncclAllReduce enqueued between the two phases from the one C call of a run) on a 1-rank
+    nccl group: communicator set-up with its rank agreement, the run, and equality with the single-rank fused step."""
+    import os
+    import torch.distributed as dist
+    from velocycle_amd.svi import SVIRunner
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_vel_lrmn_joint.npz")
+    spec = H.spec_from_fixture(z)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29537")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        outs = []
+        for kw in (dict(force_reduce=True, exchange="engine"), dict()):
+            e = _mk(spec)
+            r = SVIRunner(e, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=11, **kw)
+            assert r.adam_impl == ("sharded" if kw else "fused3") and r.exchange == ("engine" if kw else None) and not r.use_graph
+            r.run_perf(10)
+            outs.append((e.params.clone().cpu(), r.perf_losses(), e.status()))
+            e.close()
+        a, b = outs[0][0].double().numpy(), outs[1][0].double().numpy()
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin) and np.allclose(a[fin], b[fin], rtol=2e-5, atol=2e-6), np.abs(a[fin] - b[fin]).max()
+        assert np.allclose(outs[0][1], outs[1][1], rtol=1e-6) and outs[0][2] == (True, -1, 0)
+    finally:
+        dist.destroy_process_group()

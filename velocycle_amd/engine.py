@@ -315,21 +315,33 @@ class HipEngine:
         path = self.rccl_path().encode()
         ok = 1
         ident = [None]
+        # every stage is exception-safe and every rank takes part in both collectives below whatever happened to it locally:
+        # a rank that fails alone must not leave the others waiting in a collective it never joins
         if self.rank == 0:
-            buf = (C.c_char * 128)()
-            rc = self.lib.vc_comm_rccl_unique_id(path, buf)
-            ident = [bytes(buf.raw) if rc == _lib.VC_OK else None]
+            try:
+                buf = (C.c_char * 128)()
+                if self.lib.vc_comm_rccl_unique_id(path, buf) == _lib.VC_OK:
+                    ident = [bytes(buf.raw)]
+            except Exception:
+                ident = [None]
         src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
         dist.broadcast_object_list(ident, src=src, group=process_group)
-        if ident[0] is None:
-            ok = 0
-        else:
+        # a rank that cannot create the communicator must say so BEFORE the others enter ncclCommInitRank (which would wait
+        # for it): first agree that every rank holds the id and the entry point ...
+        have = int(ident[0] is not None and hasattr(self.lib, "vc_comm_init_rccl"))
+        dev = self.device if dist.get_backend(process_group) == "nccl" else "cpu"
+        flag = torch.tensor([have], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+        if int(flag.item()) == 0:
+            return False
+        try:        # ... then create it (collective inside RCCL) ...
             ib = (C.c_char * 128).from_buffer_copy(ident[0])
-            rc = self.lib.vc_comm_init_rccl(self._h, path, ib)
-            if rc != _lib.VC_OK:
+            if self.lib.vc_comm_init_rccl(self._h, path, ib) != _lib.VC_OK:
                 ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32,
-                            device=self.device if dist.get_backend(process_group) == "nccl" else "cpu")
+        except Exception:
+            ok = 0
+        # ... and agree on the outcome
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
         return bool(int(flag.item()))
 
