@@ -6,7 +6,7 @@ cells per trip, the rotating register buffers) is located in `hipcc --cuda-devic
 are counted: all `v_*` (one issue slot per wave64 instruction; packed-math ops retire two genes per slot) and, among
 them, the transcendentals (v_exp/v_log/v_rcp/v_rsq/v_sqrt/v_sin/v_cos: quarter rate).  profiles/tools/valu_rate.hip
 measures on the GPU what a SIMD needs for exactly that instruction MIX and nothing else (no loads, no cross-lane work,
-16 independent chains) at 1..8 waves per SIMD; its output (profiles/r02_valu_rate.txt) is folded in here, scaled by
+16 independent chains) at 1..8 waves per SIMD; its output (profiles/r03_valu_rate.txt) is folded in here, scaled by
 the instruction count of each instantiation: the arithmetic floor of the cell loop that bench.py reports next to the
 HBM roofline (`roofline.valu`).  The counting runs without a GPU.
 
@@ -33,7 +33,7 @@ NOISE_NAME = {0: "nb", 1: "poisson", 2: "lognormal"}
 MIX_OF_KIND = {0: "mix phase (S only)", 1: "mix vfull (S+U)", 2: "mix vu (U only)"}
 
 
-def mix_table(path=os.path.join(ROOT, "profiles", "r02_valu_rate.txt")):
+def mix_table(path=os.path.join(ROOT, "profiles", "r03_valu_rate.txt")):
     """{mix name: {"instr": instructions per cell iteration of the mix, "ns": {waves per SIMD: ns per cell iteration}}},
     and the shader clock of the run (ticks per ns of the one-wave rows, where the stamping wave is the only one)."""
     mixes, clocks = {}, []
@@ -136,7 +136,7 @@ def main():
     out = {"mix_clock_ghz": MIX_CLOCK_GHZ, "mixes": MIXES,
            "note": "static counts of the cell loop in the gfx950 assembly (profiles/tools/valu_count.py); "
                    "floor_ns_per_cell_iter[w] = what a SIMD needs at w waves for the kernel's instruction mix alone, measured "
-                   "on MI355X (profiles/tools/valu_rate.hip -> profiles/r02_valu_rate.txt, at mix_clock_ghz) and scaled by "
+                   "on MI355X (profiles/tools/valu_rate.hip -> profiles/r03_valu_rate.txt, at mix_clock_ghz) and scaled by "
                    "valu_per_cell_iter / the mix's instruction count; arithmetic floor of a launch = floor_ns_per_cell_iter"
                    "[waves per SIMD of the launch] x (gene blocks x cells) / (CUs x 4 SIMDs) x mix_clock / clock",
            "kernels": {}}
