@@ -109,7 +109,8 @@ class FlatClippedAdam:
 class SVIRunner:
     """mode="parity": eps drawn on the host in the reference's RNG order (seed-for-seed comparable
     with the reference), loss read back every step.  mode="perf": eps from the in-kernel Philox
-    stream, the whole step captured in a hipGraph (single GPU), losses kept on the device."""
+    stream, every launch of a run enqueued from one C call (single rank: vc_svi_run_fused; cells sharded:
+    vc_svi_run_sharded with the exchange named by `exchange`), losses kept on the device."""
 
     def __init__(self, engine: HipEngine, optim_args: dict, mode: str = "parity", seed: Optional[int] = None,
                  process_group=None, use_graph: Optional[bool] = None, warmup_draw: bool = True,
