@@ -302,6 +302,26 @@ def device_identity(device):
             "cus": pr.multi_processor_count, "hbm_gb": round(pr.total_memory / 2 ** 30, 1)}
 
 
+def deadline_s() -> float:
+    """N > 1 only: how long a run may take before it is given up (VC_BENCH_DEADLINE_S, default 900 s).  A stuck collective
+    or a dead peer otherwise hangs every rank for as long as the caller is willing to wait."""
+    return float(os.environ.get("VC_BENCH_DEADLINE_S", "900"))
+
+
+def arm_watchdog(rank: int):
+    import threading
+
+    def fire():
+        sys.stderr.write(f"[bench.py rank {rank}] no result after {deadline_s():.0f} s -- a collective or a peer is stuck; exit 124\n")
+        sys.stderr.flush()
+        os._exit(124)                                  # plain exit of this rank (the launcher then ends the others); no exec
+
+    t = threading.Timer(deadline_s(), fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def self_launch(n: int) -> int:
     import socket
     import subprocess
@@ -312,7 +332,15 @@ def self_launch(n: int) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # the ranks carry their own watchdog (arm_watchdog); the parent only waits a little longer than they do
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        so_, se_ = child.communicate(timeout=deadline_s() + 120)
+    except subprocess.TimeoutExpired:
+        os.killpg(child.pid, 9)                       # exactly the process group started above
+        so_, se_ = child.communicate()
+        se_ += f"\n[bench.py] the {n}-rank job did not finish within {deadline_s() + 120:.0f} s and was ended\n"
+    proc = subprocess.CompletedProcess(cmd, child.returncode, so_, se_)
     sys.stderr.write(proc.stderr)
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     js = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
@@ -348,6 +376,8 @@ def main():
     # VC_BENCH_NCCL_GROUP=1: a 1-rank nccl group at N = 1, so that the N > 1 code path (all-reduce between the gradient
     # kernels and the optimiser) can be timed on one GPU and compared with the plain N = 1 line (profiles/)
     solo_group = (not dist_on) and os.environ.get("VC_BENCH_NCCL_GROUP", "0") == "1"
+    if dist_on:
+        arm_watchdog(rank)
     if dist_on or solo_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -64,6 +64,21 @@ def test_bench_gpus_2_launches_itself():
     assert j["n_gpus"] == 2 and j["distributed"]["world_size"] == 2 and j["steps"] == 30
 
 
+def test_a_stuck_multi_rank_run_is_given_up():
+    """A rank that cannot finish (here: a deadline shorter than start-up) ends itself with exit code 124 and the launcher
+    ends the others: an N > 1 bench run never hangs its caller for longer than VC_BENCH_DEADLINE_S (default 900 s)."""
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_BENCH_ONE_DEVICE="1", VC_BENCH_DEADLINE_S="0.2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2", *SIZE], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert two.returncode != 0 and time.time() - t0 < 200
+    assert "is stuck; exit 124" in two.stderr, two.stderr[-2000:]
+    assert not [l for l in two.stdout.splitlines() if l.startswith('{"metric"')]
+
+
 def _two_ranks(env_extra, extra_args=(), n=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_BENCH_ONE_DEVICE="1", **env_extra)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
