@@ -1,7 +1,7 @@
 // VALU issue costs on gfx950 at 1..8 waves per SIMD (256-thread workgroups = one wave per SIMD each, w of them per CU, every
 // CU busy): v_fma_f32, v_pk_fma_f32, v_exp_f32, v_log_f32, v_rcp_f32 each alone (16 independent chains per wave), and the
-// instruction MIX of the likelihood kernels' cell loops (per gene pair, from profiles/valu_model.json: S+U 43 packed : 6
-// plain : 8 exp/log : 4 rcp; U-only 22 : 5 : 6 : 2 (round 3: -log beta folded); S-only 17 : 5 : 4 : 2) with the transcendentals spread between the packed
+// instruction MIX of the likelihood kernels' cell loops (per gene pair, from profiles/valu_model.json: S+U 39 packed : 6
+// plain : 8 exp/log : 4 rcp; U-only 21 : 5 : 6 : 2; S-only 16 : 5 : 4 : 2 -- after round 3's arithmetic diet) with the transcendentals spread between the packed
 // operations as in the kernels.  Reported per wave64 instruction and SIMD: ns (hipEvents) and shader-clock ticks (s_memtime of
 // one wave), so that bench.py can price a kernel at the clock its own probe reads.  No memory traffic, no cross-lane work:
 // this is the arithmetic floor of the mix, the bound `roofline.valu` uses.
@@ -84,7 +84,7 @@ int main() {
   for (int w : {1, 2, 3, 4, 6, 8}) {
     run<0, 0, 0, 0, 0>("v_fma_f32", w); run<1, 0, 0, 0, 0>("v_pk_fma_f32", w); run<2, 0, 0, 0, 0>("v_exp_f32", w);
     run<3, 0, 0, 0, 0>("v_log_f32", w); run<4, 0, 0, 0, 0>("v_rcp_f32", w);
-    run<5, 43, 6, 8, 4>("mix vfull (S+U)", w); run<5, 22, 5, 6, 2>("mix vu (U only)", w); run<5, 17, 5, 4, 2>("mix phase (S only)", w);
+    run<5, 39, 6, 8, 4>("mix vfull (S+U)", w); run<5, 21, 5, 6, 2>("mix vu (U only)", w); run<5, 16, 5, 4, 2>("mix phase (S only)", w);
   }
   return 0;
 }

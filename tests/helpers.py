@@ -99,17 +99,42 @@ def assert_step_matches_oracle(eng, spec, eps, loss_rtol=1e-5, grad_rtol=2e-3):
     return l64, g64
 
 
-def assert_trajectory_within_float32_spread(spec, opt, n, seed, losses, named_params):
+def assert_trajectory_within_float32_spread(spec, opt, n, seed, losses, named_params, snapshots=None):
     """SURVEY §8(d) ELBO-match over n SVI steps on the same host eps stream: the first steps agree with the float64
     oracle to 1e-5; afterwards float32 and float64 Adam trajectories separate by themselves, so the yardstick is the
-    oracle's own float32 run (x4); fitted parameters within 1e-3 of each block's max-norm wherever float32 itself is."""
+    oracle's own float32 run (x4); fitted parameters within 1e-3 of each block's max-norm wherever float32 itself is.
+
+    `snapshots` = {t: named parameters at the START of step t}, recorded by the caller: teacher forcing.  Adam's first steps
+    move every parameter by ~lr * sign(gradient); where a gradient is zero to within float32 rounding (|g| = 23 next to a
+    block max of 1e6 and a float32 error of 5e3 -- observed on this very workload) its sign is a coin toss in ANY float32
+    evaluation, and the parameter starts 2 lr away from the float64 run's: a 1e-4 step in the loss one step later that says
+    nothing about the kernels.  With snapshots the strict 1e-5 bar is therefore held where it tests the kernels -- the loss
+    of step t against the float64 oracle evaluated AT the run's own parameters with the same draws -- and the free-running
+    comparison allows 5e-4 (and the fitted parameters the quantile criterion of assert_params_track_oracle)."""
     p64 = problem_from_spec(spec, torch.float64)
     l64, par64 = orc.fit(p64, opt, n, seed=seed)
     l32, par32 = orc.fit(p64.to(torch.float32), opt, n, seed=seed)
     l64, l32, losses = np.array(l64), np.array(l32), np.array(losses)
     rel_hip, rel_32 = np.abs(losses - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
-    assert rel_hip[:5].max() <= 1e-5, rel_hip[:5]
-    assert (rel_hip <= np.maximum(1e-5, 4 * np.maximum.accumulate(rel_32))).all(), (rel_hip.max(), rel_32.max())
+    assert rel_hip[0] <= 1e-5, rel_hip[:5]
+    allow = 1e-5
+    if snapshots:
+        from velocycle_amd.rng import draw_eps
+        g = torch.Generator().manual_seed(seed)
+        draw_eps(spec, g)                                   # the guide's warm-up draw (SVIRunner parity mode, orc.fit)
+        eps_t = [draw_eps(spec, g) for _ in range(max(snapshots) + 1)]
+        for t, par in sorted(snapshots.items()):
+            e64 = {k: v.double() for k, v in eps_t[t].items() if not k.startswith("_")}
+            l_tf, _, _, _ = orc.loss_and_grads(p64, {k: v.detach().cpu().double() for k, v in par.items()}, e64)
+            assert abs(losses[t] - l_tf) <= 1e-5 * abs(l_tf), (t, losses[t], l_tf)
+        allow = 5e-4
+    else:
+        assert rel_hip[:5].max() <= 1e-5, rel_hip[:5]
+    assert (rel_hip <= np.maximum(allow, 4 * np.maximum.accumulate(rel_32))).all(), (rel_hip.max(), rel_32.max())
+    if snapshots:
+        assert_params_track_oracle({k: v.detach().cpu().numpy() for k, v in named_params.items()},
+                                   {k: v.numpy() for k, v in par64.items()}, {k: v.double().numpy() for k, v in par32.items()})
+        return
     for k, v in named_params.items():
         want, got = par64[k].numpy(), v.detach().cpu().numpy().astype(np.float64)
         ref32 = par32[k].double().numpy()

@@ -52,8 +52,12 @@ def test_two_sample_trajectory_matches_oracle(two_sample):
     spec = two_sample
     eng = _mk(spec)
     run = SVIRunner(eng, OPT, mode="parity", seed=13)
-    losses = [run.step() for _ in range(40)]
-    H.assert_trajectory_within_float32_spread(spec, OPT, 40, 13, losses, eng.named())
+    losses, snaps = [], {}
+    for t in range(40):
+        if t < 6 or t in (12, 25, 39):      # teacher forcing (helpers.py): the parameters each of these steps starts from
+            snaps[t] = {k: v.clone() for k, v in eng.named().items()}
+        losses.append(run.step())
+    H.assert_trajectory_within_float32_spread(spec, OPT, 40, 13, losses, eng.named(), snapshots=snaps)
     eng.close()
 
 
@@ -133,8 +137,12 @@ def test_phase_3k_trajectory_matches_oracle(phase_3k):
     spec = phase_3k
     eng = _mk(spec)
     run = SVIRunner(eng, OPT, mode="parity", seed=17)
-    losses = [run.step() for _ in range(40)]
-    H.assert_trajectory_within_float32_spread(spec, OPT, 40, 17, losses, eng.named())
+    losses, snaps = [], {}
+    for t in range(40):
+        if t < 6 or t in (12, 25, 39):
+            snaps[t] = {k: v.clone() for k, v in eng.named().items()}
+        losses.append(run.step())
+    H.assert_trajectory_within_float32_spread(spec, OPT, 40, 17, losses, eng.named(), snapshots=snaps)
     eng.close()
 
 

@@ -53,6 +53,35 @@ def test_asm_count_loads_are_never_touched_in_flight(tu):
     assert h1, "the benchmark instantiation (H = 1, no batches, 8 genes per lane) must stay scratch-free"
 
 
+def test_asm_load_audit_catches_planted_hazards():
+    """The audit itself: on the benchmark instantiation it must be clean, and it must flag (a) loop waits that leave one
+    operation too many outstanding, (b) missing drains, (c) a compiler-style copy of a tuple right behind its load."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("check_asm_loads", os.path.join(ROOT, "profiles", "tools", "check_asm_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines, meta = mod.kernels(mod.device_asm("vc_main_vfull_nb_u16.hip"))["_Z14vc_main_kernelILi1ELi0ELi1ELi0ELi8ELi1EEv6VcDims6VcBufs"]
+    v, st = mod.audit(lines)
+    assert not v and st["in_flight_at_end"] == 0 and [n for _, n, _ in st["loop_waits"]] == [4] and st["asm_loads"] >= 6
+    v, _ = mod.audit([l.replace("s_waitcnt vmcnt(4)", "s_waitcnt vmcnt(5)") for l in lines])
+    assert v, "a wait that leaves 5 operations outstanding went unnoticed"
+    kept, in_asm = [], False
+    for l in lines:
+        in_asm = True if ";;#ASMSTART" in l else (False if ";;#ASMEND" in l else in_asm)
+        if not (in_asm and "s_waitcnt vmcnt(0)" in l):
+            kept.append(l)
+    v, st = mod.audit(kept)
+    assert v and st["in_flight_at_end"] > 0, "missing drains went unnoticed"
+    i = [k for k, l in enumerate(lines) if mod.LOAD.match(l.split(";")[0]) and ", s[" in l][4]
+    reg = re.search(r"v\[(\d+):", lines[i]).group(1)
+    j = i
+    while ";;#ASMEND" not in lines[j]:
+        j += 1
+    v, _ = mod.audit(lines[:j + 1] + [f"\tv_mov_b32_e32 v255, v{reg}"] + lines[j + 1:])
+    assert len(v) == 1 and int(reg) in v[0][2]
+
+
 def test_valu_model_is_what_bench_reads():
     """profiles/valu_model.json (written by profiles/tools/valu_count.py from the code objects and the GPU run of
     valu_rate.hip) carries, for the kernels bench.py runs, the measured floor of the instruction mix per occupancy."""

@@ -10,6 +10,26 @@
 #ifndef VC_ASM_LOADS
 #define VC_ASM_LOADS 1      // likelihood kernel: count loads issued from inline asm with hand-placed waits (vc_main_kernel.h)
 #endif
+// Arithmetic diet of the likelihood kernel's cell loop (round 3, profiles/r03_kmain.md section 5): each knob removes one packed
+// operation per gene pair and cell.  They change what the cell record holds, so every kernel that writes a record sees them.
+#ifndef VC_FOLD_LOG2E
+#define VC_FOLD_LOG2E 1     // count noise models: the gene coefficients are scaled by log2 e once per gene and the record carries
+#endif                      // cf * log2 e and omega * ln 2, so that eta * log2 e needs no multiply per (gene, cell)
+#ifndef VC_OMEGA_CS
+#define VC_OMEGA_CS 1       // velocity: the record carries k omega cos k phi, k omega sin k phi (no w * omega per gene pair)
+#endif
+#ifndef VC_HOIST_LB
+#define VC_HOIST_LB 1       // S+U kernel, count noise: sum_c k_U log beta = log beta * (sum_c k_U) leaves the loop
+#endif
+#ifndef VC_NR_MERGE
+#define VC_NR_MERGE 1       // negative-binomial U term: num * R formed once for a_U and w
+#endif
+#ifndef VC_REC_PAD
+#define VC_REC_PAD 2        // cell records are padded to a multiple of this many {x, x} pairs (2 = 16 bytes: the S+U kernel's record
+                            // of 6 pairs at H = 1 then strides 48 bytes, not 64; measured 113.8 vs 114.1-116.7 us, profiles/r03_kmain.md)
+#endif
+#define VC_LOG2E 1.4426950408889634f
+#define VC_LN2 0.6931471805599453f
 #define VC_MAXH 3
 #define VC_MAXNB 4
 #define VC_MAX_NW 64        // max Nx*Nhw (angular-speed coefficients)
@@ -29,7 +49,8 @@ struct VcDims {
   long long cell_offset;  // global index of the first local cell
   int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
   int K;                  // Nh + Nb : expression-map coefficients per gene (harmonics, then batch offsets)
-  int ctw;                // floats per cell record: {x,x} pairs of [sin k, cos k]*H, Db[Nb], omega, cf (padded)
+  int ctw;                // floats per cell record: {x,x} pairs of [sin k, cos k]*H, Db[Nb], omega, cf, S+U kernel: [k omega cos k,
+                          // k omega sin k]*H (padded); omega and cf carry the scale factors of vc_rec_*_scale
   int model, guide, noise, with_dnu;
   unsigned cond;          // bit i set <=> site i conditioned
   int kind;               // VC_KIND_*
@@ -53,6 +74,11 @@ struct VcDims {
   int nlpf;               // fused pipeline: loss slots per half of LPF = nb_post_gene + nb_tail_cell + 1
   float lgamma_alpha;     // lgamma(gamma_alpha) of the shape_inv prior, evaluated once on the host
 };
+
+// Cell record: scale factors of its omega and cf entries, and its length in {x, x} pairs
+__host__ __device__ inline float vc_rec_cf_scale(int noise) { return (VC_FOLD_LOG2E && noise != VC_NOISE_LOGNORMAL) ? VC_LOG2E : 1.f; }
+__host__ __device__ inline float vc_rec_omega_scale(int noise) { return (VC_FOLD_LOG2E && noise != VC_NOISE_LOGNORMAL) ? VC_LN2 : 1.f; }
+__host__ __device__ inline int vc_rec_pairs(int H, int Nb, bool full) { return 2 * H + Nb + 2 + ((full && VC_OMEGA_CS) ? 2 * H : 0); }
 
 // View of the exchange buffer of the sharded fused step (vc_svi_run_sharded; layout: include/velocycle_hip.h)
 struct VcXb {
@@ -83,6 +109,7 @@ struct VcBufs {
   const int *h_tptr;                        // [Ng+1] first task of every gene (tasks are sorted by gene)
   int n_tasks;
   const float *h_val, *h_cnt;
+  const float *gene_sum_u;                  // [Ng_pad] sum over this rank's cells of the unspliced counts of every gene (count noise)
   // per-step workspaces
   float *eps_used;
   float *GT;                                // gene table [K+3][Ng_pad]
@@ -121,6 +148,22 @@ struct VcBufs {
 #define VC_KSTAMP(kid, k) do {} while (0)
 #define VC_WSTAMP(kid, k) do {} while (0)
 #endif
+// The omega entries of a cell record (every value twice {x, x}: an SGPR pair is a packed operand of the likelihood kernel);
+// sk / ck = sin, cos of k phi, k = 1..H
+__device__ __forceinline__ void vc_rec_put_omega(float2* ct, const VcDims& d, float omega, const float* sk, const float* ck) {
+  const int nbk = d.with_dnu ? d.Nb : 0;
+  const float oz = omega * vc_rec_omega_scale(d.noise);
+  ct[2 * d.H + nbk] = make_float2(oz, oz);
+  if (VC_OMEGA_CS && d.kind == VC_KIND_VFULL) {          // read by the S+U kernel only; the other kinds keep the short record
+#pragma unroll
+    for (int k = 0; k < VC_MAXH; ++k)       // compile-time indices: sk / ck stay in registers
+      if (k < d.H) {
+        const float w = (float)(k + 1) * omega;
+        ct[2 * d.H + nbk + 2 + 2 * k] = make_float2(w * ck[k], w * ck[k]);
+        ct[2 * d.H + nbk + 3 + 2 * k] = make_float2(w * sk[k], w * sk[k]);
+      }
+  }
+}
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions with DPP row operations; the total lands in lane 63.
 // ---------------------------------------------------------------------------------------------

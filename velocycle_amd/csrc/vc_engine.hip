@@ -297,7 +297,7 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   d.R = (vel && d.guide == VC_GUIDE_LRMN) ? c->lrmn_rank : 0;
   d.M = d.Ng + d.NW;
   d.K = d.Nh + d.Nb;
-  d.ctw = 2 * (((2 * d.H + d.Nb + 2) + 3) / 4 * 4);   // values duplicated {x,x}, record padded to 32 B
+  d.ctw = 2 * ((vc_rec_pairs(d.H, d.Nb, false) + VC_REC_PAD - 1) / VC_REC_PAD * VC_REC_PAD);   // provisional (vc_finalize: the S+U kernel's record is longer)
   d.cond = 0;
   d.root_w = c->rank == 0 ? 1.f : 0.f;
   d.gamma_alpha = c->gamma_alpha; d.gamma_beta = c->gamma_beta;
@@ -781,6 +781,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.eps_used, (size_t)e->layout.eps_total));
   HIPCHK(e, hipMemset(b.eps_used, 0, sizeof(float) * e->layout.eps_total));
   TRY(e->dalloc(&b.GT, (size_t)(d.K + 3) * d.Ng_pad));
+  d.ctw = 2 * ((vc_rec_pairs(d.H, d.Nb, d.kind == VC_KIND_VFULL) + VC_REC_PAD - 1) / VC_REC_PAD * VC_REC_PAD);   // values duplicated {x,x}, record padded to VC_REC_PAD pairs
   TRY(e->dalloc(&b.CT, (size_t)d.Nc * d.ctw));
   HIPCHK(e, hipMemset(b.CT, 0, sizeof(float) * (size_t)d.Nc * d.ctw));
   TRY(e->dalloc(&b.lat_delta, (size_t)d.M));
@@ -902,6 +903,18 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     TRY(upload(e, val, &b.h_val));
     TRY(upload(e, cnt, &b.h_cnt));
     e->h_ptr_host = ptr; e->h_val_host = val; e->h_cnt_host = cnt;
+    {
+      // sum_c k_U per gene (this rank's cells): the S+U kernel adds -log beta * sum_c k_U once per gene instead of subtracting
+      // log beta from eta_U once per (gene, cell) (VC_HOIST_LB)
+      std::vector<float> gsu((size_t)d.Ng_pad, 0.f);
+      if (vel && want_hist)
+        for (int g = 0; g < d.Ng; ++g) {
+          double sum = 0.0;
+          for (int j = ptr[(size_t)d.Ng + g]; j < ptr[(size_t)d.Ng + g + 1]; ++j) sum += (double)val[j] * (double)cnt[j];
+          gsu[g] = (float)sum;
+        }
+      TRY(upload(e, gsu, &b.gene_sum_u));
+    }
     std::vector<float>().swap(e->hS);
     std::vector<float>().swap(e->hU);
   }

@@ -635,7 +635,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
         }
         const int nbk = d.with_dnu ? d.Nb : 0;
         if (!vel) ct[2 * d.H + nbk] = make_float2(0.f, 0.f);
-        ct[2 * d.H + nbk + 1] = make_float2(b.cf[c], b.cf[c]);
+        { const float cfs = b.cf[c] * vc_rec_cf_scale(d.noise); ct[2 * d.H + nbk + 1] = make_float2(cfs, cfs); }
         if (!vel) { b.lat_omega[c] = 0.f; b.lat_domega[c] = 0.f; }
       }
       b.lat_phi[c] = ph;
@@ -957,9 +957,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
       omega += dx * om;
       domega += dx * dd;
     }
-    float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
-    const int nbk = d.with_dnu ? d.Nb : 0;
-    ct[2 * d.H + nbk] = make_float2(omega, omega);
+    vc_rec_put_omega(reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw), d, omega, sk, ck);
     b.lat_omega[c] = omega;
     b.lat_domega[c] = domega;
   }

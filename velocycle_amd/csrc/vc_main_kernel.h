@@ -52,6 +52,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef VC_ISSUE_PIN
 #define VC_ISSUE_PIN 1    // sched_barrier behind the issue of the next cell's loads (asm path): keeps them at the top of the cell
 #endif
+#ifndef VC_REC_TOUCH
+#define VC_REC_TOUCH 1    // the record of the cell about to be processed is "used" (empty asm) BEFORE the next cell's scalar load is
+#endif                    // issued: scalar loads return out of order, so the wait hipcc puts in front of the first use of a record is
+                          // lgkmcnt(0) -- placed behind the new s_load it exposes that load's whole latency once per cell
 #ifndef VC_LB_SINGLE
 #define VC_LB_SINGLE 2    // minimum waves per SIMD the one-matrix kernels (8 genes per lane) are compiled for
 #endif
@@ -72,15 +76,18 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Cell record as stored in the cell table: every value duplicated {x, x}, so that a scalar load
 // delivers it as an SGPR pair that v_pk_*_f32 consume directly as a packed operand (no per-cell
-// v_mov splat).  Layout (pairs): sin k, cos k (k = 1..H), Db[0..NB), omega, cf.
+// v_mov splat).  Layout (pairs): sin k, cos k (k = 1..H), Db[0..NB), omega, cf, then (velocity model, VC_OMEGA_CS)
+// k omega cos k, k omega sin k (k = 1..H).  With VC_FOLD_LOG2E and a count noise model the record's omega is omega * ln 2
+// and its cf is cf * log2 e (vc_common.h: vc_rec_*_scale): eta comes out in log2 units without a multiply.
 template <int H, int NB>
 struct VcCellRec {
   v2f sn[H], cs[H];
   v2f db[NB > 0 ? NB : 1];
   v2f omega, cf;
+  v2f ocs[H], osn[H];       // S+U kernel only
 };
 
-template <int H, int NB>
+template <int H, int NB, bool XT>
 __device__ __forceinline__ VcCellRec<H, NB> vc_cell_from_pairs(const v2f* c2) {
   VcCellRec<H, NB> r;
 #pragma unroll
@@ -89,12 +96,16 @@ __device__ __forceinline__ VcCellRec<H, NB> vc_cell_from_pairs(const v2f* c2) {
   for (int q = 0; q < NB; ++q) r.db[q] = c2[2 * H + q];
   r.omega = c2[2 * H + NB];
   r.cf = c2[2 * H + NB + 1];
+  if (XT) {
+#pragma unroll
+    for (int k = 0; k < H; ++k) { r.ocs[k] = c2[2 * H + NB + 2 + 2 * k]; r.osn[k] = c2[2 * H + NB + 3 + 2 * k]; }
+  }
   return r;
 }
 // The record is read through the constant address space: the table is written by K_pre, never by this
 // kernel, and only a constant-space load of a wave-uniform address is selected as s_load_dwordx8 (scalar
 // cache, SGPR pairs as packed operands) instead of a 64-lane vector load of one address.
-template <int H, int NB>
+template <int H, int NB, bool XT>
 __device__ __forceinline__ VcCellRec<H, NB> vc_load_cell(const float* __restrict__ ct) {
 #if VC_SCALAR_REC
   typedef const __attribute__((address_space(4))) v2f* cptr;
@@ -106,9 +117,13 @@ __device__ __forceinline__ VcCellRec<H, NB> vc_load_cell(const float* __restrict
   for (int q = 0; q < NB; ++q) r.db[q] = c2[2 * H + q];
   r.omega = c2[2 * H + NB];
   r.cf = c2[2 * H + NB + 1];
+  if (XT) {
+#pragma unroll
+    for (int k = 0; k < H; ++k) { r.ocs[k] = c2[2 * H + NB + 2 + 2 * k]; r.osn[k] = c2[2 * H + NB + 3 + 2 * k]; }
+  }
   return r;
 #else
-  return vc_cell_from_pairs<H, NB>(reinterpret_cast<const v2f*>(ct));
+  return vc_cell_from_pairs<H, NB, XT>(reinterpret_cast<const v2f*>(ct));
 #endif
 }
 
@@ -117,9 +132,6 @@ __device__ __forceinline__ VcCellRec<H, NB> vc_load_cell(const float* __restrict
 // ~100 %, 4 cycles per wave64 instruction, 8 per transcendental), and v_pk_{fma,mul,add}_f32 retire two
 // genes per issue slot, so the per-element math is written on float2 pairs (4 genes/lane = 2 pairs).
 // ---------------------------------------------------------------------------------------------
-#define VC_LOG2E 1.4426950408889634f
-#define VC_LN2 0.6931471805599453f
-
 __device__ __forceinline__ v2f v2(float x) { return v2f{x, x}; }
 __device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 // hardware base-2 transcendentals; arguments are never denormal here (t = r + mu >= r > 0, zp >= 1e-5)
@@ -215,6 +227,10 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   constexpr bool LN = (NOISE == VC_NOISE_LOGNORMAL);
   constexpr int NQ = (KIND == VC_KIND_PHASE) ? K + 1 : (KIND == VC_KIND_VFULL ? K + 3 : 2);
   constexpr int NCO = FULL ? 3 : 1;
+  constexpr bool L2 = VC_FOLD_LOG2E && !LN;          // eta, dd, e2 in log2 units (coefficients scaled once per gene)
+  constexpr bool OCS = VC_OMEGA_CS && FULL;          // k omega cos / sin from the record
+  constexpr bool HLB = VC_HOIST_LB && FULL && !LN;   // -log beta sum_c k_U added once per gene (epilogue)
+  static_assert(!(VC_FOLD_LOG2E && !VC_OMEGA_CS), "VC_FOLD_LOG2E stores omega * ln 2 in the record: the S+U kernel then needs VC_OMEGA_CS for w * omega");
 
 #ifdef VC_DBG_TIMES
   const unsigned long long dbg_t0 = wall_clock64();
@@ -295,7 +311,18 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       if (HAS_S) load_counts(Sp + (size_t)cn * GBW * ESZ, s_bf[j]);
       if (HAS_U) load_counts(Up + (size_t)cn * GBW * ESZ, u_bf[j]);
     }
-    rec_bf[j] = vc_load_cell<H, NB>(b.CT + (size_t)cn * d.ctw);
+    rec_bf[j] = vc_load_cell<H, NB, OCS>(b.CT + (size_t)cn * d.ctw);
+  };
+  // every SGPR of a record named as an input of an empty asm statement: hipcc's wait for the record's scalar load lands here
+  auto touch_rec = [&](const VcCellRec<H, NB>& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      asm volatile("" ::"s"(r.sn[k]), "s"(r.cs[k]));
+      if (OCS) asm volatile("" ::"s"(r.ocs[k]), "s"(r.osn[k]));
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) asm volatile("" ::"s"(r.db[q]));
+    asm volatile("" ::"s"(r.omega), "s"(r.cf));
   };
   // asm path: the counts of buffer j are readable once at most `pend` younger fetches are outstanding
   auto wait_counts = [&](int j, auto pend) __attribute__((always_inline)) {
@@ -303,6 +330,10 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     if (HAS_S && HAS_U) vc_wait<N>(s_q[j], u_q[j]);
     else if (HAS_S) vc_wait<N>(s_q[j]);
     else vc_wait<N>(u_q[j]);
+  };
+  auto drain_counts = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NBUF; ++j) wait_counts(j, std::integral_constant<int, 0>());
   };
   if (VC_EARLY_FETCH && ncell > 0) {
 #pragma unroll
@@ -323,7 +354,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)K * d.Ng_pad + 4 * q4);
       const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(K + 1) * d.Ng_pad + 4 * q4);
       const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(K + 2) * d.Ng_pad + 4 * q4);
-      lb2[2 * q4] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[2 * q4 + 1] = v2f{v0.z, v0.w} * VC_LOG2E;
+      if (!HLB) { lb2[2 * q4] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[2 * q4 + 1] = v2f{v0.z, v0.w} * VC_LOG2E; }
+      else lb2[2 * q4] = lb2[2 * q4 + 1] = v2(0.f);      // not used in the loop (epilogue re-reads log beta)
       ib[2 * q4] = v2f{__expf(-v0.x), __expf(-v0.y)}; ib[2 * q4 + 1] = v2f{__expf(-v0.z), __expf(-v0.w)};   // 1/beta
       gam[2 * q4] = v2f{v1.x, v1.y}; gam[2 * q4 + 1] = v2f{v1.z, v1.w};
       rr[2 * q4] = v2f{v2r.x, v2r.y}; rr[2 * q4 + 1] = v2f{v2r.z, v2r.w};
@@ -332,6 +364,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         // harmonic once per gene instead of being subtracted once per (gene, cell) (-4 packed operations per cell iteration
         // of 145; the S+U kernel needs eta_S on its own for the S likelihood)
         nu[0][2 * q4] -= v2f{v0.x, v0.y}; nu[0][2 * q4 + 1] -= v2f{v0.z, v0.w};
+      }
+      if (L2) {
+        // log2 units from here on: eta * log2 e = (nu * log2 e) . zeta + cf * log2 e (the record's cf is scaled), and dd, e2 come
+        // out scaled as well -- z = dd * omega is restored by the record's omega * ln 2, the per-cell sums A1..A3 by one
+        // multiply where they are stored
+#pragma unroll
+        for (int k = 0; k < K; ++k) { nu[k][2 * q4] *= VC_LOG2E; nu[k][2 * q4 + 1] *= VC_LOG2E; }
       }
     }
   }
@@ -393,7 +432,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 #pragma unroll
       for (int q = 0; q < NB; ++q) es = v2_fma(nu[NH + q][p], rec.db[q], es);
 
-      const v2f es2 = es * VC_LOG2E;
+      const v2f es2 = L2 ? es : es * VC_LOG2E;
       v2f a = v2(0.f), w = v2(0.f), muS = v2(0.f);
       if (HAS_S) {
         v2f aS;
@@ -412,7 +451,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         v2f m;      // one packed multiply with the clamp output modifier (hipcc does not fold fmed3 into v_pk_mul)
         asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(m) : "v"(z), "v"(v2(1.2676506e30f)));
         const v2f zp = v2_fma(z, m, v2(1e-5f));
-        const v2f eu2 = (VC_FOLD_LOGBETA && KIND == VC_KIND_VU) ? es2 + v2_log2(zp) : (es2 - lb2[p]) + v2_log2(zp);
+        const v2f eu2 = ((VC_FOLD_LOGBETA && KIND == VC_KIND_VU) || HLB) ? es2 + v2_log2(zp) : (es2 - lb2[p]) + v2_log2(zp);
         v2f aU;
         if (VC_RCP_MERGE && NOISE == VC_NOISE_NB) {
           // one reciprocal for 1/t_U and 1/zp: R = 1/(t_U zp), a_U = r (k - mu) zp R, w = a_U m / zp = r (k - mu) m R
@@ -421,8 +460,14 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           const v2f lt2 = v2_log2(t);
           const v2f R = v2_rcp(t * zp);
           const v2f num = rr[p] * (uv[p] - muU);
-          aU = num * (R * zp);
-          w = num * (R * m);                                                    // torch.relu': 0 at z <= 0
+          if (VC_NR_MERGE) {
+            const v2f nR = num * R;
+            aU = nR * zp;
+            w = nR * m;                                                         // torch.relu': 0 at z <= 0
+          } else {
+            aU = num * (R * zp);
+            w = num * (R * m);
+          }
           ll[p] = v2_fma(uv[p], eu2 - lt2, ll[p]);
           lt[p] += lt2;
         } else {
@@ -441,12 +486,15 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         gw[p] += w;
       }
       if (KIND != VC_KIND_VU) {
-        const v2f wo = w * rec.omega;
+        const v2f wo = OCS ? w : w * rec.omega;
         gnu[0][p] += a;
 #pragma unroll
         for (int k = 0; k < H; ++k) {
           const float kk = (float)(k + 1);
-          if (FULL) {
+          if (OCS) {           // d z / d nu_s = k omega cos k phi, d z / d nu_c = -k omega sin k phi: both in the record
+            gnu[2 * k + 1][p] = v2_fma(a, rec.sn[k], v2_fma(w, rec.ocs[k], gnu[2 * k + 1][p]));
+            gnu[2 * k + 2][p] = v2_fma(a, rec.cs[k], v2_fma(-w, rec.osn[k], gnu[2 * k + 2][p]));
+          } else if (FULL) {
             const v2f wk = (k == 0) ? wo : wo * kk;
             gnu[2 * k + 1][p] = v2_fma(a, rec.sn[k], v2_fma(wk, rec.cs[k], gnu[2 * k + 1][p]));
             gnu[2 * k + 2][p] = v2_fma(a, rec.cs[k], v2_fma(-wk, rec.sn[k], gnu[2 * k + 2][p]));
@@ -463,10 +511,12 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       if (HAS_U) A3 = v2_fma(w, dd, A3);
     }
     // per-lane partials of the per-cell sums over the genes of this wave
+    // (with L2 they carry a factor log2 e from dd / e2: removed where they are stored, once per cell and row)
     if (KIND == VC_KIND_PHASE) { p0 = A1.x + A1.y; }
     else if (KIND == VC_KIND_VU) { p0 = A3.x + A3.y; }
     else { p0 = A1.x + A1.y; p1 = A2.x + A2.y; p2 = A3.x + A3.y; }
   };
+  constexpr float CO_SCALE = L2 ? VC_LN2 : 1.f;
   // 64-lane sums of one cell's partials, staged in lane i of keep0..2
   auto stage1 = [&](float p0, float p1, float p2, const int i) __attribute__((always_inline)) {
     const float t0 = vc_wave_sum(p0);
@@ -521,7 +571,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       float4 acc = src[0];
 #pragma unroll
       for (int q = 1; q < 16; ++q) { const float4 v = src[q]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-      const float t = (acc.x + acc.y) + (acc.z + acc.w);
+      const float t = ((acc.x + acc.y) + (acc.z + acc.w)) * CO_SCALE;
       if (c < n) b.CO[((size_t)gb * NCO + row) * d.Nc + cb + c] = t;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -529,8 +579,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   auto flush = [&](long long cb, int n) {      // coalesced store of the staged per-cell sums of the last n <= 64 cells
     if (lane < n) {
       float* co = b.CO + ((size_t)gb * NCO) * d.Nc + cb + lane;
-      co[0] = keep0;
-      if (NCO == 3) { co[(size_t)d.Nc] = keep1; co[2 * (size_t)d.Nc] = keep2; }
+      co[0] = keep0 * CO_SCALE;
+      if (NCO == 3) { co[(size_t)d.Nc] = keep1 * CO_SCALE; co[2 * (size_t)d.Nc] = keep2 * CO_SCALE; }
     }
   };
 
@@ -591,7 +641,14 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
           const int i = i0 + j;
-          if (i >= ncell) break;
+          if (i >= ncell) {
+            // hipcc routes this exit through the loop's latch block (whose own test then leaves the loop: i0 + NBUF > i >= ncell).
+            // The marker tells the static audit of the asm loads (profiles/tools/check_asm_loads.py walks every static path)
+            // that a path through here does not re-enter the loop -- the one fact about the source it is given.
+            asm volatile("; vc_loop_exit");
+            break;
+          }
+          if (VC_REC_TOUCH) touch_rec(rec_bf[j]);
           fetch((j + PF) % NBUF, i + PF);
           if (ASM) {
             if (VC_ISSUE_PIN) __builtin_amdgcn_sched_barrier(0);
@@ -610,13 +667,11 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           }
         }
       }
-      if (ASM) {
-        // the last PF fetches (re-fetches of the last cell) are still in flight: nothing may re-use their registers before
-        // they have landed
-#pragma unroll
-        for (int j = 0; j < NBUF; ++j) wait_counts(j, std::integral_constant<int, 0>());
-      }
     }
+    // the last PF fetches (re-fetches of the last cell) are still in flight: nothing may re-use their registers before they
+    // have landed.  Outside the `ncell > 0` scope on purpose: every static path from a fetch to the epilogue passes through
+    // this drain, including the ones a path-insensitive audit cannot rule out (early fetch taken, loop skipped)
+    if (ASM) drain_counts();
   }
 
   VC_STAMP(2);
@@ -645,6 +700,18 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     // likelihood partial in natural units: ln2 * (sum k (eta2 - log2 t) - r sum log2 t) for NB.
     // Padded genes are masked here (their nu~ is 0, so they never reached A1..A3).
     float l = 0.f;
+    if (HLB && chunk == 0 && wave == 0) {
+      // sum_c k_U * (-log2 beta) over ALL of this rank's cells, added once per gene by the first wave of the gene block
+      const float* lbp = b.GT + (size_t)K * d.Ng_pad + g0;
+      const float* sup = b.gene_sum_u + g0;
+#pragma unroll
+      for (int q4 = 0; q4 < NV4; ++q4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(lbp + 4 * q4);
+        const float4 su = *reinterpret_cast<const float4*>(sup + 4 * q4);
+        ll[2 * q4] -= v2f{v0.x * su.x, v0.y * su.y} * VC_LOG2E;
+        ll[2 * q4 + 1] -= v2f{v0.z * su.z, v0.w * su.w} * VC_LOG2E;
+      }
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const v2f lj = ((NOISE == VC_NOISE_NB) ? ll[p] - rr[p] * lt[p] : ll[p]) * VC_LN2;

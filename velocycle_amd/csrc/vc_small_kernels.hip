@@ -392,8 +392,8 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
         ct[2 * d.H + q] = make_float2(v, v);
       }
       const int nbk = d.with_dnu ? d.Nb : 0;
-      ct[2 * d.H + nbk] = make_float2(omega, omega);
-      ct[2 * d.H + nbk + 1] = make_float2(b.cf[c], b.cf[c]);
+      vc_rec_put_omega(ct, d, omega, sk, ck);
+      { const float cfs = b.cf[c] * vc_rec_cf_scale(d.noise); ct[2 * d.H + nbk + 1] = make_float2(cfs, cfs); }
       b.lat_phi[c] = phi;
       b.lat_omega[c] = omega;
       b.lat_domega[c] = domega;
