@@ -24,6 +24,9 @@
 #ifndef VC_NR_MERGE
 #define VC_NR_MERGE 1       // negative-binomial U term: num * R formed once for a_U and w
 #endif
+#ifndef VC_TILE_TABLE
+#define VC_TILE_TABLE 1     // likelihood kernel: a wave's cell range from the table vc_finalize wrote (one scalar load) instead of
+#endif                      // evaluating the tiling function itself
 #ifndef VC_REC_PAD
 #define VC_REC_PAD 2        // cell records are padded to a multiple of this many {x, x} pairs (2 = 16 bytes: the S+U kernel's record
                             // of 6 pairs at H = 1 then strides 48 bytes, not 64; measured 113.8 vs 114.1-116.7 us, profiles/r03_kmain.md)
@@ -109,6 +112,7 @@ struct VcBufs {
   const int *h_tptr;                        // [Ng+1] first task of every gene (tasks are sorted by gene)
   int n_tasks;
   const float *h_val, *h_cnt;
+  const int *wg_tile;                       // [n_main_wg][2] {first cell of wave 0, cells per wave} of the likelihood kernel's workgroups
   const float *gene_sum_u;                  // [Ng_pad] sum over this rank's cells of the unspliced counts of every gene (count noise)
   // per-step workspaces
   float *eps_used;

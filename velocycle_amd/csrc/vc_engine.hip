@@ -751,6 +751,19 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     for (int p = 0; p < 4; ++p) d.pass_cw[p] = t.pass_cw[p];
     d.n_main_wg = d.nGB * d.n_chunks;
   }
+  {
+    // the tiling as a table: {first cell of wave 0, cells per wave} of every workgroup of the likelihood kernel, evaluated
+    // HERE by the function the kernel used to run itself (vc_host_logic.h; 64-bit divisions = ~700 scalar instructions in
+    // front of every wave's first load)
+    std::vector<int> tile(2 * (size_t)d.n_main_wg);
+    for (int w = 0; w < d.n_main_wg; ++w) {
+      int cw = 0;
+      const long long first = vc_wave_first_cell(w / d.nGB, w % d.nGB, 0, d.nGB, d.pass_wgs, d.pass_cw, VC_WAVES, &cw);
+      tile[2 * (size_t)w] = (int)std::min<long long>(first, 0x7fffffff);
+      tile[2 * (size_t)w + 1] = cw;
+    }
+    TRY(upload(e, tile, &b.wg_tile));
+  }
   d.nb_pre_gene = d.Ng_pad / 64;       // 64 genes per block, the sites of a gene spread over its 4 waves
   d.nb_pre_cell = (d.Nc + 255) / 256;
   d.nb_post_gene = d.Ng_pad / 64;

@@ -56,6 +56,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define VC_REC_TOUCH 1    // the record of the cell about to be processed is "used" (empty asm) BEFORE the next cell's scalar load is
 #endif                    // issued: scalar loads return out of order, so the wait hipcc puts in front of the first use of a record is
                           // lgkmcnt(0) -- placed behind the new s_load it exposes that load's whole latency once per cell
+#ifndef VC_A_FMA
+#define VC_A_FMA 0        // negative-binomial S term: d loglik / d eta as fma(fma(r, k, r^2), 1 / (r + mu), -r) -- one packed operation
+#endif                    // less than r (k - mu) / (r + mu), one more register pair per gene pair (r^2)
 #ifndef VC_LB_SINGLE
 #define VC_LB_SINGLE 2    // minimum waves per SIMD the one-matrix kernels (8 genes per lane) are compiled for
 #endif
@@ -147,12 +150,13 @@ __device__ __forceinline__ v2f v2_rcp(v2f x) { return v2f{__builtin_amdgcn_rcpf(
 // Nothing else of the NB needs per-element work: sum_c (r+k)/(r+mu) = n + (sum_c a)/r, and the r-only
 // terms (r log r, lgamma) come from the per-gene count histograms (K_pre / K_post).
 template <int NOISE>
-__device__ __forceinline__ void vc_obs_counts(v2f k, v2f eta2, v2f mu, v2f r, v2f& a, v2f& ll, v2f& lt) {
+__device__ __forceinline__ void vc_obs_counts(v2f k, v2f eta2, v2f mu, v2f r, v2f r2, v2f& a, v2f& ll, v2f& lt) {
   if (NOISE == VC_NOISE_NB) {
     const v2f t = r + mu;
     const v2f lt2 = v2_log2(t);
     const v2f it = v2_rcp(t);
-    a = (r * (k - mu)) * it;
+    if (VC_A_FMA) a = v2_fma(v2_fma(r, k, r2), it, -r);      // r (k - mu) / (r + mu) = r (k + r) / (r + mu) - r, r2 = r * r
+    else a = (r * (k - mu)) * it;
     ll = v2_fma(k, eta2 - lt2, ll);
     lt += lt2;
   } else {
@@ -253,7 +257,15 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // CU, and the SIMD arbiter serves the oldest wave first; the passes may therefore take unequal shares of the cells
   // (pass_cw[p] cells per wave in pass p), so that the waves of a SIMD end together (vc_host_logic.h: vc_tile_cells).
   int my_cw;
-  long long cbeg = vc_wave_first_cell(chunk, gb, wave, d.nGB, d.pass_wgs, d.pass_cw, VC_WAVES, &my_cw);
+  long long cbeg;
+  if (VC_TILE_TABLE) {
+    typedef const __attribute__((address_space(4))) int* ciptr;       // constant address space: a scalar load
+    ciptr tl = (ciptr)(const void*)(b.wg_tile + 2 * (size_t)blockIdx.x);
+    my_cw = tl[1];
+    cbeg = (long long)tl[0] + (long long)wave * my_cw;
+  } else {
+    cbeg = vc_wave_first_cell(chunk, gb, wave, d.nGB, d.pass_wgs, d.pass_cw, VC_WAVES, &my_cw);
+  }
   long long cend = cbeg + my_cw;
   if (cbeg > d.Nc) cbeg = d.Nc;
   if (cend > d.Nc) cend = d.Nc;
@@ -374,6 +386,9 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       }
     }
   }
+  v2f rr2[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) rr2[p] = rr[p] * rr[p];
   const float inv_s2_s = 1.0f / (d.sigma_ln_s * d.sigma_ln_s);
   const float inv_s2_u = 1.0f / (d.sigma_ln_u * d.sigma_ln_u);
 
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         if (LN) vc_obs_lognormal(sv[p], es, inv_s2_s, aS, ll[p]);
         else {
           muS = v2_exp2(es2);
-          vc_obs_counts<NOISE>(sv[p], es2, muS, rr[p], aS, ll[p], lt[p]);
+          vc_obs_counts<NOISE>(sv[p], es2, muS, rr[p], rr2[p], aS, ll[p], lt[p]);
         }
         a += aS;
       }
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           else {
             // exp(eta_U) = exp(eta_S) * zp / beta: no second exponential when exp(eta_S) is at hand
             const v2f muU = FULL ? muS * (ib[p] * zp) : v2_exp2(eu2);
-            vc_obs_counts<NOISE>(uv[p], eu2, muU, rr[p], aU, ll[p], lt[p]);
+            vc_obs_counts<NOISE>(uv[p], eu2, muU, rr[p], rr2[p], aU, ll[p], lt[p]);
           }
           w = aU * q;
         }
