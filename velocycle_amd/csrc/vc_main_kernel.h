@@ -56,6 +56,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define VC_REC_TOUCH 1    // the record of the cell about to be processed is "used" (empty asm) BEFORE the next cell's scalar load is
 #endif                    // issued: scalar loads return out of order, so the wait hipcc puts in front of the first use of a record is
                           // lgkmcnt(0) -- placed behind the new s_load it exposes that load's whole latency once per cell
+#ifndef VC_GT_LDS
+#define VC_GT_LDS 0       // per-gene latents through an LDS copy of the gene block's table rows (one global read per workgroup
+#endif                    // instead of one per wave)
 #ifndef VC_A_FMA
 #define VC_A_FMA 0        // negative-binomial S term: d loglik / d eta as fma(fma(r, k, r^2), 1 / (r + mu), -r) -- one packed operation
 #endif                    // less than r (k - mu) / (r + mu), one more register pair per gene pair (r^2)
@@ -352,20 +355,43 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     for (int j = 0; j < PF; ++j) fetch(j, j);
   }
 
+  constexpr int RPP = NQ < VC_EPI_ROWS ? NQ : VC_EPI_ROWS;           // output rows staged per epilogue pass
+  constexpr int TILE_C = 16, TILE_S = 68;                            // LDS reduction tile: cells, padded row stride (floats)
+  constexpr bool LDSR = VC_LDS_REDUCE && FULL;
+  constexpr int TILE_F = LDSR ? VC_WAVES * TILE_C * NCO * TILE_S : 0;
+  constexpr int EPI_F = VC_WAVES * RPP * GBW + VC_WAVES;
+  constexpr int GT_F = VC_GT_LDS ? (K + 3) * GBW : 0;                // the gene block's rows of the gene table, staged once per workgroup
+  constexpr int LDS_F = (EPI_F > TILE_F ? EPI_F : TILE_F) > GT_F ? (EPI_F > TILE_F ? EPI_F : TILE_F) : GT_F;
+  __shared__ float4 lds4[(LDS_F + 3) / 4];   // gene-table staging / reduction tiles / epilogue staging (4-wave combine), in turn
+
   // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
   v2f nu[K][NP], lb2[NP], ib[NP], gam[NP], rr[NP];
   {
+    // VC_GT_LDS: the four waves of a workgroup work on the SAME genes: the block's (K + 3) x GBW floats cross the L2 once per
+    // workgroup (256 threads x float4, coalesced) instead of once per wave, and every lane picks its genes' values from the LDS
     const float* gt = b.GT + g0;
+    size_t gt_stride = (size_t)d.Ng_pad;
+    if (VC_GT_LDS) {
+      float* gs = reinterpret_cast<float*>(lds4);
+      const float* gblk = b.GT + (size_t)gb * GBW;
+      for (int idx = threadIdx.x * 4; idx < (K + 3) * GBW; idx += 256 * 4) {
+        const int row = idx / GBW, col = idx - row * GBW;
+        *reinterpret_cast<float4*>(gs + idx) = *reinterpret_cast<const float4*>(gblk + (size_t)row * d.Ng_pad + col);
+      }
+      __syncthreads();
+      gt = gs + gl;
+      gt_stride = GBW;
+    }
 #pragma unroll
     for (int q4 = 0; q4 < NV4; ++q4) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)k * d.Ng_pad + 4 * q4);
+        const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)k * gt_stride + 4 * q4);
         nu[k][2 * q4] = v2f{v.x, v.y}; nu[k][2 * q4 + 1] = v2f{v.z, v.w};
       }
-      const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)K * d.Ng_pad + 4 * q4);
-      const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(K + 1) * d.Ng_pad + 4 * q4);
-      const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(K + 2) * d.Ng_pad + 4 * q4);
+      const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)K * gt_stride + 4 * q4);
+      const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(K + 1) * gt_stride + 4 * q4);
+      const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(K + 2) * gt_stride + 4 * q4);
       if (!HLB) { lb2[2 * q4] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[2 * q4 + 1] = v2f{v0.z, v0.w} * VC_LOG2E; }
       else lb2[2 * q4] = lb2[2 * q4 + 1] = v2(0.f);      // not used in the loop (epilogue re-reads log beta)
       ib[2 * q4] = v2f{__expf(-v0.x), __expf(-v0.y)}; ib[2 * q4 + 1] = v2f{__expf(-v0.z), __expf(-v0.w)};   // 1/beta
@@ -385,6 +411,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         for (int k = 0; k < K; ++k) { nu[k][2 * q4] *= VC_LOG2E; nu[k][2 * q4 + 1] *= VC_LOG2E; }
       }
     }
+    if (VC_GT_LDS) __syncthreads();          // the staging area is the reduction tiles' / the epilogue's next
   }
   v2f rr2[NP];
 #pragma unroll
@@ -403,12 +430,6 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     gau[p] = gw[p] = ll[p] = lt[p] = v2(0.f);
   }
 
-  constexpr int RPP = NQ < VC_EPI_ROWS ? NQ : VC_EPI_ROWS;           // output rows staged per epilogue pass
-  constexpr int TILE_C = 16, TILE_S = 68;                            // LDS reduction tile: cells, padded row stride (floats)
-  constexpr bool LDSR = VC_LDS_REDUCE && FULL;
-  constexpr int TILE_F = LDSR ? VC_WAVES * TILE_C * NCO * TILE_S : 0;
-  constexpr int EPI_F = VC_WAVES * RPP * GBW + VC_WAVES;
-  __shared__ float4 lds4[((EPI_F > TILE_F ? EPI_F : TILE_F) + 3) / 4];   // epilogue staging (4-wave combine) / reduction tiles
 
 #ifdef VC_DBG_TIMES
   asm volatile("" ::"v"(nu[0][0]), "v"(rr[0]));   // stamp 1 sits behind the latents' loads
