@@ -163,7 +163,18 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       if (chain) {
         in[0] = b.GT[(size_t)(K + 2) * NP + g];
         if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
-        for (int t = b.h_tptr[g]; t < b.h_tptr[g + 1]; ++t) { HLg += b.HL[t]; HDg += b.HD[t]; }
+        {
+          // the gene's histogram terms (usually 2..4 tasks): four requested per trip instead of one (a dependent round trip
+          // each on this role's way to the barrier), the sums formed in task order as before
+          const int t0 = b.h_tptr[g], t1 = b.h_tptr[g + 1];
+          for (int tb = t0; tb < t1; tb += 4) {
+            double hl[4], hd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int t = tb + k < t1 ? tb + k : tb; hl[k] = b.HL[t]; hd[k] = b.HD[t]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (tb + k < t1) { HLg += hl[k]; HDg += hd[k]; }
+          }
+        }
       }
     } else if (r_mf || r_core || r_cov) {
       in[2] = b.sd_g[g]; in[3] = b.mu_g[g]; in[5] = b.sd_b[g]; in[6] = b.mu_b[g];
