@@ -84,6 +84,44 @@ def test_asm_load_audit_catches_planted_hazards():
     assert len(v) == 1 and int(reg) in v[0][2]
 
 
+def test_asm_load_audit_path_rules_on_synthetic_code():
+    """The audit's three path rules on hand-written snippets: (1) a boolean set by s_cselect and tested twice answers both
+    tests the same way (hipcc's "set a flag, finish the section, test the flag"); (2) a path through the `; vc_loop_exit`
+    marker does not re-enter the loop; (3) without either, the same code IS flagged (the rules prune, they do not hide)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_loads", os.path.join(ROOT, "profiles", "tools", "check_asm_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def asm(*ins):
+        return ["\t;;#ASMSTART", *["\t" + i for i in ins], "\t;;#ASMEND"]
+
+    def loop(flagged_exit, marker):
+        # three rotating buffers A = v[2:3], B = v[4:5], C = v[6:7], two loads in flight across the back edge (the S+U kernel's
+        # shape).  An exit between sections 1 and 2 that is followed around the latch meets section 0 with A's load in flight.
+        def section(load, use):
+            return asm(f"global_load_dwordx2 {load}, v1, s[2:3]") + asm("s_waitcnt vmcnt(2)") + [f"\tv_add_f32_e32 v10, {use}"]
+        body = [".LBB0_1:"] + section("v[6:7]", "v2, v3") + section("v[2:3]", "v4, v5")
+        body += ["\ts_cmp_lt_i32 s8, s9", "\ts_cselect_b64 s[10:11], -1, 0"]
+        if flagged_exit:
+            body += ["\ts_and_b64 vcc, exec, s[10:11]", "\ts_cbranch_vccnz .LBB0_2"]
+            body += asm("; vc_loop_exit") if marker else []
+            body += [".LBB0_2:", "\tv_mul_f32_e32 v11, v10, v10", "\ts_andn2_b64 vcc, exec, s[10:11]", "\ts_cbranch_vccnz .LBB0_3"]
+        else:
+            body += ["\ts_and_b64 vcc, exec, s[10:11]", "\ts_cbranch_vccz .LBB0_4"]
+        body += section("v[4:5]", "v6, v7")
+        body += [".LBB0_3:", "\ts_cmp_lt_i32 s12, s13", "\ts_cbranch_scc1 .LBB0_1"]
+        tail = [".LBB0_4:"] + asm("s_waitcnt vmcnt(0)") + ["\tv_mov_b32_e32 v2, 0", "\ts_endpgm"]
+        return asm("global_load_dwordx2 v[2:3], v1, s[2:3]") + asm("global_load_dwordx2 v[4:5], v1, s[2:3]") + body + tail
+
+    clean = loop(flagged_exit=False, marker=False)                      # exit straight to the drain: nothing to prune
+    assert not mod.audit(clean)[0]
+    pruned = loop(flagged_exit=True, marker=True)                       # hipcc's form: flag + marker + latch back to the header
+    assert not mod.audit(pruned)[0], mod.audit(pruned)[0]
+    unmarked = loop(flagged_exit=True, marker=False)                    # the same without the marker: the latch path is walked
+    assert mod.audit(unmarked)[0], "the exit path around the latch was not walked"
+
+
 def test_valu_model_is_what_bench_reads():
     """profiles/valu_model.json (written by profiles/tools/valu_count.py from the code objects and the GPU run of
     valu_rate.hip) carries, for the kernels bench.py runs, the measured floor of the instruction mix per occupancy."""
