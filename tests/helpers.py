@@ -132,7 +132,8 @@ def assert_trajectory_within_float32_spread(spec, opt, n, seed, losses, named_pa
         assert rel_hip[:5].max() <= 1e-5, rel_hip[:5]
     # free-running comparison: step by step against the float32 oracle's accumulated drift -- or, with teacher forcing (the
     # run may have left the float64 trajectory a few steps EARLIER than the float32 oracle happened to), against its largest
-    yard = 4 * (np.full_like(rel_32, rel_32.max()) if snapshots else np.maximum.accumulate(rel_32))
+    # (x 8 there: two float32 runs of a flow that has left the float64 one are as far from each other as from it)
+    yard = (8 * np.full_like(rel_32, rel_32.max())) if snapshots else 4 * np.maximum.accumulate(rel_32)
     assert (rel_hip <= np.maximum(allow, yard)).all(), (rel_hip.max(), rel_32.max())
     if snapshots:
         assert_params_track_oracle({k: v.detach().cpu().numpy() for k, v in named_params.items()},

@@ -24,6 +24,13 @@
 #ifndef VC_NR_MERGE
 #define VC_NR_MERGE 1       // negative-binomial U term: num * R formed once for a_U and w
 #endif
+#ifndef VC_PW_INLINE
+#define VC_PW_INLINE 1      // tutorial flow on one rank (U-only kernel, phases conditioned): the per-workgroup partials of
+#endif                      // d loglik / d nu_omega[j] = sum_c A3_c W_cj come out of the likelihood kernel itself -- the sum is linear
+                            // in the gene blocks' shares of A3, and the kernel holds those per cell when it stores them (lane = cell,
+                            // 64 cells per flush); W = D[x,c] zeta_omega_h(phi_c) of the wave's cells waits in the LDS
+#define VC_PWQ 4            // coefficients the likelihood kernel carries (Nx * Nhw <= VC_PWQ, else K_tail's cell blocks do it)
+#define VC_PW_MAXCW 256     // ... and cells per wave it stages W for (4 waves x 256 cells x 16 bytes of LDS)
 #ifndef VC_TILE_TABLE
 #define VC_TILE_TABLE 1     // likelihood kernel: a wave's cell range from the table vc_finalize wrote (one scalar load) instead of
 #endif                      // evaluating the tiling function itself
@@ -52,6 +59,7 @@ struct VcDims {
   long long cell_offset;  // global index of the first local cell
   int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
   int K;                  // Nh + Nb : expression-map coefficients per gene (harmonics, then batch offsets)
+  int pw_inline;          // 1: K_main (U-only kernel) writes PWM, K_omega / K_fin read it instead of the cell blocks' PW
   int ctw;                // floats per cell record: {x,x} pairs of [sin k, cos k]*H, Db[Nb], omega, cf, S+U kernel: [k omega cos k,
                           // k omega sin k]*H (padded); omega and cf carry the scale factors of vc_rec_*_scale
   int model, guide, noise, with_dnu;
@@ -126,6 +134,8 @@ struct VcBufs {
   float *LO;                                // likelihood partial per main workgroup
   double *LP;                               // loss partials of pre (nb_pre_gene + nb_pre_cell) and post_gene blocks
   float *PW;                                // [nb_post_cell][NW] partial angular-speed gradients
+  float *PWM;                               // [n_main_wg][VC_PWQ] the same partials, per workgroup of K_main (pw_inline)
+  float *WT;                                // [Nc][VC_PWQ] W_cj = D[x,c] zeta_omega_h(phi_c), j = x * Nhw + h (pw_inline; j >= NW: 0)
   double *HL, *HD;                          // per histogram task: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
   double const_loss;                        // step-invariant part of the loss
   long long* status;                        // [0] number of steps with a non-finite loss, [1] 1 + index of the first one
@@ -165,6 +175,19 @@ __device__ __forceinline__ void vc_rec_put_omega(float2* ct, const VcDims& d, fl
         const float w = (float)(k + 1) * omega;
         ct[2 * d.H + nbk + 2 + 2 * k] = make_float2(w * ck[k], w * ck[k]);
         ct[2 * d.H + nbk + 3 + 2 * k] = make_float2(w * sk[k], w * sk[k]);
+      }
+  }
+}
+// Row c of the W table of the U-only kernel (pw_inline): sk / ck = sin, cos of k phi_c up to Hw
+__device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c, const float* sk, const float* ck) {
+  if (!(d.pw_inline && d.kind == VC_KIND_VU)) return;
+  for (int xq = 0; xq < d.Nx; ++xq) {
+    const float dx = b.Dm[(size_t)xq * d.Nc + c];
+#pragma unroll
+    for (int h = 0; h < 2 * VC_MAXH + 1; ++h)
+      if (h < d.Nhw) {
+        const float z = (h == 0) ? 1.f : ((h & 1) ? sk[(h - 1) >> 1] : ck[(h - 1) >> 1]);
+        b.WT[(size_t)c * VC_PWQ + xq * d.Nhw + h] = dx * z;
       }
   }
 }
@@ -417,6 +440,9 @@ void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* g
                        hipStream_t st);
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st);
+// tutorial flow on one rank (pw_inline, nothing per cell left to learn): K_tail's gene blocks and K_omega's blocks in one launch
+void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                           const VcAdamArgs& a, double* loss_dev, long long loss_slots, hipStream_t st);
 void vc_launch_p2p_xchg(const VcP2p& p, long long step, float* out, long long n, long long* status, double timeout_s,
                         hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,

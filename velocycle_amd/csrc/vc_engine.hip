@@ -298,6 +298,7 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   d.M = d.Ng + d.NW;
   d.K = d.Nh + d.Nb;
   d.ctw = 2 * ((vc_rec_pairs(d.H, d.Nb, false) + VC_REC_PAD - 1) / VC_REC_PAD * VC_REC_PAD);   // provisional (vc_finalize: the S+U kernel's record is longer)
+  d.pw_inline = 0;
   d.cond = 0;
   d.root_w = c->rank == 0 ? 1.f : 0.f;
   d.gamma_alpha = c->gamma_alpha; d.gamma_beta = c->gamma_beta;
@@ -811,6 +812,14 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   HIPCHK(e, hipMemset(b.dbg, 0, VC_DBG_WORDS(d.n_main_wg) * 8));
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
+  // tutorial flow on one rank: the angular-speed gradient partials come out of K_main (vc_common.h: VC_PW_INLINE)
+  d.pw_inline = (VC_PW_INLINE && d.kind == VC_KIND_VU && d.NW <= VC_PWQ && e->cfg.world_size == 1 && d.cw <= VC_PW_MAXCW &&
+                 d.pass_cw[0] <= VC_PW_MAXCW) ? 1 : 0;
+  if (const char* env = getenv("VC_PW_INLINE")) d.pw_inline = d.pw_inline && atoi(env) != 0;
+  TRY(e->dalloc(&b.PWM, (size_t)d.n_main_wg * VC_PWQ));
+  HIPCHK(e, hipMemset(b.PWM, 0, sizeof(float) * (size_t)d.n_main_wg * VC_PWQ));
+  TRY(e->dalloc(&b.WT, (size_t)VC_PWQ * d.Nc));
+  HIPCHK(e, hipMemset(b.WT, 0, sizeof(float) * (size_t)VC_PWQ * d.Nc));
   TRY(e->dalloc(&b.PW, (size_t)((d.Nc + 255) / 256) * std::max(1, d.NW)));      // K_post: 1024-cell blocks; K_tail: 256
   // K_tail's cell blocks: 256 cells on 4 of the block's 16 waves keep the per-cell chain shortest, but a block still takes a
   // 1024-thread slot when it is placed (2 per CU): beyond ~2 rounds of them the placement is what costs (400 000 cells:
@@ -840,8 +849,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   HIPCHK(e, hipMemset(b.LPF, 0, 2 * sizeof(double) * d.nlpf));
   TRY(e->dalloc(&b.LPP, (size_t)d.nb_post_gene));
   HIPCHK(e, hipMemset(b.LPP, 0, sizeof(double) * d.nb_post_gene));
-  TRY(e->dalloc(&b.NWS, 4 * (size_t)VC_MAX_NW * (VC_MAX_RANK + 2)));
-  HIPCHK(e, hipMemset(b.NWS, 0, 4 * sizeof(float) * VC_MAX_NW * (VC_MAX_RANK + 2)));
+  TRY(e->dalloc(&b.NWS, 2 * 4 * (size_t)VC_MAX_NW * (VC_MAX_RANK + 2)));      // two copies, by the parity of the step
+  HIPCHK(e, hipMemset(b.NWS, 0, 2 * 4 * sizeof(float) * VC_MAX_NW * (VC_MAX_RANK + 2)));
   TRY(e->dalloc(&b.EPS, 3 * (size_t)e->layout.eps_total));
   HIPCHK(e, hipMemset(b.EPS, 0, 3 * sizeof(float) * e->layout.eps_total));
   b.step_ctr = nullptr;
@@ -1055,6 +1064,11 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
   VcBufs b2 = e->b;
   b2.step_ctr = (long long*)step_dev;
   b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l;
+  // Tutorial flow (U-only kernel with its own nu_omega partials, no histogram terms per step): from the third step of a call on,
+  // K_tail's gene blocks and K_omega's blocks go out as ONE launch (vc_launch_tail_merged: why that is safe); the first two
+  // steps fill both halves of the loss terms the absent cell blocks would have written.
+  bool merged = e->d.pw_inline && e->d.kind == VC_KIND_VU && !with_hist && (e->d.cond >> VC_SITE_PHIXY & 1u);
+  if (const char* env = getenv("VC_TAIL_MERGED")) merged = merged && atoi(env) != 0;
   for (int64_t i = 0; i < n_steps; ++i) {
     if (e->timing) {
       if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
@@ -1065,8 +1079,12 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
     } else {
       e->main_fn(e->d, b2, st);
     }
-    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 0, VcXb{}, st);
-    vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
+    if (merged && i >= 2) {
+      vc_launch_tail_merged(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, st);
+    } else {
+      vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 0, VcXb{}, st);
+      vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
+    }
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));

@@ -21,6 +21,10 @@
 // and of the next sample from that ring -- slots that no block of the same launch writes.
 // Reference semantics restated: velocity_inference_guide.py:9-141, phase_inference_guide.py:10-56, priors of
 // velocity_inference_model.py:322-353,383 / phase_inference_model.py:360-366,392, pyro ClippedAdam.
+// No compiler-chosen fused multiply-adds in this translation unit: the same source statement has to give the same bits in every
+// kernel it is inlined into (K_post / K_fin, K_tail / K_omega, the sharded phases, the merged tail launch) -- hipcc's contraction
+// of a * b + c depends on the surroundings of the statement.  Where a fused operation is wanted it is written as fmaf().
+#pragma clang fp contract(off)
 #include "vc_common.h"
 
 #define VC_PG_WAVES 16
@@ -593,13 +597,14 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   if (vel && cblock == 0) {
     const bool lrmn = d.guide == VC_GUIDE_LRMN;
     const int fin_per = lrmn ? d.R + 2 : 2;
+    float* __restrict__ nws = b.NWS + (size_t)(s & 1) * 4 * VC_NWE;      // the copy K_omega reads at this step (two: by parity)
     for (int tt = threadIdx.x; tt < d.NW * fin_per; tt += VC_TC) {
       const long long off = vc_nuw_elem_off(d, lrmn, tt / fin_per, tt % fin_per);
-      b.NWS[tt] = P[off];
-      b.NWS[VC_NWE + tt] = Mm[off - header];
-      b.NWS[2 * VC_NWE + tt] = Vv[off - header];
+      nws[tt] = P[off];
+      nws[VC_NWE + tt] = Mm[off - header];
+      nws[2 * VC_NWE + tt] = Vv[off - header];
     }
-    if ((int)threadIdx.x < d.NW) b.NWS[3 * VC_NWE + threadIdx.x] = b.lat[VC_SITE_NUOMEGA][threadIdx.x];
+    if ((int)threadIdx.x < d.NW) nws[3 * VC_NWE + threadIdx.x] = b.lat[VC_SITE_NUOMEGA][threadIdx.x];
   }
   // sharded step: the exchange buffer comes back from the sum holding every rank's contribution; the elements no block of
   // this rank writes (PW rows beyond this rank's cell blocks, the header, the nu_omega slots of the gradient region) are
@@ -633,7 +638,8 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
       sincosf(ph, &s1, &c1);
       float sk[VC_MAXH], ck[VC_MAXH];
       sk[0] = s1; ck[0] = c1;
-      for (int k = 1; k < d.H && k < VC_MAXH; ++k) {
+      const int hm = d.H > d.Hw ? d.H : d.Hw;          // the W table (vc_put_w) goes up to Hw
+      for (int k = 1; k < hm && k < VC_MAXH; ++k) {
         sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
         ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
       }
@@ -647,6 +653,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
         const int nbk = d.with_dnu ? d.Nb : 0;
         if (!vel) ct[2 * d.H + nbk] = make_float2(0.f, 0.f);
         { const float cfs = b.cf[c] * vc_rec_cf_scale(d.noise); ct[2 * d.H + nbk + 1] = make_float2(cfs, cfs); }
+        if (vel) vc_put_w(d, b, c, sk, ck);
         if (!vel) { b.lat_omega[c] = 0.f; b.lat_domega[c] = 0.f; }
       }
       b.lat_phi[c] = ph;
@@ -827,8 +834,10 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
   const bool lrmn = d.guide == VC_GUIDE_LRMN;
   const bool first = oblk == 0;
   // phase B: the PW rows are the sums over ranks (every rank holds the complete gradient: prior / entropy weight 1)
-  const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : b.PW;
-  const int n_pw = phase == VC_PH_B ? xb.pw_cap : d.nb_tail_cell;
+  const bool pwm = phase != VC_PH_B && d.pw_inline;           // single rank, U-only kernel: K_main's own partials
+  const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : (pwm ? b.PWM : b.PW);
+  const int n_pw = phase == VC_PH_B ? xb.pw_cap : (pwm ? d.n_main_wg : d.nb_tail_cell);
+  const int pw_ld = pwm ? VC_PWQ : d.NW;
   const float rw = phase == VC_PH_B ? 1.f : d.root_w;
   const int nw = d.NW;
   const int fin_per = lrmn ? d.R + 2 : 2;
@@ -842,6 +851,8 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
   };
   const float* __restrict__ eps_new = b.EPS + (size_t)(s % 3) * d.eps_total;
   const float* __restrict__ eps_old = b.EPS + (size_t)((s + 2) % 3) * d.eps_total;
+  const float* __restrict__ nws = b.NWS + (size_t)(s & 1) * 4 * VC_NWE;        // the nu_omega snapshot of this step ...
+  float* __restrict__ nws_next = b.NWS + (size_t)((s + 1) & 1) * 4 * VC_NWE;   // ... and the copy block 0 fills for the next
   // this block's cells: the basis of the next phase (written by K_tail) is requested now
   const int c = oblk * 256 + t;
   float s1 = 0.f, c1 = 1.f;
@@ -857,7 +868,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
     for (int q = 0; q < 2; ++q) {
       const int j = wv + 4 * q;
       if (j < nw)
-        for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * d.NW + j];
+        for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -866,7 +877,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
     }
     for (int j = wv + 8; j < nw; j += 4) {
       double r = 0.0;
-      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * d.NW + j];
+      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
       r = vc_wave_sum_d63(r);
       if (lane == 63) sm_up[j] = (float)r;
     }
@@ -878,11 +889,11 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
   for (int tt = t; tt < nelem; tt += 256) {
     const int j = tt / fin_per, ce = tt % fin_per;
     const long long off = vc_nuw_elem_off(d, lrmn, j, ce);
-    float p = b.NWS[tt];                       // the snapshot K_tail took: block 0 overwrites P / m / v below
+    float p = nws[tt];                         // the snapshot of this step: block 0 overwrites P / m / v below
     if (!boot) {
       float gx = 0.f;
       if (!cnd) {
-        const float x = b.NWS[3 * VC_NWE + j], sd = b.sd_w[j];
+        const float x = nws[3 * VC_NWE + j], sd = b.sd_w[j];
         gx = sm_up[j] - rw * (x - b.mu_w[j]) / (sd * sd);
       }
       const long long ei = eps_index(j, ce);
@@ -901,9 +912,16 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
           gv = -gx * eo / (2.f * sqrtf(dg)) * dg;
         }
       }
-      float mm = b.NWS[VC_NWE + tt], vv = b.NWS[2 * VC_NWE + tt];
+      float mm = nws[VC_NWE + tt], vv = nws[2 * VC_NWE + tt];
       p = vc_adam_elem(p, gv, mm, vv, step_size, a.b1, a.b2, a.eps, a.clip);
-      if (first) { G[off] = gv; a.m[off - a.header] = mm; a.v[off - a.header] = vv; P[off] = p; }
+      if (first) {
+        G[off] = gv; a.m[off - a.header] = mm; a.v[off - a.header] = vv; P[off] = p;
+        // ... and the snapshot of the NEXT step (the other copy: nobody reads it in this launch), for a step whose K_tail
+        // runs no cell block that would take it (vc_launch_tail_merged)
+        nws_next[tt] = p; nws_next[VC_NWE + tt] = mm; nws_next[2 * VC_NWE + tt] = vv;
+      }
+    } else if (first) {
+      nws_next[tt] = p; nws_next[VC_NWE + tt] = nws[VC_NWE + tt]; nws_next[2 * VC_NWE + tt] = nws[2 * VC_NWE + tt];
     }
     s_np[tt] = p;
   }
@@ -932,6 +950,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
     const float x = cnd ? b.cnd[VC_SITE_NUOMEGA][j] : val;
     if (first) {
       b.lat[VC_SITE_NUOMEGA][j] = x;
+      nws_next[3 * VC_NWE + j] = x;
       const float lp = vc_normal_lp(x, b.mu_w[j], b.sd_w[j]);
       sm_lq[j] = -(double)d.root_w * ((double)lp - ((cnd || lrmn) ? 0.0 : (double)lq));
     }
@@ -1011,6 +1030,44 @@ void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* g
   // (the gene blocks of phase B neither reduce nor stage rows: the smallest row bound keeps their registers free)
   hipLaunchKernelGGL(vc_phase_b_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots,
                      nb_cell, nb_hist, xb);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tutorial flow on one rank (U-only kernel with pw_inline, phases / nu / shape_inv conditioned): K_tail's gene blocks and K_omega's
+// blocks in ONE launch, side by side, with no dependency between them:
+//   * the partials of d loglik / d nu_omega come from K_main (PWM), not from K_tail's cell blocks -- which, with the phases
+//     conditioned, have nothing else to do and are not launched (their loss terms are constants both halves of LPF hold after
+//     two ordinary steps; the nu_omega snapshot they took comes from K_omega's block 0 of the step before);
+//   * LPP (the r-only likelihood terms the loss block adds) is step-invariant with shape_inv conditioned: the gene blocks
+//     rewrite the same doubles while the loss block reads them;
+//   * no histogram blocks (shape_inv conditioned), the eps blocks depend on nothing.
+// vc_svi_run_fused runs the first two steps of every call the ordinary way and the rest through this launch.
+// ---------------------------------------------------------------------------------------------
+template <int MQ>
+__global__ __launch_bounds__(1024) void vc_tail_merged_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
+                                                              float* __restrict__ G, const long long* __restrict__ step_dev,
+                                                              uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
+                                                              long long loss_slots, int nb_ocell) {
+  const long long s = *step_dev;
+  if ((int)blockIdx.x < d.nb_post_gene) {
+    VcOpt o;
+    o.step_size = b.step_size[0];
+    o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip;
+    vc_tail_gene_block<MQ, VC_PH_ALL>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, VcXb{});
+    return;
+  }
+  if (threadIdx.x >= 256) return;          // K_omega's blocks are 256 threads wide: the other waves leave before any barrier
+  vc_omega_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_ocell, 0, blockIdx.x - d.nb_post_gene, VC_PH_ALL, VcXb{});
+}
+
+void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                           const VcAdamArgs& a, double* loss_dev, long long loss_slots, hipStream_t st) {
+  const int nb_ocell = (d.Nc + 255) / 256;
+  const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
+  const dim3 grid(d.nb_post_gene + nb_ocell + 1 + nb_eps), block(1024);
+  if (d.nq <= 2) hipLaunchKernelGGL((vc_tail_merged_kernel<2>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
+  else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail_merged_kernel<6>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
+  else hipLaunchKernelGGL((vc_tail_merged_kernel<VC_MAXQ>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
 }
 
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,

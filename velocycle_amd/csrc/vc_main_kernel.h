@@ -237,6 +237,15 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   constexpr bool L2 = VC_FOLD_LOG2E && !LN;          // eta, dd, e2 in log2 units (coefficients scaled once per gene)
   constexpr bool OCS = VC_OMEGA_CS && FULL;          // k omega cos / sin from the record
   constexpr bool HLB = VC_HOIST_LB && FULL && !LN;   // -log beta sum_c k_U added once per gene (epilogue)
+  // U-only kernel on one rank (pw_inline): per-workgroup partials of d loglik / d nu_omega[j] = sum_c A3_c W_cj, formed where
+  // the per-cell sums are stored (lane = cell, 64 cells per flush).  The W rows of the wave's cells are copied into the LDS
+  // before the loop: a compiler-visible VECTOR load inside the loop body would bring hipcc's conservative vmcnt waits back
+  // into every trip; an LDS read in the (rare) flush branch costs a lgkmcnt wait there and nothing elsewhere.
+  constexpr bool PWI = VC_PW_INLINE && KIND == VC_KIND_VU;
+  const bool pw_on = PWI && d.pw_inline != 0;
+  float pwacc[VC_PWQ];
+#pragma unroll
+  for (int j = 0; j < VC_PWQ; ++j) pwacc[j] = 0.f;
   static_assert(!(VC_FOLD_LOG2E && !VC_OMEGA_CS), "VC_FOLD_LOG2E stores omega * ln 2 in the record: the S+U kernel then needs VC_OMEGA_CS for w * omega");
 
 #ifdef VC_DBG_TIMES
@@ -363,6 +372,11 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   constexpr int GT_F = VC_GT_LDS ? (K + 3) * GBW : 0;                // the gene block's rows of the gene table, staged once per workgroup
   constexpr int LDS_F = (EPI_F > TILE_F ? EPI_F : TILE_F) > GT_F ? (EPI_F > TILE_F ? EPI_F : TILE_F) : GT_F;
   __shared__ float4 lds4[(LDS_F + 3) / 4];   // gene-table staging / reduction tiles / epilogue staging (4-wave combine), in turn
+  __shared__ float4 lds_w[PWI ? VC_WAVES * VC_PW_MAXCW : 1];      // pw_inline: W rows of this wave's cells
+  if (PWI && pw_on) {
+    float4* mine = lds_w + wave * VC_PW_MAXCW;
+    for (int i = lane; i < ncell; i += 64) mine[i] = reinterpret_cast<const float4*>(b.WT)[cbeg + i];
+  }
 
   // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
   v2f nu[K][NP], lb2[NP], ib[NP], gam[NP], rr[NP];
@@ -613,6 +627,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   auto flush = [&](long long cb, int n) {      // coalesced store of the staged per-cell sums of the last n <= 64 cells
+    if (PWI && pw_on) {
+      const float a3 = lane < n ? keep0 : 0.f;
+      const int iw = (int)(cb - cbeg) + (lane < n ? lane : 0);
+      const float4 w = lds_w[wave * VC_PW_MAXCW + iw];
+      pwacc[0] = __builtin_fmaf(a3, w.x, pwacc[0]); pwacc[1] = __builtin_fmaf(a3, w.y, pwacc[1]);
+      pwacc[2] = __builtin_fmaf(a3, w.z, pwacc[2]); pwacc[3] = __builtin_fmaf(a3, w.w, pwacc[3]);
+    }
     if (lane < n) {
       float* co = b.CO + ((size_t)gb * NCO) * d.Nc + cb + lane;
       co[0] = keep0 * CO_SCALE;
@@ -788,6 +809,18 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     if (q0 + RPP < NQ) __syncthreads();
   }
   if (threadIdx.x == 0) b.LO[blockIdx.x] = (sm_ll[0] + sm_ll[1]) + (sm_ll[2] + sm_ll[3]);
+  if (PWI && pw_on) {
+    __shared__ float sm_pw[VC_WAVES][VC_PWQ];
+#pragma unroll
+    for (int q = 0; q < VC_PWQ; ++q) {
+      const float t = vc_wave_sum(pwacc[q]);
+      if (lane == 0) sm_pw[wave][q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < VC_PWQ)
+      b.PWM[(size_t)blockIdx.x * VC_PWQ + threadIdx.x] =
+          ((sm_pw[0][threadIdx.x] + sm_pw[1][threadIdx.x]) + (sm_pw[2][threadIdx.x] + sm_pw[3][threadIdx.x])) * CO_SCALE;
+  }
   // fused pipeline (vc_svi_step_fused): nothing in this launch reads the device step counter, so it is advanced here;
   // the two launches that follow read s = t + 1 (= the 1-based optimiser step, = the index of the next sample)
   if (b.step_ctr && blockIdx.x == 0 && threadIdx.x == 0) {

@@ -8,6 +8,10 @@
 //   vc_fin           loss assembly in fp64, angular-speed gradients, loss header
 // Reference semantics restated: velocity_inference_guide.py:9-141, phase_inference_guide.py:10-56,
 // priors of velocity_inference_model.py:322-353,383 / phase_inference_model.py:360-366,392.
+// No compiler-chosen fused multiply-adds in this translation unit: the same source statement has to give the same bits in every
+// kernel it is inlined into (K_post / K_fin, K_tail / K_omega, the sharded phases, the merged tail launch) -- hipcc's contraction
+// of a * b + c depends on the surroundings of the statement.  Where a fused operation is wanted it is written as fmaf().
+#pragma clang fp contract(off)
 #include "vc_common.h"
 #include "vc_host_logic.h"     // VC_HIST_CAP
 
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
       const int nbk = d.with_dnu ? d.Nb : 0;
       vc_rec_put_omega(ct, d, omega, sk, ck);
       { const float cfs = b.cf[c] * vc_rec_cf_scale(d.noise); ct[2 * d.H + nbk + 1] = make_float2(cfs, cfs); }
+      vc_put_w(d, b, c, sk, ck);
       b.lat_phi[c] = phi;
       b.lat_omega[c] = omega;
       b.lat_domega[c] = domega;
@@ -749,11 +754,14 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
     for (int i = t; i < d.n_main_wg; i += 256) s -= (double)b.LO[i];   // loss = -loglik
     double u[2] = {0.0, 0.0};              // up to two coefficients per wave without a second round trip
     const int nw = d.model == VC_MODEL_VELOCITY ? d.NW : 0;
+    // the partials of d loglik / d nu_omega: K_post's cell blocks', or (pw_inline) K_main's workgroups'
+    const float* __restrict__ PWs = d.pw_inline ? b.PWM : b.PW;
+    const int n_pw = d.pw_inline ? d.n_main_wg : d.nb_post_cell, pw_ld = d.pw_inline ? VC_PWQ : d.NW;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int j = wv + 4 * q;
       if (j < nw)
-        for (int i = lane; i < d.nb_post_cell; i += 64) u[q] += (double)b.PW[(size_t)i * d.NW + j];
+        for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
     }
     s = vc_wave_sum_d(s);
     if (lane == 0) sm_lossw[wv] = s;
@@ -764,7 +772,7 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
     }
     for (int j = wv + 8; j < nw; j += 4) {          // more than 8 coefficients: the rest one after the other
       double r = 0.0;
-      for (int i = lane; i < d.nb_post_cell; i += 64) r += (double)b.PW[(size_t)i * d.NW + j];
+      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
       r = vc_wave_sum_d(r);
       if (lane == 0) sm_up[j] = (float)r;
     }
