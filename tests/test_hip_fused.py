@@ -54,6 +54,35 @@ def test_fused_step_equals_unfused_sequence(case):
     assert torch.equal(nz(a["p"]), nz(b["p"])) and np.array_equal(a["l"], b["l"])
 
 
+@pytest.mark.parametrize("mode,ncond", [("vcond", 1), ("vcond", 2), ("vcond_mf", 1)])
+def test_tutorial_flow_two_launch_step_equals_the_three_launch_step(mode, ncond, monkeypatch):
+    """Tutorial flow on one rank (U-only kernel, phases / nu / shape_inv conditioned): from the third step of a run on, K_tail's
+    gene blocks and K_omega's blocks go out as ONE launch (vc_launch_tail_merged) and K_tail's cell blocks not at all -- the
+    partials of d loglik / d nu_omega come from K_main (pw_inline).  The launch structure changes nothing: bit-identical
+    parameters, moments and losses after 25 steps (VC_TAIL_MERGED=0: three launches).  Against the cell blocks' own partial
+    sums (VC_PW_INLINE=0) only the association of one sum over the cells differs: equal to float32 rounding after 2 steps."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.workloads import make_velocity_spec
+    spec = make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5)
+    e = HipEngine(spec)
+    assert e.stats["main_kernel"].startswith("vc_main_kernel<1,") and "vu_" in e.stats["main_kernel"]
+    e.close()
+    two = _run(spec, "fused3", 25, False)
+    monkeypatch.setenv("VC_TAIL_MERGED", "0")
+    three = _run(spec, "fused3", 25, False)
+    nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+    assert np.array_equal(two["l"], three["l"]) and torch.equal(nz(two["p"]), nz(three["p"]))
+    assert torch.equal(nz(two["m"]), nz(three["m"])) and torch.equal(nz(two["v"]), nz(three["v"]))
+    assert two["sd"] == 25 and two["status"][0]
+    monkeypatch.delenv("VC_TAIL_MERGED")
+    a = _run(spec, "fused3", 2, False)
+    monkeypatch.setenv("VC_PW_INLINE", "0")
+    b = _run(spec, "fused3", 2, False)
+    assert np.allclose(a["l"], b["l"], rtol=2e-7, atol=0)
+    _same(a["p"], b["p"], "params after 2 steps", rtol=2e-6, atol=2e-7)
+    _same(a["g"][4:], b["g"][4:], "gradient of step 2", rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("mode,ncond,cw", [("vjoint", 1, "37"), ("vcond", 2, None), ("vjoint", 2, "29"), ("vcond_mf", 1, None)])
 def test_fused_step_medium_sizes(mode, ncond, cw, monkeypatch):
     """3001 (x n_conditions) cells x 300 genes: several gene blocks, many cell blocks, ragged tails, Nx = Nb = 2."""

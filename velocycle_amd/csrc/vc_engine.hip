@@ -100,6 +100,9 @@ struct vc_engine {
   long long gs = 0, cs = 0;          // strides of the host copies hS / hU
   long long dgs = 0, dcs = 0;        // strides of the dense device sources
   bool hist_each_step = false;
+  // tutorial flow: ordinary (three-launch) fused steps since the tables were last primed; from the third on the merged tail
+  // launch may be used (both halves of the loss terms K_tail's cell blocks write are then in place)
+  int plain_steps = 0;
   // optional hipEvent timing of the likelihood kernel (bench.py roofline)
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -1060,13 +1063,14 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
   if (prime && n_steps > 0) {   // sample the step *step_dev from the parameters as they are: tables, site values, prior terms
     vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 1, 0, VcXb{}, st);
     vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 1, with_hist, st);
+    e->plain_steps = 0;
   }
   VcBufs b2 = e->b;
   b2.step_ctr = (long long*)step_dev;
   b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l;
-  // Tutorial flow (U-only kernel with its own nu_omega partials, no histogram terms per step): from the third step of a call on,
-  // K_tail's gene blocks and K_omega's blocks go out as ONE launch (vc_launch_tail_merged: why that is safe); the first two
-  // steps fill both halves of the loss terms the absent cell blocks would have written.
+  // Tutorial flow (U-only kernel with its own nu_omega partials, no histogram terms per step): from the third step after the
+  // tables were primed, K_tail's gene blocks and K_omega's blocks go out as ONE launch (vc_launch_tail_merged: why that is
+  // safe); the first two steps fill both halves of the loss terms the absent cell blocks would have written.
   bool merged = e->d.pw_inline && e->d.kind == VC_KIND_VU && !with_hist && (e->d.cond >> VC_SITE_PHIXY & 1u);
   if (const char* env = getenv("VC_TAIL_MERGED")) merged = merged && atoi(env) != 0;
   for (int64_t i = 0; i < n_steps; ++i) {
@@ -1079,11 +1083,12 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
     } else {
       e->main_fn(e->d, b2, st);
     }
-    if (merged && i >= 2) {
+    if (merged && e->plain_steps >= 2) {
       vc_launch_tail_merged(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, st);
     } else {
       vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 0, VcXb{}, st);
       vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
+      if (e->plain_steps < 2) ++e->plain_steps;
     }
   }
   hipError_t err = hipGetLastError();
