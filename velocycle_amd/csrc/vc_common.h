@@ -29,8 +29,11 @@
 #endif                      // d loglik / d nu_omega[j] = sum_c A3_c W_cj come out of the likelihood kernel itself -- the sum is linear
                             // in the gene blocks' shares of A3, and the kernel holds those per cell when it stores them (lane = cell,
                             // 64 cells per flush); W = D[x,c] zeta_omega_h(phi_c) of the wave's cells waits in the LDS
-#define VC_PWQ 4            // coefficients the likelihood kernel carries (Nx * Nhw <= VC_PWQ, else K_tail's cell blocks do it)
-#define VC_PW_MAXCW 256     // ... and cells per wave it stages W for (4 waves x 256 cells x 16 bytes of LDS)
+#define VC_PWQ 8            // coefficients the likelihood kernel carries (Nx * Nhw <= VC_PWQ, else K_tail's cell blocks do it): rows of
+                            // 4 floats (pw_inline = 4) or 8 (pw_inline = 8: e.g. two samples x three harmonics of omega)
+#define VC_PW_SLOTS(gpl) ((gpl) == 8 ? 512 : 256)   // float4 slots per wave for the staged W rows (cells x float4 per row): 32 KB of
+                            // LDS per workgroup for the 8-genes-per-lane kernels (3 workgroups per CU), 16 KB for the 4-genes-per-
+                            // lane ones (small shards, 4-5 workgroups per CU)
 #ifndef VC_TILE_TABLE
 #define VC_TILE_TABLE 1     // likelihood kernel: a wave's cell range from the table vc_finalize wrote (one scalar load) instead of
 #endif                      // evaluating the tiling function itself
@@ -59,7 +62,8 @@ struct VcDims {
   long long cell_offset;  // global index of the first local cell
   int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
   int K;                  // Nh + Nb : expression-map coefficients per gene (harmonics, then batch offsets)
-  int pw_inline;          // 1: K_main (U-only kernel) writes PWM, K_omega / K_fin read it instead of the cell blocks' PW
+  int pw_inline;          // 4 | 8: K_main (U-only kernel) writes PWM rows of that many floats, K_omega / K_fin read them instead of the
+                          // cell blocks' PW; 0: off
   int ctw;                // floats per cell record: {x,x} pairs of [sin k, cos k]*H, Db[Nb], omega, cf, S+U kernel: [k omega cos k,
                           // k omega sin k]*H (padded); omega and cf carry the scale factors of vc_rec_*_scale
   int model, guide, noise, with_dnu;
@@ -134,8 +138,8 @@ struct VcBufs {
   float *LO;                                // likelihood partial per main workgroup
   double *LP;                               // loss partials of pre (nb_pre_gene + nb_pre_cell) and post_gene blocks
   float *PW;                                // [nb_post_cell][NW] partial angular-speed gradients
-  float *PWM;                               // [n_main_wg][VC_PWQ] the same partials, per workgroup of K_main (pw_inline)
-  float *WT;                                // [Nc][VC_PWQ] W_cj = D[x,c] zeta_omega_h(phi_c), j = x * Nhw + h (pw_inline; j >= NW: 0)
+  float *PWM;                               // [n_main_wg][pw_inline] the same partials, per workgroup of K_main
+  float *WT;                                // [Nc][pw_inline] W_cj = D[x,c] zeta_omega_h(phi_c), j = x * Nhw + h (j >= NW: 0)
   double *HL, *HD;                          // per histogram task: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
   double const_loss;                        // step-invariant part of the loss
   long long* status;                        // [0] number of steps with a non-finite loss, [1] 1 + index of the first one
@@ -187,7 +191,7 @@ __device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c
     for (int h = 0; h < 2 * VC_MAXH + 1; ++h)
       if (h < d.Nhw) {
         const float z = (h == 0) ? 1.f : ((h & 1) ? sk[(h - 1) >> 1] : ck[(h - 1) >> 1]);
-        b.WT[(size_t)c * VC_PWQ + xq * d.Nhw + h] = dx * z;
+        b.WT[(size_t)c * d.pw_inline + xq * d.Nhw + h] = dx * z;
       }
   }
 }

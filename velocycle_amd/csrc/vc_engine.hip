@@ -816,9 +816,12 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
   // tutorial flow on one rank: the angular-speed gradient partials come out of K_main (vc_common.h: VC_PW_INLINE)
-  d.pw_inline = (VC_PW_INLINE && d.kind == VC_KIND_VU && d.NW <= VC_PWQ && e->cfg.world_size == 1 && d.cw <= VC_PW_MAXCW &&
-                 d.pass_cw[0] <= VC_PW_MAXCW) ? 1 : 0;
-  if (const char* env = getenv("VC_PW_INLINE")) d.pw_inline = d.pw_inline && atoi(env) != 0;
+  {
+    const int row = d.NW <= 4 ? 4 : 8, cwmax = std::max(d.cw, d.pass_cw[0]);
+    const bool ok = VC_PW_INLINE && d.kind == VC_KIND_VU && d.NW <= VC_PWQ && e->cfg.world_size == 1 && cwmax * (row / 4) <= VC_PW_SLOTS(d.gpl);
+    d.pw_inline = ok ? row : 0;
+  }
+  if (const char* env = getenv("VC_PW_INLINE")) { if (atoi(env) == 0) d.pw_inline = 0; }
   TRY(e->dalloc(&b.PWM, (size_t)d.n_main_wg * VC_PWQ));
   HIPCHK(e, hipMemset(b.PWM, 0, sizeof(float) * (size_t)d.n_main_wg * VC_PWQ));
   TRY(e->dalloc(&b.WT, (size_t)VC_PWQ * d.Nc));

@@ -837,7 +837,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
   const bool pwm = phase != VC_PH_B && d.pw_inline;           // single rank, U-only kernel: K_main's own partials
   const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : (pwm ? b.PWM : b.PW);
   const int n_pw = phase == VC_PH_B ? xb.pw_cap : (pwm ? d.n_main_wg : d.nb_tail_cell);
-  const int pw_ld = pwm ? VC_PWQ : d.NW;
+  const int pw_ld = pwm ? d.pw_inline : d.NW;
   const float rw = phase == VC_PH_B ? 1.f : d.root_w;
   const int nw = d.NW;
   const int fin_per = lrmn ? d.R + 2 : 2;

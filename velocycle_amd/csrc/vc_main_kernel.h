@@ -372,10 +372,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   constexpr int GT_F = VC_GT_LDS ? (K + 3) * GBW : 0;                // the gene block's rows of the gene table, staged once per workgroup
   constexpr int LDS_F = (EPI_F > TILE_F ? EPI_F : TILE_F) > GT_F ? (EPI_F > TILE_F ? EPI_F : TILE_F) : GT_F;
   __shared__ float4 lds4[(LDS_F + 3) / 4];   // gene-table staging / reduction tiles / epilogue staging (4-wave combine), in turn
-  __shared__ float4 lds_w[PWI ? VC_WAVES * VC_PW_MAXCW : 1];      // pw_inline: W rows of this wave's cells
+  constexpr int PW_SLOTS = VC_PW_SLOTS(GPL);
+  __shared__ float4 lds_w[PWI ? VC_WAVES * PW_SLOTS : 1];      // pw_inline: W rows of this wave's cells
+  const int pw_rq = pw_on ? d.pw_inline / 4 : 1;      // float4 per W row: 1 or 2
   if (PWI && pw_on) {
-    float4* mine = lds_w + wave * VC_PW_MAXCW;
-    for (int i = lane; i < ncell; i += 64) mine[i] = reinterpret_cast<const float4*>(b.WT)[cbeg + i];
+    float4* mine = lds_w + wave * PW_SLOTS;
+    const float4* src = reinterpret_cast<const float4*>(b.WT) + (size_t)cbeg * pw_rq;
+    for (int i = lane; i < ncell * pw_rq; i += 64) mine[i] = src[i];
   }
 
   // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
@@ -630,9 +633,14 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     if (PWI && pw_on) {
       const float a3 = lane < n ? keep0 : 0.f;
       const int iw = (int)(cb - cbeg) + (lane < n ? lane : 0);
-      const float4 w = lds_w[wave * VC_PW_MAXCW + iw];
+      const float4 w = lds_w[wave * PW_SLOTS + iw * pw_rq];
       pwacc[0] = __builtin_fmaf(a3, w.x, pwacc[0]); pwacc[1] = __builtin_fmaf(a3, w.y, pwacc[1]);
       pwacc[2] = __builtin_fmaf(a3, w.z, pwacc[2]); pwacc[3] = __builtin_fmaf(a3, w.w, pwacc[3]);
+      if (pw_rq == 2) {
+        const float4 w1 = lds_w[wave * PW_SLOTS + iw * 2 + 1];
+        pwacc[4] = __builtin_fmaf(a3, w1.x, pwacc[4]); pwacc[5] = __builtin_fmaf(a3, w1.y, pwacc[5]);
+        pwacc[6] = __builtin_fmaf(a3, w1.z, pwacc[6]); pwacc[7] = __builtin_fmaf(a3, w1.w, pwacc[7]);
+      }
     }
     if (lane < n) {
       float* co = b.CO + ((size_t)gb * NCO) * d.Nc + cb + lane;
@@ -817,8 +825,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       if (lane == 0) sm_pw[wave][q] = t;
     }
     __syncthreads();
-    if (threadIdx.x < VC_PWQ)
-      b.PWM[(size_t)blockIdx.x * VC_PWQ + threadIdx.x] =
+    if ((int)threadIdx.x < d.pw_inline)
+      b.PWM[(size_t)blockIdx.x * d.pw_inline + threadIdx.x] =
           ((sm_pw[0][threadIdx.x] + sm_pw[1][threadIdx.x]) + (sm_pw[2][threadIdx.x] + sm_pw[3][threadIdx.x])) * CO_SCALE;
   }
   // fused pipeline (vc_svi_step_fused): nothing in this launch reads the device step counter, so it is advanced here;

@@ -756,7 +756,7 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
     const int nw = d.model == VC_MODEL_VELOCITY ? d.NW : 0;
     // the partials of d loglik / d nu_omega: K_post's cell blocks', or (pw_inline) K_main's workgroups'
     const float* __restrict__ PWs = d.pw_inline ? b.PWM : b.PW;
-    const int n_pw = d.pw_inline ? d.n_main_wg : d.nb_post_cell, pw_ld = d.pw_inline ? VC_PWQ : d.NW;
+    const int n_pw = d.pw_inline ? d.n_main_wg : d.nb_post_cell, pw_ld = d.pw_inline ? d.pw_inline : d.NW;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int j = wv + 4 * q;
