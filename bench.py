@@ -44,6 +44,19 @@ def baseline_metric():
         return "SVI steps/sec + ELBO-match, velocity_inference 50k cells\u00d72k genes, 1/2/4/8 GPU"
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from: the key that ties a committed PMC
+    pass (profiles/latest_traffic.json) to the code it was collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "velocycle_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")) or fn == "Makefile":
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +137,7 @@ def valu_bound(engine, kernel_avg_s, clock_mhz=None):
                       "alone on one SIMD (profiles/tools/valu_rate.hip, no loads, no cross-lane work)"}
 
 
-def kernel_roofline(engine, run, steps):
+def kernel_roofline(engine, run, steps, step_s=None):
     """Average duration of the likelihood kernel over `steps` eager SVI steps, from hipEvents recorded
     by the library on the launch stream around that kernel only."""
     saved_graph, saved_flag = run._graph, run.use_graph
@@ -139,11 +152,18 @@ def kernel_roofline(engine, run, steps):
     st = engine.stats
     achieved = st["algorithmic_bytes"] / avg_s / 1e9
     traffic, traffic_src = None, None
-    try:     # PMC numbers cannot be collected from inside the process: they come from the committed rocprofv3 passes
+    try:     # PMC numbers cannot be collected from inside the process: they come from the committed rocprofv3 passes, and
+        # only when that file was collected on THIS kernel (name) built from THESE sources (csrc hash) at this workload
         tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
         ent = tj["kernels"].get(st["main_kernel"])
-        if ent and tj.get("workload") == f"{engine.spec.Nc}x{engine.spec.Ng}" and engine.world_size == 1:
-            traffic, traffic_src = int(ent["traffic_bytes"]), "profiles/latest_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per gfx950 note)"
+        if (ent and tj.get("workload") == f"{engine.spec.Nc}x{engine.spec.Ng}" and engine.world_size == 1
+                and tj.get("csrc_sha16") == csrc_sha16()):
+            traffic = int(ent["traffic_bytes"])
+            traffic_src = ("profiles/latest_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per gfx950 "
+                           f"note; collected on kernel sources {tj['csrc_sha16']} = this build)")
+        elif ent:
+            traffic_src = ("none: profiles/latest_traffic.json was collected on other kernel sources "
+                           f"({tj.get('csrc_sha16')} vs this build {csrc_sha16()}) or another workload")
     except Exception:
         pass
     pipe = (traffic if traffic else st["streamed_bytes"]) / avg_s / 1e9
@@ -162,7 +182,12 @@ def kernel_roofline(engine, run, steps):
             vb["bound_us_at_in_loop_clock"] = round(b_us, 1)
             vb["frac_at_in_loop_clock"] = round(b_us / (avg_s * 1e6), 4)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            # the same algorithmic bytes against the WHOLE driver-timed step (likelihood kernel + the small launches around it):
+            # what a user of fit() gets, next to the kernel-level fraction
+            "step_frac": None if not step_s else round(st["algorithmic_bytes"] / step_s / 1e9 / HBM_PEAK_GBS, 4),
+            "step_overhead_us": None if not step_s else round((step_s - avg_s) * 1e6, 2),
+            "traffic": traffic, "traffic_source": traffic_src,
             "hbm_pipe_GBs": round(pipe, 1), "hbm_pipe_frac": round(pipe / HBM_PEAK_GBS, 4),
             "valu": vb,
             "kernel": st["main_kernel"], "kernel_avg_us": round(avg_s * 1e6, 2), "launches": int(n),
@@ -212,7 +237,9 @@ def cpu_baseline(args, mode, device=None):
 
         def one():
             eps = orc.draw_eps(p, gen)
-            _, grads, _, _ = orc.loss_and_grads(p, st["params"], eps)
+            loss, grads, _, _ = orc.loss_and_grads(p, st["params"], eps)
+            if "first" not in st:      # (params, eps, loss) of the first evaluation: the ELBO-match input at this size
+                st["first"] = ({k: v.detach().clone() for k, v in st["params"].items()}, eps, float(loss))
             st["params"] = opt.step(st["params"], grads)
         return one, st, gen
 
@@ -222,14 +249,20 @@ def cpu_baseline(args, mode, device=None):
     eps0 = orc.draw_eps(p_s, gen_s)
     loss_cpu, _, _, _ = orc.loss_and_grads(p_s, st_s["params"], eps0)
     elbo_match = None
-    if device is not None:
+
+    def hip_loss(spec, params, eps):
+        """-ELBO of the HIP engine (unfused kernel sequence, host eps) on exactly these parameters and draws."""
         from velocycle_amd.engine import HipEngine
-        eng = HipEngine(spec_s, device=device)
-        eng.set_params({k: v.float() for k, v in st_s["params"].items()})
-        eng.elbo_grad(eps=eng.pack_eps({k: v.float() for k, v in eps0.items() if not k.startswith("_")}))
+        eng = HipEngine(spec, device=device)
+        eng.set_params({k: v.float() for k, v in params.items()})
+        eng.elbo_grad(eps=eng.pack_eps({k: v.float() for k, v in eps.items() if not k.startswith("_")}))
         torch.cuda.synchronize(device)
-        loss_hip = eng.loss()
+        out = eng.loss()
         eng.close()
+        return out
+
+    if device is not None:
+        loss_hip = hip_loss(spec_s, st_s["params"], eps0)
         elbo_match = {"loss_hip": loss_hip, "loss_cpu_port": float(loss_cpu),
                       "rel_err": abs(loss_hip - float(loss_cpu)) / abs(float(loss_cpu)),
                       "note": f"one ELBO evaluation on the {n_small}-cell sample with identical params and eps; the port "
@@ -272,13 +305,23 @@ def cpu_baseline(args, mode, device=None):
     except Exception:
         avail = 0.0
     full = None
+    elbo_match_full = None
     if args.cells > n_mid and avail >= need:
-        _, p_f = problem(args.cells)
-        one_f, _, _ = stepper(p_f)
-        one_f()                                           # warm-up (allocator)
+        spec_f, p_f = problem(args.cells)
+        one_f, st_f, _ = stepper(p_f)
+        one_f()                                           # warm-up (allocator); its loss is kept for the ELBO-match
         nf, dtf = timed(one_f, 0.0, nmin=3, nmax=3)
         full = (nf, dtf)
-        del p_f, one_f
+        if device is not None:
+            # the metric's "ELBO-match" at the QUOTED configuration: the port's first full-size evaluation against the HIP
+            # engine on the same (params, eps) -- float32 on both sides
+            par_f, eps_f, loss_f = st_f["first"]
+            loss_hip_f = hip_loss(spec_f, par_f, eps_f)
+            elbo_match_full = {"cells": args.cells, "genes": args.genes, "loss_hip": loss_hip_f, "loss_cpu_port": loss_f,
+                               "rel_err": abs(loss_hip_f - loss_f) / abs(loss_f),
+                               "note": "one ELBO evaluation at the full benchmark size with identical params and eps (the "
+                                       "port's warm-up step); float32 on both sides"}
+        del p_f, one_f, st_f, spec_f
     torch.set_num_threads(default_nt)
     if full is not None:
         t_full = full[1] / full[0]
@@ -291,7 +334,7 @@ def cpu_baseline(args, mode, device=None):
         how = (f"first {n_mid} of {args.cells} cells x {args.genes} genes: {nm} steps in {dtm:.1f}s = {t_mid:.3f} s/step, scaled "
                f"LINEARLY in cells (the host has {avail / 2 ** 30:.0f} GiB available, the full size needs ~{need / 2 ** 30:.0f} GiB)")
     return {"value": round(1.0 / t_full, 4), "unit": "SVI steps/s", "cores": best_nt,
-            "kind": "port", "elbo_match": elbo_match, "cells_exponent": None if expo is None else round(expo, 3),
+            "kind": "port", "elbo_match": elbo_match, "elbo_match_full": elbo_match_full, "cells_exponent": None if expo is None else round(expo, 3),
             "sample": "oracle (op-by-op torch fp32 + autograd + ClippedAdam), " + how + f"; {best_nt} torch threads = fastest of "
                       f"sweep { {k: round(v, 3) for k, v in sweep.items()} } s/step on {n_mid} cells; host cpu_count={os.cpu_count()}"}
 
@@ -427,7 +470,7 @@ def main():
     losses = run.perf_losses()
     ok, first_bad, n_bad = eng.status()
     n_timed = args.warmup + args.steps * len(times)          # steps run up to the end of the last timed region
-    roof = kernel_roofline(eng, run, args.roofline_launches)
+    roof = kernel_roofline(eng, run, args.roofline_launches, dt / args.steps)
     if dist_on:
         roof["note"] = f"per-rank kernel on {eng.Nc_local} of {args.cells} cells"
     # "loss read back each step unless stated" -- the headline keeps the losses on the device and reads them
@@ -503,16 +546,18 @@ def main():
         for m in [x for x in ("vcond", "phase", "vjoint") if x != args.mode][:2]:
             s2, e2, r2, _ = build(m)
             ts2 = time_steps(r2, args.steps, args.warmup, False, device, args.repeats)
-            rf = kernel_roofline(e2, r2, args.roofline_launches)
-            extra[m] = {"steps_per_s": round(args.steps / median(ts2), 2), "kernel": rf["kernel"],
+            rf = kernel_roofline(e2, r2, args.roofline_launches, median(ts2) / args.steps)
+            extra[m] = {"steps_per_s": round(args.steps / median(ts2), 2), "ms_per_step": round(1e3 * median(ts2) / args.steps, 4),
+                        "kernel": rf["kernel"],
                         "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"],
-                        "hbm_frac": rf["frac"], "hbm_pipe_frac": rf["hbm_pipe_frac"], "valu_frac": (rf["valu"] or {}).get("frac"),
+                        "hbm_frac": rf["frac"], "step_frac": rf["step_frac"], "step_overhead_us": rf["step_overhead_us"], "hbm_pipe_frac": rf["hbm_pipe_frac"], "valu_frac": (rf["valu"] or {}).get("frac"),
                         "valu_frac_at_in_loop_clock": (rf["valu"] or {}).get("frac_at_in_loop_clock")}
             del s2, e2, r2
             torch.cuda.empty_cache()
         out["modes"] = extra
     if rank == 0 and not dist_on and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.mode, device)
+        out["elbo_match_full"] = out["cpu_baseline"].get("elbo_match_full")     # the metric's second half, at the quoted size
     if dist_on or solo_group:
         import torch.distributed as dist
         dist.barrier()

@@ -443,17 +443,21 @@ class ClippedAdam:
 
 
 def fit(p: Problem, optim_args: dict, num_steps: int, seed: Optional[int] = None,
-        eps_list=None, params=None, warmup_draw: bool = True, num_particles: int = 1):
+        eps_list=None, params=None, warmup_draw: bool = True, num_particles: int = 1, opt=None):
     """The SVI loop of `XFitModel.fit` with verbose=False, early_exit=False.  With `seed`, eps is
     drawn from a torch CPU generator in the reference's order, including (warmup_draw) the extra
     guide pass Trace_ELBO makes before its first step.  num_particles = K: `Trace_ELBO(num_particles=K)` -- K guide
     draws per step, one after the other, loss and gradients averaged over them before the optimiser step (the `loss=`
     argument of fit(), velocity_inference_model.py:79,111); eps_list then holds num_steps * K draws.
+    `params` + `opt` (a ClippedAdam that has stepped before) continue an earlier fit the way a second `fit()` does when the
+    param store was not cleared: `pyro.param(name, init)` returns the stored value (velocity_inference_guide.py:25-43,
+    phase_inference_guide.py:36-45) and PyroOptim keeps one optimiser state per parameter tensor, so the SAME optimizer object
+    carries its moments, step count and decayed learning rate on; a new optimizer object starts them afresh.
     Returns (losses, final unconstrained params)."""
     gen = None
     if seed is not None:
         gen = torch.Generator().manual_seed(seed)
-    opt = ClippedAdam(optim_args)
+    opt = ClippedAdam(optim_args) if opt is None else opt
     losses = []
     first = draw_eps(p, gen) if (eps_list is None and warmup_draw) else None
     K = int(num_particles)

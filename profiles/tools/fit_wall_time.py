@@ -63,6 +63,8 @@ with clock("handover_and_preprocess_velocity"):
     cond = {"ϕxy": pf.phase_pyro.phi_xy_tensor.T, "ν": pf.cycle_pyro.means_tensor.T.unsqueeze(-2),
             "shape_inv": torch.tensor(pf.disp_pyro).unsqueeze(-1)}
     spd = C.AngularSpeed.trivial_prior(condition_names=["all"], harmonics=0)
+    from velocycle_amd import pyro_compat as pyro
+    pyro.clear_param_store()                  # as the tutorials do between the stages (a fit() continues from the store)
     mv = P.preprocess_for_velocity_estimation(ad, pf.cycle_pyro, pf.phase_pyro, spd, torch.ones(Nc, 1), torch.ones(Nc, 1),
                                               n_harmonics=1, count_factor=mp.count_factor, ω_n_harmonics=0, condition_on=cond)
 with clock("velocity_fit_total"):

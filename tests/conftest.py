@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fresh_param_store():
+    """The param store is process-global, as Pyro's is: a fit() continues from whatever an earlier fit left there
+    (velocycle_amd/pyro_compat.py).  Tests are independent of each other: each starts with an empty store."""
+    try:
+        from velocycle_amd import pyro_compat
+        pyro_compat.clear_param_store()
+    except Exception:
+        pass
+    yield

@@ -411,7 +411,95 @@ def make_particles(seed=11, K=3, n=12):
         print(f"[fit K={K}] {name}: {n} steps, ref final loss {fitm.losses[-1]:.4f}, oracle {o_losses[-1]:.4f}")
 
 
+def _case_inputs(name, seed):
+    """(metaparams, condition dict, fit class, Problem64) of one CASES entry, built like make_case does."""
+    c = CASES[name]
+    d, ad, cyc, ph, Db = build_inputs(c["Nc"], c["Ng"], c["H"], c["nb"], seed)
+    Nc = ad.n_obs
+    rs = np.random.RandomState(seed + 1)
+    cond = {}
+    if c["kind"] == "phase":
+        mp = vc.preprocessing.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=c["H"], noisemodel=c["noise"],
+                                                              with_delta_nu=c["wdn"])
+        FitCls = vc.phase_inference_model.PhaseFitModel
+    else:
+        spd = vc.angularspeed.AngularSpeed.trivial_prior(condition_names=[f"b{i}" for i in range(c["nb"])], harmonics=c["Hw"])
+        if c["Hw"] == 1:
+            spd.stds.loc["nu1_cos"] = [0.05] * c["nb"]
+            spd.stds.loc["nu1_sin"] = [0.05] * c["nb"]
+        cf = torch.tensor(np.log(ad.layers["spliced"].sum(1) / ad.layers["spliced"].sum(1).mean())).float()[None, None, :]
+        for site in c.get("cond", []):
+            if site == "ϕxy":
+                cond[site] = ph.phi_xy_tensor.T + torch.tensor(0.05 * rs.randn(Nc, 2)).float()
+            elif site == "ν":
+                cond[site] = cyc.means_tensor.T.unsqueeze(-2) + torch.tensor(0.05 * rs.randn(c["Ng"], 1, 2 * c["H"] + 1)).float()
+            elif site == "shape_inv":
+                cond[site] = torch.tensor(rs.uniform(0.2, 1.0, (c["Ng"], 1))).float()
+        mp = vc.preprocessing.preprocess_for_velocity_estimation(
+            ad, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=c["H"], ω_n_harmonics=c["Hw"], count_factor=cf,
+            noisemodel=c["noise"], with_delta_nu=c["wdn"], condition_on=cond, model_type=c.get("model_type", "lrmn"))
+        FitCls = vc.velocity_inference_model.VelocityFitModel
+    return mp, cond, FitCls, orc.problem_from_metaparams(mp, c["kind"], cond, dtype=torch.float64)
+
+
+def make_continue(seed=11, n=10):
+    """A second `fit()` WITHOUT `pyro.clear_param_store()` in between: the guides' `pyro.param(name, init)` return the stored
+    values (velocity_inference_guide.py:25-43, phase_inference_guide.py:36-45), so the optimisation continues; the reference's
+    own comment at velocity_inference_model.py:79 plans exactly that (two fits, another ELBO object for the second).  Two
+    scenarios per case, both run by the reference's own fit drivers:
+      same   the SAME optimizer and ELBO objects again: moments, step count and the decayed learning rate carry on, and the
+             used ELBO object makes no extra guide pass;
+      new    a NEW optimizer and a NEW Trace_ELBO object: parameters carry on, optimiser state and learning-rate schedule
+             start afresh, and the fresh ELBO object makes its extra guide pass (one eps set drawn and discarded).
+    The global RNG is re-seeded before the second fit (the posterior draws at the end of the first fit consume it in a way
+    that is not part of the path).  -> ref_fit_continue_<case>.npz"""
+    for name in ("vel_mf_joint", "phase_nb", "vel_lrmn_cond"):
+        mp, cond, FitCls, p64 = _case_inputs(name, seed)
+        p32 = p64.to(torch.float32)
+        opt_args = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1 / (2 * n)), "betas": (0.80, 0.99)}
+        fo = problem_arrays(p32)
+        for scen in ("same", "new"):
+            fitm = FitCls(mp, condition_on=cond, num_samples=4, n_per_bin=2)
+            pyro.clear_param_store()
+            opt1, elbo1 = pyro.optim.ClippedAdam(dict(opt_args)), pyro.infer.Trace_ELBO(num_particles=1)
+            torch.manual_seed(seed)
+            fitm.fit(opt1, loss=elbo1, num_steps=n, verbose=False)
+            l1 = list(fitm.losses)
+            par1, _ = ref_params_canonical(p32)
+            opt2, elbo2 = (opt1, elbo1) if scen == "same" else (pyro.optim.ClippedAdam(dict(opt_args)), pyro.infer.Trace_ELBO(num_particles=1))
+            torch.manual_seed(seed + 1)
+            fitm.fit(opt2, loss=elbo2, num_steps=n, verbose=False)              # NO clear_param_store in between
+            l2 = list(fitm.losses)
+            par2, _ = ref_params_canonical(p32)
+            # the oracle, told the same story
+            oopt = orc.ClippedAdam(opt_args)
+            ol1, opar1 = orc.fit(p32, opt_args, n, seed=seed, opt=oopt)
+            check(ol1, l1, f"{name}/{scen}: first fit losses", 1e-4, 1e-2)
+            ol2, opar2 = orc.fit(p32, opt_args, n, seed=seed + 1, params={k: v.clone() for k, v in opar1.items()},
+                                 warmup_draw=(scen == "new"), opt=(oopt if scen == "same" else None))
+            check(ol2, l2, f"{name}/{scen}: second fit losses", 1e-4, 1e-2)
+            for k in par2:
+                check(opar2[k], par2[k], f"{name}/{scen}: fitted {k}", 2e-3, 2e-3)
+            o64 = orc.ClippedAdam(opt_args)
+            l64a, par64a = orc.fit(p64, opt_args, n, seed=seed, opt=o64)
+            l64b, par64b = orc.fit(p64, opt_args, n, seed=seed + 1, params={k: v.clone() for k, v in par64a.items()},
+                                   warmup_draw=(scen == "new"), opt=(o64 if scen == "same" else None))
+            fo.update({f"{scen}_reffit1_" + k: v.numpy() for k, v in par1.items()})
+            fo.update({f"{scen}_reffit2_" + k: v.numpy() for k, v in par2.items()})
+            fo.update({f"{scen}_fit64_" + k: v.numpy() for k, v in par64b.items()})
+            fo[f"{scen}_ref_losses1"], fo[f"{scen}_ref_losses2"] = np.array(l1), np.array(l2)
+            fo[f"{scen}_losses64_1"], fo[f"{scen}_losses64_2"] = np.array(l64a), np.array(l64b)
+            print(f"[continue/{scen}] {name}: {n}+{n} steps, ref losses {l1[-1]:.4f} -> {l2[0]:.4f} .. {l2[-1]:.4f}, oracle {ol2[-1]:.4f}")
+        fo.update(num_steps=np.array(n), seed=np.array(seed))
+        for k, v in opt_args.items():
+            fo["opt_" + k] = np.array(v)
+        np.savez_compressed(os.path.join(OUT, f"ref_fit_continue_{name}.npz"), **fo)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["--continue"]:
+        make_continue()
+        sys.exit(0)
     if sys.argv[1:] == ["--particles"]:
         make_particles()
         sys.exit(0)

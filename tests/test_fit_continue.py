@@ -1,0 +1,152 @@
+"""GPU: a second fit() WITHOUT pyro.clear_param_store() continues the optimisation, as the reference does -- its guides'
+`pyro.param(name, init)` return the stored value (velocity_inference_guide.py:25-43, phase_inference_guide.py:36-45) and
+PyroOptim keeps one optimiser state per parameter tensor, so the SAME optimizer object carries moments / step count / decayed
+learning rate on while a new one starts afresh (the comment at velocity_inference_model.py:79 plans such a two-part fit).
+Pinned by the reference's own fit drivers run twice (tests/golden/make_golden.py --continue -> ref_fit_continue_<case>.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.test_fit_api import _close, _objects, _opt
+
+pytestmark = pytest.mark.gpu
+
+
+def _metaparams(z):
+    from velocycle_amd import containers as C, preprocessing as P
+    from velocycle_amd.fit_models import PhaseFitModel, VelocityFitModel
+    ad, cyc, ph, Db = _objects(z)
+    if str(z["in_kind"]) == "phase":
+        mp = P.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=int(z["in_H"]), with_delta_nu=False)
+        return mp, {}, PhaseFitModel
+    Hw = int(z["in_Hw"])
+    spd = C.AngularSpeed.from_array(z["in_mu_nuw"].T if Hw else z["in_mu_nuw"].reshape(-1),
+                                    z["in_sd_nuw"].T if Hw else z["in_sd_nuw"].reshape(-1), ["b0"], Nhω=2 * Hw + 1)
+    cond = {}
+    for k, v in z.items():
+        if k.startswith("cond_"):
+            name, t = k[5:], torch.tensor(v)
+            cond[name] = {"ν": lambda t: t.unsqueeze(-2), "shape_inv": lambda t: t.unsqueeze(-1)}.get(name, lambda t: t)(t)
+    mp = P.preprocess_for_velocity_estimation(
+        ad, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=int(z["in_H"]), ω_n_harmonics=Hw,
+        count_factor=torch.tensor(z["in_count_factor"])[None, None, :], with_delta_nu=False, condition_on=cond,
+        model_type="lrmn" if str(z["in_guide"]) == "lrmn" else "normal")
+    return mp, cond, VelocityFitModel
+
+
+def _fitted(fit, z, prefix):
+    par = fit.engine.named()
+    for k, v in par.items():
+        want = z[prefix + k]
+        got = v.detach().cpu().numpy().reshape(want.shape)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin), k
+        assert np.allclose(got[fin], want[fin], rtol=2e-3, atol=2e-3), (k, np.abs(got[fin] - want[fin]).max())
+
+
+@pytest.mark.parametrize("case", ["vel_mf_joint", "phase_nb", "vel_lrmn_cond"])
+@pytest.mark.parametrize("scen", ["same", "new"])
+def test_second_fit_continues_from_the_param_store(case, scen):
+    from velocycle_amd import pyro_compat as pyro
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fit_continue_{case}.npz")
+    mp, cond, Cls = _metaparams(z)
+    n, seed = int(z["num_steps"]), int(z["seed"])
+    fit = Cls(mp, condition_on=cond, num_samples=4, n_per_bin=2)
+    pyro.clear_param_store()
+    opt1, elbo1 = _opt(z), pyro.infer.Trace_ELBO(num_particles=1)
+    fit.fit(opt1, loss=elbo1, num_steps=n, verbose=False, mode="parity", seed=seed)
+    assert np.allclose(fit.losses, z[f"{scen}_ref_losses1"], rtol=1e-4, atol=1e-2)
+    _fitted(fit, z, f"{scen}_reffit1_")
+    opt2, elbo2 = (opt1, elbo1) if scen == "same" else (_opt(z), pyro.infer.Trace_ELBO(num_particles=1))
+    fit.fit(opt2, loss=elbo2, num_steps=n, verbose=False, mode="parity", seed=seed + 1)       # NO clear_param_store
+    assert np.allclose(fit.losses, z[f"{scen}_ref_losses2"], rtol=1e-4, atol=1e-2), (fit.losses, z[f"{scen}_ref_losses2"])
+    _fitted(fit, z, f"{scen}_reffit2_")
+    # the continuation is visible: the first loss of the second fit is not the first loss of a fresh fit
+    assert abs(fit.losses[0] - z[f"{scen}_ref_losses1"][0]) > 1e-3 * abs(fit.losses[0])
+    # a NEW model object of the same layout continues too (the store is global, by name) ...
+    fit_b = Cls(mp, condition_on=cond, num_samples=4, n_per_bin=2)
+    fit_b.fit(_opt(z), loss=pyro.infer.Trace_ELBO(num_particles=1), num_steps=2, verbose=False, mode="parity", seed=seed + 2)
+    assert abs(fit_b.losses[0] - z[f"{scen}_ref_losses1"][0]) > 1e-3 * abs(fit_b.losses[0])
+    # ... and clear_param_store() restarts from the guides' initial values
+    pyro.clear_param_store()
+    fit_c = Cls(mp, condition_on=cond, num_samples=4, n_per_bin=2)
+    fit_c.fit(_opt(z), loss=pyro.infer.Trace_ELBO(num_particles=1), num_steps=n, verbose=False, mode="parity", seed=seed)
+    assert np.allclose(fit_c.losses, z[f"{scen}_ref_losses1"], rtol=1e-4, atol=1e-2)
+
+
+def test_perf_mode_two_fits_equal_one_long_fit():
+    """mode="perf" (fused step, Philox eps): fit(n) + fit(n) with the SAME optimizer object and seed continues the very
+    trajectory of fit(2n) -- parameters, moments, step count, learning-rate schedule, Philox stream and the losses, bit for
+    bit -- because everything the step reads is carried over."""
+    from velocycle_amd import pyro_compat as pyro
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fit_continue_vel_mf_joint.npz")
+    mp, cond, Cls = _metaparams(z)
+    n = 12
+    pyro.clear_param_store()
+    long = Cls(mp, condition_on=cond, get_posterior=False)
+    long.fit(_opt(z), num_steps=2 * n, verbose=False, mode="perf", seed=5)
+    want = {k: v.detach().cpu().clone() for k, v in long.engine.named().items()}
+    pyro.clear_param_store()
+    two = Cls(mp, condition_on=cond, get_posterior=False)
+    opt = _opt(z)
+    two.fit(opt, num_steps=n, verbose=False, mode="perf", seed=5)
+    first = list(two.losses)
+    two.fit(opt, num_steps=n, verbose=False, mode="perf", seed=5)
+    assert len(two.losses) == n and first + list(two.losses) == list(long.losses)
+    for k, v in two.engine.named().items():
+        assert torch.equal(v.detach().cpu(), want[k]), k
+    assert two._runner.adam_impl == "fused3"
+
+
+def test_a_store_of_another_layout_is_refused_like_pyro_shape_mismatch():
+    from velocycle_amd import pyro_compat as pyro
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fit_continue_phase_nb.npz")
+    mp, cond, Cls = _metaparams(z)
+    pyro.clear_param_store()
+    Cls(mp, num_samples=2, n_per_bin=2).fit(_opt(z), num_steps=2, verbose=False, mode="parity", seed=1)
+    z2 = H.load_fixture(f"{H.GOLDEN}/ref_fit_continue_vel_mf_joint.npz")          # same gene count? no: another data set
+    mp2, cond2, Cls2 = _metaparams(z2)
+    if int(mp2.Nc) == int(mp.Nc) and int(mp2.Ng) == int(mp.Ng):
+        pytest.skip("fixtures share their sizes")
+    with pytest.raises(RuntimeError, match="clear_param_store"):
+        Cls2(mp2, condition_on=cond2, num_samples=2, n_per_bin=2).fit(_opt(z2), num_steps=2, verbose=False, mode="parity", seed=1)
+
+
+def test_mixed_step_counts_follow_per_parameter_optimisers():
+    """The same optimizer object used for a phase fit and then (store not cleared) for a velocity fit of the same data: ν_locs,
+    ϕxy_locs, shape_inv_locs continue with their step count, the velocity-only parameters start at step 0 -- PyroOptim keeps
+    one optimiser per parameter.  Held against the closed form on one element."""
+    from velocycle_amd import pyro_compat as pyro
+    from velocycle_amd.svi import FlatClippedAdam
+    opt = FlatClippedAdam(4, {"lr": 0.1, "lrd": 0.9, "betas": (0.5, 0.5)}, "cuda:0")
+    opt.t_vec = torch.tensor([0.0, 0.0, 3.0, 3.0], dtype=torch.float64, device="cuda:0")
+    p = torch.zeros(4, device="cuda:0")
+    g = torch.ones(4, device="cuda:0")
+    opt.step(p, g)
+    # m = 0.5, v = 0.5 after one step from zero moments; step size lr0 lrd^t sqrt(1 - b2^t) / (1 - b1^t)
+    def ss(t):
+        return 0.1 * 0.9 ** t * np.sqrt(1 - 0.5 ** t) / (1 - 0.5 ** t)
+    upd = 0.5 / (np.sqrt(0.5) + 1e-8)
+    assert np.allclose(p.cpu().numpy(), [-ss(1) * upd] * 2 + [-ss(4) * upd] * 2, rtol=1e-6)
+    # end to end: phase fit, then a velocity fit with the same optimizer object and an uncleared store runs (mixed counts ->
+    # the torch optimiser with per-element schedules) and starts from the phase fit's ν_locs
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fit_continue_vel_mf_joint.npz")
+    mpv, cond, ClsV = _metaparams(z)
+    from velocycle_amd import preprocessing as P
+    from velocycle_amd.fit_models import PhaseFitModel
+    ad, cyc, ph, Db = _objects(z)
+    mpp = P.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=int(z["in_H"]), with_delta_nu=False)
+    pyro.clear_param_store()
+    o = _opt(z)
+    pf = PhaseFitModel(mpp, num_samples=2, n_per_bin=2)
+    pf.fit(o, num_steps=5, verbose=False, mode="perf", seed=1)
+    nu_after_phase = pf.engine.named()["ν_locs"].detach().cpu().clone()
+    vf = ClsV(mpv, condition_on=cond, get_posterior=False)
+    vf.fit(o, num_steps=1, verbose=False, mode="perf", seed=2)
+    assert vf._runner.adam_impl == "torch" and vf._runner.opt.t_vec is not None
+    st = o._vc_state["names"]
+    assert st["ν_locs"]["t"] == 6 and st["logγg_locs"]["t"] == 1
+    # one small optimiser step away from where the phase fit left ν_locs (not from the prior means)
+    d_cont = (vf.engine.named()["ν_locs"].detach().cpu() - nu_after_phase).abs().max()
+    assert d_cont < 0.2

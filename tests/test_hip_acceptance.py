@@ -125,6 +125,8 @@ def test_perf_mode_tutorial_flow_recovers_two_sample_speeds():
     cond = {"ϕxy": pf.phase_pyro.phi_xy_tensor.T, "ν": pf.cycle_pyro.means_tensor.T.unsqueeze(-2),
             "Δν": torch.tensor(pf.delta_nus), "shape_inv": torch.tensor(pf.disp_pyro).unsqueeze(-1)}
     spd = C.AngularSpeed.trivial_prior(condition_names=["s0", "s1"], harmonics=0)
+    from velocycle_amd import pyro_compat as pyro
+    pyro.clear_param_store()                              # as the tutorials do between the two stages
     mv = P.preprocess_for_velocity_estimation(ad, pf.cycle_pyro, pf.phase_pyro, spd, Db.float(), Db.float(), n_harmonics=1,
                                               count_factor=mp.count_factor, ω_n_harmonics=0, condition_on=cond)
     vf = VelocityFitModel(mv, condition_on=cond, num_samples=200, n_per_bin=50)

@@ -297,6 +297,16 @@ def test_engine_owned_rccl_exchange_single_rank():
             assert r.adam_impl == ("sharded" if kw else "fused3") and r.exchange == ("engine" if kw else None) and not r.use_graph
             r.run_perf(10)
             outs.append((e.params.clone().cpu(), r.perf_losses(), e.status()))
+            if kw:
+                # fit() keeps the engine and builds a new SVIRunner per call -- the second runner must find the
+                # engine's communicator (idempotent set-up), not fall back to the torch exchange with a warning
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("error")
+                    r2 = SVIRunner(e, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=12, init=False, **kw)
+                assert r2.exchange == "engine"
+                r2.run_perf(3)
+                assert all(np.isfinite(r2.perf_losses())) and e.status()[0]
             e.close()
         a, b = outs[0][0].double().numpy(), outs[1][0].double().numpy()
         fin = np.isfinite(b)

@@ -190,7 +190,7 @@ def test_gene_selection_copies_only_the_layers_that_are_read():
     keep = [genes[7], genes[2], genes[9]]
     sub = ad[:, keep].copy()
     assert list(sub.var.index) == keep and sub.shape == (50, 3)
-    assert not dict.__contains__(sub.layers, "logS") and "logS" in sub.layers          # present, not materialised
+    assert "logS" not in sub.layers._d and "logS" in sub.layers                        # present, not materialised
     assert np.array_equal(sub.layers["unspliced"], U[:, [7, 2, 9]]) and np.array_equal(sub.X, S[:, [7, 2, 9]])
     sub.layers["unspliced"][0, 0] = -1.0
     assert ad.layers["unspliced"][0, 7] == U[0, 7]                                     # a copy, not a view
@@ -201,6 +201,36 @@ def test_gene_selection_copies_only_the_layers_that_are_read():
     assert again is sub                                                               # already owns its data
     rows = ad[[3, 1], keep]
     assert np.array_equal(rows.layers["spliced"], S[np.ix_([3, 1], [7, 2, 9])])
+
+
+def test_lazy_layers_never_leak_a_placeholder_and_copy_keeps_them_lazy():
+    """ADVICE r3 (anndata_lite.py): `adata.layers` is a MutableMapping, so dict(layers), {**layers}, copy(), pop(),
+    setdefault() and items() all hand out arrays, never the `_LazyLayer` placeholder of an entry that was installed lazily;
+    AnnDataLite.copy() carries such an entry over unbuilt (the memory saving the class exists for)."""
+    from velocycle_amd.anndata_lite import _LazyLayer
+    rng = np.random.default_rng(1)
+    S, U = rng.poisson(2.0, (20, 6)).astype(np.float32), rng.poisson(1.0, (20, 6)).astype(np.float32)
+    built = []
+
+    def make():
+        built.append(1)
+        return np.log(S.astype(np.float64) + 1)
+    ad = AnnDataLite(S, U)
+    ad.layers.set_lazy("logS", make)
+    cp = ad.copy()
+    assert built == [] and isinstance(cp.layers._raw("logS"), _LazyLayer)          # copy(): still lazy on both sides
+    assert np.array_equal(cp.layers["spliced"], S) and cp.layers["spliced"] is not ad.layers["spliced"]
+    lc = ad.layers.copy()
+    assert built == [] and isinstance(lc._raw("logS"), _LazyLayer)
+    for view in (dict(ad.layers), {**ad.layers}, dict(ad.layers.items())):
+        assert set(view) == {"spliced", "unspliced", "logS"}
+        assert all(isinstance(v, np.ndarray) for v in view.values())
+    assert len(built) == 1                                                          # built once, then cached
+    assert isinstance(lc.setdefault("logS", None), np.ndarray) and isinstance(lc.pop("logS"), np.ndarray)
+    assert "logS" not in lc and "logS" in ad.layers
+    assert np.array_equal(cp.layers["logS"], ad.layers["logS"])
+    sub = ad[:, list(ad.var.index)[:2]]
+    assert all(isinstance(v, np.ndarray) for v in dict(sub.layers).values()) and sub.layers["logS"].shape == (20, 2)
 
 
 def test_csr_side_channel_is_dropped_when_the_dense_counts_were_replaced_or_edited():

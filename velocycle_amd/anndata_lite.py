@@ -4,6 +4,8 @@ touch (reference velocycle/preprocessing.py:20-63,124-154,241-268): `.layers[...
 `anndata.AnnData` objects are accepted everywhere this class is."""
 from __future__ import annotations
 
+from collections.abc import MutableMapping
+
 import numpy as np
 import pandas as pd
 
@@ -40,7 +42,13 @@ class AnnDataLite:
         if isinstance(self.layers, _SelectedLayers):      # a fresh adata[cells, genes]: its layers are copies already
             return self
         out = AnnDataLite.__new__(AnnDataLite)
-        out.layers = _Layers({k: (v.copy() if _is_sparse(v) else np.array(v, copy=True)) for k, v in self.layers.items()})
+        out.layers = _Layers()
+        for k in self.layers.keys():
+            v = self.layers._raw(k) if isinstance(self.layers, _Layers) else self.layers[k]
+            if isinstance(v, _LazyLayer):                  # not built yet: the copy builds its own when somebody reads it
+                out.layers.set_lazy(k, v.fn)
+            else:
+                out.layers[k] = v.copy() if _is_sparse(v) else np.array(v, copy=True)
         out.var = self.var.copy()
         out.obs = self.obs.copy()
         out.X = out.layers["spliced"]
@@ -71,57 +79,72 @@ class AnnDataLite:
         pass
 
 
-class _Layers(dict):
-    """`adata.layers`: a dict whose entries may be installed lazily (`set_lazy(key, fn)`: built when first read) -- the
-    float64 logS / logU layers that `preprocess_for_*` leave behind are 800 MB each at 50 000 x 2 000 and are read by plots
-    only."""
-
-    def set_lazy(self, key, fn):
-        dict.__setitem__(self, key, _LazyLayer(fn))
-
-    def __getitem__(self, k):
-        v = dict.__getitem__(self, k)
-        if isinstance(v, _LazyLayer):
-            v = v.fn()
-            dict.__setitem__(self, k, v)
-        return v
-
-    def get(self, k, default=None):
-        return self[k] if k in self else default
-
-    def items(self):
-        return [(k, self[k]) for k in self.keys()]
-
-    def values(self):
-        return [self[k] for k in self.keys()]
-
-
 class _LazyLayer:
     def __init__(self, fn):
         self.fn = fn
 
 
-class _SelectedLayers(dict):
+class _Layers(MutableMapping):
+    """`adata.layers`: a mapping whose entries may be installed lazily (`set_lazy(key, fn)`: built when first read) -- the
+    float64 logS / logU layers that `preprocess_for_*` leave behind are 800 MB each at 50 000 x 2 000 and are read by plots
+    only.  A MutableMapping (not a dict subclass): every way of reading an entry -- `[]`, get, items, values, pop, setdefault,
+    dict(layers), {**layers}, copy() -- goes through `__getitem__`, so a placeholder never leaks out."""
+
+    def __init__(self, init=None):
+        self._d = {}
+        if init is not None:
+            for k in init.keys():
+                self._d[k] = init._raw(k) if isinstance(init, _Layers) else init[k]
+
+    def set_lazy(self, key, fn):
+        self._d[key] = _LazyLayer(fn)
+
+    def _raw(self, k):
+        """The stored entry, a `_LazyLayer` placeholder included (copies of the mapping carry those over unbuilt)."""
+        return self._d[k]
+
+    def __getitem__(self, k):
+        v = self._d[k]
+        if isinstance(v, _LazyLayer):
+            v = v.fn()
+            self._d[k] = v
+        return v
+
+    def __setitem__(self, k, v):
+        self._d[k] = v
+
+    def __delitem__(self, k):
+        del self._d[k]
+
+    def __iter__(self):
+        return iter(self._d)
+
+    def __len__(self):
+        return len(self._d)
+
+    def __contains__(self, k):
+        return k in self._d
+
+    def __repr__(self):
+        return "Layers(" + ", ".join(repr(k) + (" (lazy)" if isinstance(v, _LazyLayer) else "") for k, v in self._d.items()) + ")"
+
+    def copy(self):
+        """Shallow copy like dict.copy(); lazily installed entries stay lazy."""
+        return _Layers(self)
+
+    def __reduce__(self):
+        return (_Layers, (dict(self),))          # pickling materialises: a closure does not travel
+
+
+class _SelectedLayers(_Layers):
     """Layers of adata[cells, genes]: every layer is selected (= copied) the first time it is read, so that layers nobody
     asks for -- the float64 logS / logU a phase preprocess left behind, 800 MB each at 50 000 x 2 000 -- are never copied."""
 
     def __init__(self, parent, ridx, cidx):
         super().__init__()
         # (a snapshot of the parent's entries; lazily installed ones stay lazy until this selection reads them)
-        self._parent = {k: dict.__getitem__(parent, k) if isinstance(parent, dict) else parent[k] for k in parent.keys()}
+        self._parent = {k: (parent._raw(k) if isinstance(parent, _Layers) else parent[k]) for k in parent.keys()}
         self._ridx, self._cidx = np.asarray(ridx), np.asarray(cidx)
-
-    def set_lazy(self, key, fn):
-        dict.__setitem__(self, key, _LazyLayer(fn))
-
-    def __getitem__(self, k):
-        if dict.__contains__(self, k):
-            v = dict.__getitem__(self, k)
-            if isinstance(v, _LazyLayer):
-                v = v.fn()
-                dict.__setitem__(self, k, v)
-            return v
-        return self.__missing__(k)
 
     def _take(self, v):
         if isinstance(v, _LazyLayer):
@@ -133,28 +156,42 @@ class _SelectedLayers(dict):
             return np.take(v, self._cidx, axis=1)        # all cells: one gather along the genes
         return v[np.ix_(self._ridx, self._cidx)]
 
-    def __missing__(self, k):
-        v = self._take(self._parent[k])                   # KeyError if the parent has no such layer either
-        dict.__setitem__(self, k, v)
-        return v
+    def _raw(self, k):
+        if k in self._d:
+            return self._d[k]
+        parent_entry = self._parent[k]                    # KeyError if the parent has no such layer either
+        return _LazyLayer(lambda: self._take(parent_entry))
+
+    def __getitem__(self, k):
+        if k not in self._d:
+            self._d[k] = self._take(self._parent[k])      # KeyError if the parent has no such layer either
+        return super().__getitem__(k)
+
+    def __delitem__(self, k):
+        found = False
+        if k in self._d:
+            del self._d[k]
+            found = True
+        if k in self._parent:
+            del self._parent[k]
+            found = True
+        if not found:
+            raise KeyError(k)
 
     def __contains__(self, k):
-        return dict.__contains__(self, k) or k in self._parent
-
-    def keys(self):
-        return list(dict.fromkeys(list(self._parent) + list(dict.keys(self))))
+        return k in self._d or k in self._parent
 
     def __iter__(self):
-        return iter(self.keys())
+        return iter(dict.fromkeys(list(self._parent) + list(self._d)))
 
     def __len__(self):
-        return len(self.keys())
+        return len(dict.fromkeys(list(self._parent) + list(self._d)))
 
-    def items(self):
-        return [(k, self[k]) for k in self.keys()]
+    def copy(self):
+        return _Layers(self)
 
-    def values(self):
-        return [self[k] for k in self.keys()]
+    def __reduce__(self):
+        return (_Layers, (dict(self),))
 
 
 def _is_sparse(x):

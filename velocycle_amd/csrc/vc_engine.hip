@@ -59,6 +59,7 @@ struct vc_engine {
   VcP2p p2p{};
   void* p2p_own = nullptr;            // this rank's region (hipMalloc, IPC-exported)
   bool p2p_connected = false;
+  int p2p_mem_kind = -1;              // 0 fine-grained, 1 uncached, 2 plain hipMalloc (vc_p2p_alloc)
   long long p2p_step = 0;             // steps exchanged so far: slot parity and flag value, identical on every rank
   double p2p_timeout_s = 2.0;
   VcDims d{};
@@ -578,7 +579,11 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
           hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
         if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
         const int ngb8 = (d.Ng + 511) / 512;
-        const VcTiling t8 = vc_tile_cells(d.Nc, ngb8, n_cu, bpc8, VC_WAVES, 0, nullptr, 12);
+        // decided from a RANK-INVARIANT cell count (the largest balanced shard): balanced shards differ by one cell, and two
+        // ranks on opposite sides of the threshold would disagree on Ng_pad -- and with it on the exchange buffer's layout
+        const long long world = e->cfg.world_size, ncg = e->cfg.Nc_global > 0 ? e->cfg.Nc_global : d.Nc;
+        const int shard_cells = world > 1 ? (int)((ncg + world - 1) / world) : d.Nc;
+        const VcTiling t8 = vc_tile_cells(shard_cells, ngb8, n_cu, bpc8, VC_WAVES, 0, nullptr, 12);
         const int small_cw = d.kind == VC_KIND_VFULL ? 52 : 10;
         if (t8.cw <= small_cw) d.gpl = 4;
       }
@@ -1149,11 +1154,25 @@ extern "C" int vc_p2p_alloc(vc_engine* e, void* ipc_handle_out) {
   p.flag_words = p.world * 16;                                   // one 64-byte line per flag
   p.slot_floats = (e->xb_total + 15) / 16 * 16;
   const size_t bytes = ((size_t)p.flag_words + 2 * (size_t)p.slot_floats) * sizeof(float);
-  HIPCHK(e, hipMalloc(&e->p2p_own, bytes));
-  HIPCHK(e, hipMemset(e->p2p_own, 0, bytes));
-  HIPCHK(e, hipDeviceSynchronize());
+  // Fine-grained device memory: peers raise the flags with remote stores and the owner polls them in LOCAL memory; on
+  // coarse-grained memory (plain hipMalloc) the owner's L2 may keep serving the old line until a kernel boundary.
+  // Tried in this order: fine-grained, uncached, plain (the last only so that a driver without IPC for the first two still
+  // runs the opt-in path; p2p_mem_kind says which one the region got)
+  const unsigned kinds[3] = {hipDeviceMallocFinegrained, hipDeviceMallocUncached, hipDeviceMallocDefault};
   hipIpcMemHandle_t h;
-  HIPCHK(e, hipIpcGetMemHandle(&h, e->p2p_own));
+  hipError_t last = hipSuccess;
+  for (int k = 0; k < 3 && !e->p2p_own; ++k) {
+    void* ptr = nullptr;
+    last = hipExtMallocWithFlags(&ptr, bytes, kinds[k]);
+    if (last != hipSuccess) { (void)hipGetLastError(); continue; }
+    last = hipMemset(ptr, 0, bytes);
+    if (last == hipSuccess) last = hipDeviceSynchronize();
+    if (last == hipSuccess) last = hipIpcGetMemHandle(&h, ptr);
+    if (last != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); continue; }
+    e->p2p_own = ptr;
+    e->p2p_mem_kind = k;
+  }
+  if (!e->p2p_own) return e->fail(VC_ERR_HIP, "vc_p2p_alloc: no IPC-exportable region: %s", hipGetErrorString(last));
   memcpy(ipc_handle_out, &h, sizeof h);
   if (const char* env = getenv("VC_P2P_TIMEOUT_S")) { if (atof(env) > 0.0) e->p2p_timeout_s = atof(env); }
   return VC_OK;

@@ -15,10 +15,14 @@
 // Two slots suffice: a rank can start writing slot p again (step s + 2) only after its K_xchg(s + 1) has seen every peer's
 // flag s + 2, which a peer raises after its phase A(s + 1), i.e. after its reads of step s.
 // The kernel boundary in front of K_xchg is what makes phase A's plain stores visible to the peers (end-of-kernel release);
-// the flag stores are system-scope atomics.  The wait is BOUNDED (a peer that died must not hang the device): on time-out the
-// kernel records it in status[2] and the sum proceeds on whatever is there -- vc_get_status reports VC_ERR_STATE.
-// Correctness across processes is tested with two processes on one device (tests/test_hip_p2p.py); across xGMI it cannot be
-// tested or timed on a 1-GPU box: default stays RCCL, this path is opt-in (VC_EXCHANGE=p2p).
+// the flag stores are system-scope atomics, and the region is FINE-GRAINED device memory (vc_p2p_alloc: hipExtMallocWithFlags),
+// so that a peer's remote store of a flag is not shadowed by a line the owner's L2 keeps serving while it polls (coarse-grained
+// memory is only guaranteed coherent at kernel boundaries).  The wait is BOUNDED (a peer that died must not hang the device): on
+// time-out the kernel records it in status[2], SKIPS the sum and poisons the step instead -- NaN into every element of the
+// exchange buffer, so that the loss of this step is NaN, the device-side latch fires and the run stops on bad data instead of
+// optimising on partial sums -- vc_get_status reports VC_ERR_STATE.
+// Correctness across processes is tested with two processes on one device (tests/test_hip_multiproc.py); across xGMI it cannot
+// be tested or timed on a 1-GPU box: default stays RCCL, this path is opt-in (VC_EXCHANGE=p2p).
 #include "vc_common.h"
 
 #define VC_P2P_FLAG_STRIDE 16      // 64-byte line per flag (in 4-byte words)
@@ -48,8 +52,14 @@ __global__ __launch_bounds__(256) void vc_p2p_xchg_kernel(VcP2p p, long long ste
   __atomic_thread_fence(__ATOMIC_ACQUIRE);         // system scope: nothing of the peers' slots may come from a stale line
   const size_t slot_off = (size_t)p.flag_words + (size_t)(step & 1) * (size_t)p.slot_floats;
   const long long n4 = n / 4;
+  const bool dead = !sm_ok;              // block-uniform: this block gave up on a peer
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dead) {                          // poison instead of a partial sum
+      const float qn = __builtin_nanf("");
+      reinterpret_cast<float4*>(out)[i] = make_float4(qn, qn, qn, qn);
+      continue;
+    }
     for (int q = 0; q < p.world; ++q) {
       const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.region[q]) + slot_off) + i;
       float4 v;

@@ -312,6 +312,10 @@ class HipEngine:
         id is made by group rank 0 through the library and broadcast with torch.distributed (any backend).  Returns True
         when EVERY rank succeeded (agreed by a MIN all-reduce), else False on every rank."""
         import torch.distributed as dist
+        # idempotent: the engine is kept across fit() calls and every fit() builds a new SVIRunner; the communicator made
+        # by the first one is the engine's for its lifetime.  (Every rank made it together, so every rank returns here together.)
+        if getattr(self, "_rccl_ready", False):
+            return True
         path = self.rccl_path().encode()
         ok = 1
         ident = [None]
@@ -343,13 +347,16 @@ class HipEngine:
         # ... and agree on the outcome
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
-        return bool(int(flag.item()))
+        self._rccl_ready = bool(int(flag.item()))
+        return self._rccl_ready
 
     def init_p2p_exchange(self, process_group=None) -> bool:
         """The one-shot peer-to-peer exchange (vc_p2p_alloc / vc_p2p_connect): this rank's region is created and exported,
         the 64-byte IPC handles of all ranks are gathered in rank order with torch.distributed (any backend), the peers'
         regions are mapped.  Returns True when EVERY rank is connected (MIN all-reduce), else False on every rank."""
         import torch.distributed as dist
+        if getattr(self, "_p2p_ready", False):       # idempotent, like init_rccl_comm: one region per engine
+            return True
         buf = (C.c_char * 64)()
         rc = self.lib.vc_p2p_alloc(self._h, buf)
         mine = bytes(buf.raw) if rc == _lib.VC_OK else None
@@ -366,7 +373,8 @@ class HipEngine:
         flag = torch.tensor([ok], dtype=torch.int32,
                             device=self.device if dist.get_backend(process_group) == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
-        return bool(int(flag.item()))
+        self._p2p_ready = bool(int(flag.item()))
+        return self._p2p_ready
 
     def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
         """Fused HIP ClippedAdam on flat float32 buffers (same stream); optionally files the (all-reduced) loss

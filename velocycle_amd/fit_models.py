@@ -97,6 +97,9 @@ class _FitBase:
         if loss is not None and getattr(loss, "vectorize_particles", False):
             raise NotImplementedError("Trace_ELBO(vectorize_particles=True) is not supported by the HIP engine")
         exact = mode == "parity" or self.early_exit or store_output
+        # continue-from-store (pyro_compat): parameters the store still holds are the starting values, and an optimizer OBJECT
+        # that stepped on them before carries its moments / step counts on
+        plan = self._continuation_plan(optimizer)
         if mode == "parity":
             gen_seed = seed
             if gen_seed is None and self._world > 1:
@@ -116,12 +119,14 @@ class _FitBase:
         else:
             s = int(torch.initial_seed() % (2 ** 63)) if seed is None else int(seed)
             s = broadcast_int(s, self._pg, eng.device)
-            run = SVIRunner(eng, args, mode="perf", seed=s, process_group=self._pg, num_particles=particles)
+            run = SVIRunner(eng, args, mode="perf", seed=s, process_group=self._pg, num_particles=particles,
+                            adam_impl="torch" if plan["mixed"] else None)
         self._runner = run
+        t_first = self._apply_continuation(run, plan)
         losses, intermediate_output = [], []
         if mode == "perf" and not exact:
             run.run_perf(num_steps)
-            losses = run.perf_losses()
+            losses = run.perf_losses()[t_first:]
         else:
             early = False
             for step in range(num_steps):
@@ -147,6 +152,7 @@ class _FitBase:
             warnings.warn("Encountered NaN/Inf: loss" + ("" if ok else f" (first at step {first_bad}, {n_bad} steps)"),
                           UserWarning)
         self._extract()
+        self._remember_optimizer_state(optimizer, run, plan, len(losses))
         t_extract = time.perf_counter()
         if self.get_posterior:
             self._posterior()
@@ -157,25 +163,112 @@ class _FitBase:
             return intermediate_output
 
     # ------------------------------------------------------------------------------------------
+    _PYRO_SHAPES = staticmethod(lambda sp: {
+        "ν_locs": (sp.Ng, 1, sp.Nh), "ν_scales": (sp.Ng, 1, sp.Nh), "ϕxy_locs": (sp.Nc, 2),
+        "shape_inv_locs": (sp.Ng, 1), "logγg_locs": (sp.Ng, 1), "logγg_scales": (sp.Ng, 1),
+        "logβg_locs": (sp.Ng, 1), "logβg_scales": (sp.Ng, 1), "νω_locs": (sp.Nx, sp.Nhw, 1, 1),
+        "νω_scales": (sp.Nx, sp.Nhw, 1, 1),
+        "Δν_locs": (sp.Nb, sp.Ng, 1) if sp.kind == "phase" else (sp.Nb, 1, 1, sp.Ng, 1)})
+
+    def _unconstrained_host(self) -> Dict[str, torch.Tensor]:
+        """The engine's parameters as CPU tensors of the full problem (ϕxy_locs, the only rank-local block, gathered
+        once: SURVEY.md §8e), unconstrained as Pyro stores them."""
+        return {k: (self._gather(v, 0) if k == "ϕxy_locs" else v.detach().cpu().clone()) for k, v in self.engine.named().items()}
+
     def _constrained(self) -> Dict[str, torch.Tensor]:
         from ._lib import POSITIVE_PARAMS
-        out = {}
-        for k, v in self.engine.named().items():
-            # ϕxy_locs is the only rank-local block: gather the shards once at the end
-            v = self._gather(v, 0) if k == "ϕxy_locs" else v.detach().cpu().clone()
-            out[k] = v.exp() if k in POSITIVE_PARAMS else v
-        return out
+        self._raw_params = self._unconstrained_host()
+        return {k: (v.exp() if k in POSITIVE_PARAMS else v) for k, v in self._raw_params.items()}
 
     def _publish(self, par):
-        """Fill the param store with Pyro's names and shapes."""
-        sp = self.spec
-        shp = {"ν_locs": (sp.Ng, 1, sp.Nh), "ν_scales": (sp.Ng, 1, sp.Nh), "ϕxy_locs": (sp.Nc, 2),
-               "shape_inv_locs": (sp.Ng, 1), "logγg_locs": (sp.Ng, 1), "logγg_scales": (sp.Ng, 1),
-               "logβg_locs": (sp.Ng, 1), "logβg_scales": (sp.Ng, 1), "νω_locs": (sp.Nx, sp.Nhw, 1, 1),
-               "νω_scales": (sp.Nx, sp.Nhw, 1, 1),
-               "Δν_locs": (sp.Nb, sp.Ng, 1) if sp.kind == "phase" else (sp.Nb, 1, 1, sp.Ng, 1)}
+        """Fill the param store with Pyro's names and shapes (and, beside it, the raw values a later fit() continues from)."""
+        shp = self._PYRO_SHAPES(self.spec)
         for k, v in par.items():
-            pyro_compat._STORE[k] = v.reshape(shp.get(k, v.shape))
+            pyro_compat.publish(k, v.reshape(shp.get(k, v.shape)), self._raw_params[k])
+
+    # ---- continue-from-store (reference: velocity_inference_guide.py:25-43, phase_inference_guide.py:36-45) -------------
+    def _continuation_plan(self, optimizer) -> dict:
+        """Which of this model's parameters the param store still holds (they are the starting values of this fit, as
+        `pyro.param(name, init)` returns the stored value), and what the optimizer object remembers about them: PyroOptim
+        keeps one torch optimiser per parameter TENSOR, so the same optimizer object passed again carries moments, step
+        count and decayed learning rate on, a new object (or a cleared store: new tensors) starts afresh."""
+        from ._lib import POSITIVE_PARAMS
+        eng, sp = self.engine, self.spec
+        values, steps = {}, {}
+        state = getattr(optimizer, "_vc_state", None) if not isinstance(optimizer, dict) else None
+        if state is not None and state.get("generation") != pyro_compat.generation():
+            state = None
+        for name in eng.param_slices:
+            u = pyro_compat.stored_unconstrained(name, name in POSITIVE_PARAMS)
+            steps[name] = 0
+            if u is None:
+                continue
+            full = (sp.Nc, 2) if name == "ϕxy_locs" else eng.param_shape(name)
+            want = 1
+            for n in full:
+                want *= int(n)
+            if u.numel() != want:
+                raise RuntimeError(
+                    f"pyro.param({name!r}) in the param store holds {u.numel()} values, this model's guide needs {want} "
+                    f"{tuple(full)}: the store belongs to another model / data set -- call pyro.clear_param_store() before this fit()")
+            values[name] = u.reshape(full)
+            if state is not None and name in state["names"]:
+                steps[name] = int(state["names"][name]["t"])
+        ts = set(steps.values())
+        return {"values": values, "steps": steps, "state": state, "mixed": len(ts) > 1, "t0": (ts.pop() if len(ts) == 1 else 0)}
+
+    def _apply_continuation(self, run, plan) -> int:
+        """Puts the stored parameters / optimiser state into the freshly initialised runner; returns the index of this fit's
+        first step in the runner's counters (perf mode: Philox step, loss ring slot and ClippedAdam step count are one
+        device counter)."""
+        eng = self.engine
+        if not plan["values"]:
+            return 0
+        eng.set_params(plan["values"])
+        run.invalidate()
+        st, h = plan["state"], eng.header
+        if st is not None:
+            for name, (off, n) in eng.param_slices.items():
+                ent = st["names"].get(name)
+                if ent is None or name not in plan["values"]:
+                    continue
+                m, v = ent["m"], ent["v"]
+                if name == "ϕxy_locs" and m.shape[0] != eng.Nc_local:
+                    m, v = m[eng.c0:eng.c1], v[eng.c0:eng.c1]
+                run.opt.m[off - h:off - h + n].copy_(m.reshape(-1).to(eng.device))
+                run.opt.v[off - h:off - h + n].copy_(v.reshape(-1).to(eng.device))
+        if plan["mixed"]:
+            tv = torch.zeros(eng.total - h, dtype=torch.float64, device=eng.device)
+            for name, (off, n) in eng.param_slices.items():
+                tv[off - h:off - h + n] = float(plan["steps"][name])
+            run.opt.t_vec = tv
+            return 0
+        t0 = int(plan["t0"])
+        run.opt.t = t0
+        if run.mode == "perf":
+            run.step_idx = t0
+            run.step_dev.fill_(t0)
+        return t0 if run.mode == "perf" else 0
+
+    def _remember_optimizer_state(self, optimizer, run, plan, steps_done: int):
+        """After the fit: per parameter name the moments and the step count, kept ON the optimizer object (dict arguments
+        have no identity to carry state)."""
+        if isinstance(optimizer, dict):
+            return
+        eng, h = self.engine, self.engine.header
+        st = plan["state"] or {"generation": pyro_compat.generation(), "names": {}}
+        for name, (off, n) in eng.param_slices.items():
+            m = run.opt.m[off - h:off - h + n].reshape(eng.param_shape(name))
+            v = run.opt.v[off - h:off - h + n].reshape(eng.param_shape(name))
+            if name == "ϕxy_locs":
+                m, v = self._gather(m, 0), self._gather(v, 0)
+            else:
+                m, v = m.detach().cpu().clone(), v.detach().cpu().clone()
+            st["names"][name] = {"m": m, "v": v, "t": plan["steps"][name] + int(steps_done)}
+        try:
+            optimizer._vc_state = st
+        except Exception:
+            pass
 
     def _extract(self):
         sp = self.spec

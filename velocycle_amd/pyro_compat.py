@@ -7,10 +7,21 @@ from typing import Dict
 import torch
 
 _STORE: Dict[str, torch.Tensor] = {}
+# What Pyro's store really holds is the UNCONSTRAINED tensor (the constrained value is a transform of it): the values a
+# later fit() continues from, exactly as the last fit left them (canonical engine shape, CPU), next to the published object
+# they belong to -- if the user has replaced `_STORE[name]` since, the raw copy no longer describes it and is not used.
+_RAW: Dict[str, dict] = {}
+# clear_param_store() starts a new generation of parameter tensors: optimiser state kept on an optimizer object refers to
+# the tensors of the generation it was made in (PyroOptim keys its per-parameter optimisers by the tensor)
+_GENERATION = [0]
 
 
 def clear_param_store():
+    """`pyro.clear_param_store()`: the next fit() starts from the guides' initial values again, and optimizer objects that
+    stepped on the old parameters start afresh on the new ones."""
     _STORE.clear()
+    _RAW.clear()
+    _GENERATION[0] += 1
 
 
 def get_param_store():
@@ -19,6 +30,28 @@ def get_param_store():
 
 def param(name):
     return _STORE[name]
+
+
+def generation() -> int:
+    return _GENERATION[0]
+
+
+def publish(name: str, constrained: torch.Tensor, unconstrained: torch.Tensor):
+    """Called by fit(): the fitted parameter under Pyro's name and shape, and the raw values a later fit() continues from."""
+    _STORE[name] = constrained
+    _RAW[name] = {"u": unconstrained, "pub": constrained}
+
+
+def stored_unconstrained(name: str, positive: bool):
+    """The unconstrained values of a stored parameter (flat), or None when the store has no such name: the raw copy of the
+    last fit when `_STORE[name]` is still the object that fit published, else derived from whatever the user put there."""
+    if name not in _STORE:
+        return None
+    raw = _RAW.get(name)
+    if raw is not None and raw["pub"] is _STORE[name]:
+        return raw["u"].reshape(-1)
+    v = torch.as_tensor(_STORE[name]).detach().float().cpu().reshape(-1)
+    return v.log() if positive else v
 
 
 class Trace_ELBO:

@@ -74,6 +74,17 @@ class FlatClippedAdam:
         self.m.lerp_(g, 1.0 - self.b1)
         self.v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
         denom = self.v.sqrt().add_(self.eps)
+        if getattr(self, "t_vec", None) is not None:
+            # per-element step counts (a fit that continues SOME parameters of an earlier one with the same optimizer object,
+            # pyro_compat: PyroOptim keeps one step count per parameter tensor): the schedule of each element is its own
+            self.t += 1
+            self.t_vec += 1.0
+            tv = self.t_vec
+            step = self.lr0 * torch.pow(torch.tensor(self.lrd, dtype=torch.float64, device=tv.device), tv) * \
+                torch.sqrt(1.0 - torch.pow(torch.tensor(self.b2, dtype=torch.float64, device=tv.device), tv)) / \
+                (1.0 - torch.pow(torch.tensor(self.b1, dtype=torch.float64, device=tv.device), tv))
+            p.sub_((self.m / denom) * step.float())
+            return
         if not self.capturable:
             self.t += 1
             lr = self.lr0 * self.lrd ** self.t
@@ -174,7 +185,10 @@ class SVIRunner:
             import torch.distributed as dist
             want = exchange or os.environ.get("VC_EXCHANGE")
             if want is None:
-                want = "engine" if (self.world > 1 and dist.get_backend(process_group) == "nccl" and not self.use_graph) else "torch"
+                if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+                    want = "none"              # one rank, no process group: nothing to sum, nobody to call all_reduce on
+                else:
+                    want = "engine" if (self.world > 1 and dist.get_backend(process_group) == "nccl" and not self.use_graph) else "torch"
             if want == "engine":
                 if not (self.do_reduce and dist.get_backend(process_group) == "nccl"):
                     raise ValueError("exchange='engine' needs a process group on the nccl (RCCL) backend")
@@ -262,6 +276,7 @@ class SVIRunner:
         all-reduce (cells sharded) and one optimiser step."""
         e, K = self.e, self.K
         acc = torch.zeros_like(e.grad)
+        lacc = torch.zeros((), dtype=torch.float64, device=e.grad.device)
         for k in range(K):
             if eps_list is not None:
                 eps = eps_list[k]
@@ -270,8 +285,10 @@ class SVIRunner:
             else:
                 eps = draw_eps(e.spec, self.gen)
             e.elbo_grad(eps=e.pack_eps(eps), step=self.step_idx * K + k)
-            acc += e.grad                      # header included: loss hi / lo average like everything else
+            acc += e.grad
+            lacc += e.grad[:2].double().sum()          # the loss header is a float hi / lo pair: averaged in float64
         e.grad.copy_(acc / K)
+        self._put_loss_header(lacc / K)
         self._reduce()
         loss = float(e.grad[:2].double().sum().item())
         self._update()
@@ -279,16 +296,26 @@ class SVIRunner:
         self.losses.append(loss)
         return loss
 
+    def _put_loss_header(self, loss64: torch.Tensor):
+        """grad[0:2] = the float hi / lo split of a float64 loss (what K_fin writes): hi / K rounded on its own would lose
+        ~6e-8 |hi| of the double-float pair."""
+        hi = loss64.float()
+        self.e.grad[0] = hi
+        self.e.grad[1] = (loss64 - hi.double()).float()
+
     def _perf_particles(self, n_steps: int):
         """perf mode with K particles: per step the unfused kernel sequence on the Philox streams (seed, step * K + k),
         averaged on the device; losses stay in the device ring."""
         e, K = self.e, self.K
         for _ in range(n_steps):
             acc = torch.zeros_like(e.grad)
+            lacc = torch.zeros((), dtype=torch.float64, device=e.grad.device)
             for k in range(K):
                 e.elbo_grad(eps=None, seed=self.seed, step=self.step_idx * K + k)
                 acc += e.grad
+                lacc += e.grad[:2].double().sum()
             e.grad.copy_(acc / K)
+            self._put_loss_header(lacc / K)
             self._reduce()
             self.loss_hist[self.step_idx] = e.grad[:2].double().sum()
             self._update()
