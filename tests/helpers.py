@@ -10,7 +10,9 @@ from velocycle_amd.spec import ModelSpec
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STEP_CASES = sorted(os.path.basename(p)[len("ref_step_"):-4] for p in glob.glob(os.path.join(GOLDEN, "ref_step_*.npz")))
-FIT_CASES = sorted(os.path.basename(p)[len("ref_fit_"):-4] for p in glob.glob(os.path.join(GOLDEN, "ref_fit_*.npz")))
+FIT_CASES = sorted(os.path.basename(p)[len("ref_fit_"):-4] for p in glob.glob(os.path.join(GOLDEN, "ref_fit_*.npz"))
+                   if not os.path.basename(p).startswith("ref_fit_continue_"))
+CONTINUE_CASES = sorted(os.path.basename(p)[len("ref_fit_continue_"):-4] for p in glob.glob(os.path.join(GOLDEN, "ref_fit_continue_*.npz")))
 
 _TENSOR_FIELDS = ["S", "U", "count_factor", "Db", "D", "mu_nu", "sd_nu", "phixy_prior", "mu_gamma", "sd_gamma",
                   "mu_beta", "sd_beta", "mu_nuw", "sd_nuw"]

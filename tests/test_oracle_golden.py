@@ -46,6 +46,28 @@ def test_oracle_fit_matches_reference_fixture(case):
         assert np.allclose(v.numpy()[fin], want[fin], rtol=2e-3, atol=2e-3), k
 
 
+@pytest.mark.parametrize("case", H.CONTINUE_CASES)
+@pytest.mark.parametrize("scen", ["same", "new"])
+def test_oracle_continued_fit_matches_reference_fixture(case, scen):
+    """Two fits without clearing the param store (make_golden.py --continue): the oracle told the same story -- stored
+    parameters as the start, the SAME optimiser carrying its state on ("same") or a fresh one plus the fresh ELBO object's
+    extra guide pass ("new") -- against the reference's own losses and fitted parameters of both fits."""
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fit_continue_{case}.npz")
+    p = H.problem_from_fixture(z, torch.float32)
+    opt = {"lr": float(z["opt_lr"]), "lrd": float(z["opt_lrd"]), "betas": tuple(float(x) for x in z["opt_betas"])}
+    n, seed = int(z["num_steps"]), int(z["seed"])
+    o = orc.ClippedAdam(opt)
+    l1, par1 = orc.fit(p, opt, n, seed=seed, opt=o)
+    assert np.allclose(l1, z[f"{scen}_ref_losses1"], rtol=1e-4, atol=1e-2)
+    l2, par2 = orc.fit(p, opt, n, seed=seed + 1, params={k: v.clone() for k, v in par1.items()}, warmup_draw=(scen == "new"),
+                       opt=(o if scen == "same" else None))
+    assert np.allclose(l2, z[f"{scen}_ref_losses2"], rtol=1e-4, atol=1e-2)
+    for k, v in par2.items():
+        want = z[f"{scen}_reffit2_" + k]
+        fin = np.isfinite(want)
+        assert np.allclose(v.numpy()[fin], want[fin], rtol=2e-3, atol=2e-3), k
+
+
 def test_oracle_rejects_unknown_noise_model():
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_phase_nb.npz")
     p = H.problem_from_fixture(z)
