@@ -165,6 +165,11 @@ typedef struct vc_stats {
   int64_t count_storage_bytes;    /* bytes per count element in HBM: 2 (uint16: every count an integer <= 65535) or 4 */
   int32_t pass_cells[4];          /* cells per wave of the likelihood kernel's workgroups in dispatch pass 0..3 (all equal:
                                      balanced tiling; falling: the older passes take larger shares) */
+  int32_t launches_per_step;      /* kernel launches of one steady-state step of vc_svi_run_fused on this engine: 2 or 3 */
+  int32_t pw_inline;              /* floats per row of the likelihood kernel's own d loglik / d nu_omega partials (4 | 8), 0: off */
+  int32_t generic;                /* 1: the run-time-sized (slower) kernel set is in use: a configuration outside the compiled
+                                     fast set (H > 3, > 4 batches, LRMN rank > 8, > 64 angular-speed coefficients) */
+  int32_t reserved1;
 } vc_stats;
 
 /* lifecycle ------------------------------------------------------------------------------- */

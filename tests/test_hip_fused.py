@@ -228,3 +228,90 @@ def test_fused_step_with_large_shard_cell_blocks(mode, monkeypatch):
     assert a["sd"] == b["sd"] == 6 and a["status"][0] and b["status"][0]
     assert np.allclose(a["l"], b["l"], rtol=2e-7, atol=0)
     _same(a["p"], b["p"], "params", rtol=2e-4, atol=2e-5)
+
+
+def _bits_equal(a, b, what):
+    nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+    assert np.array_equal(a["l"], b["l"]), (what, "losses", np.abs(a["l"] / b["l"] - 1).max())
+    for k in ("p", "m", "v"):
+        assert torch.equal(nz(a[k]), nz(b[k])), (what, k, (nz(a[k]) - nz(b[k])).abs().max())
+    assert torch.equal(nz(a["g"][4:]), nz(b["g"][4:])), (what, "g")
+    assert a["sd"] == b["sd"] and a["status"][0] and b["status"][0]
+
+
+@pytest.mark.parametrize("case", H.STEP_CASES)
+def test_two_launch_step_equals_three_launch_step_on_the_fixtures(case, monkeypatch):
+    """Round 4: every single-rank step in TWO launches (vc_launch_tail2: K_tail's gene blocks, its cell blocks with the nu_omega
+    chain inside on K_main's own partials, the loss block, the histogram blocks re-deriving the shape_inv update, the eps
+    blocks -- side by side).  The launch structure changes nothing: parameters, moments, gradients AND losses bit for bit equal
+    to the three-launch step (VC_TAIL2=0) after 15 steps, on every model / guide / noise / conditioning of the step fixtures."""
+    from velocycle_amd.engine import HipEngine
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
+    spec = H.spec_from_fixture(z)
+    e = HipEngine(spec)
+    assert e.stats["launches_per_step"] == 2, e.stats          # every fixture is small enough for K_main's own partials
+    e.close()
+    two = _run(spec, "fused3", 15, False)
+    monkeypatch.setenv("VC_TAIL2", "0")
+    monkeypatch.setenv("VC_TAIL_MERGED", "0")
+    e = HipEngine(spec)
+    assert e.stats["launches_per_step"] == 3
+    e.close()
+    three = _run(spec, "fused3", 15, False)
+    _bits_equal(two, three, case)
+
+
+@pytest.mark.parametrize("mode,ncond,cw,tc", [("vjoint", 1, "37", None), ("vjoint", 2, "29", None), ("phase", 1, "41", None),
+                                              ("vjoint", 1, None, "1024"), ("phase", 1, None, "1024"), ("vjoint", 2, None, None)])
+def test_two_launch_step_medium_sizes(mode, ncond, cw, tc, monkeypatch):
+    """The same at 3001 (x n_conditions) cells x 300 genes -- several gene blocks, many cell blocks, ragged tiles, two samples
+    (6 angular-speed coefficients: rows of 8 floats), 1024-cell blocks -- over 25 steps, and through a hipGraph replay."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
+    if cw:
+        monkeypatch.setenv("VC_CELLS_PER_WAVE", cw)
+    if tc:
+        monkeypatch.setenv("VC_TAIL_TC", tc)
+    spec = make_phase_spec(3001, 300, seed=5) if mode == "phase" else make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5)
+    e = HipEngine(spec)
+    assert e.stats["launches_per_step"] == 2 and (mode == "phase" or e.stats["pw_inline"] == (4 if ncond == 1 else 8)), e.stats
+    e.close()
+    two = _run(spec, "fused3", 25, False)
+    two_g = _run(spec, "fused3", 25, True)
+    monkeypatch.setenv("VC_TAIL2", "0")
+    three = _run(spec, "fused3", 25, False)
+    _bits_equal(two, three, f"{mode} x{ncond}")
+    _bits_equal(two_g, three, f"{mode} x{ncond} (graph)")
+    if mode != "phase":
+        # ... and against the cell blocks' own partial sums of d loglik / d nu_omega (VC_PW_INLINE=0: three launches, nothing
+        # from K_main): only the association of one sum over the cells differs -- float32 rounding after 2 steps
+        monkeypatch.delenv("VC_TAIL2")
+        a = _run(spec, "fused3", 2, False)
+        monkeypatch.setenv("VC_PW_INLINE", "0")
+        b = _run(spec, "fused3", 2, False)
+        assert np.allclose(a["l"], b["l"], rtol=2e-7, atol=0)
+        _same(a["p"], b["p"], "params after 2 steps", rtol=2e-6, atol=2e-7)
+        _same(a["g"][4:], b["g"][4:], "gradient of step 2", rtol=1e-5, atol=1e-5)
+
+
+def test_two_launch_step_resumes_and_mixes_with_step_with_loss():
+    """Checkpoint / resume into a new engine and run_perf mixed with step_with_loss on the two-launch step: the same
+    trajectory bit for bit (the histogram halves, the shape_inv snapshot and the nu_omega snapshot are re-primed)."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    from velocycle_amd.workloads import make_velocity_spec
+    spec = make_velocity_spec(3001, 300, "vjoint", n_conditions=1, Hw=1, seed=6)
+    ref = _run(spec, "fused3", 13, False)
+    e1 = HipEngine(spec)
+    assert e1.stats["launches_per_step"] == 2
+    r1 = SVIRunner(e1, OPT, mode="perf", seed=7)
+    r1.run_perf(4)
+    l = r1.perf_losses() + [r1.step_with_loss() for _ in range(3)]
+    sd = r1.state_dict()
+    e2 = HipEngine(spec)
+    r2 = SVIRunner(e2, OPT, mode="perf", seed=7)
+    r2.load_state_dict(sd)
+    r2.run_perf(6)
+    assert torch.equal(e2.params.cpu(), ref["p"]) and np.array_equal(np.array(r2.perf_losses()), ref["l"])
+    assert l == list(ref["l"][:7])
+    e1.close(); e2.close()

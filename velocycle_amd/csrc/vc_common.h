@@ -31,9 +31,8 @@
                             // 64 cells per flush); W = D[x,c] zeta_omega_h(phi_c) of the wave's cells waits in the LDS
 #define VC_PWQ 8            // coefficients the likelihood kernel carries (Nx * Nhw <= VC_PWQ, else K_tail's cell blocks do it): rows of
                             // 4 floats (pw_inline = 4) or 8 (pw_inline = 8: e.g. two samples x three harmonics of omega)
-#define VC_PW_SLOTS(gpl) ((gpl) == 8 ? 512 : 256)   // float4 slots per wave for the staged W rows (cells x float4 per row): 32 KB of
-                            // LDS per workgroup for the 8-genes-per-lane kernels (3 workgroups per CU), 16 KB for the 4-genes-per-
-                            // lane ones (small shards, 4-5 workgroups per CU)
+// (the staged W rows live in DYNAMIC shared memory: d.pw_slots float4 per wave, + 32 float4 of accumulators per wave for the
+// S+U kernel; vc_main_dyn_lds() is what the launch asks for -- 0 bytes when pw_inline is off)
 #ifndef VC_TILE_TABLE
 #define VC_TILE_TABLE 1     // likelihood kernel: a wave's cell range from the table vc_finalize wrote (one scalar load) instead of
 #endif                      // evaluating the tiling function itself
@@ -62,8 +61,9 @@ struct VcDims {
   long long cell_offset;  // global index of the first local cell
   int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
   int K;                  // Nh + Nb : expression-map coefficients per gene (harmonics, then batch offsets)
-  int pw_inline;          // 4 | 8: K_main (U-only kernel) writes PWM rows of that many floats, K_omega / K_fin read them instead of the
-                          // cell blocks' PW; 0: off
+  int pw_inline;          // 4 | 8: K_main (U-only and S+U kernels) writes PWM rows of that many floats, K_omega / K_fin read them
+                          // instead of the cell blocks' PW; 0: off
+  int pw_slots;           // float4 slots per wave of K_main's staged W rows (>= cells per wave x float4 per row)
   int ctw;                // floats per cell record: {x,x} pairs of [sin k, cos k]*H, Db[Nb], omega, cf, S+U kernel: [k omega cos k,
                           // k omega sin k]*H (padded); omega and cf carry the scale factors of vc_rec_*_scale
   int model, guide, noise, with_dnu;
@@ -77,6 +77,9 @@ struct VcDims {
   int pass_cw[4];         // cells per wave of the workgroups of pass 0..3 (later passes: as pass 3); all equal to cw unless the
                           // passes take unequal shares of the cells (vc_engine.hip, tiling)
   int hist_has_S, hist_has_U;
+  int hist_par;           // 1: shape_inv is learned -- the fused steps keep the histogram sums of the sample of step s in half s & 1 of
+                          // HL / HD (the launch that finishes step s - 1 reads half (s - 1) & 1 while its histogram blocks write half
+                          // s & 1); 0: evaluated once (half 0)
   int nmat_r;             // matrices whose NB constant r*log r is evaluated per step
   float root_w;           // 1 on rank 0, 0 elsewhere: weight of replicated prior / entropy terms
   float gamma_alpha, gamma_beta, sigma_ln_s, sigma_ln_u, rho_mean, rho_std, rho_scale;
@@ -89,6 +92,12 @@ struct VcDims {
   int nlpf;               // fused pipeline: loss slots per half of LPF = nb_post_gene + nb_tail_cell + 1
   float lgamma_alpha;     // lgamma(gamma_alpha) of the shape_inv prior, evaluated once on the host
 };
+
+// dynamic shared memory of a K_main launch (bytes)
+__host__ __device__ inline unsigned vc_main_dyn_lds(const VcDims& d) {
+  if (!d.pw_inline) return 0u;
+  return (unsigned)(VC_WAVES * (d.pw_slots + (d.kind == VC_KIND_VFULL ? 32 : 0)) * 16);
+}
 
 // Cell record: scale factors of its omega and cf entries, and its length in {x, x} pairs
 __host__ __device__ inline float vc_rec_cf_scale(int noise) { return (VC_FOLD_LOG2E && noise != VC_NOISE_LOGNORMAL) ? VC_LOG2E : 1.f; }
@@ -140,7 +149,8 @@ struct VcBufs {
   float *PW;                                // [nb_post_cell][NW] partial angular-speed gradients
   float *PWM;                               // [n_main_wg][pw_inline] the same partials, per workgroup of K_main
   float *WT;                                // [Nc][pw_inline] W_cj = D[x,c] zeta_omega_h(phi_c), j = x * Nhw + h (j >= NW: 0)
-  double *HL, *HD;                          // per histogram task: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r))
+  double *HL, *HD;                          // [2][n_tasks] per histogram task: sum cnt*(lgamma(r+k)-lgamma(r)), sum cnt*(psi(r+k)-psi(r));
+                                            // the unfused kernels use half 0, the fused steps the half of the sample's step (d.hist_par)
   double const_loss;                        // step-invariant part of the loss
   long long* status;                        // [0] number of steps with a non-finite loss, [1] 1 + index of the first one
   // fused single-rank pipeline (vc_svi_step_fused)
@@ -148,7 +158,12 @@ struct VcBufs {
   float* step_size;                         // ... and leaves the ClippedAdam step size of the new step here (fp64 math, once)
   double adam_lr0, adam_lrd_l, adam_b1l, adam_b2l;
   double* LPF;                              // [2][nlpf] prior / guide loss terms of the samples of step s in half s & 1
-  double* LPP;                              // [nb_post_gene] r-only likelihood terms of the gene blocks (K_tail)
+  double* LPP;                              // [nb_post_gene] r-only likelihood terms of the gene blocks (phase A of the sharded step)
+  double* LPR;                              // [2][nb_post_gene] -nmat_r Nc sum_g r log r of the sample of step s in half s & 1 (written when
+                                            // the sample is drawn: the loss block of the launch that finishes the step reads it)
+  float* SIS;                               // [2][4][Ng_pad] shape_inv {parameter, exp_avg, exp_avg_sq, value} as they stand after the
+                                            // launch that drew the sample of step s (half s & 1): the histogram blocks of the NEXT
+                                            // launch re-derive the update from it while the gene blocks of that launch rewrite the originals
   float* NWS;                               // [4][VC_MAX_NW * (VC_MAX_RANK + 2)] snapshot of the nu_omega parameters, moments, value
   float* EPS;                               // [3][eps_total] ring of standard-normal draws: slot (step % 3) holds the draws of `step`
 #ifdef VC_DBG_TIMES
@@ -184,7 +199,7 @@ __device__ __forceinline__ void vc_rec_put_omega(float2* ct, const VcDims& d, fl
 }
 // Row c of the W table of the U-only kernel (pw_inline): sk / ck = sin, cos of k phi_c up to Hw
 __device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c, const float* sk, const float* ck) {
-  if (!(d.pw_inline && d.kind == VC_KIND_VU)) return;
+  if (!(d.pw_inline && (d.kind == VC_KIND_VU || d.kind == VC_KIND_VFULL))) return;
   for (int xq = 0; xq < d.Nx; ++xq) {
     const float dx = b.Dm[(size_t)xq * d.Nc + c];
 #pragma unroll
@@ -366,11 +381,20 @@ __device__ __forceinline__ float vc_adam_step_size(long long t, double lr0, doub
   return (float)(lr0 * exp(td * lrd_l) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));
 }
 
+// d(-ELBO) / d(unconstrained shape_inv) of one gene (the statements of K_post's / K_tail's shape_inv role): r = 1 / shape_inv,
+// U_r = sum_c d loglik / d r from K_main, HDg = the gene's histogram digamma sums, rw = weight of the prior term on this rank
+__device__ __forceinline__ float vc_si_grad(const VcDims& d, float r, float si, float U_r, double HDg, float rw) {
+  const double lr = (double)logf(r);
+  const double dr = (double)U_r + (double)d.nmat_r * d.Nc * (lr + 1.0) + HDg;
+  const double gsi = -(double)r * (double)r * dr + (double)rw * ((d.gamma_alpha - 1.f) / si - d.gamma_beta);
+  return (float)(-gsi * (double)si);
+}
+
 // One wave per histogram TASK (<= 64 distinct count values of one gene and matrix, one per lane), so the
 // latency of the kernel is one pass whatever the spread of a gene's counts; K_post adds the few task sums of
 // a gene in fixed order.
 __device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, const float* __restrict__ P,
-                                             int cond_only, int task, int lane, float si_given = -1.f) {
+                                             int cond_only, int task, int lane, float si_given = -1.f, int half = 0) {
   const int g = b.h_task[4 * task], m = b.h_task[4 * task + 1];
   const int beg = b.h_task[4 * task + 2], end = b.h_task[4 * task + 3];
   double hl = 0.0, hd = 0.0;
@@ -390,7 +414,7 @@ __device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, c
     hl = vc_wave_sum_d(hl);
     hd = vc_wave_sum_d(hd);
   }
-  if (lane == 0) { b.HL[task] = hl; b.HD[task] = hd; }
+  if (lane == 0) { b.HL[(size_t)half * b.n_tasks + task] = hl; b.HD[(size_t)half * b.n_tasks + task] = hd; }
 }
 
 #endif  // __HIPCC__
@@ -447,6 +471,11 @@ void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* gra
 // tutorial flow on one rank (pw_inline, nothing per cell left to learn): K_tail's gene blocks and K_omega's blocks in one launch
 void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                            const VcAdamArgs& a, double* loss_dev, long long loss_slots, hipStream_t st);
+// the rest of a single-rank step in ONE launch (round 4): K_tail's gene blocks, its cell blocks with the nu_omega chain inside
+// (K_main supplies the partials: pw_inline), the loss block, the histogram blocks (re-deriving the shape_inv update) and the eps
+// blocks, side by side
+void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                     const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, hipStream_t st);
 void vc_launch_p2p_xchg(const VcP2p& p, long long step, float* out, long long n, long long* status, double timeout_s,
                         hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,

@@ -715,16 +715,21 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // this kernel (occupancy x 256 CUs); each wave gets an equal share of the cells of its gene block,
   // so no partially filled last round is left over (a 2.04-round grid costs 3 rounds).
   {
-    int blocks_per_cu = 0, n_cu = 256;
-    HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, main_kernel, 256, 0));
+    int n_cu = 256;
     hipDeviceProp_t prop;
     int dev = 0;
     HIPCHK(e, hipGetDevice(&dev));
     HIPCHK(e, hipGetDeviceProperties(&prop, dev));
     if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
-    const char* env = getenv("VC_BLOCKS_PER_CU");
-    if (env && atoi(env) > 0) blocks_per_cu = atoi(env);
+    auto occupancy = [&](unsigned dyn_bytes, int* out) -> int {
+      int bpc = 0;
+      if (dyn_bytes > 0) (void)hipFuncSetAttribute(main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes);
+      HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, main_kernel, 256, dyn_bytes));
+      const char* env = getenv("VC_BLOCKS_PER_CU");
+      if (env && atoi(env) > 0) bpc = atoi(env);
+      *out = bpc;
+      return VC_OK;
+    };
     // Unequal shares per dispatch pass.  The workgroups of pass p (the p-th one on every CU) are older than those of pass
     // p + 1 and the SIMD arbiter issues the oldest ready wave first: with equal shares the first pass ends its cells at
     // ~60 % of the kernel and the last pass then runs alone, one wave per SIMD (profiles/tools/wave_timeline.py).  Measured
@@ -732,33 +737,64 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     // kernel by 5-9 %; that is the default for a full multi-pass grid.  VC_PASS_SHARES="a:b[:c[:d]]" overrides ("1:1" = the
     // balanced tiling).  The tiling (vc_host_logic.h, also what the kernel evaluates per wave) stays a pure function of
     // (Nc, Ng, occupancy, CUs): results are reproducible.
-    double share[4] = {1.0, 0.5, 0.25, 0.125};
-    if (VC_ASM_LOADS && d.kind == VC_KIND_VFULL && blocks_per_cu == 2) {
-      // round 3: with two cells of the S+U kernel's counts in flight (hand-placed waits) the older wave of a SIMD stalls less
-      // and leaves the younger one fewer issue slots: 0.67 : 0.33 ends the passes at 104 / 120 us, 0.75 : 0.25 together
-      // (profiles/r03_kmain.md: 119.4 vs 121.4 us)
-      share[1] = 1.0 / 3.0; share[2] = 1.0 / 9.0; share[3] = 1.0 / 27.0;
-    } else if (VC_ASM_LOADS && d.kind != VC_KIND_VFULL && blocks_per_cu == 3) {
-      // the three-pass one-matrix kernels: 0.62 : 0.26 : 0.12 instead of 0.57 : 0.29 : 0.14 (the third pass ended 12 us after
-      // the first): phase 58.3 -> 56.2-56.9 us, U only 70.6 -> 70.0-70.1 us (profiles/r03_kmain.md section 3)
-      share[1] = 0.42; share[2] = 0.19; share[3] = 0.09;
+    auto tile = [&](int blocks_per_cu) {
+      if (blocks_per_cu < 1) blocks_per_cu = 1;
+      double share[4] = {1.0, 0.5, 0.25, 0.125};
+      if (d.kind == VC_KIND_VFULL && blocks_per_cu == 2) {
+        // round 3: with two cells of the S+U kernel's counts in flight (hand-placed waits) the older wave of a SIMD stalls less
+        // and leaves the younger one fewer issue slots: 0.67 : 0.33 ends the passes at 104 / 120 us, 0.75 : 0.25 together
+        // (profiles/r03_kmain.md: 119.4 vs 121.4 us)
+        share[1] = 1.0 / 3.0; share[2] = 1.0 / 9.0; share[3] = 1.0 / 27.0;
+      } else if (d.kind != VC_KIND_VFULL && blocks_per_cu == 3) {
+        // the three-pass one-matrix kernels: 0.62 : 0.26 : 0.12 instead of 0.57 : 0.29 : 0.14 (the third pass ended 12 us after
+        // the first): phase 58.3 -> 56.2-56.9 us, U only 70.6 -> 70.0-70.1 us (profiles/r03_kmain.md section 3)
+        share[1] = 0.42; share[2] = 0.19; share[3] = 0.09;
+      }
+      bool want = true;
+      if (const char* se = getenv("VC_PASS_SHARES")) {
+        int n = sscanf(se, "%lf%*[,:]%lf%*[,:]%lf%*[,:]%lf", &share[0], &share[1], &share[2], &share[3]);
+        want = n >= 2;
+        for (int p = (n > 0 ? n : 1); p < 4; ++p) share[p] = share[p - 1] * (n >= 2 ? share[n - 1] / share[n - 2] : 1.0);
+      }
+      const char* cwe = getenv("VC_CELLS_PER_WAVE");
+      const char* mce = getenv("VC_PASS_MIN_CW");
+      // below 12 cells per wave the passes' fixed prologue / epilogue dominate (measured at the 6 250-cell shard)
+      const VcTiling t = vc_tile_cells(d.Nc, d.nGB, n_cu, blocks_per_cu, VC_WAVES, cwe && atoi(cwe) > 0 ? atoi(cwe) : 0,
+                                       want ? share : nullptr, mce && atoi(mce) > 0 ? atoi(mce) : 12);
+      d.cw = t.cw;
+      d.n_chunks = t.n_chunks;
+      d.pass_wgs = n_cu;
+      for (int p = 0; p < 4; ++p) d.pass_cw[p] = t.pass_cw[p];
+      d.n_main_wg = d.nGB * d.n_chunks;
+    };
+    int bpc0 = 0;
+    TRY(occupancy(0, &bpc0));
+    tile(bpc0);
+    // K_main's own partials of d loglik / d nu_omega (vc_common.h: VC_PW_INLINE; one rank, <= VC_PWQ coefficients): the W rows of a
+    // wave's cells are staged in DYNAMIC shared memory, which may cost the kernel a resident workgroup per CU -- the tiling
+    // follows the occupancy the launch will really have (at most one adjustment; if even that does not fit: off)
+    d.pw_inline = 0;
+    d.pw_slots = 0;
+    const bool pw_kind = VC_PW_INLINE && (d.kind == VC_KIND_VU || d.kind == VC_KIND_VFULL) && d.NW >= 1 && d.NW <= VC_PWQ &&
+                         e->cfg.world_size == 1;
+    const char* pwe = getenv("VC_PW_INLINE");
+    if (pw_kind && !(pwe && atoi(pwe) == 0)) {
+      const int row = d.NW <= 4 ? 4 : 8;
+      int bpc = bpc0;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        const int cwmax = std::max(d.cw, std::max(std::max(d.pass_cw[0], d.pass_cw[1]), std::max(d.pass_cw[2], d.pass_cw[3])));
+        VcDims probe = d;
+        probe.pw_inline = row;
+        probe.pw_slots = (cwmax * (row / 4) + 15) / 16 * 16;
+        const unsigned dyn = vc_main_dyn_lds(probe);
+        int got = 0;
+        if (dyn > 96u * 1024u || occupancy(dyn, &got) != VC_OK || got < 1) break;
+        if (got == bpc) { d.pw_inline = row; d.pw_slots = probe.pw_slots; break; }
+        bpc = got;                      // the W rows cost a workgroup per CU: tile for what is left and look again
+        tile(bpc);
+      }
+      if (!d.pw_inline) tile(bpc0);     // off: the tiling of the plain kernel
     }
-    bool want = true;
-    if (const char* se = getenv("VC_PASS_SHARES")) {
-      int n = sscanf(se, "%lf%*[,:]%lf%*[,:]%lf%*[,:]%lf", &share[0], &share[1], &share[2], &share[3]);
-      want = n >= 2;
-      for (int p = (n > 0 ? n : 1); p < 4; ++p) share[p] = share[p - 1] * (n >= 2 ? share[n - 1] / share[n - 2] : 1.0);
-    }
-    const char* cwe = getenv("VC_CELLS_PER_WAVE");
-    const char* mce = getenv("VC_PASS_MIN_CW");
-    // below 12 cells per wave the passes' fixed prologue / epilogue dominate (measured at the 6 250-cell shard)
-    const VcTiling t = vc_tile_cells(d.Nc, d.nGB, n_cu, blocks_per_cu, VC_WAVES, cwe && atoi(cwe) > 0 ? atoi(cwe) : 0,
-                                     want ? share : nullptr, mce && atoi(mce) > 0 ? atoi(mce) : 12);
-    d.cw = t.cw;
-    d.n_chunks = t.n_chunks;
-    d.pass_wgs = n_cu;
-    for (int p = 0; p < 4; ++p) d.pass_cw[p] = t.pass_cw[p];
-    d.n_main_wg = d.nGB * d.n_chunks;
   }
   {
     // the tiling as a table: {first cell of wave 0, cells per wave} of every workgroup of the likelihood kernel, evaluated
@@ -781,6 +817,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   d.hist_has_U = nb && vel;
   d.nmat_r = nb ? (d.kind == VC_KIND_VFULL ? 2 : 1) : 0;
   e->hist_each_step = nb && !cond(e, VC_SITE_SHAPE_INV);
+  d.hist_par = e->hist_each_step ? 1 : 0;
 
   // uploads
   TRY(upload(e, e->h_prior[VC_PRIOR_MU_NU], &b.mu_nu));
@@ -820,13 +857,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   HIPCHK(e, hipMemset(b.dbg, 0, VC_DBG_WORDS(d.n_main_wg) * 8));
 #endif
   TRY(e->dalloc(&b.LP, (size_t)(d.nb_pre_gene + d.nb_pre_cell + d.nb_post_gene)));
-  // tutorial flow on one rank: the angular-speed gradient partials come out of K_main (vc_common.h: VC_PW_INLINE)
-  {
-    const int row = d.NW <= 4 ? 4 : 8, cwmax = std::max(d.cw, d.pass_cw[0]);
-    const bool ok = VC_PW_INLINE && d.kind == VC_KIND_VU && d.NW <= VC_PWQ && e->cfg.world_size == 1 && cwmax * (row / 4) <= VC_PW_SLOTS(d.gpl);
-    d.pw_inline = ok ? row : 0;
-  }
-  if (const char* env = getenv("VC_PW_INLINE")) { if (atoi(env) == 0) d.pw_inline = 0; }
+  // (pw_inline -- the angular-speed gradient partials out of K_main -- was decided with the tiling above)
   TRY(e->dalloc(&b.PWM, (size_t)d.n_main_wg * VC_PWQ));
   HIPCHK(e, hipMemset(b.PWM, 0, sizeof(float) * (size_t)d.n_main_wg * VC_PWQ));
   TRY(e->dalloc(&b.WT, (size_t)VC_PWQ * d.Nc));
@@ -860,6 +891,10 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   HIPCHK(e, hipMemset(b.LPF, 0, 2 * sizeof(double) * d.nlpf));
   TRY(e->dalloc(&b.LPP, (size_t)d.nb_post_gene));
   HIPCHK(e, hipMemset(b.LPP, 0, sizeof(double) * d.nb_post_gene));
+  TRY(e->dalloc(&b.LPR, 2 * (size_t)d.nb_post_gene));
+  HIPCHK(e, hipMemset(b.LPR, 0, 2 * sizeof(double) * d.nb_post_gene));
+  TRY(e->dalloc(&b.SIS, 2 * 4 * (size_t)d.Ng_pad));
+  HIPCHK(e, hipMemset(b.SIS, 0, 2 * 4 * sizeof(float) * d.Ng_pad));
   TRY(e->dalloc(&b.NWS, 2 * 4 * (size_t)VC_MAX_NW * (VC_MAX_RANK + 2)));      // two copies, by the parity of the step
   HIPCHK(e, hipMemset(b.NWS, 0, 2 * 4 * sizeof(float) * VC_MAX_NW * (VC_MAX_RANK + 2)));
   TRY(e->dalloc(&b.EPS, 3 * (size_t)e->layout.eps_total));
@@ -928,10 +963,10 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     b.n_tasks = (int)task.size() / 4;
     TRY(upload(e, task, &b.h_task));
     TRY(upload(e, tptr, &b.h_tptr));
-    TRY(e->dalloc(&b.HL, (size_t)std::max(1, b.n_tasks)));
-    TRY(e->dalloc(&b.HD, (size_t)std::max(1, b.n_tasks)));
-    HIPCHK(e, hipMemset(b.HL, 0, sizeof(double) * std::max(1, b.n_tasks)));
-    HIPCHK(e, hipMemset(b.HD, 0, sizeof(double) * std::max(1, b.n_tasks)));
+    TRY(e->dalloc(&b.HL, 2 * (size_t)std::max(1, b.n_tasks)));       // two halves: by the parity of the sample's step (d.hist_par)
+    TRY(e->dalloc(&b.HD, 2 * (size_t)std::max(1, b.n_tasks)));
+    HIPCHK(e, hipMemset(b.HL, 0, 2 * sizeof(double) * std::max(1, b.n_tasks)));
+    HIPCHK(e, hipMemset(b.HD, 0, 2 * sizeof(double) * std::max(1, b.n_tasks)));
     TRY(upload(e, ptr, &b.h_ptr));
     TRY(upload(e, val, &b.h_val));
     TRY(upload(e, cnt, &b.h_cnt));
@@ -965,6 +1000,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     // hoist the S likelihood: with phi, nu, dnu, shape_inv fixed it does not change between steps
     VcDims d2 = d;
     d2.kind = VC_KIND_PHASE; d2.nq = nq_of(VC_KIND_PHASE); d2.nco = 1;
+    d2.pw_inline = 0; d2.pw_slots = 0;
     d2.hist_has_S = nb; d2.hist_has_U = 0;
     vc_launch_pre(d2, b, nullptr, nullptr, 0, 0, nullptr, 1, nb ? 1 : 0, st);
     e->phase_fn(d2, b, st);
@@ -1046,6 +1082,22 @@ extern "C" int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64
   return VC_OK;
 }
 
+// Which launch follows K_main in the steady state of vc_svi_run_fused: 1 = the tutorial flow's merged tail (vc_launch_tail_merged),
+// 2 = the one-launch tail of every other single-rank step that has what it needs (vc_launch_tail2), 0 = K_tail + K_omega
+static int fused_tail_kind(const vc_engine* e) {
+  const bool with_hist = e->hist_each_step;
+  bool merged = e->d.pw_inline && e->d.kind == VC_KIND_VU && !with_hist && (e->d.cond >> VC_SITE_PHIXY & 1u);
+  if (const char* env = getenv("VC_TAIL_MERGED")) merged = merged && atoi(env) != 0;
+  if (merged) return 1;
+  // Round 4: every other single-rank step in TWO launches as well -- the phase model (no nu_omega chain), and the velocity
+  // models whenever K_main supplies the partials of d loglik / d nu_omega itself (pw_inline), so that the chain runs inside the
+  // cell blocks.  VC_TAIL2=0 keeps the three-launch step (A/B, tests: the same bits).
+  bool tail2 = e->cfg.world_size == 1 && (e->d.model == VC_MODEL_PHASE || e->d.pw_inline != 0);
+  if (const char* env = getenv("VC_TAIL2")) tail2 = tail2 && atoi(env) != 0;
+  return tail2 ? 2 : 0;
+}
+static int fused_launches_per_step(const vc_engine* e) { return fused_tail_kind(e) ? 2 : 3; }
+
 extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, float* grad,
                                 double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
                                 double lrd, double beta1, double beta2, double adam_eps, double clip_norm, int prime,
@@ -1079,8 +1131,8 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
   // Tutorial flow (U-only kernel with its own nu_omega partials, no histogram terms per step): from the third step after the
   // tables were primed, K_tail's gene blocks and K_omega's blocks go out as ONE launch (vc_launch_tail_merged: why that is
   // safe); the first two steps fill both halves of the loss terms the absent cell blocks would have written.
-  bool merged = e->d.pw_inline && e->d.kind == VC_KIND_VU && !with_hist && (e->d.cond >> VC_SITE_PHIXY & 1u);
-  if (const char* env = getenv("VC_TAIL_MERGED")) merged = merged && atoi(env) != 0;
+  const int tail_kind = fused_tail_kind(e);
+  const bool merged = tail_kind == 1, tail2 = tail_kind == 2;
   for (int64_t i = 0; i < n_steps; ++i) {
     if (e->timing) {
       if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
@@ -1093,6 +1145,8 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
     }
     if (merged && e->plain_steps >= 2) {
       vc_launch_tail_merged(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, st);
+    } else if (tail2) {
+      vc_launch_tail2(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, with_hist, st);
     } else {
       vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 0, VcXb{}, st);
       vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
@@ -1371,6 +1425,9 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   out->hist_on_device = e->hist_on_device;
   out->setup_transient_bytes = (int64_t)e->setup_transient_bytes;
   for (int p = 0; p < 4; ++p) out->pass_cells[p] = d.pass_cw[p];
+  out->launches_per_step = fused_launches_per_step(e);
+  out->pw_inline = d.pw_inline;
+  out->generic = 0;
   snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.Nb, e->main_name, d.gpl,
            d.c16 ? ",u16" : "");
   return VC_OK;

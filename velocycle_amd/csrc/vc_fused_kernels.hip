@@ -169,12 +169,16 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
         if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
         {
           // the gene's histogram terms (usually 2..4 tasks): four requested per trip instead of one (a dependent round trip
-          // each on this role's way to the barrier), the sums formed in task order as before
+          // each on this role's way to the barrier), the sums formed in task order as before.  They belong to the sample of
+          // the step being finished: half (s - 1) & 1 when shape_inv is learned (the histogram blocks of THIS launch write
+          // the other half)
+          const double* __restrict__ HLs = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
+          const double* __restrict__ HDs = b.HD + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
           const int t0 = b.h_tptr[g], t1 = b.h_tptr[g + 1];
           for (int tb = t0; tb < t1; tb += 4) {
             double hl[4], hd[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int t = tb + k < t1 ? tb + k : tb; hl[k] = b.HL[t]; hd[k] = b.HD[t]; }
+            for (int k = 0; k < 4; ++k) { const int t = tb + k < t1 ? tb + k : tb; hl[k] = HLs[t]; hd[k] = HDs[t]; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (tb + k < t1) { HLg += hl[k]; HDg += hd[k]; }
           }
@@ -221,6 +225,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
         if (upd) { pm[k] = Mm[off[k] - header]; pv[k] = Vv[off[k] - header]; }
         if (upd && phase == VC_PH_B) gg[k] = xb.x[off[k]];          // the gradient summed over ranks
       }
+    if (r_si && !upd && samp) { pm[0] = Mm[off[0] - header]; pv[0] = Vv[off[0] - header]; }     // boot: for the snapshot below
     // phase A: the histogram blocks of phase B re-derive the shape_inv update while the gene blocks of the same launch
     // rewrite it -- they read this snapshot {parameter, exp_avg, exp_avg_sq}
     if (phase == VC_PH_A && r_si) {
@@ -282,14 +287,10 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       } else if (r_si) {
         const float r = in[0];
         const float U_r = (d.kind == VC_KIND_PHASE) ? T(K) : (d.kind == VC_KIND_VFULL ? T(K + 2) : 0.f);
-        const double lr = (double)logf(r);
-        if (d.nmat_r > 0) loss_post -= (double)d.nmat_r * d.Nc * (double)r * lr + HLg;
-        if (!CND(VC_SITE_SHAPE_INV)) {
-          const float si = in[1];
-          const double dr = (double)U_r + (double)d.nmat_r * d.Nc * (lr + 1.0) + HDg;
-          const double gsi = -(double)r * (double)r * dr + (double)rw * ((d.gamma_alpha - 1.f) / si - d.gamma_beta);
-          gg[0] = (float)(-gsi * (double)si);
-        }
+        // (single rank: the r-only loss terms are split -- LPR was written when this sample was drawn, the histogram sums are
+        // added by the loss block; the sharded step sends them over the exchange per gene block)
+        if (phase == VC_PH_A && d.nmat_r > 0) loss_post -= (double)d.nmat_r * d.Nc * (double)r * (double)logf(r) + HLg;
+        if (!CND(VC_SITE_SHAPE_INV)) gg[0] = vc_si_grad(d, r, in[1], U_r, HDg, rw);
       } else if (r_mf || r_core || r_cov) {
         const float gam = in[0];
         float U_lb, U_lg;
@@ -350,11 +351,11 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
           if (k < nown) xb.x[off[k]] = gg[k];
       }
     }
-    if (role == 12) {
+    if (phase == VC_PH_A && role == 12) {
       const double tot = vc_wave_sum_d63(loss_post);
       if (lane == 63) {
         b.LPP[gblock] = tot;
-        if (phase == VC_PH_A) vc_loss_split(tot, xb.x + xb.loss_off + VC_LOSS_PIECES * (1 + gblock));
+        vc_loss_split(tot, xb.x + xb.loss_off + VC_LOSS_PIECES * (1 + gblock));
       }
     }
   }
@@ -376,6 +377,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   VC_WSTAMP(0, 4);
   // ---- the guide sample of step s from the fresh parameters (statement by statement vc_pre_kernel) ---------------
   float logp = 0.f, logq = 0.f;
+  double lpr = 0.0;
   if (g < d.Ng_pad && !live) {
     if (boot && wave == 0) {       // padded gene: nu~ = 0 (never reaches a per-cell sum), loss masked in K_main
       float* GT = b.GT + g;
@@ -406,7 +408,14 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       const float si = CND(VC_SITE_SHAPE_INV) ? b.cnd[VC_SITE_SHAPE_INV][g] : expf(pp[0]);
       logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) - d.gamma_beta * si - d.lgamma_alpha;
       b.lat[VC_SITE_SHAPE_INV][g] = si;
-      GT[(K + 2) * NP] = 1.0f / si;
+      const float r = 1.0f / si;
+      GT[(K + 2) * NP] = r;
+      // the r-only likelihood term of THIS sample, for the loss of the step it belongs to (half s & 1)
+      if (d.nmat_r > 0) lpr = -((double)d.nmat_r * d.Nc * (double)r * (double)logf(r));
+      if (!CND(VC_SITE_SHAPE_INV)) {      // what the histogram blocks of the next launch re-derive the update from
+        float* sis = b.SIS + (size_t)(s & 1) * 4 * NP + g;
+        sis[0] = pp[0]; sis[NP] = pm[0]; sis[2 * NP] = pv[0]; sis[3 * NP] = si;
+      }
     } else if (role == 12 && boot && !nb) {
       GT[(K + 2) * NP] = 1.0f;
     } else if (r_mf && role == 13) {
@@ -474,6 +483,10 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     GT[K * NP] = lbv;
     GT[(K + 1) * NP] = expf(lg);
   }
+  if (role == 12) {                                // (every gene block has this wave; 0 without a negative binomial)
+    const double tot = vc_wave_sum_d63(lpr);
+    if (lane == 63) b.LPR[(size_t)(s & 1) * d.nb_post_gene + gblock] = tot;
+  }
   if (live && !vel && role == 13 && boot) {      // phase model: the velocity rows of the gene table are constants
     b.GT[(size_t)K * NP + g] = 0.f;
     b.GT[(size_t)(K + 1) * NP + g] = 1.f;
@@ -500,7 +513,18 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 // shards (vc_engine.hip) use all 16 waves, 1024 cells per block, because the number of blocks to place then dominates
 // ---------------------------------------------------------------------------------------------
 #define VC_TC_MAX 1024
-template <int phase>
+struct VcNuwShared {     // LDS of the nu_omega chain (vc_nuw_chain, below)
+  float up[VC_MAX_NW];
+  float np[VC_NWE];
+  float nuw[VC_MAX_NW];
+  double lq[VC_MAX_NW];
+};
+__device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                             long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
+                                             const VcXb& xb, int c, float s1, float c1, int nthr, VcNuwShared& sh);
+// OMEGA: the nu_omega chain of K_omega runs INSIDE this block (every cell block redundantly, block 0 stores), on K_main's own
+// partials (pw_inline) -- the cell record of step s leaves this block complete, omega_c included (vc_tail2_kernel)
+template <int phase, bool OMEGA = false>
 __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs& b, float* __restrict__ P,
                                                    float* __restrict__ G, float* __restrict__ Mm, float* __restrict__ Vv,
                                                    int header, int cblock, long long s, uint64_t seed, const VcOpt o,
@@ -572,7 +596,8 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
     }
   }
   VC_WSTAMP(0, 3);
-  if (vel && !boot) {
+  // (single rank with K_main's own partials: nobody reads the cell blocks' -- K_omega / the chain below take PWM)
+  if (vel && !boot && !(phase == VC_PH_ALL && d.pw_inline)) {
     // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c) at the phases of step s - 1
     // (their sin / cos are in the cell record; higher harmonics by the angle-addition recurrence, as K_pre built them)
     const float a3 = in_range ? (d.kind == VC_KIND_VFULL ? A[2] : A[0]) : 0.f;
@@ -594,7 +619,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   }
   // ---- snapshot of the nu_omega-related parameters, their moments and the nu_omega value of the step being finished:
   // K_omega's blocks all READ this copy while its block 0 stores the updated values (no reader ever races the writer)
-  if (vel && cblock == 0) {
+  if (vel && cblock == 0 && !OMEGA) {      // (OMEGA: the chain's block 0 of the launch before wrote this copy itself)
     const bool lrmn = d.guide == VC_GUIDE_LRMN;
     const int fin_per = lrmn ? d.R + 2 : 2;
     float* __restrict__ nws = b.NWS + (size_t)(s & 1) * 4 * VC_NWE;      // the copy K_omega reads at this step (two: by parity)
@@ -620,6 +645,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   }
   VC_WSTAMP(0, 4);
   // ---- phi_xy sample of step s, phase, Fourier basis, cell record (omega is filled by K_omega) -------------------
+  float s1_new = sc_old.x, c1_new = sc_old.y;      // conditioned phases: the record keeps its sin / cos
   if (in_range) {
     const float px = pxy.x, py = pxy.y;
     float x, y;
@@ -643,8 +669,10 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
         sk[k] = sk[k - 1] * c1 + ck[k - 1] * s1;
         ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
       }
+      s1_new = s1; c1_new = c1;
       float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
       for (int k = 0; k < d.H; ++k) { ct[2 * k] = make_float2(sk[k], sk[k]); ct[2 * k + 1] = make_float2(ck[k], ck[k]); }
+      if (vel) vc_put_w(d, b, c, sk, ck);      // the W row of K_main's nu_omega partials follows the phase
       if (boot) {              // step-invariant entries of the record
         for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
           const float v = b.Dbm[(size_t)q * d.Nc + c];
@@ -653,18 +681,23 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
         const int nbk = d.with_dnu ? d.Nb : 0;
         if (!vel) ct[2 * d.H + nbk] = make_float2(0.f, 0.f);
         { const float cfs = b.cf[c] * vc_rec_cf_scale(d.noise); ct[2 * d.H + nbk + 1] = make_float2(cfs, cfs); }
-        if (vel) vc_put_w(d, b, c, sk, ck);
         if (!vel) { b.lat_omega[c] = 0.f; b.lat_domega[c] = 0.f; }
       }
       b.lat_phi[c] = ph;
     }
   }
   VC_WSTAMP(0, 5);
+  if (OMEGA && vel) {
+    // the nu_omega chain (gradient from K_main's partials, optimiser, next sample) and omega_c of this block's cells
+    __shared__ VcNuwShared sh_nuw;
+    vc_nuw_chain(d, b, P, G, s, seed, VcAdamArgs{Mm, Vv, 0.0, 0.0, 0.0, 0.0, o.b1, o.b2, o.eps, o.clip, header}, boot, cblock == 0, phase,
+                 xb, in_range ? c : d.Nc, s1_new, c1_new, VC_TC, sh_nuw);
+  }
   {
     const double ws = vc_wave_sum_d63(loss);
     if (lane == 63) sm_lc[wave] = ws;
     __syncthreads();                        // (only the live waves take part; also orders sm_w)
-    if (vel && !boot && (int)threadIdx.x < d.NW) {
+    if (vel && !boot && !(phase == VC_PH_ALL && d.pw_inline) && (int)threadIdx.x < d.NW) {
       const int j = threadIdx.x;
       float t = 0.f;
       for (int w = 0; w < VC_TC / 64; ++w) t += sm_w[w][j];
@@ -749,11 +782,20 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
     // every rank's loss terms, summed piece by piece by the exchange: base + one per gene block, fixed order
     for (int i = t; i < 1 + d.nb_post_gene; i += 256) sl += vc_loss_join(xb.x + xb.loss_off + VC_LOSS_PIECES * i);
   } else {
+    // everything below belongs to the sample of the finished step s - 1 and was complete BEFORE this launch: prior / guide
+    // terms and the r-only likelihood term (written when the sample was drawn, half (s - 1) & 1), its histogram sums (half
+    // (s - 1) & 1 when shape_inv is learned), K_main's likelihood partials -- no block of this launch writes any of it
     const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
 #pragma unroll 4
     for (int i = t; i < d.nlpf; i += 256) sl += lpf[i];
+    const double* lpr = b.LPR + (size_t)((s - 1) & 1) * d.nb_post_gene;
 #pragma unroll 4
-    for (int i = t; i < d.nb_post_gene; i += 256) sl += b.LPP[i];
+    for (int i = t; i < d.nb_post_gene; i += 256) sl += lpr[i];
+    if (d.nmat_r > 0) {
+      const double* hl = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
+#pragma unroll 4
+      for (int i = t; i < b.n_tasks; i += 256) sl -= hl[i];
+    }
 #pragma unroll 4
     for (int i = t; i < d.n_main_wg; i += 256) sl -= (double)b.LO[i];
   }
@@ -776,65 +818,103 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
   }
 }
 
-// One block of K_omega's grid (256 threads; `oblk` = its index in that grid).  Also called from the 1024-thread launch of
-// phase B, where the waves beyond the fourth have left before the first barrier.
-__device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
-                                               const long long s, uint64_t seed, const VcAdamArgs& a,
-                                               double* __restrict__ loss_dev, long long loss_slots, int boot, int nb_cell,
-                                               int nb_hist, int oblk, int phase, const VcXb xb) {
-  __shared__ float sm_up[VC_MAX_NW];
-  __shared__ float s_np[VC_NWE];
-  __shared__ float s_nuw[VC_MAX_NW];
-  __shared__ double sm_lq[VC_MAX_NW];
+// Histogram terms of shape_inv(s) for one task while the gene blocks of the SAME launch are still computing shape_inv(s): the
+// update is re-derived here from the snapshot the launch before took (SIS, half (s - 1) & 1), K_main's partials and the
+// histogram sums of the finished step -- statement by statement what the owning (gene, role 12) thread runs, the second-stage
+// reduction in its order included (wave w adds chunks w, w + 16, ...; the 16 wave sums are added in wave order): the same bits.
+__device__ __forceinline__ void vc_hist_rederive_wave(const VcDims& d, const VcBufs& b, const float* __restrict__ P, long long s,
+                                                      const VcAdamArgs& a, int task, int lane) {
+  const int g = b.h_task[4 * task];
+  const size_t NP = d.Ng_pad;
+  const float* sis = b.SIS + (size_t)((s - 1) & 1) * 4 * NP + g;
+  const float p0 = sis[0], si = sis[3 * NP];
+  float mm = sis[NP], vv = sis[2 * NP];
+  const int q = d.kind == VC_KIND_PHASE ? d.K : d.K + 2;
+  float acc = 0.f;
+  if (lane < VC_PG_WAVES)
+    for (int ch = lane; ch < d.n_chunks; ch += VC_PG_WAVES) acc += b.GO[((size_t)ch * d.nq + q) * NP + g];
+  float U_r = 0.f;
+#pragma unroll
+  for (int w = 0; w < VC_PG_WAVES; ++w) U_r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), w));
+  if (d.kind == VC_KIND_VU) U_r = 0.f;
+  double HDg = 0.0;
+  {
+    const double* __restrict__ HDs = b.HD + (size_t)((s - 1) & 1) * b.n_tasks;
+    const int t0 = b.h_tptr[g], t1 = b.h_tptr[g + 1];
+    for (int tb = t0; tb < t1; tb += 4) {
+      double hd[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hd[k] = HDs[tb + k < t1 ? tb + k : tb];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (tb + k < t1) HDg += hd[k];
+    }
+  }
+  const float gg = vc_si_grad(d, 1.0f / si, si, U_r, HDg, d.root_w);
+  const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip);
+  vc_hist_wave(d, b, P, 0, task, lane, expf(np), (int)(s & 1));
+}
+
+// The blocks of K_omega's grid that are off the nu_omega chain (256 threads; `xblk` = index behind the cell blocks): 0 = the loss
+// of the finished step, then nb_hist histogram blocks (4 tasks each), then the eps blocks.  rederive: the gene blocks of the
+// same launch are computing shape_inv(s) right now (vc_tail2_kernel)
+__device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                                     const long long s, uint64_t seed, const VcAdamArgs& a,
+                                                     double* __restrict__ loss_dev, long long loss_slots, int boot, int nb_hist,
+                                                     int xblk, int phase, const VcXb xb, bool rederive) {
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
-  VC_WSTAMP(1, 0);
-  if (oblk >= nb_cell) {
-    int xblk = oblk - nb_cell;
-    if (xblk == 0) {                                 // the loss of the finished step
-      if (!boot) vc_omega_loss_block(d, b, G, s, loss_dev, loss_slots, phase, xb);
-      return;
-    }
-    xblk -= 1;
-    if (xblk < nb_hist) {                            // histogram terms of shape_inv(s), one wave per task
-      const int task = xblk * 4 + wv;
-      if (task < b.n_tasks) {
-        if (phase == VC_PH_B && !CND(VC_SITE_SHAPE_INV)) {
-          // the gene blocks of this launch are rewriting shape_inv: re-derive its update from phase A's snapshot and the
-          // summed gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
-          const int g = b.h_task[4 * task];
-          const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
-          float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
-          const float np = vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip);
-          vc_hist_wave(d, b, P, 0, task, lane, expf(np));
-        } else {
-          vc_hist_wave(d, b, P, 0, task, lane);
-        }
-      }
-      return;
-    }
-    xblk -= nb_hist;
-    // eps ring: the draws of step s + 1 (and, when booting, of step s) -- one Philox block = two consecutive indices.
-    // Three slots: this launch reads the slots of s - 1 and s and writes the slot of s + 1.  The ring holds this rank's slice
-    // of the stream: replicated sites at their global index, phi_xy shifted by the rank's first cell.
-    const long long pair = (long long)xblk * 256 + t;
-    if (2 * pair < d.eps_total) {
-      const uint64_t gpair = (uint64_t)(pair + (2 * pair >= d.eps_n_global ? d.cell_offset : 0));
-      float n0, n1;
-      vc_philox_normal2(seed, s + 1, gpair, n0, n1);
-      *reinterpret_cast<float2*>(b.EPS + (size_t)((s + 1) % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
-      if (boot) {
-        vc_philox_normal2(seed, s, gpair, n0, n1);
-        *reinterpret_cast<float2*>(b.EPS + (size_t)(s % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
+  if (xblk == 0) {                                 // the loss of the finished step
+    if (!boot) vc_omega_loss_block(d, b, G, s, loss_dev, loss_slots, phase, xb);
+    return;
+  }
+  xblk -= 1;
+  if (xblk < nb_hist) {                            // histogram terms of shape_inv(s), one wave per task
+    const int task = xblk * 4 + wv;
+    const int half = d.hist_par ? (int)(s & 1) : 0;
+    if (task < b.n_tasks) {
+      if (rederive && !CND(VC_SITE_SHAPE_INV)) {
+        vc_hist_rederive_wave(d, b, P, s, a, task, lane);
+      } else if (phase == VC_PH_B && !CND(VC_SITE_SHAPE_INV)) {
+        // the gene blocks of this launch are rewriting shape_inv: re-derive its update from phase A's snapshot and the
+        // summed gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
+        const int g = b.h_task[4 * task];
+        const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
+        float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
+        const float np = vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip);
+        vc_hist_wave(d, b, P, 0, task, lane, expf(np), half);
+      } else {
+        vc_hist_wave(d, b, P, 0, task, lane, -1.f, half);
       }
     }
     return;
   }
-  const bool vel = d.model == VC_MODEL_VELOCITY;
-  if (!vel) return;
+  xblk -= nb_hist;
+  // eps ring: the draws of step s + 1 (and, when booting, of step s) -- one Philox block = two consecutive indices.
+  // Three slots: this launch reads the slots of s - 1 and s and writes the slot of s + 1.  The ring holds this rank's slice
+  // of the stream: replicated sites at their global index, phi_xy shifted by the rank's first cell.
+  const long long pair = (long long)xblk * 256 + t;
+  if (2 * pair < d.eps_total) {
+    const uint64_t gpair = (uint64_t)(pair + (2 * pair >= d.eps_n_global ? d.cell_offset : 0));
+    float n0, n1;
+    vc_philox_normal2(seed, s + 1, gpair, n0, n1);
+    *reinterpret_cast<float2*>(b.EPS + (size_t)((s + 1) % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
+    if (boot) {
+      vc_philox_normal2(seed, s, gpair, n0, n1);
+      *reinterpret_cast<float2*>(b.EPS + (size_t)(s % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
+    }
+  }
+}
+
+// The nu_omega chain for a block of `nthr` threads (256: K_omega's blocks; the cell-block size of the one-launch tail): per-coefficient
+// sums of the partials of d loglik / d nu_omega (redundantly in every block, fixed order) -> gradient + ClippedAdam of the
+// nu_omega-related parameters on a snapshot (`first`: this block stores them and the snapshot of the next step) -> the nu_omega
+// sample of step s -> omega_c and d omega / d phi of cell c (sin, cos of its phase of step s: s1, c1) into its record.
+__device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                             long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
+                                             const VcXb& xb, int c, float s1, float c1, int nthr, VcNuwShared& sh) {
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, nwv = nthr >> 6;
   const bool lrmn = d.guide == VC_GUIDE_LRMN;
-  const bool first = oblk == 0;
   // phase B: the PW rows are the sums over ranks (every rank holds the complete gradient: prior / entropy weight 1)
-  const bool pwm = phase != VC_PH_B && d.pw_inline;           // single rank, U-only kernel: K_main's own partials
+  const bool pwm = phase != VC_PH_B && d.pw_inline;           // single rank: K_main's own partials
   const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : (pwm ? b.PWM : b.PW);
   const int n_pw = phase == VC_PH_B ? xb.pw_cap : (pwm ? d.n_main_wg : d.nb_tail_cell);
   const int pw_ld = pwm ? d.pw_inline : d.NW;
@@ -853,40 +933,34 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
   const float* __restrict__ eps_old = b.EPS + (size_t)((s + 2) % 3) * d.eps_total;
   const float* __restrict__ nws = b.NWS + (size_t)(s & 1) * 4 * VC_NWE;        // the nu_omega snapshot of this step ...
   float* __restrict__ nws_next = b.NWS + (size_t)((s + 1) & 1) * 4 * VC_NWE;   // ... and the copy block 0 fills for the next
-  // this block's cells: the basis of the next phase (written by K_tail) is requested now
-  const int c = oblk * 256 + t;
-  float s1 = 0.f, c1 = 1.f;
-  if (c < d.Nc) {
-    const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)c * d.ctw);
-    s1 = ct[0].x; c1 = ct[1].x;
-  }
   VC_WSTAMP(1, 1);
-  // ---- per-coefficient sums of the cell blocks' partials of d loglik / d nu_omega: every block, fixed order -------------
+  // ---- per-coefficient sums of the partials of d loglik / d nu_omega: every block, fixed order (lane i adds rows i, i + 64, ...
+  // in double, then the 64 lanes: independent of the number of waves that share the coefficients) ------------------------
   if (!boot) {
     double u[2] = {0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int j = wv + 4 * q;
+      const int j = wv + nwv * q;
       if (j < nw)
         for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int j = wv + 4 * q;
-      if (j < nw) { const double r = vc_wave_sum_d63(u[q]); if (lane == 63) sm_up[j] = (float)r; }
+      const int j = wv + nwv * q;
+      if (j < nw) { const double r = vc_wave_sum_d63(u[q]); if (lane == 63) sh.up[j] = (float)r; }
     }
-    for (int j = wv + 8; j < nw; j += 4) {
+    for (int j = wv + 2 * nwv; j < nw; j += nwv) {
       double r = 0.0;
       for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
       r = vc_wave_sum_d63(r);
-      if (lane == 63) sm_up[j] = (float)r;
+      if (lane == 63) sh.up[j] = (float)r;
     }
   }
   __syncthreads();
   VC_WSTAMP(1, 2);
   // ---- gradient + ClippedAdam of the nu_omega-related parameters: one thread per element, every block alike ----------
   const float step_size = boot ? 0.f : b.step_size[0];
-  for (int tt = t; tt < nelem; tt += 256) {
+  for (int tt = t; tt < nelem; tt += nthr) {
     const int j = tt / fin_per, ce = tt % fin_per;
     const long long off = vc_nuw_elem_off(d, lrmn, j, ce);
     float p = nws[tt];                         // the snapshot of this step: block 0 overwrites P / m / v below
@@ -894,7 +968,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
       float gx = 0.f;
       if (!cnd) {
         const float x = nws[3 * VC_NWE + j], sd = b.sd_w[j];
-        gx = sm_up[j] - rw * (x - b.mu_w[j]) / (sd * sd);
+        gx = sh.up[j] - rw * (x - b.mu_w[j]) / (sd * sd);
       }
       const long long ei = eps_index(j, ce);
       const float eo = ei >= 0 ? eps_old[ei] : 0.f;          // eps of the finished step for this element
@@ -917,20 +991,20 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
       if (first) {
         G[off] = gv; a.m[off - a.header] = mm; a.v[off - a.header] = vv; P[off] = p;
         // ... and the snapshot of the NEXT step (the other copy: nobody reads it in this launch), for a step whose K_tail
-        // runs no cell block that would take it (vc_launch_tail_merged)
+        // runs no cell block that would take it (vc_launch_tail_merged, vc_launch_tail2)
         nws_next[tt] = p; nws_next[VC_NWE + tt] = mm; nws_next[2 * VC_NWE + tt] = vv;
       }
     } else if (first) {
       nws_next[tt] = p; nws_next[VC_NWE + tt] = nws[VC_NWE + tt]; nws_next[2 * VC_NWE + tt] = nws[2 * VC_NWE + tt];
     }
-    s_np[tt] = p;
+    sh.np[tt] = p;
   }
   __syncthreads();
   VC_WSTAMP(1, 3);
   // ---- the nu_omega sample of step s ------------------------------------------------------------------------------
-  if (t < VC_MAX_NW) sm_lq[t] = 0.0;
-  for (int j = t; j < nw; j += 256) {
-    const float* np = s_np + j * fin_per;
+  if (t < VC_MAX_NW) sh.lq[t] = 0.0;
+  for (int j = t; j < nw; j += nthr) {
+    const float* np = sh.np + j * fin_per;
     float val, lq = 0.f;
     const long long i = (long long)d.Ng + j;
     auto en = [&](int ce) { const long long ei = eps_index(j, ce); return boot ? vc_philox_normal(seed, s, ei) : eps_new[ei]; };
@@ -952,15 +1026,15 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
       b.lat[VC_SITE_NUOMEGA][j] = x;
       nws_next[3 * VC_NWE + j] = x;
       const float lp = vc_normal_lp(x, b.mu_w[j], b.sd_w[j]);
-      sm_lq[j] = -(double)d.root_w * ((double)lp - ((cnd || lrmn) ? 0.0 : (double)lq));
+      sh.lq[j] = -(double)d.root_w * ((double)lp - ((cnd || lrmn) ? 0.0 : (double)lq));
     }
-    s_nuw[j] = x;
+    sh.nuw[j] = x;
   }
   __syncthreads();
   VC_WSTAMP(1, 4);
   if (first && t == 0) {
     double tot = 0.0;
-    for (int j = 0; j < nw; ++j) tot += sm_lq[j];
+    for (int j = 0; j < nw; ++j) tot += sh.lq[j];
     b.LPF[(size_t)(s & 1) * d.nlpf + d.nlpf - 1] = tot;
   }
   // ---- omega_c and d omega / d phi of step s into the cell records ---------------------------------------------------
@@ -975,7 +1049,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
     }
     float omega = 0.f, domega = 0.f;
     for (int xq = 0; xq < d.Nx; ++xq) {
-      const float* nwp = s_nuw + xq * d.Nhw;
+      const float* nwp = sh.nuw + xq * d.Nhw;
       float om = nwp[0], dd = 0.f;
 #pragma unroll
       for (int k = 0; k < VC_MAXH; ++k)
@@ -992,6 +1066,29 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
     b.lat_domega[c] = domega;
   }
   VC_WSTAMP(1, 5);
+}
+
+// One block of K_omega's grid (256 threads; `oblk` = its index in that grid).  Also called from the 1024-thread launch of
+// phase B, where the waves beyond the fourth have left before the first barrier.
+__device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                               const long long s, uint64_t seed, const VcAdamArgs& a,
+                                               double* __restrict__ loss_dev, long long loss_slots, int boot, int nb_cell,
+                                               int nb_hist, int oblk, int phase, const VcXb xb) {
+  VC_WSTAMP(1, 0);
+  if (oblk >= nb_cell) {
+    vc_omega_extra_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, boot, nb_hist, oblk - nb_cell, phase, xb, false);
+    return;
+  }
+  if (d.model != VC_MODEL_VELOCITY) return;
+  __shared__ VcNuwShared sh_nuw;
+  // this block's cells: the basis of the next phase (written by K_tail) is requested now
+  const int c = oblk * 256 + (int)threadIdx.x;
+  float s1 = 0.f, c1 = 1.f;
+  if (c < d.Nc) {
+    const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)c * d.ctw);
+    s1 = ct[0].x; c1 = ct[1].x;
+  }
+  vc_nuw_chain(d, b, P, G, s, seed, a, boot, oblk == 0, phase, xb, c, s1, c1, 256, sh_nuw);
 }
 
 __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
@@ -1068,6 +1165,53 @@ void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, floa
   if (d.nq <= 2) hipLaunchKernelGGL((vc_tail_merged_kernel<2>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
   else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail_merged_kernel<6>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
   else hipLaunchKernelGGL((vc_tail_merged_kernel<VC_MAXQ>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The rest of a single-rank step in ONE launch (round 4): everything K_tail and K_omega do, side by side, with no dependency
+// between the blocks of the launch:
+//   * gene blocks: K_tail's, unchanged;
+//   * cell blocks: K_tail's with the nu_omega chain INSIDE (vc_nuw_chain) -- the partials of d loglik / d nu_omega come out of
+//     K_main (pw_inline: PWM), so the chain needs nothing from the other cell blocks; block 0 stores the nu_omega parameters
+//     and the snapshot the next launch reads.  The phase model has no such chain;
+//   * the loss block: every term of the finished step's loss was complete before the launch (LPF / LPR of its sample, its
+//     histogram sums, K_main's partials);
+//   * the histogram blocks: shape_inv(s) is being computed by the gene blocks of this very launch, so every task wave re-derives
+//     that update from the snapshot of the launch before (vc_hist_rederive_wave: the same bits) and writes the other half
+//     of HL / HD;
+//   * the eps blocks depend on nothing.
+// Launch structures give the same bits: tests/test_hip_fused.py.
+// ---------------------------------------------------------------------------------------------
+template <int MQ>
+__global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
+                                                        float* __restrict__ G, const long long* __restrict__ step_dev,
+                                                        uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
+                                                        long long loss_slots, int nb_hist) {
+  const long long s = *step_dev;
+  VcOpt o;
+  o.step_size = b.step_size[0];
+  o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip;
+  if ((int)blockIdx.x < d.nb_post_gene) {
+    vc_tail_gene_block<MQ, VC_PH_ALL>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, VcXb{});
+    return;
+  }
+  if ((int)blockIdx.x < d.nb_post_gene + d.nb_tail_cell) {
+    vc_tail_cell_block<VC_PH_ALL, true>(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, 0, VcXb{});
+    return;
+  }
+  if (threadIdx.x >= 256) return;          // the remaining blocks are 256 threads wide: the other waves leave before any barrier
+  vc_omega_extra_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, blockIdx.x - d.nb_post_gene - d.nb_tail_cell,
+                       VC_PH_ALL, VcXb{}, true);
+}
+
+void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                     const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, hipStream_t st) {
+  const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
+  const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
+  const dim3 grid(d.nb_post_gene + d.nb_tail_cell + 1 + nb_hist + nb_eps), block(1024);
+  if (d.nq <= 2) hipLaunchKernelGGL((vc_tail2_kernel<2>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
+  else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail2_kernel<6>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
+  else hipLaunchKernelGGL((vc_tail2_kernel<VC_MAXQ>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
 }
 
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,

@@ -241,7 +241,11 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // the per-cell sums are stored (lane = cell, 64 cells per flush).  The W rows of the wave's cells are copied into the LDS
   // before the loop: a compiler-visible VECTOR load inside the loop body would bring hipcc's conservative vmcnt waits back
   // into every trip; an LDS read in the (rare) flush branch costs a lgkmcnt wait there and nothing elsewhere.
-  constexpr bool PWI = VC_PW_INLINE && KIND == VC_KIND_VU;
+  // Since round 4 the S+U kernel does the same at its LDS-tile flush (lane = (row, cell) of a 16-cell tile: the lanes of row
+  // A3 multiply), with the accumulators in the LDS as well -- it has no registers to spare.  With those partials at hand the
+  // nu_omega chain no longer depends on the cell blocks of the launch that follows, which is what lets the whole rest of
+  // the step go out as ONE launch (vc_fused_kernels.hip: vc_tail2_kernel).
+  constexpr bool PWI = VC_PW_INLINE && (KIND == VC_KIND_VU || KIND == VC_KIND_VFULL);
   const bool pw_on = PWI && d.pw_inline != 0;
   float pwacc[VC_PWQ];
 #pragma unroll
@@ -372,13 +376,18 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   constexpr int GT_F = VC_GT_LDS ? (K + 3) * GBW : 0;                // the gene block's rows of the gene table, staged once per workgroup
   constexpr int LDS_F = (EPI_F > TILE_F ? EPI_F : TILE_F) > GT_F ? (EPI_F > TILE_F ? EPI_F : TILE_F) : GT_F;
   __shared__ float4 lds4[(LDS_F + 3) / 4];   // gene-table staging / reduction tiles / epilogue staging (4-wave combine), in turn
-  constexpr int PW_SLOTS = VC_PW_SLOTS(GPL);
-  __shared__ float4 lds_w[PWI ? VC_WAVES * PW_SLOTS : 1];      // pw_inline: W rows of this wave's cells
+  // pw_inline: W rows of this wave's cells (d.pw_slots float4 per wave) and, S+U kernel, 32 float4 of accumulators per wave
+  // behind them -- DYNAMIC shared memory, sized by the launch (0 bytes when the feature is off: a sharded run, a tile that
+  // does not fit), so that it costs occupancy only where it is used
+  extern __shared__ float4 lds_w[];
+  const int PW_SLOTS = d.pw_slots;
   const int pw_rq = pw_on ? d.pw_inline / 4 : 1;      // float4 per W row: 1 or 2
+  float4* pw_acc = lds_w + (size_t)VC_WAVES * PW_SLOTS + wave * 32;      // [16 cells of a tile][2]
   if (PWI && pw_on) {
     float4* mine = lds_w + wave * PW_SLOTS;
     const float4* src = reinterpret_cast<const float4*>(b.WT) + (size_t)cbeg * pw_rq;
     for (int i = lane; i < ncell * pw_rq; i += 64) mine[i] = src[i];
+    if (FULL && lane < 32) pw_acc[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
@@ -624,13 +633,31 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       float4 acc = src[0];
 #pragma unroll
       for (int q = 1; q < 16; ++q) { const float4 v = src[q]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-      const float t = ((acc.x + acc.y) + (acc.z + acc.w)) * CO_SCALE;
+      const float ts = (acc.x + acc.y) + (acc.z + acc.w);
+      const float t = ts * CO_SCALE;
       if (c < n) b.CO[((size_t)gb * NCO + row) * d.Nc + cb + c] = t;
+      if (PWI && pw_on && row == 2 && c < n) {
+        // this lane holds A3 of cell cb + c over the wave's genes: d loglik / d nu_omega[j] += A3_c W_cj (accumulators in the LDS,
+        // one slot per tile cell: nothing is carried in registers across the cell loop)
+        const int iw = (int)(cb - cbeg) + c;
+        const float4 w = lds_w[wave * PW_SLOTS + iw * pw_rq];
+        float4 a0 = pw_acc[2 * c];
+        a0.x = __builtin_fmaf(ts, w.x, a0.x); a0.y = __builtin_fmaf(ts, w.y, a0.y);
+        a0.z = __builtin_fmaf(ts, w.z, a0.z); a0.w = __builtin_fmaf(ts, w.w, a0.w);
+        pw_acc[2 * c] = a0;
+        if (pw_rq == 2) {
+          const float4 w1 = lds_w[wave * PW_SLOTS + iw * 2 + 1];
+          float4 a1 = pw_acc[2 * c + 1];
+          a1.x = __builtin_fmaf(ts, w1.x, a1.x); a1.y = __builtin_fmaf(ts, w1.y, a1.y);
+          a1.z = __builtin_fmaf(ts, w1.z, a1.z); a1.w = __builtin_fmaf(ts, w1.w, a1.w);
+          pw_acc[2 * c + 1] = a1;
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   auto flush = [&](long long cb, int n) {      // coalesced store of the staged per-cell sums of the last n <= 64 cells
-    if (PWI && pw_on) {
+    if (PWI && !FULL && pw_on) {
       const float a3 = lane < n ? keep0 : 0.f;
       const int iw = (int)(cb - cbeg) + (lane < n ? lane : 0);
       const float4 w = lds_w[wave * PW_SLOTS + iw * pw_rq];
@@ -819,6 +846,12 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   if (threadIdx.x == 0) b.LO[blockIdx.x] = (sm_ll[0] + sm_ll[1]) + (sm_ll[2] + sm_ll[3]);
   if (PWI && pw_on) {
     __shared__ float sm_pw[VC_WAVES][VC_PWQ];
+    if (FULL) {        // lane c < 16 picks up the accumulators of tile cell c (DS operations of one wave execute in order)
+      const float4 a0 = lane < 16 ? pw_acc[2 * lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 a1 = lane < 16 ? pw_acc[2 * lane + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+      pwacc[0] = a0.x; pwacc[1] = a0.y; pwacc[2] = a0.z; pwacc[3] = a0.w;
+      pwacc[4] = a1.x; pwacc[5] = a1.y; pwacc[6] = a1.z; pwacc[7] = a1.w;
+    }
 #pragma unroll
     for (int q = 0; q < VC_PWQ; ++q) {
       const float t = vc_wave_sum(pwacc[q]);
@@ -850,7 +883,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 
 template <int H, int NB, int KIND, int NOISE, int GPL, int C16>
 static void vc_main_launch(const VcDims& d, const VcBufs& b, hipStream_t st) {
-  hipLaunchKernelGGL((vc_main_kernel<H, NB, KIND, NOISE, GPL, C16>), dim3(d.n_main_wg), dim3(256), 0, st, d, b);
+  hipLaunchKernelGGL((vc_main_kernel<H, NB, KIND, NOISE, GPL, C16>), dim3(d.n_main_wg), dim3(256), vc_main_dyn_lds(d), st, d, b);
 }
 
 struct VcMainEntry { int H, NB, kind, noise, gpl, c16; vc_main_launch_fn fn; const void* kernel; };

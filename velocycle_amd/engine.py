@@ -172,7 +172,8 @@ class HipEngine:
                           main_kernel=st.main_kernel_name.decode(), hist_on_device=bool(st.hist_on_device),
                           setup_transient_bytes=st.setup_transient_bytes,
                           count_storage="u16" if st.count_storage_bytes == 2 else "f32",
-                          pass_cells=[int(x) for x in st.pass_cells])
+                          pass_cells=[int(x) for x in st.pass_cells], launches_per_step=int(st.launches_per_step),
+                          pw_inline=int(st.pw_inline), generic=bool(st.generic))
 
     # ------------------------------------------------------------------------------------------
     def param_shape(self, name):
