@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Per-wave wall-clock timeline of the step's second launch (vc_tail2_kernel, or K_tail + K_omega with VC_TAIL2=0), from the
+VC_DBG_TIMES build:
+  make -C velocycle_amd/csrc BUILD=build_dbg OUT=../../scratch/libs/dbg.so EXTRA=-DVC_DBG_TIMES
+  VC_LIB_PATH=$PWD/scratch/libs/dbg.so python profiles/tools/tail2_timeline.py [vjoint|phase|vcond] [cells] [genes]
+Stamps are s_memrealtime (100 MHz): 1 tick = 10 ns.  Printed: K_main's span, the gap to the first wave of the next launch, when
+each stage of the gene / cell blocks is reached (relative to that launch's first wave entry; median / max over waves), the
+stages of the nu_omega chain inside the cell blocks, the last stamp of the launch, and the gap back to K_main."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.getcwd())
+os.environ["VC_DBG_TIMES_OUT"] = "/tmp/vc_times.bin"
+from velocycle_amd.engine import HipEngine
+from velocycle_amd.svi import SVIRunner
+from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "vjoint"
+NC = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+NG = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+dev = torch.device("cuda:0")
+spec = make_phase_spec(NC, NG, seed=0, device=dev) if mode == "phase" else make_velocity_spec(NC, NG, mode, 1, 1, seed=0, device=dev)
+eng = HipEngine(spec, device=dev)
+nwg = eng.stats["main_grid"]
+print(mode, NC, NG, eng.stats["main_kernel"], "launches per step", eng.stats["launches_per_step"], "pw_inline", eng.stats["pw_inline"])
+run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=0, use_graph=False)
+run.run_perf(60, sync=True)
+del run
+eng.close()
+del eng
+raw = np.fromfile("/tmp/vc_times.bin", dtype=np.uint64).astype(np.int64)
+main = raw[: nwg * 32].reshape(-1, 8)
+w = raw[nwg * 32 + 3 * 4096 * 8:].reshape(2, 4096, 16, 8)
+mt0 = main[main[:, 0] > 0][:, 0].min()
+mt3 = main[:, 3].max()
+print(f"K_main (last launch of the run): first entry -> last exit {(mt3 - mt0) / 100:.2f} us; median wave exit {(np.median(main[:, 3]) - mt0) / 100:.2f}")
+NGB = ((NG + 63) // 64 * 64 + 255) // 256 * 256 // 64 if False else None
+s0 = w[0]
+live = s0[:, :, 0] > 0
+z = s0[:, :, 0][live].min()
+print(f"K_main last exit -> first wave of the next launch: {(z - mt3) / 100:.2f} us")
+nblk = np.where(live.any(1))[0]
+print(f"blocks with stamps: {len(nblk)} (indices {nblk.min()}..{nblk.max()})")
+u = (s0 - z) / 100.0
+ngb = int(os.environ.get("NGB", 0)) or (((NG + 511) // 512) * 512 // 64)
+
+
+def show(tag, arr, sel, ks=range(8)):
+    for k in ks:
+        v = arr[:, :, k][sel & (arr[:, :, k] > -1e8)]
+        if len(v):
+            print(f"   {tag:34s} stamp{k}: min {v.min():6.2f} med {np.median(v):6.2f} max {v.max():6.2f}  (n={len(v)})")
+
+
+u[s0 <= 0] = -1e9
+gene = np.zeros_like(live); gene[:ngb] = True
+show("gene blocks (all waves)", u, live & gene)
+for wv, role in ((0, "nu[0]"), (12, "shape_inv"), (13, "role 14"), (15, "role 13")):
+    r = np.zeros_like(live); r[:ngb, wv] = True
+    show(f"gene wave {wv} ({role})", u, live & r)
+cell = np.zeros_like(live); cell[ngb:] = True
+show("cell blocks", u, live & cell)
+s1 = w[1]
+live1 = s1[:, :, 1] > 0
+if live1.any():
+    u1 = (s1 - z) / 100.0
+    u1[s1 <= 0] = -1e9
+    show("nu_omega chain (same clock origin)", u1, live1, ks=range(1, 6))
+    end = max(u[u > -1e8].max(), u1[u1 > -1e8].max())
+else:
+    end = u[u > -1e8].max()
+for k, tag in ((6, "histogram waves: update re-derived"), (7, "histogram waves: done"), (0, "loss block: done")):
+    sel = s1[:, :, k] > 0
+    if sel.any():
+        v = (s1[:, :, k][sel] - z) / 100.0
+        print(f"   {tag:34s} stamp{k}: min {v.min():6.2f} med {np.median(v):6.2f} max {v.max():6.2f}  (n={len(v)})")
+        end = max(end, v.max())
+print(f"   last stamp of the launch at {end:.2f} us")

@@ -77,6 +77,8 @@ struct VcDims {
   int pass_cw[4];         // cells per wave of the workgroups of pass 0..3 (later passes: as pass 3); all equal to cw unless the
                           // passes take unequal shares of the cells (vc_engine.hip, tiling)
   int hist_has_S, hist_has_U;
+  int hist_dense;         // 1: the histogram sums come from the dense tail-count tables (one task per gene and matrix, evaluated per
+                          // gene block: vc_hist_dense_block); 0: from the (value, multiplicity) lists, one wave per task of <= 64 values
   int hist_par;           // 1: shape_inv is learned -- the fused steps keep the histogram sums of the sample of step s in half s & 1 of
                           // HL / HD (the launch that finishes step s - 1 reads half (s - 1) & 1 while its histogram blocks write half
                           // s & 1); 0: evaluated once (half 0)
@@ -133,6 +135,10 @@ struct VcBufs {
   const int *h_tptr;                        // [Ng+1] first task of every gene (tasks are sorted by gene)
   int n_tasks;
   const float *h_val, *h_cnt;
+  // dense histograms (d.hist_dense; vc_host_logic.h: vc_build_dense_hist): tail counts C_j of every gene, [gene block of 64][j][gene]
+  const float* HC;                          // rows of 64 floats
+  const int* hc_off;                        // [2][Ng_pad / 64] first row of a gene block (matrix S, then U)
+  const int* hc_rows;                       // [2][Ng_pad / 64] rows of a gene block = 1 + its largest count
   const int *wg_tile;                       // [n_main_wg][2] {first cell of wave 0, cells per wave} of the likelihood kernel's workgroups
   const float *gene_sum_u;                  // [Ng_pad] sum over this rank's cells of the unspliced counts of every gene (count noise)
   // per-step workspaces
@@ -417,9 +423,139 @@ __device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, c
   if (lane == 0) { b.HL[(size_t)half * b.n_tasks + task] = hl; b.HD[(size_t)half * b.n_tasks + task] = hd; }
 }
 
+// shape_inv of gene g as a histogram evaluation takes it from the parameters as they stand (the logic of vc_hist_wave)
+__device__ __forceinline__ float vc_hist_si(const VcDims& d, const VcBufs& b, const float* __restrict__ P, int cond_only, int g) {
+  if (g >= d.Ng) return 1.f;
+  if (CND(VC_SITE_SHAPE_INV)) return b.cnd[VC_SITE_SHAPE_INV][g];
+  return cond_only ? 1.f : expf(P[d.poff[VC_P_SHAPE_INV_ULOCS] + g]);
+}
+
+// Dense form (d.hist_dense): the histogram sums of the 64 genes of gene block `gb` (lane = gene; this thread's gene has
+// r = 1 / si) for every matrix the model uses, by ALL `nwv` waves of the block (nwv = 4 or 16; called by every thread of the
+// block: barriers inside).  Sixteen slices of the count axis (j = v, v + 16, ...) are summed one after the other in double and
+// then added in slice order -- by whichever wave holds them: the result does not depend on the number of waves.
+// sm: [16][2][64] doubles.
+__device__ __forceinline__ void vc_hist_dense_block(const VcDims& d, const VcBufs& b, int gb, float si, int half, int nwv,
+                                                    double* sm /* 2048 doubles */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nblk = d.Ng_pad / 64, nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
+  const int g = gb * 64 + lane;
+  const float r = 1.0f / si;
+  for (int m = 0; m < nm; ++m) {
+    const bool used = (m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U);
+    const int rows = used ? b.hc_rows[m * nblk + gb] : 0;
+    const float* __restrict__ tabp = b.HC + (size_t)b.hc_off[m * nblk + gb] * 64 + lane;
+    for (int v = wv; v < 16; v += nwv) {
+      // eight count levels requested per trip (a plain load-and-add loop is one memory round trip per level); the hardware
+      // log2 / reciprocal (v_log_f32, v_rcp_f32: 1 ulp) are what K_main itself uses per element; log2 -> ln once per gene
+      double al = 0.0, ad = 0.0;
+      constexpr int UB = 8;
+      for (int j0 = v; j0 < rows; j0 += 16 * UB) {
+        float c[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const int j = j0 + 16 * u; c[u] = j < rows ? tabp[(size_t)j * 64] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const float t = r + (float)(j0 + 16 * u);
+          al += (double)c[u] * (double)__builtin_amdgcn_logf(t);
+          ad += (double)c[u] * (double)__builtin_amdgcn_rcpf(t);
+        }
+      }
+      sm[(v * 2 + 0) * 64 + lane] = al;
+      sm[(v * 2 + 1) * 64 + lane] = ad;
+    }
+    __syncthreads();
+    if (wv == 0 && g < d.Ng) {
+      double hl = 0.0, hd = 0.0;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { hl += sm[(v * 2 + 0) * 64 + lane]; hd += sm[(v * 2 + 1) * 64 + lane]; }
+      const size_t t = (size_t)half * b.n_tasks + (size_t)nm * g + m;
+      b.HL[t] = hl * 0.6931471805599453094;
+      b.HD[t] = hd;
+    }
+    __syncthreads();
+  }
+}
+
+// The same for a block of exactly 16 waves (the 1024-thread launches: one-launch tail, phase B), in two halves so that the caller
+// can put its own work between the request and the use of the table rows: wave v owns slice v of the count axis; `issue`
+// requests its first 16 count levels of every matrix (nothing is consumed), `finish` -- once shape_inv of the lane's gene
+// is known -- adds them up (+ further levels of a block whose largest count exceeds 256), one barrier, and waves 0 / 1 add
+// the slices of matrix S / U in slice order.  Same sums as vc_hist_dense_block, bit for bit.
+struct VcHistPre { float c[2][16]; int rows[2], off[2]; };
+__device__ __forceinline__ void vc_hist_dense16_rows(const VcDims& d, const VcBufs& b, int gb, VcHistPre& h) {
+  const int nblk = d.Ng_pad / 64, nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const bool used = m < nm && ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U));
+    h.rows[m] = used ? b.hc_rows[m * nblk + gb] : 0;
+    h.off[m] = used ? b.hc_off[m * nblk + gb] : 0;
+  }
+}
+__device__ __forceinline__ void vc_hist_dense16_issue(const VcDims& d, const VcBufs& b, VcHistPre& h) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const float* __restrict__ tabp = b.HC + (size_t)h.off[m] * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {        // (no branch around a load: a clamped row, the value dropped afterwards)
+      const int j = wv + 16 * u, jc = j < h.rows[m] ? j : (h.rows[m] > 0 ? h.rows[m] - 1 : 0);
+      const float x = tabp[(size_t)jc * 64];
+      h.c[m][u] = j < h.rows[m] ? x : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const VcBufs& b, int gb, float si, int half, const VcHistPre& h,
+                                                       double* sm /* 4096 doubles */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
+  const int g = gb * 64 + lane;
+  const float r = 1.0f / si;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    double al = 0.0, ad = 0.0;
+    if (m < nm) {
+      const float* __restrict__ tabp = b.HC + (size_t)h.off[m] * 64 + lane;
+      constexpr int UB = 8;            // (the association of vc_hist_dense_block: levels in increasing order, one by one)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float t = r + (float)(wv + 16 * u);
+        al += (double)h.c[m][u] * (double)__builtin_amdgcn_logf(t);
+        ad += (double)h.c[m][u] * (double)__builtin_amdgcn_rcpf(t);
+      }
+      for (int j0 = wv + 256; j0 < h.rows[m]; j0 += 16 * UB) {
+        float c[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const int j = j0 + 16 * u; c[u] = j < h.rows[m] ? tabp[(size_t)j * 64] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const float t = r + (float)(j0 + 16 * u);
+          al += (double)c[u] * (double)__builtin_amdgcn_logf(t);
+          ad += (double)c[u] * (double)__builtin_amdgcn_rcpf(t);
+        }
+      }
+    }
+    sm[((m * 16 + wv) * 2 + 0) * 64 + lane] = al;
+    sm[((m * 16 + wv) * 2 + 1) * 64 + lane] = ad;
+  }
+  __syncthreads();
+  if (wv < nm && g < d.Ng) {
+    const int m = wv;
+    double hl = 0.0, hd = 0.0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { hl += sm[((m * 16 + v) * 2 + 0) * 64 + lane]; hd += sm[((m * 16 + v) * 2 + 1) * 64 + lane]; }
+    const size_t t = (size_t)half * b.n_tasks + (size_t)nm * g + m;
+    b.HL[t] = hl * 0.6931471805599453094;
+    b.HD[t] = hd;
+  }
+}
+
 #endif  // __HIPCC__
 
 // launchers implemented in the .hip translation units -----------------------------------------
+static inline int vc_hist_blocks(const VcDims& d, const VcBufs& b, int waves) {
+  return d.hist_dense ? d.Ng_pad / 64 : (b.n_tasks + waves - 1) / waves;
+}
 typedef void (*vc_main_launch_fn)(const VcDims& d, const VcBufs& b, hipStream_t st);
 vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, int c16, const char** name,
                                       const void** kernel);

@@ -171,6 +171,7 @@ struct vc_engine {
   }
 
 static bool cond(const vc_engine* e, int site) { return (e->d.cond >> site) & 1u; }
+static int fused_tail_kind(const vc_engine* e);
 
 static long long site_size(const vc_engine* e, int site) {
   const VcDims& d = e->d;
@@ -867,7 +868,12 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // 1024-thread slot when it is placed (2 per CU): beyond ~2 rounds of them the placement is what costs (400 000 cells:
   // K_tail 68 us), and 1024 cells per block -- every wave busy, a quarter of the blocks -- is faster (measured threshold)
   d.tail_tc = d.Nc > 160000 ? 1024 : 256;
-  if (const char* env = getenv("VC_TAIL_TC")) { if (atoi(env) == 256 || atoi(env) == 1024) d.tail_tc = atoi(env); }
+  // the one-launch tail (vc_launch_tail2) puts the loss / histogram / eps blocks into the same launch, and every 1024-thread block
+  // of it holds a CU on its own: with 256-cell blocks the cell blocks alone take most of the chip's 256 slots and the others
+  // wait a round (50k x 2k: phase 17.5 -> 13.0 us outside K_main with 1024-cell blocks, V-joint 25 -> 22.5)
+  // -- and with the dense histogram tables (S+U kernel) 512: its cell blocks carry the longest chain of that launch (nu_omega inside)
+  if (fused_tail_kind(e) == 2 && d.Nc > 16384) d.tail_tc = d.kind == VC_KIND_VFULL ? 512 : 1024;
+  if (const char* env = getenv("VC_TAIL_TC")) { if (atoi(env) == 256 || atoi(env) == 512 || atoi(env) == 1024) d.tail_tc = atoi(env); }
   d.nb_tail_cell = (d.Nc + d.tail_tc - 1) / d.tail_tc;
   d.nlpf = d.nb_post_gene + d.nb_tail_cell + 1;
   d.lgamma_alpha = lgammaf(d.gamma_alpha);
@@ -910,6 +916,9 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   {
     std::vector<int> ptr;
     std::vector<float> val, cnt;
+    bool dense_ok = false;
+    std::vector<float> hc;
+    std::vector<int> hc_off, hc_rows;
     if (want_hist) {
       bool bad_host = false, fallback = false;
       unsigned novf[2] = {0, 0};
@@ -919,8 +928,18 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       }
       if (dev_hist && !fallback) {
         std::vector<unsigned> htab((size_t)d.Ng * VC_HIST_CAP);
+        // dense tail-count tables (vc_host_logic.h: vc_build_dense_hist) when every non-zero count of the matrices is an integer
+        // below VC_HIST_CAP (no overflow entries): the histogram sums then cost a logarithm and a reciprocal per (gene, count
+        // level) and are evaluated per gene block.
+        const char* hde = getenv("VC_HIST_DENSE");
+        // Default: the S+U kernel's models only -- 4 000+ task waves there (two matrices) against 32 blocks; measured at 50k x 2k
+        // (profiles/r04_two_launch.md) V-joint 21-24 -> 17.5-19 us outside K_main, phase (one matrix, nothing to hide the blocks
+        // of its few outlier genes behind) 13.4 -> 15.5: the phase model keeps the lists.  VC_HIST_DENSE=1 / 0 forces either.
+        dense_ok = nb && novf[0] == 0 && novf[1] == 0 && d.Nc <= (1 << 24) &&
+                   (hde ? atoi(hde) != 0 : d.kind == VC_KIND_VFULL);
         for (int m = 0; m < (vel ? 2 : 1); ++m) {
           HIPCHK(e, hipMemcpy(htab.data(), tab[m], htab.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+          if (dense_ok) vc_build_dense_hist(htab.data(), d.Ng, d.Ng_pad, hc, hc_off, hc_rows);
           std::vector<float> ov(novf[m]);
           std::vector<int> og(novf[m]);
           if (novf[m]) {
@@ -959,7 +978,27 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     e->setup_transient_bytes = transient;
     // tasks: runs of <= 64 histogram entries of one gene and matrix, sorted by gene
     std::vector<int> task, tptr;
-    vc_build_hist_tasks(ptr, d.Ng, task, tptr);
+    d.hist_dense = dense_ok ? 1 : 0;
+    if (dense_ok) {
+      // one task per gene and matrix, in that order: what role 12 / the loss block / K_post add up per gene is unchanged
+      const int nm = vel ? 2 : 1, nblk = d.Ng_pad / 64;
+      for (int g = 0; g < d.Ng; ++g) {
+        tptr.push_back(nm * g);
+        for (int m = 0; m < nm; ++m) task.insert(task.end(), {g, m, 0, 0});
+      }
+      tptr.push_back(nm * d.Ng);
+      if (!vel) {                               // the U half of the tables: empty
+        hc_off.resize(2 * (size_t)nblk, (int)(hc.size() / 64));
+        hc_rows.resize(2 * (size_t)nblk, 0);
+      }
+      hc.resize(hc.size() + 64, 0.f);          // (a row of padding: the prefetch of an empty block reads row 0)
+      TRY(upload(e, hc, &b.HC));
+      TRY(upload(e, hc_off, &b.hc_off));
+      TRY(upload(e, hc_rows, &b.hc_rows));
+    } else {
+      vc_build_hist_tasks(ptr, d.Ng, task, tptr);
+      b.HC = nullptr; b.hc_off = nullptr; b.hc_rows = nullptr;
+    }
     b.n_tasks = (int)task.size() / 4;
     TRY(upload(e, task, &b.h_task));
     TRY(upload(e, tptr, &b.h_tptr));

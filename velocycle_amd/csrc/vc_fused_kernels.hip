@@ -35,6 +35,8 @@
 struct VcOpt { float step_size, b1, b2, eps, clip; };
 
 #define VC_NWE (VC_MAX_NW * (VC_MAX_RANK + 2))      // nu_omega-related parameter elements at most
+#define VC_HIST_ROUNDS 1     // one-launch tail, list form: rounds of 16 histogram tasks per 1024-thread block (2: measured slower)
+#define VC_EPS_PER_THREAD 4  // one-launch tail: Philox pairs per thread of an eps block
 
 // ---------------------------------------------------------------------------------------------
 // Cells sharded over ranks (vc_svi_run_sharded): the same step cut at its ONE exchange.
@@ -519,6 +521,12 @@ struct VcNuwShared {     // LDS of the nu_omega chain (vc_nuw_chain, below)
   float nuw[VC_MAX_NW];
   double lq[VC_MAX_NW];
 };
+#define VC_NUW_RAW 12          // rows per lane held in registers: n_pw <= 768 partial rows (3 workgroups per CU x 256 CUs)
+struct VcNuwRaw { float r[2][VC_NUW_RAW]; };
+__device__ __forceinline__ void vc_nuw_sums_issue(const VcDims& d, const VcBufs& b, int boot, int phase, const VcXb& xb, int nthr,
+                                                  VcNuwRaw& raw);
+__device__ __forceinline__ void vc_nuw_sums_finish(const VcDims& d, const VcBufs& b, int boot, int phase, const VcXb& xb, int nthr,
+                                                   const VcNuwRaw& raw, VcNuwShared& sh);
 __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
                                              long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
                                              const VcXb& xb, int c, float s1, float c1, int nthr, VcNuwShared& sh);
@@ -534,6 +542,11 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   const int VC_TC = d.tail_tc;
   if ((int)threadIdx.x >= VC_TC) return;   // 256-cell blocks: waves 4..15 of the block have nothing to do
   VC_WSTAMP(0, 0);
+  __shared__ VcNuwShared sh_nuw;
+  // OMEGA: the sums of K_main's partials of d loglik / d nu_omega depend on nothing in this block -- requested first, so that their
+  // round trip runs beside the cell part's
+  VcNuwRaw nuw_raw;
+  if (OMEGA && d.model == VC_MODEL_VELOCITY) vc_nuw_sums_issue(d, b, boot, phase, xb, VC_TC, nuw_raw);
   const int c = cblock * VC_TC + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool vel = d.model == VC_MODEL_VELOCITY;
@@ -596,6 +609,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
     }
   }
   VC_WSTAMP(0, 3);
+  if (OMEGA && vel) vc_nuw_sums_finish(d, b, boot, phase, xb, VC_TC, nuw_raw, sh_nuw);      // (their rows arrived with the cell's own loads)
   // (single rank with K_main's own partials: nobody reads the cell blocks' -- K_omega / the chain below take PWM)
   if (vel && !boot && !(phase == VC_PH_ALL && d.pw_inline)) {
     // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c) at the phases of step s - 1
@@ -689,7 +703,6 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   VC_WSTAMP(0, 5);
   if (OMEGA && vel) {
     // the nu_omega chain (gradient from K_main's partials, optimiser, next sample) and omega_c of this block's cells
-    __shared__ VcNuwShared sh_nuw;
     vc_nuw_chain(d, b, P, G, s, seed, VcAdamArgs{Mm, Vv, 0.0, 0.0, 0.0, 0.0, o.b1, o.b2, o.eps, o.clip, header}, boot, cblock == 0, phase,
                  xb, in_range ? c : d.Nc, s1_new, c1_new, VC_TC, sh_nuw);
   }
@@ -815,28 +828,48 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
     G[1] = (float)(loss - (double)hi);
     G[2] = 0.f;
     G[3] = 0.f;
+    VC_WSTAMP(1, 0);
   }
 }
 
-// Histogram terms of shape_inv(s) for one task while the gene blocks of the SAME launch are still computing shape_inv(s): the
-// update is re-derived here from the snapshot the launch before took (SIS, half (s - 1) & 1), K_main's partials and the
-// histogram sums of the finished step -- statement by statement what the owning (gene, role 12) thread runs, the second-stage
-// reduction in its order included (wave w adds chunks w, w + 16, ...; the 16 wave sums are added in wave order): the same bits.
-__device__ __forceinline__ void vc_hist_rederive_wave(const VcDims& d, const VcBufs& b, const float* __restrict__ P, long long s,
-                                                      const VcAdamArgs& a, int task, int lane) {
-  const int g = b.h_task[4 * task];
+// Histogram terms of shape_inv(s) for the 16 tasks of one 1024-thread block while the gene blocks of the SAME launch are still
+// computing shape_inv(s): the update is re-derived here from the snapshot the launch before took (SIS, half (s - 1) & 1),
+// K_main's partials and the histogram sums of the finished step -- statement by statement what the owning (gene, role 12) thread
+// runs, the second-stage reduction in its order included: the same bits.  The 16 tasks of a block belong to a handful of
+// consecutive genes; wave v adds, for the gene of every task, the chunks v, v + 16, ... (what wave v of that gene's gene block
+// adds), lane i for task i; the 16 wave sums meet in the LDS and every wave adds them in wave order for its own task's gene.
+// K_main's partial row of shape_inv is read about once this way (a wave per task on its own read it sixteen times over: 34 MB).
+__device__ __forceinline__ void vc_hist_rederive_block(const VcDims& d, const VcBufs& b, const float* __restrict__ P, long long s,
+                                                       const VcAdamArgs& a, int task0) {
+  __shared__ float sm_a[VC_PG_WAVES][VC_PG_WAVES];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t NP = d.Ng_pad;
+  const int q = d.kind == VC_KIND_PHASE ? d.K : d.K + 2;
+  const int task = task0 + wv;
+  const bool have = task < b.n_tasks;
+  // everything that depends on the task table only, requested together
+  const int ti = task0 + (lane < VC_PG_WAVES ? lane : 0);
+  const int gi = b.h_task[4 * (ti < b.n_tasks ? ti : b.n_tasks - 1)];          // lane i < 16: the gene of task i of this block
+  const int g = b.h_task[4 * (have ? task : b.n_tasks - 1)];                   // this wave's own gene
+  float acc = 0.f;
+  if (lane < VC_PG_WAVES && d.kind != VC_KIND_VU) {
+    // eight chunks requested per trip, added in chunk order (a plain `acc += load` loop is eight dependent round trips)
+    constexpr int UB = 8;
+    for (int ch0 = wv; ch0 < d.n_chunks; ch0 += UB * VC_PG_WAVES) {
+      float v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int ch = ch0 + u * VC_PG_WAVES;
+        v[u] = b.GO[((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq + q) * NP + gi];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (ch0 + u * VC_PG_WAVES < d.n_chunks) acc += v[u];
+    }
+  }
   const float* sis = b.SIS + (size_t)((s - 1) & 1) * 4 * NP + g;
   const float p0 = sis[0], si = sis[3 * NP];
   float mm = sis[NP], vv = sis[2 * NP];
-  const int q = d.kind == VC_KIND_PHASE ? d.K : d.K + 2;
-  float acc = 0.f;
-  if (lane < VC_PG_WAVES)
-    for (int ch = lane; ch < d.n_chunks; ch += VC_PG_WAVES) acc += b.GO[((size_t)ch * d.nq + q) * NP + g];
-  float U_r = 0.f;
-#pragma unroll
-  for (int w = 0; w < VC_PG_WAVES; ++w) U_r += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), w));
-  if (d.kind == VC_KIND_VU) U_r = 0.f;
   double HDg = 0.0;
   {
     const double* __restrict__ HDs = b.HD + (size_t)((s - 1) & 1) * b.n_tasks;
@@ -849,9 +882,74 @@ __device__ __forceinline__ void vc_hist_rederive_wave(const VcDims& d, const VcB
       for (int k = 0; k < 4; ++k) if (tb + k < t1) HDg += hd[k];
     }
   }
+  if (lane < VC_PG_WAVES) sm_a[wv][lane] = acc;
+  __syncthreads();
+  float U_r = 0.f;
+#pragma unroll
+  for (int w = 0; w < VC_PG_WAVES; ++w) U_r += sm_a[w][wv];          // wave order, as the gene block's T()
+  if (d.kind == VC_KIND_VU) U_r = 0.f;
   const float gg = vc_si_grad(d, 1.0f / si, si, U_r, HDg, d.root_w);
   const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip);
-  vc_hist_wave(d, b, P, 0, task, lane, expf(np), (int)(s & 1));
+  VC_WSTAMP(1, 6);
+  if (have) vc_hist_wave(d, b, P, 0, task, lane, expf(np), (int)(s & 1));
+  VC_WSTAMP(1, 7);
+}
+
+// The same with the dense tables (d.hist_dense): ONE block per gene block -- lane = gene, wave v adds the chunks v, v + 16, ... of
+// K_main's shape_inv row exactly as wave v of the gene block does (coalesced rows), the 16 wave sums meet in the LDS, every wave
+// then holds shape_inv(s) of the block's 64 genes and takes its slices of the count axis (vc_hist_dense_block).
+__device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const VcBufs& b, long long s, const VcAdamArgs& a, int gb,
+                                                       double* sm_hd) {
+  __shared__ float sm_a[VC_PG_WAVES][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t NP = d.Ng_pad;
+  const int q = d.kind == VC_KIND_PHASE ? d.K : d.K + 2;
+  const int g = gb * 64 + lane;
+  const bool live = g < d.Ng;
+  VcHistPre hp;
+  vc_hist_dense16_rows(d, b, gb, hp);          // (arrives with the loads below)
+  float acc = 0.f;
+  if (d.kind != VC_KIND_VU) {
+    constexpr int UB = 8;
+    for (int ch0 = wv; ch0 < d.n_chunks; ch0 += UB * VC_PG_WAVES) {
+      float v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int ch = ch0 + u * VC_PG_WAVES;
+        v[u] = b.GO[((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq + q) * NP + g];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (ch0 + u * VC_PG_WAVES < d.n_chunks) acc += v[u];
+    }
+  }
+  vc_hist_dense16_issue(d, b, hp);             // the table rows travel while the update is re-derived
+  const float* sis = b.SIS + (size_t)((s - 1) & 1) * 4 * NP + g;
+  const float p0 = sis[0], si = live ? sis[3 * NP] : 1.f;
+  float mm = sis[NP], vv = sis[2 * NP];
+  double HDg = 0.0;
+  if (live) {
+    const double* __restrict__ HDs = b.HD + (size_t)((s - 1) & 1) * b.n_tasks;
+    const int t0 = b.h_tptr[g], t1 = b.h_tptr[g + 1];
+    for (int tb = t0; tb < t1; tb += 4) {
+      double hd[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hd[k] = HDs[tb + k < t1 ? tb + k : tb];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (tb + k < t1) HDg += hd[k];
+    }
+  }
+  sm_a[wv][lane] = acc;
+  __syncthreads();
+  float U_r = 0.f;
+#pragma unroll
+  for (int w = 0; w < VC_PG_WAVES; ++w) U_r += sm_a[w][lane];          // wave order, as the gene block's T()
+  if (d.kind == VC_KIND_VU) U_r = 0.f;
+  const float gg = vc_si_grad(d, 1.0f / si, si, U_r, HDg, d.root_w);
+  const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip);
+  VC_WSTAMP(1, 6);
+  vc_hist_dense16_finish(d, b, gb, live ? expf(np) : 1.f, (int)(s & 1), hp, sm_hd);
+  VC_WSTAMP(1, 7);
 }
 
 // The blocks of K_omega's grid that are off the nu_omega chain (256 threads; `xblk` = index behind the cell blocks): 0 = the loss
@@ -860,20 +958,49 @@ __device__ __forceinline__ void vc_hist_rederive_wave(const VcDims& d, const VcB
 __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
                                                      const long long s, uint64_t seed, const VcAdamArgs& a,
                                                      double* __restrict__ loss_dev, long long loss_slots, int boot, int nb_hist,
-                                                     int xblk, int phase, const VcXb xb, bool rederive) {
+                                                     int xblk, int phase, const VcXb xb, bool rederive, int nthr = 256) {
+  // nthr = 256: K_omega's own grid (4 tasks / 256 eps pairs per block); 1024: a launch of 1024-thread blocks (vc_tail2_kernel) --
+  // a block is placed as a whole 16-wave slot there (2 per CU), so every wave of it takes a task / 64 pairs: a quarter of the
+  // blocks, or the extras alone would need three more rounds of slots than the chains they run beside
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
   if (xblk == 0) {                                 // the loss of the finished step
+    if (t >= 256) return;                          // (a 256-thread job: the other waves leave before its barrier)
     if (!boot) vc_omega_loss_block(d, b, G, s, loss_dev, loss_slots, phase, xb);
     return;
   }
   xblk -= 1;
-  if (xblk < nb_hist) {                            // histogram terms of shape_inv(s), one wave per task
-    const int task = xblk * 4 + wv;
+  if (xblk < nb_hist) {                            // histogram terms of shape_inv(s)
     const int half = d.hist_par ? (int)(s & 1) : 0;
+    if (d.hist_dense) {                            // dense tables: one block per gene block (barriers inside)
+      __shared__ double sm_hd[4096];
+      if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense(d, b, s, a, xblk, sm_hd); return; }
+      const int g = xblk * 64 + lane;
+      VcHistPre hp;
+      if (nthr == 1024) { vc_hist_dense16_rows(d, b, xblk, hp); vc_hist_dense16_issue(d, b, hp); }
+      float si = vc_hist_si(d, b, P, 0, g);
+      if (phase == VC_PH_B && !CND(VC_SITE_SHAPE_INV) && g < d.Ng) {
+        // the gene blocks of this launch are rewriting shape_inv: re-derive its update from phase A's snapshot and the summed
+        // gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
+        const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
+        float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
+        si = expf(vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip));
+      }
+      if (nthr == 1024) vc_hist_dense16_finish(d, b, xblk, si, half, hp, sm_hd);
+      else vc_hist_dense_block(d, b, xblk, si, half, nthr >> 6, sm_hd);
+      return;
+    }
+    const int task = xblk * (nthr >> 6) + wv;      // lists of distinct values: one wave per task
+    if (rederive && !CND(VC_SITE_SHAPE_INV)) {           // (block-wide: barriers inside; nthr == 1024)
+      // two rounds of 16 tasks per block: half the blocks to place (every 1024-thread block of this launch holds a CU on its own)
+#pragma unroll 1
+      for (int rnd = 0; rnd < VC_HIST_ROUNDS; ++rnd) {
+        vc_hist_rederive_block(d, b, P, s, a, (xblk * VC_HIST_ROUNDS + rnd) * (nthr >> 6));
+        __syncthreads();                                   // the LDS rows of the next round overwrite this one's
+      }
+      return;
+    }
     if (task < b.n_tasks) {
-      if (rederive && !CND(VC_SITE_SHAPE_INV)) {
-        vc_hist_rederive_wave(d, b, P, s, a, task, lane);
-      } else if (phase == VC_PH_B && !CND(VC_SITE_SHAPE_INV)) {
+      if (phase == VC_PH_B && !CND(VC_SITE_SHAPE_INV)) {
         // the gene blocks of this launch are rewriting shape_inv: re-derive its update from phase A's snapshot and the
         // summed gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
         const int g = b.h_task[4 * task];
@@ -891,15 +1018,18 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
   // eps ring: the draws of step s + 1 (and, when booting, of step s) -- one Philox block = two consecutive indices.
   // Three slots: this launch reads the slots of s - 1 and s and writes the slot of s + 1.  The ring holds this rank's slice
   // of the stream: replicated sites at their global index, phi_xy shifted by the rank's first cell.
-  const long long pair = (long long)xblk * 256 + t;
-  if (2 * pair < d.eps_total) {
-    const uint64_t gpair = (uint64_t)(pair + (2 * pair >= d.eps_n_global ? d.cell_offset : 0));
-    float n0, n1;
-    vc_philox_normal2(seed, s + 1, gpair, n0, n1);
-    *reinterpret_cast<float2*>(b.EPS + (size_t)((s + 1) % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
-    if (boot) {
-      vc_philox_normal2(seed, s, gpair, n0, n1);
-      *reinterpret_cast<float2*>(b.EPS + (size_t)(s % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
+  const int per = nthr == 1024 ? VC_EPS_PER_THREAD : 1;          // pairs per thread (1024-thread launches: fewer, fatter blocks)
+  for (int k = 0; k < per; ++k) {
+    const long long pair = ((long long)xblk * per + k) * nthr + t;
+    if (2 * pair < d.eps_total) {
+      const uint64_t gpair = (uint64_t)(pair + (2 * pair >= d.eps_n_global ? d.cell_offset : 0));
+      float n0, n1;
+      vc_philox_normal2(seed, s + 1, gpair, n0, n1);
+      *reinterpret_cast<float2*>(b.EPS + (size_t)((s + 1) % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
+      if (boot) {
+        vc_philox_normal2(seed, s, gpair, n0, n1);
+        *reinterpret_cast<float2*>(b.EPS + (size_t)(s % 3) * d.eps_total + 2 * pair) = make_float2(n0, n1);
+      }
     }
   }
 }
@@ -908,16 +1038,73 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
 // sums of the partials of d loglik / d nu_omega (redundantly in every block, fixed order) -> gradient + ClippedAdam of the
 // nu_omega-related parameters on a snapshot (`first`: this block stores them and the snapshot of the next step) -> the nu_omega
 // sample of step s -> omega_c and d omega / d phi of cell c (sin, cos of its phase of step s: s1, c1) into its record.
-__device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
-                                             long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
-                                             const VcXb& xb, int c, float s1, float c1, int nthr, VcNuwShared& sh) {
+// part 1 of the chain: per-coefficient sums of the partials of d loglik / d nu_omega into sh.up -- every block, fixed order (lane i
+// adds rows i, i + 64, ... in double, then the 64 lanes: independent of the number of waves that share the coefficients).
+// In two halves, so that a caller can put its own loads between them: `issue` only REQUESTS the rows of this wave's first two
+// coefficients (registers, nothing consumed), `finish` adds them up.
+__device__ __forceinline__ void vc_nuw_sums_issue(const VcDims& d, const VcBufs& b, int boot, int phase, const VcXb& xb, int nthr,
+                                                  VcNuwRaw& raw) {
   const int t = threadIdx.x, wv = t >> 6, lane = t & 63, nwv = nthr >> 6;
-  const bool lrmn = d.guide == VC_GUIDE_LRMN;
+  const bool pwm = phase != VC_PH_B && d.pw_inline;           // single rank: K_main's own partials
+  const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : (pwm ? b.PWM : b.PW);
+  const int n_pw = phase == VC_PH_B ? xb.pw_cap : (pwm ? d.n_main_wg : d.nb_tail_cell);
+  const int pw_ld = pwm ? d.pw_inline : d.NW;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = wv + nwv * q;
+#pragma unroll
+    for (int k = 0; k < VC_NUW_RAW; ++k) {
+      const int i = lane + 64 * k;
+      raw.r[q][k] = (!boot && j < d.NW && i < n_pw && n_pw <= 64 * VC_NUW_RAW) ? PWs[(size_t)i * pw_ld + j] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void vc_nuw_sums_finish(const VcDims& d, const VcBufs& b, int boot, int phase, const VcXb& xb, int nthr,
+                                                   const VcNuwRaw& raw, VcNuwShared& sh) {
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, nwv = nthr >> 6;
   // phase B: the PW rows are the sums over ranks (every rank holds the complete gradient: prior / entropy weight 1)
   const bool pwm = phase != VC_PH_B && d.pw_inline;           // single rank: K_main's own partials
   const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : (pwm ? b.PWM : b.PW);
   const int n_pw = phase == VC_PH_B ? xb.pw_cap : (pwm ? d.n_main_wg : d.nb_tail_cell);
   const int pw_ld = pwm ? d.pw_inline : d.NW;
+  const int nw = d.NW;
+  VC_WSTAMP(1, 1);
+  if (!boot) {
+    double u[2] = {0.0, 0.0};
+    if (n_pw <= 64 * VC_NUW_RAW) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < VC_NUW_RAW; ++k)
+          if (lane + 64 * k < n_pw) u[q] += (double)raw.r[q][k];          // rows lane, lane + 64, ... in this order
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int j = wv + nwv * q;
+        if (j < nw)
+          for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = wv + nwv * q;
+      if (j < nw) { const double r = vc_wave_sum_d63(u[q]); if (lane == 63) sh.up[j] = (float)r; }
+    }
+    for (int j = wv + 2 * nwv; j < nw; j += nwv) {
+      double r = 0.0;
+      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
+      r = vc_wave_sum_d63(r);
+      if (lane == 63) sh.up[j] = (float)r;
+    }
+  }
+}
+
+// part 2 (sh.up filled by every wave that took part in part 1; the barrier below orders it)
+__device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                             long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
+                                             const VcXb& xb, int c, float s1, float c1, int nthr, VcNuwShared& sh) {
+  const int t = threadIdx.x;
+  const bool lrmn = d.guide == VC_GUIDE_LRMN;
   const float rw = phase == VC_PH_B ? 1.f : d.root_w;
   const int nw = d.NW;
   const int fin_per = lrmn ? d.R + 2 : 2;
@@ -933,29 +1120,6 @@ __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, f
   const float* __restrict__ eps_old = b.EPS + (size_t)((s + 2) % 3) * d.eps_total;
   const float* __restrict__ nws = b.NWS + (size_t)(s & 1) * 4 * VC_NWE;        // the nu_omega snapshot of this step ...
   float* __restrict__ nws_next = b.NWS + (size_t)((s + 1) & 1) * 4 * VC_NWE;   // ... and the copy block 0 fills for the next
-  VC_WSTAMP(1, 1);
-  // ---- per-coefficient sums of the partials of d loglik / d nu_omega: every block, fixed order (lane i adds rows i, i + 64, ...
-  // in double, then the 64 lanes: independent of the number of waves that share the coefficients) ------------------------
-  if (!boot) {
-    double u[2] = {0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int j = wv + nwv * q;
-      if (j < nw)
-        for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int j = wv + nwv * q;
-      if (j < nw) { const double r = vc_wave_sum_d63(u[q]); if (lane == 63) sh.up[j] = (float)r; }
-    }
-    for (int j = wv + 2 * nwv; j < nw; j += nwv) {
-      double r = 0.0;
-      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
-      r = vc_wave_sum_d63(r);
-      if (lane == 63) sh.up[j] = (float)r;
-    }
-  }
   __syncthreads();
   VC_WSTAMP(1, 2);
   // ---- gradient + ClippedAdam of the nu_omega-related parameters: one thread per element, every block alike ----------
@@ -1088,6 +1252,9 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
     const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)c * d.ctw);
     s1 = ct[0].x; c1 = ct[1].x;
   }
+  VcNuwRaw nuw_raw;
+  vc_nuw_sums_issue(d, b, boot, phase, xb, 256, nuw_raw);
+  vc_nuw_sums_finish(d, b, boot, phase, xb, 256, nuw_raw, sh_nuw);
   vc_nuw_chain(d, b, P, G, s, seed, a, boot, oblk == 0, phase, xb, c, s1, c1, 256, sh_nuw);
 }
 
@@ -1113,15 +1280,21 @@ __global__ __launch_bounds__(1024) void vc_phase_b_kernel(const VcDims d, const 
     vc_tail_gene_block<MQ, VC_PH_B>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, xb);
     return;
   }
+  const int oblk = blockIdx.x - d.nb_post_gene;
+  if (d.hist_dense && oblk > nb_cell && oblk - nb_cell - 1 < nb_hist) {
+    // dense histogram blocks: all 16 waves of the block share the count axis (a quarter of the chain of a 4-wave block)
+    vc_omega_extra_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, oblk - nb_cell, VC_PH_B, xb, false, 1024);
+    return;
+  }
   if (threadIdx.x >= 256) return;          // K_omega's blocks are 256 threads wide: the other waves leave before any barrier
-  vc_omega_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_cell, nb_hist, blockIdx.x - d.nb_post_gene, VC_PH_B, xb);
+  vc_omega_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_cell, nb_hist, oblk, VC_PH_B, xb);
 }
 
 void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                        const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, const VcXb& xb,
                        hipStream_t st) {
   const int nb_cell = d.model == VC_MODEL_VELOCITY ? (d.Nc + 255) / 256 : 0;
-  const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
+  const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
   const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
   const dim3 grid(d.nb_post_gene + nb_cell + 1 + nb_hist + nb_eps), block(1024);
   // (the gene blocks of phase B neither reduce nor stage rows: the smallest row bound keeps their registers free)
@@ -1177,7 +1350,7 @@ void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, floa
 //   * the loss block: every term of the finished step's loss was complete before the launch (LPF / LPR of its sample, its
 //     histogram sums, K_main's partials);
 //   * the histogram blocks: shape_inv(s) is being computed by the gene blocks of this very launch, so every task wave re-derives
-//     that update from the snapshot of the launch before (vc_hist_rederive_wave: the same bits) and writes the other half
+//     that update from the snapshot of the launch before (vc_hist_rederive_block: the same bits) and writes the other half
 //     of HL / HD;
 //   * the eps blocks depend on nothing.
 // Launch structures give the same bits: tests/test_hip_fused.py.
@@ -1199,15 +1372,14 @@ __global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const Vc
     vc_tail_cell_block<VC_PH_ALL, true>(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, 0, VcXb{});
     return;
   }
-  if (threadIdx.x >= 256) return;          // the remaining blocks are 256 threads wide: the other waves leave before any barrier
   vc_omega_extra_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, blockIdx.x - d.nb_post_gene - d.nb_tail_cell,
-                       VC_PH_ALL, VcXb{}, true);
+                       VC_PH_ALL, VcXb{}, true, 1024);
 }
 
 void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, hipStream_t st) {
-  const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
-  const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
+  const int nb_hist = !with_hist ? 0 : (d.hist_dense ? d.Ng_pad / 64 : (b.n_tasks + 16 * VC_HIST_ROUNDS - 1) / (16 * VC_HIST_ROUNDS));
+  const int nb_eps = (int)((d.eps_total / 2 + 1024 * VC_EPS_PER_THREAD - 1) / (1024 * VC_EPS_PER_THREAD));
   const dim3 grid(d.nb_post_gene + d.nb_tail_cell + 1 + nb_hist + nb_eps), block(1024);
   if (d.nq <= 2) hipLaunchKernelGGL((vc_tail2_kernel<2>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
   else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail2_kernel<6>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
@@ -1217,7 +1389,7 @@ void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* gra
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st) {
   const int nb_cell = d.model == VC_MODEL_VELOCITY ? (d.Nc + 255) / 256 : 0;
-  const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
+  const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
   const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
   hipLaunchKernelGGL(vc_omega_kernel, dim3(nb_cell + 1 + nb_hist + nb_eps), dim3(256), 0, st, d, b, params, grad, step_dev,
                      seed, a, loss_dev, loss_slots, boot, nb_cell, nb_hist);

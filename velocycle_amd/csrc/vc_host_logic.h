@@ -113,6 +113,42 @@ static inline double vc_build_hist_host(const float* M, long long gs, long long 
   return tot;
 }
 
+// Dense form of the same sufficient statistic (round 4), for matrices whose non-zero counts are all integers < VC_HIST_CAP:
+//   sum_k cnt_k [lgamma(r + k) - lgamma(r)] = sum_{j >= 0} C_j log(r + j),   C_j = number of cells with count > j
+//   sum_k cnt_k [psi(r + k)    - psi(r)]    = sum_{j >= 0} C_j / (r + j)
+// (lgamma(r + k) - lgamma(r) = sum_{j < k} log(r + j) for integer k): a logarithm and a reciprocal per (gene, j) instead of a
+// Stirling-series evaluation per distinct count value, and -- laid out [gene block of 64][j][gene] -- 64 genes per wave
+// instruction.  Appends the rows of one matrix: rows[gb] = 1 + the largest count of the block's genes (0: all zero),
+// off[gb] = index of the block's first row in HC (rows of 64 floats).  Counts are exact in float up to 2^24 cells.
+static inline void vc_build_dense_hist(const unsigned* tab, int Ng, int Ng_pad, std::vector<float>& HC, std::vector<int>& off,
+                                       std::vector<int>& rows) {
+  const int nblk = Ng_pad / 64;
+  for (int gb = 0; gb < nblk; ++gb) {
+    int kmax = 0;
+    for (int l = 0; l < 64; ++l) {
+      const int g = gb * 64 + l;
+      if (g >= Ng) break;
+      const unsigned* row = tab + (size_t)g * VC_HIST_CAP;
+      for (int k = VC_HIST_CAP - 1; k > kmax; --k)
+        if (row[k]) { kmax = k; break; }
+    }
+    off.push_back((int)(HC.size() / 64));
+    rows.push_back(kmax);
+    const size_t base = HC.size();
+    HC.resize(base + (size_t)kmax * 64, 0.f);
+    for (int l = 0; l < 64; ++l) {
+      const int g = gb * 64 + l;
+      if (g >= Ng) break;
+      const unsigned* row = tab + (size_t)g * VC_HIST_CAP;
+      unsigned long long tail = 0;                       // cells with count > j, built from the top
+      for (int j = kmax - 1; j >= 0; --j) {
+        tail += row[j + 1];
+        HC[base + (size_t)j * 64 + l] = (float)tail;
+      }
+    }
+  }
+}
+
 // Tasks of the histogram kernel: runs of <= 64 histogram entries of one gene and matrix {gene, matrix, begin, end},
 // sorted by gene; tptr[g] = first task of gene g.  ptr is the CSR of [S genes..., U genes..., end].
 static inline void vc_build_hist_tasks(const std::vector<int>& ptr, int Ng, std::vector<int>& task, std::vector<int>& tptr) {

@@ -133,6 +133,24 @@ __device__ __forceinline__ VcCellRec<H, NB> vc_load_cell(const float* __restrict
 #endif
 }
 
+// The kernel's partial sums (GO: one row per workgroup and output, written by every workgroup in its last microsecond; CO: per-cell
+// sums) are read by the NEXT launch.  Left dirty in the eight L2s they are written back at the kernel boundary, which then
+// costs their bytes / 6 TB/s on top of the boundary itself (MI355X_MICROARCH.md, "boundary": 2.8-3.8 us behind 12.6-16.8 MB of
+// fp32 partials).  VC_WT_STORES=1: they go out as write-through stores (system-scope relaxed atomic store = global_store ... sc0 sc1),
+// so that the write-back overlaps the workgroups that are still computing.
+// Measured (profiles/r04_two_launch.md): the step gains 0.5 % (V-joint 50k x 2k), the kernel itself reads 2-3 us longer because the
+// write-back now happens inside it -- off by default.
+#ifndef VC_WT_STORES
+#define VC_WT_STORES 0
+#endif
+__device__ __forceinline__ void vc_store_out(float* p, float v) {
+#if VC_WT_STORES
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+  *p = v;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Packed-pair arithmetic.  The kernel is VALU-issue bound before it is HBM bound (rocprof: VALU busy
 // ~100 %, 4 cycles per wave64 instruction, 8 per transcendental), and v_pk_{fma,mul,add}_f32 retire two
@@ -193,15 +211,27 @@ template <> struct VcCnt<2> { v2u a; };
 template <> struct VcCnt<4> { v4u a; };
 template <> struct VcCnt<8> { v4u a, b; };
 
-__device__ __forceinline__ void vc_issue(VcCnt<2>& c, uint32_t voff, const char* sbase) {
-  asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(c.a) : "v"(voff), "s"(sbase) : "memory");
+// VC_NT_LOADS: the counts are read exactly once per step -- the S+U kernel marks its loads non-temporal (streaming: no reuse).
+// Measured (50k x 2k, same box, profiles/r04_two_launch.md): the S+U kernel 115.6 -> 114.3 us (7 243 -> 7 332 steps/s), the
+// U-only kernel unchanged, the S-only (phase) kernel 55.3 -> 65.4 us -- so only the S+U kernel marks its loads (NT = FULL).
+#ifndef VC_NT_LOADS
+#define VC_NT_LOADS 1
+#endif
+template <bool NT> __device__ __forceinline__ void vc_issue(VcCnt<2>& c, uint32_t voff, const char* sbase) {
+  if (NT && VC_NT_LOADS) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 nt" : "=&v"(c.a) : "v"(voff), "s"(sbase) : "memory");
+  else asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=&v"(c.a) : "v"(voff), "s"(sbase) : "memory");
 }
-__device__ __forceinline__ void vc_issue(VcCnt<4>& c, uint32_t voff, const char* sbase) {
-  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(c.a) : "v"(voff), "s"(sbase) : "memory");
+template <bool NT> __device__ __forceinline__ void vc_issue(VcCnt<4>& c, uint32_t voff, const char* sbase) {
+  if (NT && VC_NT_LOADS) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=&v"(c.a) : "v"(voff), "s"(sbase) : "memory");
+  else asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(c.a) : "v"(voff), "s"(sbase) : "memory");
 }
-__device__ __forceinline__ void vc_issue(VcCnt<8>& c, uint32_t voff, const char* sbase) {
-  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
-               : "=&v"(c.a), "=&v"(c.b) : "v"(voff), "s"(sbase) : "memory");
+template <bool NT> __device__ __forceinline__ void vc_issue(VcCnt<8>& c, uint32_t voff, const char* sbase) {
+  if (NT && VC_NT_LOADS)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 nt\n\tglobal_load_dwordx4 %1, %2, %3 offset:16 nt"
+                 : "=&v"(c.a), "=&v"(c.b) : "v"(voff), "s"(sbase) : "memory");
+  else
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+                 : "=&v"(c.a), "=&v"(c.b) : "v"(voff), "s"(sbase) : "memory");
 }
 // wait until at most N vector-memory operations of this wave are outstanding; the tuples named are readable afterwards
 template <int N> __device__ __forceinline__ void vc_wait(VcCnt<2>& c) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(c.a) : "n"(N)); }
@@ -328,8 +358,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       if (i < NBUF)
 #endif
       {
-        if (HAS_S) vc_issue(s_q[j], lane_off, Sb + row);
-        if (HAS_U) vc_issue(u_q[j], lane_off, Ub + row);
+        if (HAS_S) vc_issue<FULL>(s_q[j], lane_off, Sb + row);
+        if (HAS_U) vc_issue<FULL>(u_q[j], lane_off, Ub + row);
       }
     } else
 #ifdef VC_NO_LOADS           // measurement aid: only the first cells are fetched, the loop re-uses them (results are meaningless):
@@ -635,7 +665,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       for (int q = 1; q < 16; ++q) { const float4 v = src[q]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
       const float ts = (acc.x + acc.y) + (acc.z + acc.w);
       const float t = ts * CO_SCALE;
-      if (c < n) b.CO[((size_t)gb * NCO + row) * d.Nc + cb + c] = t;
+      if (c < n) vc_store_out(&b.CO[((size_t)gb * NCO + row) * d.Nc + cb + c], t);
       if (PWI && pw_on && row == 2 && c < n) {
         // this lane holds A3 of cell cb + c over the wave's genes: d loglik / d nu_omega[j] += A3_c W_cj (accumulators in the LDS,
         // one slot per tile cell: nothing is carried in registers across the cell loop)
@@ -837,8 +867,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     for (int r = 0; r < RPP; ++r) {
       if (q0 + r < NQ) {
         for (int t = threadIdx.x; t < GBW; t += 256)
-          go[(size_t)(q0 + r) * d.Ng_pad + t] = (sm[(0 * RPP + r) * GBW + t] + sm[(1 * RPP + r) * GBW + t]) +
-                                                (sm[(2 * RPP + r) * GBW + t] + sm[(3 * RPP + r) * GBW + t]);
+          vc_store_out(&go[(size_t)(q0 + r) * d.Ng_pad + t], (sm[(0 * RPP + r) * GBW + t] + sm[(1 * RPP + r) * GBW + t]) +
+                                                              (sm[(2 * RPP + r) * GBW + t] + sm[(3 * RPP + r) * GBW + t]));
       }
     }
     if (q0 + RPP < NQ) __syncthreads();

@@ -133,16 +133,22 @@ void vc_launch_scatter_csr(const long long* indptr, const int* indices, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
-// K_hist (NB): one wave per gene, fp64 -- also runs as extra blocks of K_pre
+// K_hist (NB): one wave per task (lists of distinct values) or one block per gene block (dense tables), fp64 -- also runs as
+// extra blocks of K_pre
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBufs b,
                                                       const float* __restrict__ P, int cond_only) {
+  if (d.hist_dense) {
+    __shared__ double sm_hd[2048];
+    vc_hist_dense_block(d, b, blockIdx.x, vc_hist_si(d, b, P, cond_only, blockIdx.x * 64 + (threadIdx.x & 63)), 0, 4, sm_hd);
+    return;
+  }
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (task < b.n_tasks) vc_hist_wave(d, b, P, cond_only, task, threadIdx.x & 63);
 }
 
 void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int cond_only, hipStream_t st) {
-  hipLaunchKernelGGL(vc_hist_kernel, dim3((b.n_tasks + 3) / 4), dim3(256), 0, st, d, b, params, cond_only);
+  hipLaunchKernelGGL(vc_hist_kernel, dim3(vc_hist_blocks(d, b, 4)), dim3(256), 0, st, d, b, params, cond_only);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,8 +170,14 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
   double loss = 0.0;
 
   if ((int)blockIdx.x >= d.nb_pre_gene + d.nb_pre_cell) {
-    // ------------------------------- histogram part (NB): one wave per gene -------------------------
-    const int task = (blockIdx.x - d.nb_pre_gene - d.nb_pre_cell) * 4 + (threadIdx.x >> 6);
+    // ------------------------------- histogram part (NB) -------------------------------------------
+    const int hb = blockIdx.x - d.nb_pre_gene - d.nb_pre_cell;
+    if (d.hist_dense) {          // one block per gene block, the dense tail-count tables
+      __shared__ double sm_hd[2048];
+      vc_hist_dense_block(d, b, hb, vc_hist_si(d, b, P, cond_only, hb * 64 + (threadIdx.x & 63)), 0, 4, sm_hd);
+      return;
+    }
+    const int task = hb * 4 + (threadIdx.x >> 6);          // one wave per task of <= 64 distinct values
     if (task < b.n_tasks) vc_hist_wave(d, b, P, cond_only, task, threadIdx.x & 63);
     return;
   }
@@ -413,7 +425,7 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
                    hipStream_t st) {
-  const int nb_hist = with_hist ? (b.n_tasks + 3) / 4 : 0;
+  const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
   hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), 0, st, d, b,
                      params, eps, seed, step, step_dev, cond_only);
 }
