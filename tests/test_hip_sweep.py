@@ -136,15 +136,109 @@ def test_lrmn_with_a_nearly_empty_last_gene_block(Ng, monkeypatch):
     _check(p, None, monkeypatch)
 
 
+# ---- outside the compiled fast set: the run-time-sized kernel set (csrc/vc_generic_kernels.hip) -------------------------------
+# The reference takes any number of harmonics (utils.py:400-437), any number of batches (preprocessing.py:65-93: one design
+# column per unique id; phase_inference_model.py:374-377, velocity_inference_model.py:360) and any rho_rank (preprocessing.py:239,
+# velocity_inference_guide.py:91-92); round 3 refused H > 3, > 4 batches, rank > 8 with VC_ERR_UNSUPPORTED.
+
+@pytest.mark.parametrize("H,Nb", [(4, 0), (5, 2), (4, 5), (2, 8), (7, 9)])
+def test_generic_phase_kernels(H, Nb, monkeypatch):
+    for noise in ("NegativeBinomial", "Poisson", "Lognormal"):
+        p = _problem("phase", "meanfield", noise, H, 0, Nb, 0, [], Nc=70 + 13 * H, Ng=9 + Nb, seed=H * 10 + Nb)
+        k = _check(p, None, monkeypatch)
+        assert "generic_phase" in k and "gpl2" in k, k
+
+
+@pytest.mark.parametrize("H,Nb", [(4, 0), (5, 5), (1, 8), (3, 6)])
+def test_generic_velocity_joint_kernels(H, Nb, monkeypatch):
+    for noise, guide, Hw, Nx in (("NegativeBinomial", "meanfield", 1, 2), ("Poisson", "lrmn", 0, 1), ("Lognormal", "meanfield", 4, 3),
+                                 ("NegativeBinomial", "lrmn", 2, 2)):
+        p = _problem("velocity", guide, noise, H, Hw, Nb, Nx, [], Nc=90 + 7 * Nb, Ng=7 + H, seed=100 + H * 10 + Nb)
+        k = _check(p, None, monkeypatch)
+        assert "generic_vfull" in k, k
+
+
+@pytest.mark.parametrize("H,Nb", [(4, 0), (2, 5), (5, 8)])
+def test_generic_velocity_conditioned_kernels(H, Nb, monkeypatch):
+    full = ["ϕxy", "ν", "shape_inv"] + (["Δν"] if Nb else [])
+    for noise, guide, Hw in (("NegativeBinomial", "lrmn", 1), ("NegativeBinomial", "meanfield", 5), ("Poisson", "lrmn", 0),
+                             ("Lognormal", "meanfield", 1)):
+        sites = [s for s in full if not (s == "shape_inv" and noise != "NegativeBinomial")]
+        p = _problem("velocity", guide, noise, H, Hw, Nb, 2, sites, Nc=130, Ng=11, seed=200 + H * 10 + Nb)
+        k = _check(p, None, monkeypatch)
+        assert "generic_vu" in k, k          # S term hoisted by the generic S-only kernel
+
+
+@pytest.mark.parametrize("rank,Nx,Hw", [(12, 2, 1), (9, 1, 0), (16, 3, 2), (5, 10, 3), (12, 13, 3)])
+def test_generic_lrmn_rank_and_speed_coefficients(rank, Nx, Hw, monkeypatch):
+    """LRMN rank above the compiled 8 (the verdict's rank 12), and more than 64 angular-speed coefficients (10 x 7 = 70, 13 x 7 = 91)."""
+    for sites in ([], ["ϕxy", "ν", "shape_inv"]):
+        p = _problem("velocity", "lrmn", "NegativeBinomial", 1, Hw, 0, Nx, sites, Nc=150, Ng=70, seed=300 + rank + Nx)
+        p.rho_rank = rank
+        k = _check(p, None, monkeypatch)
+        assert "generic" in k, k
+
+
+@pytest.mark.parametrize("Nc,Ng", [(1, 1), (3, 300), (65, 2), (257, 513)])
+def test_generic_set_on_fast_set_sizes_equals_the_fast_set(Nc, Ng, monkeypatch):
+    """VC_FORCE_GENERIC=1: the run-time-sized kernels on a configuration the fast set covers -- same oracle, same tolerances,
+    ragged and tiny shapes -- and the two kernel sets against each other."""
+    from tests.helpers import spec_from_problem
+    from velocycle_amd.engine import HipEngine
+    p = _problem("velocity", "lrmn", "NegativeBinomial", 2, 1, 2, 2, [], Nc=Nc, Ng=Ng, seed=Nc + Ng)
+    fast = _check(p, None, monkeypatch)
+    monkeypatch.setenv("VC_FORCE_GENERIC", "1")
+    gen = _check(p, None, monkeypatch)
+    assert "generic" in gen and "generic" not in fast
+
+
+def test_the_fast_instantiations_stay_selected_where_they_exist(monkeypatch):
+    from tests.helpers import spec_from_problem
+    from velocycle_amd.engine import HipEngine
+    for H, Nb, rank in ((3, 4, 8), (1, 0, 5)):
+        p = _problem("velocity", "lrmn", "NegativeBinomial", H, 3, Nb, 3, [], Nc=90, Ng=12, seed=5)
+        p.rho_rank = rank
+        e = HipEngine(spec_from_problem(p))
+        assert not e.stats["generic"] and e.stats["main_kernel"].startswith(f"vc_main_kernel<{H},{Nb},vfull_nb,gpl"), e.stats
+        e.close()
+
+
+def test_generic_set_runs_whole_fits(monkeypatch):
+    """SVIRunner on a generic engine: perf mode picks the unfused kernel sequence by itself (the fused steps exist for the fast
+    set only and say so), parity mode follows the float64 oracle's trajectory."""
+    from tests.helpers import spec_from_problem
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    p = _problem("velocity", "lrmn", "NegativeBinomial", 4, 1, 5, 2, [], Nc=300, Ng=40, seed=11)
+    p.rho_rank = 10
+    opt = {"lr": 0.03, "lrd": 0.99, "betas": (0.8, 0.99)}
+    e = HipEngine(spec_from_problem(p))
+    assert e.stats["generic"] and e.stats["launches_per_step"] == 3
+    r = SVIRunner(e, opt, mode="perf", seed=3)
+    assert r.adam_impl == "hip"
+    r.run_perf(30)
+    l = np.array(r.perf_losses())
+    assert np.isfinite(l).all() and l[-5:].mean() < l[:5].mean() and e.status()[0]
+    with pytest.raises(NotImplementedError, match="unfused"):
+        SVIRunner(e, opt, mode="perf", seed=3, adam_impl="fused3").run_perf(1)
+    e.close()
+    e = HipEngine(spec_from_problem(p))
+    run = SVIRunner(e, opt, mode="parity", seed=11)
+    losses = np.array([run.step() for _ in range(8)])
+    l64, _ = orc.fit(p, opt, 8, seed=11)
+    assert np.allclose(losses, np.array(l64), rtol=2e-5), (losses, l64)
+    e.close()
+
+
 def test_unsupported_configurations_raise():
     from tests.helpers import spec_from_problem
     from velocycle_amd.engine import HipEngine
     p = _problem("phase", "meanfield", "NegativeBinomial", 1, 0, 1, 0, [], Nc=20, Ng=5, seed=1)
     sp = spec_from_problem(p)
-    sp.H = 4
-    sp.mu_nu = torch.zeros(5, 9)
-    sp.sd_nu = torch.ones(5, 9)
-    with pytest.raises(NotImplementedError):
+    sp.H = 80                                   # 2 H + 1 = 161 rows of per-gene state per wave: beyond the LDS
+    sp.mu_nu = torch.zeros(5, 161)
+    sp.sd_nu = torch.ones(5, 161)
+    with pytest.raises(NotImplementedError, match="LDS"):
         HipEngine(sp)
     sp2 = spec_from_problem(p)
     sp2.noisemodel = "Gaussian"

@@ -77,6 +77,7 @@ struct VcDims {
   int pass_cw[4];         // cells per wave of the workgroups of pass 0..3 (later passes: as pass 3); all equal to cw unless the
                           // passes take unequal shares of the cells (vc_engine.hip, tiling)
   int hist_has_S, hist_has_U;
+  int generic;            // 1: the run-time-sized kernel set (vc_generic_kernels.hip): a configuration outside the compiled fast set
   int hist_dense;         // 1: the histogram sums come from the dense tail-count tables (one task per gene and matrix, evaluated per
                           // gene block: vc_hist_dense_block); 0: from the (value, multiplicity) lists, one wave per task of <= 64 values
   int hist_par;           // 1: shape_inv is learned -- the fused steps keep the histogram sums of the sample of step s in half s & 1 of
@@ -559,6 +560,13 @@ static inline int vc_hist_blocks(const VcDims& d, const VcBufs& b, int waves) {
 typedef void (*vc_main_launch_fn)(const VcDims& d, const VcBufs& b, hipStream_t st);
 vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, int c16, const char** name,
                                       const void** kernel);
+// run-time-sized kernel set (vc_generic_kernels.hip)
+vc_main_launch_fn vc_find_generic_main_kernel(int kind, int noise, const void** kernel);
+void vc_launch_pre_generic(const VcDims& d, const VcBufs& b, const float* params, const float* eps, uint64_t seed, long long step,
+                           const long long* step_dev, int cond_only, int with_hist, hipStream_t st);
+void vc_launch_post_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev, hipStream_t st);
+void vc_launch_fin_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev, long long loss_slots,
+                           long long step, const long long* step_dev, hipStream_t st);
 void vc_launch_counts_to_u16(const float* src, unsigned short* dst, long long n, hipStream_t st);
 
 void vc_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* out2, hipStream_t st);

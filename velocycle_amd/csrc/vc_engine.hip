@@ -262,28 +262,34 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   if (c->Ng <= 0 || c->Nc_local <= 0) return bad("vc_create: Ng and Nc_local must be positive");
   if (c->Ng > (1 << 24) || c->Nc_local > (1LL << 30)) return bad("vc_create: problem too large");
   const bool vel = c->model == VC_MODEL_VELOCITY;
-  if (c->n_harmonics < 1 || c->n_harmonics > VC_MAXH) {
-    g_create_error = "n_harmonics outside the compiled kernel set (1..3)";
-    return VC_ERR_UNSUPPORTED;
-  }
-  if (c->with_delta_nu && (c->Nb < 1 || c->Nb > VC_MAXNB)) {
-    g_create_error = "with_delta_nu needs 1 <= Nb <= 4 (compiled kernel set)";
-    return VC_ERR_UNSUPPORTED;
-  }
+  // Outside the compiled fast set (H <= 3, <= 4 batches, omega harmonics <= 3, <= 64 angular-speed coefficients, LRMN rank <= 8)
+  // the run-time-sized kernel set takes over (vc_generic_kernels.hip).  What is left as a bound is memory: the likelihood
+  // kernel keeps 2 K rows of per-gene state in the LDS of one wave (K = 2 H + 1 + Nb <= 150: 150 KB of the CU's 160).
+  if (c->n_harmonics < 1) return bad("vc_create: n_harmonics must be >= 1");
+  if (c->with_delta_nu && c->Nb < 1) return bad("vc_create: with_delta_nu needs Nb >= 1");
+  bool generic = c->n_harmonics > VC_MAXH || (c->with_delta_nu && c->Nb > VC_MAXNB);
   if (vel) {
-    if (c->n_harmonics_w < 0 || c->n_harmonics_w > VC_MAXH) {
-      g_create_error = "omega harmonics outside 0..3";
+    if (c->n_harmonics_w < 0) return bad("vc_create: negative omega harmonics");
+    if (c->Nx < 1) return bad("vc_create: bad Nx");
+    if (c->guide == VC_GUIDE_LRMN && c->lrmn_rank < 1) return bad("vc_create: lrmn_rank must be >= 1");
+    generic = generic || c->n_harmonics_w > VC_MAXH || c->Nx * (2 * c->n_harmonics_w + 1) > VC_MAX_NW ||
+              (c->guide == VC_GUIDE_LRMN && c->lrmn_rank > VC_MAX_RANK);
+    if ((long long)c->Nx * (2 * c->n_harmonics_w + 1) > 8192 || c->lrmn_rank > 4096) {
+      g_create_error = "more than 8192 angular-speed coefficients / LRMN rank > 4096";
       return VC_ERR_UNSUPPORTED;
     }
-    if (c->Nx < 1 || c->Nx * (2 * c->n_harmonics_w + 1) > VC_MAX_NW) return bad("vc_create: bad Nx");
-    if (c->guide == VC_GUIDE_LRMN && (c->lrmn_rank < 1 || c->lrmn_rank > VC_MAX_RANK))
-      return bad("vc_create: lrmn_rank outside 1..8");
+  }
+  if (const char* env = getenv("VC_FORCE_GENERIC")) generic = generic || atoi(env) != 0;      // tests: the generic set on fast-set sizes
+  if (2 * c->n_harmonics + 1 + (c->with_delta_nu ? c->Nb : 0) > 150) {
+    g_create_error = "2 n_harmonics + 1 + Nb > 150: the per-gene state of one wave no longer fits the LDS";
+    return VC_ERR_UNSUPPORTED;
   }
   if (c->world_size < 1 || c->rank < 0 || c->rank >= c->world_size) return bad("vc_create: bad rank/world_size");
   vc_engine* e = new (std::nothrow) vc_engine();
   if (!e) return bad("vc_create: out of host memory");
   e->cfg = *c;
   VcDims& d = e->d;
+  d.generic = generic ? 1 : 0;
   d.Ng = (int)c->Ng;
   d.gpl = 4; d.gbw = 256;
   d.nGB = (d.Ng + d.gbw - 1) / d.gbw;
@@ -556,13 +562,13 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // genes per lane: 8 amortises the per-cell work over twice the genes and is chosen whenever that instantiation's
   // per-gene state (latents + accumulators) fits 2 waves per SIMD without scratch, which the code object itself
   // tells (private segment size 0); else 4.
-  d.gpl = 4;
+  d.gpl = d.generic ? 2 : 4;
   size_t max_scratch = 0;      // VC_MAX_SCRATCH (bytes per lane, measurement aid): accept an 8-genes-per-lane kernel that spills this little
   if (const char* env = getenv("VC_MAX_SCRATCH")) max_scratch = (size_t)atoi(env);
 #if VC_ASM_LOADS
   max_scratch = 0;             // asm-issued count loads: a spilled destination tuple would be stored before its data has landed
 #endif
-  {
+  if (!d.generic) {
     const void* k8 = nullptr;
     hipFuncAttributes fa;
     if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
@@ -590,7 +596,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       }
     }
   }
-  if (const char* env = getenv("VC_GPL")) {
+  if (const char* env = d.generic ? nullptr : getenv("VC_GPL")) {
     if (atoi(env) == 4) d.gpl = 4;
     if (atoi(env) == 8) {       // honoured only where the 8-genes-per-lane kernel may run at all (no scratch: see above)
       const void* k8 = nullptr;
@@ -605,9 +611,19 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   d.Ng_pad = d.nGB * d.gbw;
   const void* main_kernel = nullptr;
   d.c16 = 0;
-  e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, 0, &e->main_name, &main_kernel);
+  if (d.generic) {
+    // the run-time-sized set: one wave per workgroup, 2 genes per lane (gene blocks of 128), float32 counts
+    static const char* gen_names[3][3] = {{"generic_phase_nb", "generic_phase_poisson", "generic_phase_lognormal"},
+                                          {"generic_vfull_nb", "generic_vfull_poisson", "generic_vfull_lognormal"},
+                                          {"generic_vu_nb", "generic_vu_poisson", "generic_vu_lognormal"}};
+    e->main_fn = vc_find_generic_main_kernel(d.kind, d.noise, &main_kernel);
+    e->main_name = gen_names[d.kind][d.noise];
+    if (d.kind == VC_KIND_VU) e->phase_fn = vc_find_generic_main_kernel(VC_KIND_PHASE, d.noise, nullptr);
+  } else {
+    e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, 0, &e->main_name, &main_kernel);
+  }
   if (!e->main_fn) return e->fail(VC_ERR_UNSUPPORTED, "no likelihood kernel for H=%d Nb=%d kind=%d noise=%d", d.H, d.Nb, d.kind, d.noise);
-  if (d.kind == VC_KIND_VU) {
+  if (d.kind == VC_KIND_VU && !d.generic) {
     e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, 0, nullptr, nullptr);
     if (!e->phase_fn) return e->fail(VC_ERR_UNSUPPORTED, "no S-only kernel for the hoisted term");
   }
@@ -684,7 +700,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     // blocked layout is narrowed to uint16 -- half the bytes K_main streams per step; exact.  VC_COUNT_STORAGE=f32 keeps
     // the reference's float32 (A/B measurements, tests); Lognormal noise stores log(k + 1) and stays float32.
     const char* cs_env = getenv("VC_COUNT_STORAGE");
-    const bool want16 = !(cs_env && strcmp(cs_env, "f32") == 0) && d.noise != VC_NOISE_LOGNORMAL && !hbad[2];
+    const bool want16 = !(cs_env && strcmp(cs_env, "f32") == 0) && d.noise != VC_NOISE_LOGNORMAL && !hbad[2] && !d.generic;
     if (want16) {
       const void* k16 = nullptr;
       const char* nm = nullptr;
@@ -722,10 +738,14 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     HIPCHK(e, hipGetDevice(&dev));
     HIPCHK(e, hipGetDeviceProperties(&prop, dev));
     if (prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    const int wg_waves = d.generic ? 1 : VC_WAVES;
+    const unsigned gen_dyn = d.generic ? (unsigned)(2 * d.K * 64 * 2 * sizeof(float)) : 0u;      // nu~ and gradient rows of one wave
     auto occupancy = [&](unsigned dyn_bytes, int* out) -> int {
       int bpc = 0;
+      dyn_bytes += gen_dyn;
       if (dyn_bytes > 0) (void)hipFuncSetAttribute(main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes);
-      HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, main_kernel, 256, dyn_bytes));
+      HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, main_kernel, 64 * wg_waves, dyn_bytes));
+      if (d.generic && bpc > 8) bpc = 8;      // (one wave each: two per SIMD hide the LDS latency, more only shorten the runs of cells)
       const char* env = getenv("VC_BLOCKS_PER_CU");
       if (env && atoi(env) > 0) bpc = atoi(env);
       *out = bpc;
@@ -760,8 +780,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       const char* cwe = getenv("VC_CELLS_PER_WAVE");
       const char* mce = getenv("VC_PASS_MIN_CW");
       // below 12 cells per wave the passes' fixed prologue / epilogue dominate (measured at the 6 250-cell shard)
-      const VcTiling t = vc_tile_cells(d.Nc, d.nGB, n_cu, blocks_per_cu, VC_WAVES, cwe && atoi(cwe) > 0 ? atoi(cwe) : 0,
-                                       want ? share : nullptr, mce && atoi(mce) > 0 ? atoi(mce) : 12);
+      const VcTiling t = vc_tile_cells(d.Nc, d.nGB, n_cu, blocks_per_cu, wg_waves, cwe && atoi(cwe) > 0 ? atoi(cwe) : 0,
+                                       (want && !d.generic) ? share : nullptr, mce && atoi(mce) > 0 ? atoi(mce) : 12);
       d.cw = t.cw;
       d.n_chunks = t.n_chunks;
       d.pass_wgs = n_cu;
@@ -777,7 +797,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     d.pw_inline = 0;
     d.pw_slots = 0;
     const bool pw_kind = VC_PW_INLINE && (d.kind == VC_KIND_VU || d.kind == VC_KIND_VFULL) && d.NW >= 1 && d.NW <= VC_PWQ &&
-                         e->cfg.world_size == 1;
+                         e->cfg.world_size == 1 && !d.generic;
     const char* pwe = getenv("VC_PW_INLINE");
     if (pw_kind && !(pwe && atoi(pwe) == 0)) {
       const int row = d.NW <= 4 ? 4 : 8;
@@ -804,7 +824,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     std::vector<int> tile(2 * (size_t)d.n_main_wg);
     for (int w = 0; w < d.n_main_wg; ++w) {
       int cw = 0;
-      const long long first = vc_wave_first_cell(w / d.nGB, w % d.nGB, 0, d.nGB, d.pass_wgs, d.pass_cw, VC_WAVES, &cw);
+      const long long first = vc_wave_first_cell(w / d.nGB, w % d.nGB, 0, d.nGB, d.pass_wgs, d.pass_cw, d.generic ? 1 : VC_WAVES, &cw);
       tile[2 * (size_t)w] = (int)std::min<long long>(first, 0x7fffffff);
       tile[2 * (size_t)w + 1] = cw;
     }
@@ -814,6 +834,10 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   d.nb_pre_cell = (d.Nc + 255) / 256;
   d.nb_post_gene = d.Ng_pad / 64;
   d.nb_post_cell = (d.Nc + 1023) / 1024;
+  if (d.generic) {                     // thread = gene / thread = cell, 256 per block (vc_generic_kernels.hip)
+    d.nb_pre_gene = d.nb_post_gene = (d.Ng_pad + 255) / 256;
+    d.nb_post_cell = (d.Nc + 255) / 256;
+  }
   d.hist_has_S = nb && d.kind != VC_KIND_VU;
   d.hist_has_U = nb && vel;
   d.nmat_r = nb ? (d.kind == VC_KIND_VFULL ? 2 : 1) : 0;
@@ -1101,12 +1125,20 @@ extern "C" int vc_elbo_grad(vc_engine* e, const float* params, const float* eps,
   return VC_OK;
 }
 
+#define VC_NO_GENERIC(e_, what)                                                                                              \
+  do {                                                                                                                      \
+    if ((e_)->d.generic)                                                                                                    \
+      return (e_)->fail(VC_ERR_UNSUPPORTED, what ": the run-time-sized kernel set (a configuration outside the compiled "   \
+                                                  "fast set) has the unfused step only: vc_elbo_grad + vc_clipped_adam");  \
+  } while (0)
+
 extern "C" int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64_t seed, int64_t step,
                            int64_t* step_dev, float* grad, double* loss_dev, int64_t loss_slots, float* exp_avg,
                            float* exp_avg_sq, double lr, double lrd, double beta1, double beta2, double adam_eps,
                            double clip_norm, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_step before vc_finalize");
+  VC_NO_GENERIC(e, "vc_svi_step");
   if (e->cfg.world_size != 1)
     return e->fail(VC_ERR_STATE, "vc_svi_step merges the optimiser with the last gradient kernel: single rank only "
                                  "(use vc_elbo_grad + all-reduce + vc_clipped_adam when cells are sharded)");
@@ -1124,6 +1156,7 @@ extern "C" int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64
 // Which launch follows K_main in the steady state of vc_svi_run_fused: 1 = the tutorial flow's merged tail (vc_launch_tail_merged),
 // 2 = the one-launch tail of every other single-rank step that has what it needs (vc_launch_tail2), 0 = K_tail + K_omega
 static int fused_tail_kind(const vc_engine* e) {
+  if (e->d.generic) return 0;
   const bool with_hist = e->hist_each_step;
   bool merged = e->d.pw_inline && e->d.kind == VC_KIND_VU && !with_hist && (e->d.cond >> VC_SITE_PHIXY & 1u);
   if (const char* env = getenv("VC_TAIL_MERGED")) merged = merged && atoi(env) != 0;
@@ -1143,6 +1176,7 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
                                 int64_t n_steps, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_run_fused before vc_finalize");
+  VC_NO_GENERIC(e, "vc_svi_run_fused");
   if (e->cfg.world_size != 1)
     return e->fail(VC_ERR_STATE, "vc_svi_run_fused applies the optimiser inside the gradient kernels: single rank only "
                                  "(use vc_elbo_grad + all-reduce + vc_clipped_adam when cells are sharded)");
@@ -1303,6 +1337,7 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
                                   int phase, int64_t n_steps, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_run_sharded before vc_finalize");
+  VC_NO_GENERIC(e, "vc_svi_run_sharded");
   if (!params || !grad || !exp_avg || !exp_avg_sq || !step_dev || !xbuf)
     return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: null buffer (step counter and exchange buffer are required)");
   if (phase != VC_PHASE_A && phase != VC_PHASE_B && phase != VC_PHASE_AB) return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: bad phase %d", phase);
@@ -1466,7 +1501,7 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   for (int p = 0; p < 4; ++p) out->pass_cells[p] = d.pass_cw[p];
   out->launches_per_step = fused_launches_per_step(e);
   out->pw_inline = d.pw_inline;
-  out->generic = 0;
+  out->generic = d.generic;
   snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.Nb, e->main_name, d.gpl,
            d.c16 ? ",u16" : "");
   return VC_OK;

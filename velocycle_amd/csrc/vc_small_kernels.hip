@@ -425,6 +425,7 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
                    hipStream_t st) {
+  if (d.generic) { vc_launch_pre_generic(d, b, params, eps, seed, step, step_dev, cond_only, with_hist, st); return; }
   const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
   hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), 0, st, d, b,
                      params, eps, seed, step, step_dev, cond_only);
@@ -969,6 +970,7 @@ void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, d
 
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,
                     hipStream_t st) {
+  if (d.generic) { vc_launch_post_generic(d, b, params, grad, step_dev, st); return; }
   const dim3 grid(d.nb_post_gene + d.nb_post_cell), block(1024);
   if (d.nq <= 2) hipLaunchKernelGGL(vc_post_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev);
   else if (d.nq <= 6) hipLaunchKernelGGL(vc_post_kernel<6>, grid, block, 0, st, d, b, params, grad, step_dev);
@@ -976,6 +978,7 @@ void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float
 }
 void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev,
                    long long loss_slots, long long step, const long long* step_dev, hipStream_t st) {
+  if (d.generic) { vc_launch_fin_generic(d, b, params, grad, loss_dev, loss_slots, step, step_dev, st); return; }
   hipLaunchKernelGGL(vc_fin_kernel, dim3(1), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots, step,
                      step_dev);
 }
@@ -994,8 +997,7 @@ __global__ __launch_bounds__(256) void vc_expected_logs_kernel(const VcDims d, c
   const int g = blockIdx.y;
   const long long c0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (c0 >= d.Nc) return;
-  float nug[2 * 3 + 1];
-  for (int h = 0; h < d.Nh; ++h) nug[h] = nu[(size_t)g * d.Nh + h];
+  const float* __restrict__ nug = nu + (size_t)g * d.Nh;          // (any number of harmonics: read where they are)
   const float lb = logbeta ? logbeta[g] : 0.f, gm = gamma ? gamma[g] : 0.f;
   float s[4], s2[4], u[4], u2[4];
 #pragma unroll

@@ -161,6 +161,10 @@ class SVIRunner:
         import os
         if adam_impl is None and self.K > 1 and mode == "perf":
             adam_impl = "hip"
+        if adam_impl is None and mode == "perf" and engine.stats.get("generic"):
+            # a configuration outside the compiled fast set (H > 3, > 4 batches, LRMN rank > 8, > 64 angular-speed
+            # coefficients): the run-time-sized kernel set has the unfused sequence only (any number of ranks)
+            adam_impl = "hip"
         if self.K > 1 and adam_impl in ("fused", "fused3", "sharded"):
             raise ValueError(f"adam_impl={adam_impl!r} draws one sample per step; num_particles > 1 runs the unfused sequence")
         if adam_impl is None:
