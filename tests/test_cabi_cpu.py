@@ -40,12 +40,17 @@ def test_struct_sizes_match_header_layout():
 def test_create_validates_and_reports_errors():
     mod, lib = _lib()
     h = C.c_void_p()
-    cfg = mod.vc_config(abi_version=mod.VC_ABI_VERSION, model=1, guide=0, noise=0, with_delta_nu=0, n_harmonics=7,
+    cfg = mod.vc_config(abi_version=mod.VC_ABI_VERSION, model=1, guide=0, noise=0, with_delta_nu=0, n_harmonics=80,
                         n_harmonics_w=1, Nb=1, Nx=1, lrmn_rank=5, rank=0, world_size=1, Ng=10, Nc_local=10,
                         Nc_global=10, cell_offset=0, gamma_alpha=1, gamma_beta=2, sigma_ln_s=.1, sigma_ln_u=.1,
                         rho_mean=4, rho_std=1, rho_scale=1)
+    # 80 harmonics: 161 rows of per-gene state per wave, beyond the LDS (7 harmonics, refused until round 3, run on the
+    # run-time-sized kernel set since round 4)
     assert lib.vc_create(C.byref(cfg), C.byref(h)) == mod.VC_ERR_UNSUPPORTED
     assert b"n_harmonics" in lib.vc_last_error(None)
+    cfg.n_harmonics = 7
+    assert lib.vc_create(C.byref(cfg), C.byref(h)) == mod.VC_OK
+    lib.vc_destroy(h)
     cfg.n_harmonics = 1
     cfg.abi_version = 99
     assert lib.vc_create(C.byref(cfg), C.byref(h)) == mod.VC_ERR_ARG

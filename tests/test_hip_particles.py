@@ -63,6 +63,31 @@ def test_perf_mode_particles_average_the_philox_streams(case):
     eng.close()
 
 
+@pytest.mark.parametrize("case", ["vel_mf_joint", "phase_nb", "vel_lrmn_cond"])
+def test_particles_from_one_c_call_equal_the_host_loop(case, monkeypatch):
+    """vc_svi_run_particles (every launch of an n-step, K-particle run enqueued from one C call; the particles' gradients averaged
+    by a kernel) against the host loop of K x vc_elbo_grad + PyTorch averaging + vc_clipped_adam it replaces
+    (VC_PARTICLES_HOST_LOOP=1): the same kernels on the same Philox streams -- parameters, moments and losses bit for bit."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fitK3_{case}.npz")
+    spec = H.spec_from_fixture(z)
+    out = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("VC_PARTICLES_HOST_LOOP", host)
+        eng = HipEngine(spec)
+        run = SVIRunner(eng, _opt(z), mode="perf", seed=5, num_particles=3)
+        run.run_perf(4)
+        run.run_perf(5)
+        out.append((eng.params.clone().cpu(), run.opt.m.clone().cpu(), run.opt.v.clone().cpu(), run.perf_losses(),
+                    int(run.step_dev.item()), run.opt.t, eng.status()))
+        eng.close()
+    nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+    a, b = out
+    assert torch.equal(nz(a[0]), nz(b[0])) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3] == b[3] and len(a[3]) == 9 and a[4] == b[4] == 9 and a[5] == b[5] == 9 and a[6] == b[6] == (True, -1, 0)
+
+
 def test_fit_reads_num_particles_from_the_loss_object():
     """The drop-in API: PhaseFitModel.fit(optimizer, loss=Trace_ELBO(num_particles=3)) reproduces the reference's fit with
     the same object; an object asking for vectorised particles is refused by name."""

@@ -7,9 +7,6 @@
 #include "../../include/velocycle_hip.h"
 
 #define VC_WAVES 4          // waves per workgroup of the likelihood kernel
-#ifndef VC_ASM_LOADS
-#define VC_ASM_LOADS 1      // likelihood kernel: count loads issued from inline asm with hand-placed waits (vc_main_kernel.h)
-#endif
 // Arithmetic diet of the likelihood kernel's cell loop (round 3, profiles/r03_kmain.md section 5): each knob removes one packed
 // operation per gene pair and cell.  They change what the cell record holds, so every kernel that writes a record sees them.
 #ifndef VC_FOLD_LOG2E
@@ -563,7 +560,9 @@ vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gp
 // run-time-sized kernel set (vc_generic_kernels.hip)
 vc_main_launch_fn vc_find_generic_main_kernel(int kind, int noise, const void** kernel);
 void vc_launch_pre_generic(const VcDims& d, const VcBufs& b, const float* params, const float* eps, uint64_t seed, long long step,
-                           const long long* step_dev, int cond_only, int with_hist, hipStream_t st);
+                           const long long* step_dev, int cond_only, int with_hist, hipStream_t st, int particles, int particle);
+void vc_launch_particle_acc(float* acc, float* g, long long n, int K, int k, double* lsum, double* loss_ring, long long loss_slots,
+                            long long step, hipStream_t st);
 void vc_launch_post_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev, hipStream_t st);
 void vc_launch_fin_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev, long long loss_slots,
                            long long step, const long long* step_dev, hipStream_t st);
@@ -583,7 +582,7 @@ void vc_launch_expected_logs(const VcDims& d, const VcBufs& b, const float* nu, 
                              float* out_S2, float* out_U, float* out_U2, hipStream_t st);
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
-                   hipStream_t st);
+                   hipStream_t st, int particles = 1, int particle = 0);
 void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int cond_only, hipStream_t st);
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,
                     hipStream_t st);

@@ -52,6 +52,7 @@ static VcRccl g_rccl;
 struct vc_engine {
   vc_config cfg{};
   VcNcclComm comm = nullptr;          // the engine's own communicator (vc_comm_init_rccl), or null
+  double* particle_lsum = nullptr;    // vc_svi_run_particles: [0] running sum of the particles' losses, [1] scratch slot of K_fin
   float* sis = nullptr;               // phase A's snapshot of shape_inv {parameter, exp_avg, exp_avg_sq} [3][Ng_pad]
   int xb_pw_off = 0, xb_pw_cap = 0, xb_loss_off = 0;
   long long xb_total = 0;
@@ -565,9 +566,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   d.gpl = d.generic ? 2 : 4;
   size_t max_scratch = 0;      // VC_MAX_SCRATCH (bytes per lane, measurement aid): accept an 8-genes-per-lane kernel that spills this little
   if (const char* env = getenv("VC_MAX_SCRATCH")) max_scratch = (size_t)atoi(env);
-#if VC_ASM_LOADS
   max_scratch = 0;             // asm-issued count loads: a spilled destination tuple would be stored before its data has landed
-#endif
   if (!d.generic) {
     const void* k8 = nullptr;
     hipFuncAttributes fa;
@@ -1225,6 +1224,50 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
       vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 0, with_hist, st);
       if (e->plain_steps < 2) ++e->plain_steps;
     }
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
+extern "C" int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, int64_t step0, float* grad,
+                                    float* grad_acc, double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq,
+                                    double lr, double lrd, double beta1, double beta2, double adam_eps, double clip_norm,
+                                    int num_particles, int64_t n_steps, void* hip_stream) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_svi_run_particles before vc_finalize");
+  if (e->cfg.world_size != 1)
+    return e->fail(VC_ERR_STATE, "vc_svi_run_particles applies the optimiser right after the particles' average: single rank only "
+                                 "(cells sharded: vc_elbo_grad per particle, average, all-reduce, vc_clipped_adam)");
+  if (!params || !grad || !grad_acc || !exp_avg || !exp_avg_sq || !step_dev) return e->fail(VC_ERR_ARG, "vc_svi_run_particles: null buffer");
+  if (num_particles < 1 || n_steps < 0) return e->fail(VC_ERR_ARG, "vc_svi_run_particles: num_particles >= 1, n_steps >= 0");
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (!e->particle_lsum) {
+    TRY(e->dalloc(&e->particle_lsum, 2));
+    HIPCHK(e, hipMemsetAsync(e->particle_lsum, 0, 2 * sizeof(double), st));
+  }
+  const int K = num_particles;
+  const long long total = e->layout.total, header = e->layout.header;
+  for (int64_t i = 0; i < n_steps; ++i) {
+    for (int k = 0; k < K; ++k) {
+      // the unfused sequence of particle k on the Philox stream (seed, t K + k), t read from the device counter
+      vc_launch_pre(e->d, e->b, params, nullptr, seed, 0, (const long long*)step_dev, 0, e->hist_each_step ? 1 : 0, st, K, k);
+      if (e->timing) {
+        if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
+        auto& pr = e->ev_pool[e->ev_used++];
+        HIPCHK(e, hipEventRecord(pr.first, st));
+        e->main_fn(e->d, e->b, st);
+        HIPCHK(e, hipEventRecord(pr.second, st));
+      } else {
+        e->main_fn(e->d, e->b, st);
+      }
+      // (the step counter advances once per step: with the last particle)
+      vc_launch_post(e->d, e->b, params, grad, k == K - 1 ? (long long*)step_dev : nullptr, st);
+      vc_launch_fin(e->d, e->b, params, grad, e->particle_lsum + 1, 1, (long long)(step0 + i), nullptr, st);
+      vc_launch_particle_acc(grad_acc, grad, total, K, k, e->particle_lsum, loss_dev, (long long)loss_slots, (long long)(step0 + i), st);
+    }
+    vc_launch_adam(params + header, grad + header, exp_avg, exp_avg_sq, total - header, lr, lrd, beta1, beta2, (float)adam_eps,
+                   (float)clip_norm, 0, (const long long*)step_dev, nullptr, nullptr, 0, st);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void vc_main_generic_kernel(const VcDims d, con
   }
   const v2f lb2 = HLB ? v2(0.f) : v2f{lbv.x, lbv.y} * VC_LOG2E;
   const v2f ib = v2f{__expf(-lbv.x), __expf(-lbv.y)};
-  const v2f gam = v2f{gmv.x, gmv.y}, rr = v2f{rrv.x, rrv.y}, rr2 = rr * rr;
+  const v2f gam = v2f{gmv.x, gmv.y}, rr = v2f{rrv.x, rrv.y};
   const float inv_s2_s = 1.0f / (d.sigma_ln_s * d.sigma_ln_s);
   const float inv_s2_u = 1.0f / (d.sigma_ln_u * d.sigma_ln_u);
   v2f gau = v2(0.f), gw = v2(0.f), ll = v2(0.f), lt = v2(0.f);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void vc_main_generic_kernel(const VcDims d, con
       if (LN) vc_obs_lognormal(sv, es, inv_s2_s, aS, ll);
       else {
         muS = v2_exp2(es2);
-        vc_obs_counts<NOISE>(sv, es2, muS, rr, rr2, aS, ll, lt);
+        vc_obs_counts<NOISE>(sv, es2, muS, rr, aS, ll, lt);
       }
       a += aS;
     }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void vc_main_generic_kernel(const VcDims d, con
         if (LN) vc_obs_lognormal(uv, eu2 * VC_LN2, inv_s2_u, aU, ll);
         else {
           const v2f muU = FULL ? muS * (ib * zp) : v2_exp2(eu2);
-          vc_obs_counts<NOISE>(uv, eu2, muU, rr, rr2, aU, ll, lt);
+          vc_obs_counts<NOISE>(uv, eu2, muU, rr, aU, ll, lt);
         }
         w = aU * q;
       }
@@ -228,10 +228,11 @@ vc_main_launch_fn vc_find_generic_main_kernel(int kind, int noise, const void** 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vc_pre_generic_kernel(const VcDims d, const VcBufs b, const float* __restrict__ P,
                                                              const float* __restrict__ eps_in, uint64_t seed, long long step_host,
-                                                             const long long* __restrict__ step_dev, int cond_only) {
+                                                             const long long* __restrict__ step_dev, int cond_only, int particles,
+                                                             int particle) {
   __shared__ double sm_red[16];
   extern __shared__ float s_nuw[];               // [NW] the nu_omega sample of this step (cell blocks)
-  const long long step = step_dev ? *step_dev : step_host;
+  const long long step = (step_dev ? *step_dev : step_host) * particles + particle;
   const bool vel = d.model == VC_MODEL_VELOCITY;
   const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
   const bool nb = d.noise == VC_NOISE_NB;
@@ -449,11 +450,11 @@ __global__ __launch_bounds__(256) void vc_pre_generic_kernel(const VcDims d, con
 }
 
 void vc_launch_pre_generic(const VcDims& d, const VcBufs& b, const float* params, const float* eps, uint64_t seed, long long step,
-                           const long long* step_dev, int cond_only, int with_hist, hipStream_t st) {
+                           const long long* step_dev, int cond_only, int with_hist, hipStream_t st, int particles, int particle) {
   const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
   const unsigned dyn = (unsigned)(sizeof(float) * (d.NW > 0 ? d.NW : 1));
   hipLaunchKernelGGL(vc_pre_generic_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), dyn, st, d, b, params, eps,
-                     seed, step, step_dev, cond_only);
+                     seed, step, step_dev, cond_only, particles, particle);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -27,24 +27,19 @@
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// build-time knobs (the defaults are the measured best)
-#ifndef VC_SCALAR_REC
-#define VC_SCALAR_REC 1
-#endif
-#ifndef VC_EARLY_FETCH
-#define VC_EARLY_FETCH 1   // issue the first cells' loads ahead of the per-gene latents' loads
-#endif
+// build-time knobs (the defaults are the measured best).  Variants that were measured and rejected in
+// rounds 1-3 -- two cells per reduction (v_permlane32_swap), the gene table through the LDS, d loglik / d eta as two fmas, the
+// compiler-counted load path, late first fetch, vector-loaded cell records -- are gone from the source: the measurements are in
+// profiles/r02_kmain.md / r03_kmain.md, the code in the history.
 #ifndef VC_EPI_ROWS
 #define VC_EPI_ROWS 6     // output rows staged per epilogue pass (LDS: 4 waves x rows x 64*GPL floats)
 #endif
-#ifndef VC_ASM_LOADS
-#define VC_ASM_LOADS 1    // the count loads are issued from inline asm (global_load_dwordx4 with an SGPR base) and waited for with
-#endif                    // hand-placed `s_waitcnt vmcnt(k)`, k = the loads of the cells fetched AFTER the one about to be
-                          // processed: hipcc's own wait insertion drains the queue (`vmcnt(0)`) once per loop trip as soon as
-                          // more than one cell is in flight (the exits of the unrolled loop join its latch), which is what kept
-                          // the loop at one cell of prefetch; profiles/r03_kmain.md.  0 = the compiler-counted loads of round 2.
+// The count loads are issued from inline asm (global_load_dwordx4 with an SGPR base) and waited for with hand-placed
+// `s_waitcnt vmcnt(k)`, k = the loads of the cells fetched AFTER the one about to be processed: hipcc's own wait insertion drains
+// the queue (`vmcnt(0)`) once per loop trip as soon as more than one cell is in flight (the exits of the unrolled loop join
+// its latch), which is what kept the loop at one cell of prefetch; profiles/r03_kmain.md.
 #ifndef VC_PF
-#define VC_PF (VC_ASM_LOADS ? 2 : 1)   // register path: cells in flight ahead of the one being processed
+#define VC_PF 2           // cells in flight ahead of the one being processed (S+U kernel)
 #endif
 #ifndef VC_PF_SINGLE
 #define VC_PF_SINGLE 1    // the same for the one-matrix kernels (phase, U-only): they stream half the bytes per cell and lose
@@ -56,12 +51,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define VC_REC_TOUCH 1    // the record of the cell about to be processed is "used" (empty asm) BEFORE the next cell's scalar load is
 #endif                    // issued: scalar loads return out of order, so the wait hipcc puts in front of the first use of a record is
                           // lgkmcnt(0) -- placed behind the new s_load it exposes that load's whole latency once per cell
-#ifndef VC_GT_LDS
-#define VC_GT_LDS 0       // per-gene latents through an LDS copy of the gene block's table rows (one global read per workgroup
-#endif                    // instead of one per wave)
-#ifndef VC_A_FMA
-#define VC_A_FMA 0        // negative-binomial S term: d loglik / d eta as fma(fma(r, k, r^2), 1 / (r + mu), -r) -- one packed operation
-#endif                    // less than r (k - mu) / (r + mu), one more register pair per gene pair (r^2)
 #ifndef VC_LB_SINGLE
 #define VC_LB_SINGLE 2    // minimum waves per SIMD the one-matrix kernels (8 genes per lane) are compiled for
 #endif
@@ -69,9 +58,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define VC_LDS_REDUCE 1   // S+U kernel (3 per-cell sums): through an LDS tile of 16 cells (lane t adds up the 64 lanes' partials
 #endif                    // of one (cell, row)) instead of three 64-lane DPP trees per cell: -1.6 % measured; the one-sum kernels
                           // keep the DPP tree (the tile costs them +5 %), profiles/r02_kmain.md
-#ifndef VC_SWAP_REDUCE
-#define VC_SWAP_REDUCE 0  // 1: the per-cell sums of TWO consecutive cells share one 64-lane reduction (v_permlane32_swap)
-#endif
 #ifndef VC_FOLD_LOGBETA
 #define VC_FOLD_LOGBETA 1 // U-only kernel: -log beta folded into the per-gene constant harmonic (round 2 measured -2 % for it, unbuilt)
 #endif
@@ -93,27 +79,11 @@ struct VcCellRec {
   v2f ocs[H], osn[H];       // S+U kernel only
 };
 
-template <int H, int NB, bool XT>
-__device__ __forceinline__ VcCellRec<H, NB> vc_cell_from_pairs(const v2f* c2) {
-  VcCellRec<H, NB> r;
-#pragma unroll
-  for (int k = 0; k < H; ++k) { r.sn[k] = c2[2 * k]; r.cs[k] = c2[2 * k + 1]; }
-#pragma unroll
-  for (int q = 0; q < NB; ++q) r.db[q] = c2[2 * H + q];
-  r.omega = c2[2 * H + NB];
-  r.cf = c2[2 * H + NB + 1];
-  if (XT) {
-#pragma unroll
-    for (int k = 0; k < H; ++k) { r.ocs[k] = c2[2 * H + NB + 2 + 2 * k]; r.osn[k] = c2[2 * H + NB + 3 + 2 * k]; }
-  }
-  return r;
-}
 // The record is read through the constant address space: the table is written by K_pre, never by this
 // kernel, and only a constant-space load of a wave-uniform address is selected as s_load_dwordx8 (scalar
 // cache, SGPR pairs as packed operands) instead of a 64-lane vector load of one address.
 template <int H, int NB, bool XT>
 __device__ __forceinline__ VcCellRec<H, NB> vc_load_cell(const float* __restrict__ ct) {
-#if VC_SCALAR_REC
   typedef const __attribute__((address_space(4))) v2f* cptr;
   cptr c2 = (cptr)(const void*)ct;
   VcCellRec<H, NB> r;
@@ -128,9 +98,6 @@ __device__ __forceinline__ VcCellRec<H, NB> vc_load_cell(const float* __restrict
     for (int k = 0; k < H; ++k) { r.ocs[k] = c2[2 * H + NB + 2 + 2 * k]; r.osn[k] = c2[2 * H + NB + 3 + 2 * k]; }
   }
   return r;
-#else
-  return vc_cell_from_pairs<H, NB, XT>(reinterpret_cast<const v2f*>(ct));
-#endif
 }
 
 // The kernel's partial sums (GO: one row per workgroup and output, written by every workgroup in its last microsecond; CO: per-cell
@@ -171,13 +138,12 @@ __device__ __forceinline__ v2f v2_rcp(v2f x) { return v2f{__builtin_amdgcn_rcpf(
 // Nothing else of the NB needs per-element work: sum_c (r+k)/(r+mu) = n + (sum_c a)/r, and the r-only
 // terms (r log r, lgamma) come from the per-gene count histograms (K_pre / K_post).
 template <int NOISE>
-__device__ __forceinline__ void vc_obs_counts(v2f k, v2f eta2, v2f mu, v2f r, v2f r2, v2f& a, v2f& ll, v2f& lt) {
+__device__ __forceinline__ void vc_obs_counts(v2f k, v2f eta2, v2f mu, v2f r, v2f& a, v2f& ll, v2f& lt) {
   if (NOISE == VC_NOISE_NB) {
     const v2f t = r + mu;
     const v2f lt2 = v2_log2(t);
     const v2f it = v2_rcp(t);
-    if (VC_A_FMA) a = v2_fma(v2_fma(r, k, r2), it, -r);      // r (k - mu) / (r + mu) = r (k + r) / (r + mu) - r, r2 = r * r
-    else a = (r * (k - mu)) * it;
+    a = (r * (k - mu)) * it;
     ll = v2_fma(k, eta2 - lt2, ll);
     lt += lt2;
   } else {
@@ -202,7 +168,6 @@ __device__ __forceinline__ void vc_obs_lognormal(v2f y, v2f eta, float inv_s2, v
 // Address form: SGPR base (wave-uniform row of the blocked layout) + 32-bit VGPR lane offset; `s_nop 4` covers a base that was
 // produced by v_readfirstlane (VALU write of an SGPR -> VMEM read: 5 wait states).
 // ---------------------------------------------------------------------------------------------
-static_assert(!(VC_SWAP_REDUCE && VC_ASM_LOADS), "VC_SWAP_REDUCE pairs cells without the asm path's waits: build it with -DVC_ASM_LOADS=0");
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 
@@ -316,41 +281,24 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   if (cbeg > d.Nc) cbeg = d.Nc;
   if (cend > d.Nc) cend = d.Nc;
   const int ncell = (int)(cend - cbeg);
-  const size_t blk_base = ((size_t)gb * d.Nc) * GBW + gl;       // in count elements (4 or 2 bytes each)
-  constexpr int ESZ = C16 ? 2 : 4;
-  const char* Sp = HAS_S ? reinterpret_cast<const char*>(b.S) + blk_base * ESZ : nullptr;
-  const char* Up = HAS_U ? reinterpret_cast<const char*>(b.U) + blk_base * ESZ : nullptr;
+  constexpr int ESZ = C16 ? 2 : 4;       // bytes per count element
   constexpr int NP = GPL / 2;           // packed pairs per lane
   constexpr int NV4 = GPL / 4;          // float4 groups of the lane's genes (gene table loads, epilogue stores)
   constexpr int NDW = GPL * ESZ / 4;    // dwords per lane per matrix per cell: 8 / 4 (float32), 4 / 2 (uint16)
-  constexpr bool ASM = VC_ASM_LOADS != 0;
   // cells in flight ahead of the one being processed.  The S+U kernel at 8 genes per lane has room for a third count buffer
   // (8 more VGPRs) only up to K = 3 coefficients per gene (H = 1, no batch offsets: 248 VGPRs); beyond that the third buffer
   // spills, and a spilled asm-load tuple is not just slow but wrong, so those instantiations keep one cell ahead
   constexpr int PF = FULL ? ((GPL == 8 && K > 3 && VC_PF > 1) ? 1 : VC_PF) : VC_PF_SINGLE, NBUF = PF + 1;
   constexpr int LPF = (HAS_S + HAS_U) * (NDW == 8 ? 2 : 1);   // vector-memory instructions per fetched cell (asm path)
-  uint32_t s_bf[ASM ? 1 : NBUF][NDW], u_bf[ASM ? 1 : NBUF][NDW];
-  VcCnt<NDW> s_q[ASM ? NBUF : 1], u_q[ASM ? NBUF : 1];        // asm path: the count registers as load tuples
+  VcCnt<NDW> s_q[NBUF], u_q[NBUF];        // the count registers as load tuples
   VcCellRec<H, NB> rec_bf[NBUF];
-  auto load_counts = [&](const char* p, uint32_t* w) __attribute__((always_inline)) {
-    if (NDW >= 4) {
-#pragma unroll
-      for (int q = 0; q < NDW / 4; ++q) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p + 16 * q);
-        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-      }
-    } else {
-      const uint2 v = *reinterpret_cast<const uint2*>(p);
-      w[0] = v.x; w[1] = v.y;
-    }
-  };
-  // asm path: wave-uniform base of this wave's gene block (SGPR pair) + the lane's byte offset inside a row (VGPR)
+  // wave-uniform base of this wave's gene block (SGPR pair) + the lane's byte offset inside a row (VGPR)
   const char* Sb = HAS_S ? reinterpret_cast<const char*>(b.S) + ((size_t)gb * d.Nc) * GBW * ESZ : nullptr;
   const char* Ub = HAS_U ? reinterpret_cast<const char*>(b.U) + ((size_t)gb * d.Nc) * GBW * ESZ : nullptr;
   const uint32_t lane_off = (uint32_t)gl * ESZ;
   auto fetch = [&](int j, int i) __attribute__((always_inline)) {
     const long long cn = cbeg + (i < ncell ? i : (ncell > 0 ? ncell - 1 : 0));
-    if (ASM) {
+    {
       // the "s" operand needs a PROVABLY wave-uniform value (else hipcc hands the asm a VGPR pair and the assembler rejects
       // it): the cell index goes through readfirstlane, which folds away wherever the compiler already knows it is uniform
       const size_t row = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)cn) * (GBW * ESZ);
@@ -361,13 +309,6 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         if (HAS_S) vc_issue<FULL>(s_q[j], lane_off, Sb + row);
         if (HAS_U) vc_issue<FULL>(u_q[j], lane_off, Ub + row);
       }
-    } else
-#ifdef VC_NO_LOADS           // measurement aid: only the first cells are fetched, the loop re-uses them (results are meaningless):
-    if (i >= NBUF) { asm volatile("" : "+v"(s_bf[j][0]), "+v"(u_bf[j][0])); } else      // what the memory stalls cost, profiles/r02_kmain.md
-#endif
-    {
-      if (HAS_S) load_counts(Sp + (size_t)cn * GBW * ESZ, s_bf[j]);
-      if (HAS_U) load_counts(Up + (size_t)cn * GBW * ESZ, u_bf[j]);
     }
     rec_bf[j] = vc_load_cell<H, NB, OCS>(b.CT + (size_t)cn * d.ctw);
   };
@@ -382,7 +323,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     for (int q = 0; q < NB; ++q) asm volatile("" ::"s"(r.db[q]));
     asm volatile("" ::"s"(r.omega), "s"(r.cf));
   };
-  // asm path: the counts of buffer j are readable once at most `pend` younger fetches are outstanding
+  // the counts of buffer j are readable once at most `pend` younger fetches are outstanding
   auto wait_counts = [&](int j, auto pend) __attribute__((always_inline)) {
     constexpr int N = decltype(pend)::value * LPF;
     if (HAS_S && HAS_U) vc_wait<N>(s_q[j], u_q[j]);
@@ -393,7 +334,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 #pragma unroll
     for (int j = 0; j < NBUF; ++j) wait_counts(j, std::integral_constant<int, 0>());
   };
-  if (VC_EARLY_FETCH && ncell > 0) {
+  if (ncell > 0) {      // the first cells' loads go out ahead of the per-gene latents' loads
 #pragma unroll
     for (int j = 0; j < PF; ++j) fetch(j, j);
   }
@@ -403,9 +344,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   constexpr bool LDSR = VC_LDS_REDUCE && FULL;
   constexpr int TILE_F = LDSR ? VC_WAVES * TILE_C * NCO * TILE_S : 0;
   constexpr int EPI_F = VC_WAVES * RPP * GBW + VC_WAVES;
-  constexpr int GT_F = VC_GT_LDS ? (K + 3) * GBW : 0;                // the gene block's rows of the gene table, staged once per workgroup
-  constexpr int LDS_F = (EPI_F > TILE_F ? EPI_F : TILE_F) > GT_F ? (EPI_F > TILE_F ? EPI_F : TILE_F) : GT_F;
-  __shared__ float4 lds4[(LDS_F + 3) / 4];   // gene-table staging / reduction tiles / epilogue staging (4-wave combine), in turn
+  constexpr int LDS_F = EPI_F > TILE_F ? EPI_F : TILE_F;
+  __shared__ float4 lds4[(LDS_F + 3) / 4];   // reduction tiles / epilogue staging (4-wave combine), in turn
   // pw_inline: W rows of this wave's cells (d.pw_slots float4 per wave) and, S+U kernel, 32 float4 of accumulators per wave
   // behind them -- DYNAMIC shared memory, sized by the launch (0 bytes when the feature is off: a sharded run, a tile that
   // does not fit), so that it costs occupancy only where it is used
@@ -423,21 +363,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
   v2f nu[K][NP], lb2[NP], ib[NP], gam[NP], rr[NP];
   {
-    // VC_GT_LDS: the four waves of a workgroup work on the SAME genes: the block's (K + 3) x GBW floats cross the L2 once per
-    // workgroup (256 threads x float4, coalesced) instead of once per wave, and every lane picks its genes' values from the LDS
     const float* gt = b.GT + g0;
-    size_t gt_stride = (size_t)d.Ng_pad;
-    if (VC_GT_LDS) {
-      float* gs = reinterpret_cast<float*>(lds4);
-      const float* gblk = b.GT + (size_t)gb * GBW;
-      for (int idx = threadIdx.x * 4; idx < (K + 3) * GBW; idx += 256 * 4) {
-        const int row = idx / GBW, col = idx - row * GBW;
-        *reinterpret_cast<float4*>(gs + idx) = *reinterpret_cast<const float4*>(gblk + (size_t)row * d.Ng_pad + col);
-      }
-      __syncthreads();
-      gt = gs + gl;
-      gt_stride = GBW;
-    }
+    const size_t gt_stride = (size_t)d.Ng_pad;
 #pragma unroll
     for (int q4 = 0; q4 < NV4; ++q4) {
 #pragma unroll
@@ -467,11 +394,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         for (int k = 0; k < K; ++k) { nu[k][2 * q4] *= VC_LOG2E; nu[k][2 * q4 + 1] *= VC_LOG2E; }
       }
     }
-    if (VC_GT_LDS) __syncthreads();          // the staging area is the reduction tiles' / the epilogue's next
   }
-  v2f rr2[NP];
-#pragma unroll
-  for (int p = 0; p < NP; ++p) rr2[p] = rr[p] * rr[p];
   const float inv_s2_s = 1.0f / (d.sigma_ln_s * d.sigma_ln_s);
   const float inv_s2_u = 1.0f / (d.sigma_ln_u * d.sigma_ln_u);
 
@@ -531,7 +454,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         if (LN) vc_obs_lognormal(sv[p], es, inv_s2_s, aS, ll[p]);
         else {
           muS = v2_exp2(es2);
-          vc_obs_counts<NOISE>(sv[p], es2, muS, rr[p], rr2[p], aS, ll[p], lt[p]);
+          vc_obs_counts<NOISE>(sv[p], es2, muS, rr[p], aS, ll[p], lt[p]);
         }
         a += aS;
       }
@@ -569,7 +492,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           else {
             // exp(eta_U) = exp(eta_S) * zp / beta: no second exponential when exp(eta_S) is at hand
             const v2f muU = FULL ? muS * (ib[p] * zp) : v2_exp2(eu2);
-            vc_obs_counts<NOISE>(uv[p], eu2, muU, rr[p], rr2[p], aU, ll[p], lt[p]);
+            vc_obs_counts<NOISE>(uv[p], eu2, muU, rr[p], aU, ll[p], lt[p]);
           }
           w = aU * q;
         }
@@ -617,33 +540,6 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       const float t1 = vc_wave_sum(p1), t2 = vc_wave_sum(p2);
       keep1 = (lane == i) ? t1 : keep1;
       keep2 = (lane == i) ? t2 : keep2;
-    }
-  };
-  // the same for the cells i and i + 1 together: v_permlane32_swap puts cell i's lane pairs (l, l + 32) into lanes 0..31
-  // and cell i + 1's into lanes 32..63, one add folds them, then ONE 32-lane DPP reduction serves both cells
-  // (7 VALU instead of 12 per pair and row)
-  auto pair_sum = [&](float x0, float x1, float& t0, float& t1) __attribute__((always_inline)) {
-    // inline asm: hipcc 7.2 maps BOTH results of __builtin_amdgcn_permlane32_swap to the first register (x0 + x0 comes
-    // out); a VALU write needs a wait state before the swap reads it, and the compiler does not look into asm statements
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(x1));
-    float v = x0 + x1;
-    v += vc_dpp<0x111, 0xf>(v);
-    v += vc_dpp<0x112, 0xf>(v);
-    v += vc_dpp<0x114, 0xf>(v);
-    v += vc_dpp<0x118, 0xf>(v);
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa" : "+v"(v));
-    t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
-    t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-  };
-  auto stage2 = [&](const float* pa, const float* pb, const int i) __attribute__((always_inline)) {
-    float t0, t1;
-    pair_sum(pa[0], pb[0], t0, t1);
-    keep0 = (lane == i) ? t0 : ((lane == i + 1) ? t1 : keep0);
-    if (NCO == 3) {
-      pair_sum(pa[1], pb[1], t0, t1);
-      keep1 = (lane == i) ? t0 : ((lane == i + 1) ? t1 : keep1);
-      pair_sum(pa[2], pb[2], t0, t1);
-      keep2 = (lane == i) ? t0 : ((lane == i + 1) ? t1 : keep2);
     }
   };
   // LDS variant: the lane partials of cell slot ci go into this wave's tile [ci][row][lane] (conflict-free writes) ...
@@ -712,53 +608,20 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     // no branch around loads); the loop is unrolled PF + 1 times so that every buffer keeps its registers and no
     // copies are needed.
     if (ncell > 0) {
-      if (!VC_EARLY_FETCH) {
-#pragma unroll
-        for (int j = 0; j < PF; ++j) fetch(j, j);
-      }
       auto unpack = [&](int j, v2f* sv, v2f* uv) __attribute__((always_inline)) {
         auto pair_w = [&](uint32_t lo, uint32_t hi) -> v2f {      // genes 2p, 2p + 1 of the lane
           if (C16) return v2f{(float)(lo & 0xffffu), (float)(lo >> 16)};
           return v2f{__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)};
-        };
-        auto pair_of = [&](const uint32_t* w, int p) -> v2f {
-          return C16 ? pair_w(w[p], 0u) : pair_w(w[2 * p], w[2 * p + 1]);
         };
         auto pair_q = [&](const VcCnt<NDW>& c, int p) -> v2f {
           return C16 ? pair_w(vc_cnt_dword<NDW>(c, p), 0u) : pair_w(vc_cnt_dword<NDW>(c, 2 * p), vc_cnt_dword<NDW>(c, 2 * p + 1));
         };
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          if (ASM) {
-            sv[p] = HAS_S ? pair_q(s_q[j], p) : v2(0.f);
-            uv[p] = HAS_U ? pair_q(u_q[j], p) : v2(0.f);
-          } else {
-            sv[p] = HAS_S ? pair_of(s_bf[j], p) : v2(0.f);
-            uv[p] = HAS_U ? pair_of(u_bf[j], p) : v2(0.f);
-          }
+          sv[p] = HAS_S ? pair_q(s_q[j], p) : v2(0.f);
+          uv[p] = HAS_U ? pair_q(u_q[j], p) : v2(0.f);
         }
       };
-      if (VC_SWAP_REDUCE && NBUF == 2) {
-        // two cells per trip; their per-cell sums are reduced together
-        for (int i0 = 0; i0 < ncell; i0 += 2) {
-          float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f};
-          v2f sv[NP], uv[NP];
-          fetch(1, i0 + 1);
-          unpack(0, sv, uv);
-          cell(sv, uv, rec_bf[0], pa[0], pa[1], pa[2]);
-          if (i0 + 1 < ncell) {
-            fetch(0, i0 + 2);
-            unpack(1, sv, uv);
-            cell(sv, uv, rec_bf[1], pb[0], pb[1], pb[2]);
-            stage2(pa, pb, i0 & 63);
-            const int i = i0 + 1;
-            if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);
-          } else {
-            stage1(pa[0], pa[1], pa[2], i0 & 63);
-            flush(cbeg + (i0 & ~63), (i0 & 63) + 1);
-          }
-        }
-      } else
       for (int i0 = 0; i0 < ncell; i0 += NBUF) {
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
@@ -772,10 +635,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           }
           if (VC_REC_TOUCH) touch_rec(rec_bf[j]);
           fetch((j + PF) % NBUF, i + PF);
-          if (ASM) {
-            if (VC_ISSUE_PIN) __builtin_amdgcn_sched_barrier(0);
-            wait_counts(j, std::integral_constant<int, PF>());       // the PF cells fetched after this one stay in flight
-          }
+          if (VC_ISSUE_PIN) __builtin_amdgcn_sched_barrier(0);
+          wait_counts(j, std::integral_constant<int, PF>());       // the PF cells fetched after this one stay in flight
           v2f sv[NP], uv[NP];
           unpack(j, sv, uv);
           float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -793,7 +654,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     // the last PF fetches (re-fetches of the last cell) are still in flight: nothing may re-use their registers before they
     // have landed.  Outside the `ncell > 0` scope on purpose: every static path from a fetch to the epilogue passes through
     // this drain, including the ones a path-insensitive audit cannot rule out (early fetch taken, loop skipped)
-    if (ASM) drain_counts();
+    drain_counts();
   }
 
   VC_STAMP(2);

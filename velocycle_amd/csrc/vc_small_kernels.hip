@@ -159,11 +159,12 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
                                                      const float* __restrict__ eps_in, uint64_t seed,
                                                      long long step_host,
                                                      const long long* __restrict__ step_dev,
-                                                     int cond_only) {
+                                                     int cond_only, int particles, int particle) {
   __shared__ double sm_red[16];
   __shared__ float s_nuw[VC_MAX_NW];
   VC_KSTAMP(0, 0);
-  const long long step = step_dev ? *step_dev : step_host;
+  // Philox stream of this draw: (seed, step); with K particles per step the k-th draw of step t is stream t K + k
+  const long long step = (step_dev ? *step_dev : step_host) * particles + particle;
   const bool vel = d.model == VC_MODEL_VELOCITY;
   const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
   const bool nb = d.noise == VC_NOISE_NB;
@@ -424,11 +425,40 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
 
 void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const float* eps,
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
-                   hipStream_t st) {
-  if (d.generic) { vc_launch_pre_generic(d, b, params, eps, seed, step, step_dev, cond_only, with_hist, st); return; }
+                   hipStream_t st, int particles, int particle) {
+  if (d.generic) { vc_launch_pre_generic(d, b, params, eps, seed, step, step_dev, cond_only, with_hist, st, particles, particle); return; }
   const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
   hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), 0, st, d, b,
-                     params, eps, seed, step, step_dev, cond_only);
+                     params, eps, seed, step, step_dev, cond_only, particles, particle);
+}
+
+// K-particle step (vc_svi_run_particles): the gradient of one particle joins the running sum; the last one leaves the average
+// in `g` (sum / K, as the reference's Trace_ELBO averages loss and gradients over its particles: velocity_inference_model.py:79,111)
+// together with the averaged loss (header hi / lo, loss ring slot)
+__global__ __launch_bounds__(256) void vc_particle_acc_kernel(float* __restrict__ acc, float* __restrict__ g, long long n, int K,
+                                                             int k, double* __restrict__ lsum, double* __restrict__ loss_ring,
+                                                             long long loss_slots, long long step) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double l = (k == 0 ? 0.0 : lsum[0]) + ((double)g[0] + (double)g[1]);
+    lsum[0] = l;
+    if (k == K - 1) {
+      const double avg = l / (double)K;
+      const float hi = (float)avg, lo = (float)(avg - (double)hi);
+      g[0] = hi; g[1] = lo;
+      if (loss_ring) loss_ring[loss_slots > 1 ? (step % loss_slots) : 0] = (double)hi + (double)lo;
+    }
+  }
+  for (long long i = 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float a = (k == 0 ? 0.f : acc[i]) + g[i];
+    acc[i] = a;
+    if (k == K - 1) g[i] = a / (float)K;
+  }
+}
+void vc_launch_particle_acc(float* acc, float* g, long long n, int K, int k, double* lsum, double* loss_ring, long long loss_slots,
+                            long long step, hipStream_t st) {
+  long long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(vc_particle_acc_kernel, dim3((unsigned)nb), dim3(256), 0, st, acc, g, n, K, k, lsum, loss_ring, loss_slots, step);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -282,6 +282,17 @@ class HipEngine:
             C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, int(bool(prime)),
             C.c_int64(n_steps), self._stream()))
 
+    def svi_run_particles(self, grad_acc, m, v, lr, lrd, b1, b2, adam_eps, clip, seed, step_dev, step0, num_particles, n_steps,
+                          loss_buf=None):
+        """n_steps steps of Trace_ELBO(num_particles=K) enqueued from one call (vc_svi_run_particles): per step K x the unfused
+        kernel sequence on the Philox streams (seed, t K + k), the gradients averaged on the device, one ClippedAdam."""
+        lb = self.loss_dev if loss_buf is None else loss_buf
+        self._check(self.lib.vc_svi_run_particles(
+            self._h, C.c_void_p(self.params.data_ptr()), C.c_uint64(seed), C.c_void_p(step_dev.data_ptr()), C.c_int64(step0),
+            C.c_void_p(self.grad.data_ptr()), C.c_void_p(grad_acc.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_int64(lb.numel()),
+            C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, int(num_particles),
+            C.c_int64(n_steps), self._stream()))
+
     # ---- cells sharded over ranks: the fused step cut at its one exchange (vc_svi_run_sharded) ----------------------
     def exchange_size(self) -> int:
         n = C.c_int64()

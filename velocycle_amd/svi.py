@@ -311,6 +311,19 @@ class SVIRunner:
         """perf mode with K particles: per step the unfused kernel sequence on the Philox streams (seed, step * K + k),
         averaged on the device; losses stay in the device ring."""
         e, K = self.e, self.K
+        import os
+        if not self.do_reduce and self.opt.impl == "hip" and os.environ.get("VC_PARTICLES_HOST_LOOP", "0") != "1":
+            # single rank: every launch of the run from one C call (vc_svi_run_particles) -- the same kernels on the same
+            # streams, the gradients averaged by a kernel instead of PyTorch ops: the same numbers
+            if getattr(self, "_gacc", None) is None:
+                self._gacc = torch.zeros_like(e.grad)
+            o = self.opt
+            e.svi_run_particles(self._gacc, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, seed=self.seed,
+                                step_dev=self.step_dev, step0=self.step_idx, num_particles=K, n_steps=n_steps,
+                                loss_buf=self.loss_hist)
+            o.t += n_steps
+            self.step_idx += n_steps
+            return
         for _ in range(n_steps):
             acc = torch.zeros_like(e.grad)
             lacc = torch.zeros((), dtype=torch.float64, device=e.grad.device)
