@@ -77,6 +77,8 @@ def parse():
                          "short regions are repeated until ~1000 steps are timed (the sustained clock under this load takes ~30 ms "
                          "of GPU work to ramp, a 20-step region is 3 ms)")
     ap.add_argument("--roofline-launches", type=int, default=100)
+    ap.add_argument("--no-weak", action="store_true",
+                    help="N > 1: skip the weak-scaling block (--cells cells PER RANK, same kernels) that follows the strong run")
     return ap.parse_args()
 
 
@@ -437,12 +439,13 @@ def main():
 
     optim = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / 10000), "betas": (0.80, 0.99)}
 
-    def build(mode):
+    def build(mode, cells=None):
+        cells = args.cells if cells is None else cells
         t0 = time.perf_counter()
         if mode == "phase":
-            spec = make_phase_spec(args.cells, args.genes, seed=0, device=device)
+            spec = make_phase_spec(cells, args.genes, seed=0, device=device)
         else:
-            spec = make_velocity_spec(args.cells // args.conditions, args.genes, mode, args.conditions, 1, seed=0, device=device)
+            spec = make_velocity_spec(cells // args.conditions, args.genes, mode, args.conditions, 1, seed=0, device=device)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
         eng = HipEngine(spec, device=device, rank=rank, world_size=world)
@@ -536,9 +539,30 @@ def main():
         out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ids,
                               "distinct_devices": len({(i["uuid"], i["local_rank"]) for i in ids}),
                               "step_launch": "hipGraph replay (RCCL all-reduce captured)" if run.use_graph else "eager",
-                              "step_kind": run.adam_impl, "exchange": run.exchange}
+                              "step_kind": run.adam_impl, "exchange": run.exchange,
+                              "exchange_check": getattr(run, "exchange_check", None)}
     else:
         out["device"] = device_identity(device)
+    if dist_on and not args.no_weak:
+        # Weak scaling from the same invocation: --cells cells PER RANK (N x the strong problem), the same
+        # kernels and the same exchange; the strong run above stays the headline (the north-star target is phrased on the fixed
+        # 50k x 2k problem), this block says what a rank's step costs when its shard does not shrink with N.
+        del run, eng, spec
+        torch.cuda.empty_cache()
+        spec_w, eng_w, run_w, setup_w = build(args.mode, cells=args.cells * world)
+        tw = time_steps(run_w, args.steps, args.warmup, dist_on, device, max(5, args.repeats // 4))
+        rf_w = kernel_roofline(eng_w, run_w, args.roofline_launches, median(tw) / args.steps)
+        out["weak"] = {"scaling": "weak", "cells_per_rank": eng_w.Nc_local, "cells_total": args.cells * world, "genes": args.genes,
+                       "value": round(args.steps / median(tw), 2), "unit": "SVI steps/s", "ms_per_step": round(1e3 * median(tw) / args.steps, 4),
+                       "repeat_ms_per_step": [round(1e3 * t / args.steps, 4) for t in tw],
+                       "cells_per_s": round(args.cells * world * args.steps / median(tw), 1),
+                       "kernel": rf_w["kernel"], "kernel_avg_us": rf_w["kernel_avg_us"], "frac": rf_w["frac"],
+                       "step_frac": rf_w["step_frac"], "exchange": run_w.exchange, "setup_s": setup_w,
+                       "note": "every rank keeps --cells cells (the strong problem's size per GPU); value = steps/s of the N-times "
+                               "larger job; compare ms_per_step with the 1-GPU strong line"}
+        del run_w, eng_w, spec_w
+        torch.cuda.empty_cache()
+        run = eng = spec = None
     extra = {}
     if not args.no_extra_modes and not dist_on:
         del run, eng, spec

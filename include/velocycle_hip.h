@@ -311,6 +311,9 @@ int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, int64_t* step
  * calls vc_comm_init_rccl with it (collective).  vc_destroy releases the communicator. */
 int vc_comm_rccl_unique_id(const char* rccl_path, void* id_out_128_bytes);
 int vc_comm_init_rccl(vc_engine* e, const char* rccl_path, const void* id_128_bytes);
+/* Sum of a DEVICE float buffer over the ranks of that communicator, in place, on hip_stream (the collective of VC_PHASE_AB as a
+ * call of its own: the host side uses it once to check the communicator against torch.distributed's sum of the same buffer). */
+int vc_comm_allreduce(vc_engine* e, float* buf, int64_t n, void* hip_stream);
 
 /* The one-shot exchange for VC_PHASE_AB over peer-mapped device memory (SURVEY.md section 5's latency-optimised variant;
  * velocycle_amd/csrc/vc_p2p_exchange.hip): every rank publishes its exchange buffer in a region of its own HBM and a

@@ -37,6 +37,9 @@ def _host_checker(spec, monkeypatch, **kw):
 def test_device_histograms_equal_host_pass_on_fixtures(case, monkeypatch):
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
     spec = H.spec_from_fixture(z)
+    # like with like: the (value, multiplicity) lists on both sides (the S+U models evaluate the histogram sums from dense
+    # tail-count tables by default since round 4 -- another formula for the same numbers: checked at the end)
+    monkeypatch.setenv("VC_HIST_DENSE", "0")
     dev, host = _mk(spec), _host_checker(spec, monkeypatch)
     assert dev.stats["hist_on_device"]
     assert _hist_equal(dev.histogram(), host.histogram())
@@ -47,7 +50,17 @@ def test_device_histograms_equal_host_pass_on_fixtures(case, monkeypatch):
     # the constant sum lgamma(k+1) is added up per gene on one side, per host thread on the other: last-digit fp64 rounding
     assert abs(dev.loss() - host.loss()) <= 1e-13 * abs(host.loss())
     assert torch.equal(torch.nan_to_num(dev.grad[4:]), torch.nan_to_num(host.grad[4:]))
-    dev.close(); host.close()
+    # dense tail-count tables (sum_j C_j log(r + j), hardware log2 / reciprocal) against the lists (Stirling differences): the
+    # same sums to float32 rounding of their terms
+    monkeypatch.setenv("VC_HIST_DENSE", "1")
+    dense = _mk(spec)
+    dense.init_params() if spec.guide != "lrmn" else dense.init_params(torch.zeros(spec.Ng + spec.Nx * spec.Nhw, spec.rho_rank))
+    dense.elbo_grad(eps=None, seed=3, step=1)
+    torch.cuda.synchronize()
+    assert abs(dense.loss() - host.loss()) <= 2e-6 * abs(host.loss())
+    gd, gh = torch.nan_to_num(dense.grad[4:]).double(), torch.nan_to_num(host.grad[4:]).double()
+    assert float((gd - gh).abs().max()) <= 1e-4 * float(gh.abs().max())
+    dev.close(); host.close(); dense.close()
 
 
 def _spiky_spec(on_device):
@@ -138,7 +151,9 @@ def test_sparse_anndata_layers_reach_the_engine_as_csr():
     spec = make_phase_spec(900, 80, seed=2)
     S, U = spec.S.t().numpy(), spec.S.t().numpy() * 0
     out = []
+    from velocycle_amd import pyro_compat as pyro
     for sparse in (False, True):
+        pyro.clear_param_store()          # (a fit() continues from the store otherwise: the second would start where the first ended)
         ad = AnnDataLite(sp.csr_matrix(S) if sparse else S, sp.csr_matrix(U) if sparse else U)
         cyc = C.Cycle.from_array(spec.mu_nu.T.numpy(), spec.sd_nu.T.numpy(), list(ad.var.index))
         ph = C.Phases.from_array(spec.phixy_prior.T.numpy(), cell_names=list(ad.obs.index))

@@ -65,6 +65,10 @@ def test_bench_gpus_2_launches_itself():
     assert len(out_lines) == 1, two.stdout[-2000:]
     j = json.loads(out_lines[0])
     assert j["n_gpus"] == 2 and j["distributed"]["world_size"] == 2 and j["steps"] == 30
+    # the weak-scaling block of the same invocation: --cells cells per rank, the same kernels and exchange
+    w = j["weak"]
+    assert w["scaling"] == "weak" and w["cells_per_rank"] == 6000 and w["cells_total"] == 12000 and w["value"] > 0
+    assert w["exchange"] == j["distributed"]["exchange"] and len(w["repeat_ms_per_step"]) >= 5
 
 
 def test_a_stuck_multi_rank_run_is_given_up():

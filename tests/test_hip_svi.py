@@ -276,6 +276,28 @@ def test_trajectory_at_3k_x_200_stays_within_float32_spread_of_the_oracle(mode):
     eng.close()
 
 
+def test_bounded_sync_gives_up_instead_of_hanging(monkeypatch):
+    """SVIRunner._bounded_sync (what run_perf / fit() wait with when cells are sharded): a stream that never drains -- here an
+    event whose query is made to say "not yet" forever -- ends in a HipEngineError after VC_RUN_DEADLINE_S, not in a hang."""
+    from velocycle_amd.engine import HipEngineError
+    from velocycle_amd.svi import SVIRunner
+    z = H.load_fixture(f"{H.GOLDEN}/ref_step_vel_mf_joint.npz")
+    e = _mk(H.spec_from_fixture(z))
+    r = SVIRunner(e, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=1, adam_impl="sharded", exchange="none")
+    r.run_perf(3)                                  # one rank, nothing to wait for: plain synchronise
+    r.do_reduce = True                             # ... as a rank of a sharded run waits
+    monkeypatch.setenv("VC_RUN_DEADLINE_S", "0.3")
+    monkeypatch.setattr(torch.cuda.Event, "query", lambda self: False)
+    import time
+    t0 = time.time()
+    with pytest.raises(HipEngineError, match="did not finish within"):
+        r._bounded_sync()
+    assert 0.25 < time.time() - t0 < 5.0
+    monkeypatch.undo()
+    r._bounded_sync()                              # the real event completes at once
+    e.close()
+
+
 def test_engine_owned_rccl_exchange_single_rank():
     """The sharded fused step with the exchange made by the ENGINE'S OWN RCCL communicator (vc_comm_rccl_unique_id ->
     broadcast -> vc_comm_init_rccl; ncclAllReduce enqueued between the two phases from the one C call of a run) on a 1-rank
@@ -308,6 +330,20 @@ def test_engine_owned_rccl_exchange_single_rank():
                 r2.run_perf(3)
                 assert all(np.isfinite(r2.perf_losses())) and e.status()[0]
             e.close()
+        # the one-time self-check of the engine-owned exchange (first step cut open: phase A -> the buffer summed by the engine's
+        # communicator and, on a copy, by torch.distributed -> compared -> phase B), forced on the 1-rank
+        # group: verdict "ok", and the run equals the unchecked one bit for bit
+        os.environ["VC_EXCHANGE_CHECK"] = "1"
+        try:
+            e = _mk(spec)
+            r = SVIRunner(e, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=11, force_reduce=True, exchange="engine")
+            r.run_perf(10)
+            assert r.exchange_check == "ok" and r.exchange == "engine"
+            nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+            assert torch.equal(nz(e.params.cpu()), nz(outs[0][0])) and r.perf_losses() == outs[0][1]
+            e.close()
+        finally:
+            del os.environ["VC_EXCHANGE_CHECK"]
         a, b = outs[0][0].double().numpy(), outs[1][0].double().numpy()
         fin = np.isfinite(b)
         assert np.array_equal(np.isfinite(a), fin) and np.allclose(a[fin], b[fin], rtol=2e-5, atol=2e-6), np.abs(a[fin] - b[fin]).max()

@@ -89,6 +89,7 @@ EXPORTS = {
                                    C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_int, C.c_int64, C.c_void_p]),
     "vc_exchange_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "vc_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vc_svi_run_particles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                        C.c_double, C.c_int, C.c_int64, C.c_void_p]),

@@ -1312,6 +1312,14 @@ extern "C" int vc_comm_init_rccl(vc_engine* e, const char* rccl_path, const void
   VC_GUARD_END(e)
 }
 
+extern "C" int vc_comm_allreduce(vc_engine* e, float* buf, int64_t n, void* hip_stream) {
+  if (!e || !buf || n < 0) return VC_ERR_ARG;
+  if (!e->comm) return e->fail(VC_ERR_STATE, "vc_comm_allreduce before vc_comm_init_rccl");
+  const int rc = g_rccl.AllReduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, e->comm, (hipStream_t)hip_stream);
+  if (rc != 0) return e->fail(VC_ERR_STATE, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed");
+  return VC_OK;
+}
+
 extern "C" int vc_p2p_alloc(vc_engine* e, void* ipc_handle_out) {
   if (!e || !ipc_handle_out) return VC_ERR_ARG;
   VC_GUARD_BEGIN

@@ -362,6 +362,11 @@ class HipEngine:
         self._rccl_ready = bool(int(flag.item()))
         return self._rccl_ready
 
+    def comm_allreduce(self, buf: torch.Tensor):
+        """Sum of a float32 device buffer over the ranks of the engine's own RCCL communicator, in place, on the current
+        stream (vc_comm_allreduce) -- what the sharded run does between its two phases, as a call of its own."""
+        self._check(self.lib.vc_comm_allreduce(self._h, C.c_void_p(buf.data_ptr()), C.c_int64(buf.numel()), self._stream()))
+
     def init_p2p_exchange(self, process_group=None) -> bool:
         """The one-shot peer-to-peer exchange (vc_p2p_alloc / vc_p2p_connect): this rank's region is created and exported,
         the 64-byte IPC handles of all ranks are gathered in rank order with torch.distributed (any backend), the peers'

@@ -350,6 +350,34 @@ class SVIRunner:
             from . import _lib
             o = self.opt
             kw = dict(seed=self.seed, step_dev=self.step_dev, loss_buf=self.loss_hist)
+            import os
+            if (self.exchange == "engine" and (self.world > 1 or (self.do_reduce and os.environ.get("VC_EXCHANGE_CHECK") == "1"))
+                    and not getattr(self, "_exchange_checked", False) and n_steps > 0):
+                # The first step of the engine-owned exchange is cut open once: phase A -> the buffer summed by the engine's
+                # communicator AND, on a copy, by torch.distributed -> compared (the loss pieces are exact sums on fixed
+                # grids: equal bit for bit; gradient partials: the order of the ranks' adds may differ) -> phase B.  If any
+                # rank sees a difference every rank falls back to the torch exchange (MIN all-reduce of the verdict).
+                import torch.distributed as dist
+                self._exchange_checked = True
+                e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime,
+                                  phase=_lib.VC_PHASE_A, **kw)
+                ref = self.xbuf.clone()
+                dist.all_reduce(ref, group=self.pg)
+                e.comm_allreduce(self.xbuf)
+                same = torch.allclose(self.xbuf, ref, rtol=1e-5, atol=1e-6, equal_nan=True)
+                flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=e.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+                self.exchange_check = "ok" if int(flag.item()) else "mismatch"
+                if not int(flag.item()):
+                    import warnings
+                    warnings.warn("the engine's RCCL communicator did not reproduce torch.distributed's sum of the exchange "
+                                  "buffer; every rank continues with the torch exchange")
+                    self.exchange = "torch"
+                    self.xbuf.copy_(ref)
+                e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, phase=_lib.VC_PHASE_B, **kw)
+                prime, n_steps = False, n_steps - 1
+                if n_steps == 0:
+                    return
             if self.exchange in ("engine", "p2p", "none"):      # every launch and every all-reduce of the run from one C call
                 e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime,
                                   phase=_lib.VC_PHASE_AB, n_steps=n_steps, **kw)
@@ -447,7 +475,31 @@ class SVIRunner:
                     self._primed = True
         self.step_idx += n_steps
         if sync and torch.device(e.device).type == "cuda":
+            self._bounded_sync()
+
+    def _bounded_sync(self):
+        """torch.cuda.synchronize with a deadline when cells are sharded: a stuck collective or a dead peer otherwise hangs every
+        rank for as long as its caller is willing to wait (bench.py has its own watchdog; fit() / run_svi had none).  The
+        stream is polled through an event; past VC_RUN_DEADLINE_S (default 900 s) the run is given up with an exception --
+        the process is never re-executed, the device work is not cancelled (exit the process to release it)."""
+        e = self.e
+        if self.world <= 1 and not self.do_reduce:
             torch.cuda.synchronize(e.device)
+            return
+        import os
+        import time
+        limit = float(os.environ.get("VC_RUN_DEADLINE_S", "900"))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(e.device))
+        t0 = time.monotonic()
+        nap = 1e-4
+        while not ev.query():
+            if time.monotonic() - t0 > limit:
+                from .engine import HipEngineError
+                raise HipEngineError(f"rank {e.rank} of {self.world}: the sharded run did not finish within {limit:.0f} s "
+                                     f"(VC_RUN_DEADLINE_S) -- a collective or a peer is stuck (exchange: {self.exchange})")
+            time.sleep(nap)
+            nap = min(nap * 2, 0.01)
 
     _SENTINEL = -0x0007_2174_5EED_0001          # an int64 bit pattern no loss takes (a NaN with this payload)
 
