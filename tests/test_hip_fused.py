@@ -248,6 +248,9 @@ def test_two_launch_step_equals_three_launch_step_on_the_fixtures(case, monkeypa
     from velocycle_amd.engine import HipEngine
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
     spec = H.spec_from_fixture(z)
+    # like with like: the dense histogram tables are the default only where the one-launch tail runs; here both launch
+    # structures evaluate them (the four-wave and the sixteen-wave blocks add the same slices in the same order)
+    monkeypatch.setenv("VC_HIST_DENSE", "1")
     e = HipEngine(spec)
     assert e.stats["launches_per_step"] == 2, e.stats          # every fixture is small enough for K_main's own partials
     e.close()
@@ -272,6 +275,10 @@ def test_two_launch_step_medium_sizes(mode, ncond, cw, tc, monkeypatch):
         monkeypatch.setenv("VC_CELLS_PER_WAVE", cw)
     if tc:
         monkeypatch.setenv("VC_TAIL_TC", tc)
+    # K_main's own nu_omega partials even where they cost the 4-genes-per-lane S+U kernel a resident workgroup (the engine
+    # declines that trade above 12 cells per wave: profiles/r04_small_shard.md), and the dense histogram tables on both sides
+    monkeypatch.setenv("VC_PW_INLINE", "2")
+    monkeypatch.setenv("VC_HIST_DENSE", "1")
     spec = make_phase_spec(3001, 300, seed=5) if mode == "phase" else make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5)
     e = HipEngine(spec)
     assert e.stats["launches_per_step"] == 2 and (mode == "phase" or e.stats["pw_inline"] == (4 if ncond == 1 else 8)), e.stats
@@ -289,6 +296,10 @@ def test_two_launch_step_medium_sizes(mode, ncond, cw, tc, monkeypatch):
         a = _run(spec, "fused3", 2, False)
         monkeypatch.setenv("VC_PW_INLINE", "0")
         b = _run(spec, "fused3", 2, False)
+        monkeypatch.setenv("VC_HIST_DENSE", "0")      # ... and with the (value, multiplicity) lists instead of the dense tables
+        c = _run(spec, "fused3", 2, False)
+        assert np.allclose(c["l"], b["l"], rtol=5e-7, atol=0)
+        _same(c["p"], b["p"], "params after 2 steps, lists vs dense tables", rtol=2e-5, atol=2e-6)
         assert np.allclose(a["l"], b["l"], rtol=2e-7, atol=0)
         _same(a["p"], b["p"], "params after 2 steps", rtol=2e-6, atol=2e-7)
         _same(a["g"][4:], b["g"][4:], "gradient of step 2", rtol=1e-5, atol=1e-5)
@@ -301,6 +312,17 @@ def test_two_launch_step_resumes_and_mixes_with_step_with_loss():
     from velocycle_amd.svi import SVIRunner
     from velocycle_amd.workloads import make_velocity_spec
     spec = make_velocity_spec(3001, 300, "vjoint", n_conditions=1, Hw=1, seed=6)
+    import os
+    os.environ["VC_PW_INLINE"] = "2"
+    try:
+        _resume_body(spec)
+    finally:
+        del os.environ["VC_PW_INLINE"]
+
+
+def _resume_body(spec):
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
     ref = _run(spec, "fused3", 13, False)
     e1 = HipEngine(spec)
     assert e1.stats["launches_per_step"] == 2

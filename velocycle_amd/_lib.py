@@ -135,7 +135,10 @@ def load():
             "velocycle_amd has no CPU fallback")
     import torch  # noqa: F401  (its bundled libamdhip64 must be the one already mapped)
     lib = C.CDLL(LIB_PATH)
+    older = bool(os.environ.get("VC_LIB_PATH")) and os.environ.get("VC_LIB_OLDER") == "1"
     for name, (res, args) in EXPORTS.items():
+        if older and not hasattr(lib, name):
+            continue                     # measurement aid: an OLDER build of the library selected with VC_LIB_PATH for a same-box A/B
         fn = getattr(lib, name)          # AttributeError if a symbol of the header is missing
         fn.restype = res
         fn.argtypes = args

@@ -421,6 +421,17 @@ __device__ __forceinline__ void vc_hist_wave(const VcDims& d, const VcBufs& b, c
   if (lane == 0) { b.HL[(size_t)half * b.n_tasks + task] = hl; b.HD[(size_t)half * b.n_tasks + task] = hd; }
 }
 
+// Scratch of the dense histogram evaluation ([16 slices][2][64] doubles per matrix in flight): DYNAMIC shared memory, asked for by
+// the launches that evaluate dense histograms and by no other -- as a static array it would sit in every kernel that merely
+// contains the code (K_omega: 3.6 -> 36 KB per 256-thread block, half the resident blocks; measured + 13 us on the sharded step)
+__device__ __forceinline__ double* vc_hist_lds() {
+  extern __shared__ double vc_dyn_hist_lds[];
+  return vc_dyn_hist_lds;
+}
+static inline unsigned vc_hist_dyn_lds(const VcDims& d, int with_hist, int nthr) {
+  return (with_hist && d.hist_dense) ? (nthr == 1024 ? 4096u : 2048u) * (unsigned)sizeof(double) : 0u;
+}
+
 // shape_inv of gene g as a histogram evaluation takes it from the parameters as they stand (the logic of vc_hist_wave)
 __device__ __forceinline__ float vc_hist_si(const VcDims& d, const VcBufs& b, const float* __restrict__ P, int cond_only, int g) {
   if (g >= d.Ng) return 1.f;

@@ -810,7 +810,12 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         int got = 0;
         if (dyn > 96u * 1024u || occupancy(dyn, &got) != VC_OK || got < 1) break;
         if (got == bpc) { d.pw_inline = row; d.pw_slots = probe.pw_slots; break; }
-        bpc = got;                      // the W rows cost a workgroup per CU: tile for what is left and look again
+        // The W rows would cost a resident workgroup per CU (the 4-genes-per-lane S+U kernel: its reduction tiles already take
+        // 52 KB of LDS, three workgroups just fit).  Measured at 2 000 genes (profiles/r04_small_shard.md): K_main 58.9 -> 70.8 us
+        // at 25 000 cells, 33.6 -> 40.1 at 12 500, 23.0 -> 24.6 at 6 250 -- more than the launch it saves, except where a wave
+        // has so few cells that the kernel is prologue and epilogue anyway: accepted only there.
+        if (d.cw > 12 && !(pwe && atoi(pwe) == 2)) break;      // (VC_PW_INLINE=2: accept the loss anyway -- tests, A/B)
+        bpc = got;                      // tile for the occupancy that is left and look again
         tile(bpc);
       }
       if (!d.pw_inline) tile(bpc0);     // off: the tiling of the plain kernel
@@ -958,8 +963,10 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         // Default: the S+U kernel's models only -- 4 000+ task waves there (two matrices) against 32 blocks; measured at 50k x 2k
         // (profiles/r04_two_launch.md) V-joint 21-24 -> 17.5-19 us outside K_main, phase (one matrix, nothing to hide the blocks
         // of its few outlier genes behind) 13.4 -> 15.5: the phase model keeps the lists.  VC_HIST_DENSE=1 / 0 forces either.
+        // Only where the one-launch tail runs (single rank with K_main's own nu_omega partials): through K_omega's / K_pre's
+        // 4-wave blocks the dense evaluation is slower than the lists (6 250-cell shard: sharded step 41.6 -> 44.2 us).
         dense_ok = nb && novf[0] == 0 && novf[1] == 0 && d.Nc <= (1 << 24) &&
-                   (hde ? atoi(hde) != 0 : d.kind == VC_KIND_VFULL);
+                   (hde ? atoi(hde) != 0 : (d.kind == VC_KIND_VFULL && fused_tail_kind(e) == 2));
         for (int m = 0; m < (vel ? 2 : 1); ++m) {
           HIPCHK(e, hipMemcpy(htab.data(), tab[m], htab.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
           if (dense_ok) vc_build_dense_hist(htab.data(), d.Ng, d.Ng_pad, hc, hc_off, hc_rows);

@@ -955,6 +955,7 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
 // The blocks of K_omega's grid that are off the nu_omega chain (256 threads; `xblk` = index behind the cell blocks): 0 = the loss
 // of the finished step, then nb_hist histogram blocks (4 tasks each), then the eps blocks.  rederive: the gene blocks of the
 // same launch are computing shape_inv(s) right now (vc_tail2_kernel)
+template <bool TAIL2>
 __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
                                                      const long long s, uint64_t seed, const VcAdamArgs& a,
                                                      double* __restrict__ loss_dev, long long loss_slots, int boot, int nb_hist,
@@ -972,11 +973,16 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
   if (xblk < nb_hist) {                            // histogram terms of shape_inv(s)
     const int half = d.hist_par ? (int)(s & 1) : 0;
     if (d.hist_dense) {                            // dense tables: one block per gene block (barriers inside)
-      __shared__ double sm_hd[4096];
-      if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense(d, b, s, a, xblk, sm_hd); return; }
+      double* sm_hd = vc_hist_lds();
+      if (TAIL2) {                                 // (compiled into the one-launch tail only: 16-wave blocks, update re-derived)
+        if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense(d, b, s, a, xblk, sm_hd); return; }
+        VcHistPre hp;
+        vc_hist_dense16_rows(d, b, xblk, hp);
+        vc_hist_dense16_issue(d, b, hp);
+        vc_hist_dense16_finish(d, b, xblk, vc_hist_si(d, b, P, 0, xblk * 64 + lane), half, hp, sm_hd);
+        return;
+      }
       const int g = xblk * 64 + lane;
-      VcHistPre hp;
-      if (nthr == 1024) { vc_hist_dense16_rows(d, b, xblk, hp); vc_hist_dense16_issue(d, b, hp); }
       float si = vc_hist_si(d, b, P, 0, g);
       if (phase == VC_PH_B && !CND(VC_SITE_SHAPE_INV) && g < d.Ng) {
         // the gene blocks of this launch are rewriting shape_inv: re-derive its update from phase A's snapshot and the summed
@@ -985,12 +991,11 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
         float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
         si = expf(vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip));
       }
-      if (nthr == 1024) vc_hist_dense16_finish(d, b, xblk, si, half, hp, sm_hd);
-      else vc_hist_dense_block(d, b, xblk, si, half, nthr >> 6, sm_hd);
+      vc_hist_dense_block(d, b, xblk, si, half, nthr >> 6, sm_hd);
       return;
     }
     const int task = xblk * (nthr >> 6) + wv;      // lists of distinct values: one wave per task
-    if (rederive && !CND(VC_SITE_SHAPE_INV)) {           // (block-wide: barriers inside; nthr == 1024)
+    if (TAIL2 && rederive && !CND(VC_SITE_SHAPE_INV)) {           // (block-wide: barriers inside; nthr == 1024)
       // two rounds of 16 tasks per block: half the blocks to place (every 1024-thread block of this launch holds a CU on its own)
 #pragma unroll 1
       for (int rnd = 0; rnd < VC_HIST_ROUNDS; ++rnd) {
@@ -1049,13 +1054,15 @@ __device__ __forceinline__ void vc_nuw_sums_issue(const VcDims& d, const VcBufs&
   const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : (pwm ? b.PWM : b.PW);
   const int n_pw = phase == VC_PH_B ? xb.pw_cap : (pwm ? d.n_main_wg : d.nb_tail_cell);
   const int pw_ld = pwm ? d.pw_inline : d.NW;
+  const bool on = !boot && n_pw <= 64 * VC_NUW_RAW;      // (uniform)
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int j = wv + nwv * q;
+    const int j = wv + nwv * q, jc = j < d.NW ? j : 0;
 #pragma unroll
-    for (int k = 0; k < VC_NUW_RAW; ++k) {
-      const int i = lane + 64 * k;
-      raw.r[q][k] = (!boot && j < d.NW && i < n_pw && n_pw <= 64 * VC_NUW_RAW) ? PWs[(size_t)i * pw_ld + j] : 0.f;
+    for (int k = 0; k < VC_NUW_RAW; ++k) {          // no branch around a load: a clamped row, the value dropped afterwards
+      const int i = lane + 64 * k, ic = i < n_pw ? i : 0;
+      const float x = on ? PWs[(size_t)ic * pw_ld + jc] : 0.f;
+      raw.r[q][k] = (j < d.NW && i < n_pw) ? x : 0.f;
     }
   }
 }
@@ -1084,6 +1091,39 @@ __device__ __forceinline__ void vc_nuw_sums_finish(const VcDims& d, const VcBufs
         if (j < nw)
           for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
       }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = wv + nwv * q;
+      if (j < nw) { const double r = vc_wave_sum_d63(u[q]); if (lane == 63) sh.up[j] = (float)r; }
+    }
+    for (int j = wv + 2 * nwv; j < nw; j += nwv) {
+      double r = 0.0;
+      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
+      r = vc_wave_sum_d63(r);
+      if (lane == 63) sh.up[j] = (float)r;
+    }
+  }
+}
+
+// the same sums in one piece (K_omega's own blocks, phase B: nothing to put between request and use, and no 24 registers held
+// for it -- phase B's kernel stays below 64 VGPRs, two blocks per CU)
+__device__ __forceinline__ void vc_nuw_sums_direct(const VcDims& d, const VcBufs& b, int boot, int phase, const VcXb& xb, int nthr,
+                                                   VcNuwShared& sh) {
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, nwv = nthr >> 6;
+  const bool pwm = phase != VC_PH_B && d.pw_inline;
+  const float* __restrict__ PWs = phase == VC_PH_B ? xb.x + xb.pw_off : (pwm ? b.PWM : b.PW);
+  const int n_pw = phase == VC_PH_B ? xb.pw_cap : (pwm ? d.n_main_wg : d.nb_tail_cell);
+  const int pw_ld = pwm ? d.pw_inline : d.NW;
+  const int nw = d.NW;
+  VC_WSTAMP(1, 1);
+  if (!boot) {
+    double u[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = wv + nwv * q;
+      if (j < nw)
+        for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1240,7 +1280,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
                                                int nb_hist, int oblk, int phase, const VcXb xb) {
   VC_WSTAMP(1, 0);
   if (oblk >= nb_cell) {
-    vc_omega_extra_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, boot, nb_hist, oblk - nb_cell, phase, xb, false);
+    vc_omega_extra_block<false>(d, b, P, G, s, seed, a, loss_dev, loss_slots, boot, nb_hist, oblk - nb_cell, phase, xb, false);
     return;
   }
   if (d.model != VC_MODEL_VELOCITY) return;
@@ -1252,9 +1292,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
     const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)c * d.ctw);
     s1 = ct[0].x; c1 = ct[1].x;
   }
-  VcNuwRaw nuw_raw;
-  vc_nuw_sums_issue(d, b, boot, phase, xb, 256, nuw_raw);
-  vc_nuw_sums_finish(d, b, boot, phase, xb, 256, nuw_raw, sh_nuw);
+  vc_nuw_sums_direct(d, b, boot, phase, xb, 256, sh_nuw);
   vc_nuw_chain(d, b, P, G, s, seed, a, boot, oblk == 0, phase, xb, c, s1, c1, 256, sh_nuw);
 }
 
@@ -1283,7 +1321,7 @@ __global__ __launch_bounds__(1024) void vc_phase_b_kernel(const VcDims d, const 
   const int oblk = blockIdx.x - d.nb_post_gene;
   if (d.hist_dense && oblk > nb_cell && oblk - nb_cell - 1 < nb_hist) {
     // dense histogram blocks: all 16 waves of the block share the count axis (a quarter of the chain of a 4-wave block)
-    vc_omega_extra_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, oblk - nb_cell, VC_PH_B, xb, false, 1024);
+    vc_omega_extra_block<false>(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, oblk - nb_cell, VC_PH_B, xb, false, 1024);
     return;
   }
   if (threadIdx.x >= 256) return;          // K_omega's blocks are 256 threads wide: the other waves leave before any barrier
@@ -1298,8 +1336,8 @@ void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* g
   const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
   const dim3 grid(d.nb_post_gene + nb_cell + 1 + nb_hist + nb_eps), block(1024);
   // (the gene blocks of phase B neither reduce nor stage rows: the smallest row bound keeps their registers free)
-  hipLaunchKernelGGL(vc_phase_b_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots,
-                     nb_cell, nb_hist, xb);
+  hipLaunchKernelGGL(vc_phase_b_kernel<2>, grid, block, vc_hist_dyn_lds(d, with_hist, 1024), st, d, b, params, grad, step_dev, seed, a,
+                     loss_dev, loss_slots, nb_cell, nb_hist, xb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1372,8 +1410,8 @@ __global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const Vc
     vc_tail_cell_block<VC_PH_ALL, true>(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, 0, VcXb{});
     return;
   }
-  vc_omega_extra_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, blockIdx.x - d.nb_post_gene - d.nb_tail_cell,
-                       VC_PH_ALL, VcXb{}, true, 1024);
+  vc_omega_extra_block<true>(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, blockIdx.x - d.nb_post_gene - d.nb_tail_cell,
+                             VC_PH_ALL, VcXb{}, true, 1024);
 }
 
 void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
@@ -1381,9 +1419,10 @@ void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* gra
   const int nb_hist = !with_hist ? 0 : (d.hist_dense ? d.Ng_pad / 64 : (b.n_tasks + 16 * VC_HIST_ROUNDS - 1) / (16 * VC_HIST_ROUNDS));
   const int nb_eps = (int)((d.eps_total / 2 + 1024 * VC_EPS_PER_THREAD - 1) / (1024 * VC_EPS_PER_THREAD));
   const dim3 grid(d.nb_post_gene + d.nb_tail_cell + 1 + nb_hist + nb_eps), block(1024);
-  if (d.nq <= 2) hipLaunchKernelGGL((vc_tail2_kernel<2>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
-  else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail2_kernel<6>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
-  else hipLaunchKernelGGL((vc_tail2_kernel<VC_MAXQ>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
+  const unsigned dyn = vc_hist_dyn_lds(d, with_hist, 1024);
+  if (d.nq <= 2) hipLaunchKernelGGL((vc_tail2_kernel<2>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
+  else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail2_kernel<6>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
+  else hipLaunchKernelGGL((vc_tail2_kernel<VC_MAXQ>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
 }
 
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
@@ -1391,6 +1430,6 @@ void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* gra
   const int nb_cell = d.model == VC_MODEL_VELOCITY ? (d.Nc + 255) / 256 : 0;
   const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
   const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
-  hipLaunchKernelGGL(vc_omega_kernel, dim3(nb_cell + 1 + nb_hist + nb_eps), dim3(256), 0, st, d, b, params, grad, step_dev,
-                     seed, a, loss_dev, loss_slots, boot, nb_cell, nb_hist);
+  hipLaunchKernelGGL(vc_omega_kernel, dim3(nb_cell + 1 + nb_hist + nb_eps), dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st, d, b,
+                     params, grad, step_dev, seed, a, loss_dev, loss_slots, boot, nb_cell, nb_hist);
 }

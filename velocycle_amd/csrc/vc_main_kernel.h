@@ -177,8 +177,10 @@ template <> struct VcCnt<4> { v4u a; };
 template <> struct VcCnt<8> { v4u a, b; };
 
 // VC_NT_LOADS: the counts are read exactly once per step -- the S+U kernel marks its loads non-temporal (streaming: no reuse).
-// Measured (50k x 2k, same box, profiles/r04_two_launch.md): the S+U kernel 115.6 -> 114.3 us (7 243 -> 7 332 steps/s), the
-// U-only kernel unchanged, the S-only (phase) kernel 55.3 -> 65.4 us -- so only the S+U kernel marks its loads (NT = FULL).
+// Measured (2 000 genes, same box, profiles/r04_two_launch.md): the 8-genes-per-lane S+U kernel at 50 000 cells 118.3 -> 117.2 us and the
+// whole step 137.2 -> 132.1 us (the small launch behind it finds more of what it reads still cached); the 4-genes-per-lane S+U
+// kernel (shards of 6 250 ... 25 000 cells) 21.9 / 34.3 / 59.3 -> 22.8 / 35.3 / 61.4 us; the U-only kernel unchanged; the S-only (phase)
+// kernel 55.3 -> 65.4 us -- so only the 8-genes-per-lane S+U kernel marks its loads.
 #ifndef VC_NT_LOADS
 #define VC_NT_LOADS 1
 #endif
@@ -306,8 +308,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       if (i < NBUF)
 #endif
       {
-        if (HAS_S) vc_issue<FULL>(s_q[j], lane_off, Sb + row);
-        if (HAS_U) vc_issue<FULL>(u_q[j], lane_off, Ub + row);
+        if (HAS_S) vc_issue<FULL && GPL == 8>(s_q[j], lane_off, Sb + row);
+        if (HAS_U) vc_issue<FULL && GPL == 8>(u_q[j], lane_off, Ub + row);
       }
     }
     rec_bf[j] = vc_load_cell<H, NB, OCS>(b.CT + (size_t)cn * d.ctw);

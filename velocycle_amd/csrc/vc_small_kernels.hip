@@ -139,8 +139,7 @@ void vc_launch_scatter_csr(const long long* indptr, const int* indices, const fl
 __global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBufs b,
                                                       const float* __restrict__ P, int cond_only) {
   if (d.hist_dense) {
-    __shared__ double sm_hd[2048];
-    vc_hist_dense_block(d, b, blockIdx.x, vc_hist_si(d, b, P, cond_only, blockIdx.x * 64 + (threadIdx.x & 63)), 0, 4, sm_hd);
+    vc_hist_dense_block(d, b, blockIdx.x, vc_hist_si(d, b, P, cond_only, blockIdx.x * 64 + (threadIdx.x & 63)), 0, 4, vc_hist_lds());
     return;
   }
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBu
 }
 
 void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int cond_only, hipStream_t st) {
-  hipLaunchKernelGGL(vc_hist_kernel, dim3(vc_hist_blocks(d, b, 4)), dim3(256), 0, st, d, b, params, cond_only);
+  hipLaunchKernelGGL(vc_hist_kernel, dim3(vc_hist_blocks(d, b, 4)), dim3(256), vc_hist_dyn_lds(d, 1, 256), st, d, b, params, cond_only);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -174,8 +173,7 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
     // ------------------------------- histogram part (NB) -------------------------------------------
     const int hb = blockIdx.x - d.nb_pre_gene - d.nb_pre_cell;
     if (d.hist_dense) {          // one block per gene block, the dense tail-count tables
-      __shared__ double sm_hd[2048];
-      vc_hist_dense_block(d, b, hb, vc_hist_si(d, b, P, cond_only, hb * 64 + (threadIdx.x & 63)), 0, 4, sm_hd);
+      vc_hist_dense_block(d, b, hb, vc_hist_si(d, b, P, cond_only, hb * 64 + (threadIdx.x & 63)), 0, 4, vc_hist_lds());
       return;
     }
     const int task = hb * 4 + (threadIdx.x >> 6);          // one wave per task of <= 64 distinct values
@@ -428,7 +426,7 @@ void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const 
                    hipStream_t st, int particles, int particle) {
   if (d.generic) { vc_launch_pre_generic(d, b, params, eps, seed, step, step_dev, cond_only, with_hist, st, particles, particle); return; }
   const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
-  hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), 0, st, d, b,
+  hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st, d, b,
                      params, eps, seed, step, step_dev, cond_only, particles, particle);
 }
 
@@ -442,7 +440,7 @@ __global__ __launch_bounds__(256) void vc_particle_acc_kernel(float* __restrict_
     const double l = (k == 0 ? 0.0 : lsum[0]) + ((double)g[0] + (double)g[1]);
     lsum[0] = l;
     if (k == K - 1) {
-      const double avg = l / (double)K;
+      const double avg = l * (1.0 / (double)K);          // (x * (1 / K): what the host loop's PyTorch division by a scalar computes)
       const float hi = (float)avg, lo = (float)(avg - (double)hi);
       g[0] = hi; g[1] = lo;
       if (loss_ring) loss_ring[loss_slots > 1 ? (step % loss_slots) : 0] = (double)hi + (double)lo;
@@ -451,7 +449,7 @@ __global__ __launch_bounds__(256) void vc_particle_acc_kernel(float* __restrict_
   for (long long i = 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float a = (k == 0 ? 0.f : acc[i]) + g[i];
     acc[i] = a;
-    if (k == K - 1) g[i] = a / (float)K;
+    if (k == K - 1) g[i] = a * (1.0f / (float)K);
   }
 }
 void vc_launch_particle_acc(float* acc, float* g, long long n, int K, int k, double* lsum, double* loss_ring, long long loss_slots,
