@@ -517,6 +517,8 @@ def main():
                                + ", NegativeBinomial noise, H=1, Hw=1"
                                + (f", {args.conditions} samples (Nx = Nb = {args.conditions}, per-batch offsets)" if args.conditions > 1 and args.mode != "phase" else ""),
                    "cells": args.cells, "genes": args.genes, "mode": args.mode, "conditions": args.conditions,
+                   "launches_per_step": eng.stats.get("launches_per_step"),
+                   "nu_omega_partials_from_main_kernel": bool(eng.stats.get("pw_inline")),
                    "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
                    "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + (("gloo (test hook) " if one_device else "RCCL ") + "all-reduce"
                                                                             + (f" [{run.exchange}]" if run.exchange else "") + " -> " if (dist_on or solo_group) else "")
@@ -572,6 +574,7 @@ def main():
             ts2 = time_steps(r2, args.steps, args.warmup, False, device, args.repeats)
             rf = kernel_roofline(e2, r2, args.roofline_launches, median(ts2) / args.steps)
             extra[m] = {"steps_per_s": round(args.steps / median(ts2), 2), "ms_per_step": round(1e3 * median(ts2) / args.steps, 4),
+                        "launches_per_step": e2.stats.get("launches_per_step"),
                         "kernel": rf["kernel"],
                         "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"],
                         "hbm_frac": rf["frac"], "step_frac": rf["step_frac"], "step_overhead_us": rf["step_overhead_us"], "hbm_pipe_frac": rf["hbm_pipe_frac"], "valu_frac": (rf["valu"] or {}).get("frac"),
