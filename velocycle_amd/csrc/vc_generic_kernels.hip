@@ -15,7 +15,7 @@
 //   vc_post_generic_kernel                thread = gene (each needed row of K_main's partials summed over the chunks) / thread = cell
 //   vc_fin_generic_kernel                 loss assembly + the nu_omega / LRMN tail gradients for any number of coefficients
 #pragma clang fp contract(off)
-#include "vc_main_kernel.h"      // v2f helpers, observation models (no instantiation of the fast kernel is made here)
+#include "vc_main_math.h"        // v2f helpers, observation models
 
 // ---------------------------------------------------------------------------------------------
 // K_main, generic
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void vc_main_generic_kernel(const VcDims d, con
   constexpr bool HLB = VC_HOIST_LB && FULL && !LN;
   constexpr int NCO = FULL ? 3 : 1;
   constexpr float CO_SCALE = L2 ? VC_LN2 : 1.f;
-  static_assert(VC_OMEGA_CS && VC_FOLD_LOGBETA && VC_RCP_MERGE && VC_NR_MERGE, "the generic kernel restates the default arithmetic");
+  static_assert(VC_OMEGA_CS && VC_NR_MERGE, "the generic kernel restates the default arithmetic of the fast one");
   extern __shared__ v2f lds_g[];                 // [2 K][64]: nu~ rows, then the gradient accumulators
   const int lane = threadIdx.x;
   const int H = d.H, NH = 2 * H + 1, NB = d.with_dnu ? d.Nb : 0, K = d.K;

@@ -161,7 +161,7 @@ class SVIRunner:
         import os
         if adam_impl is None and self.K > 1 and mode == "perf":
             adam_impl = "hip"
-        if adam_impl is None and mode == "perf" and engine.stats.get("generic"):
+        if adam_impl is None and mode == "perf" and (getattr(engine, "stats", None) or {}).get("generic"):
             # a configuration outside the compiled fast set (H > 3, > 4 batches, LRMN rank > 8, > 64 angular-speed
             # coefficients): the run-time-sized kernel set has the unfused sequence only (any number of ranks)
             adam_impl = "hip"
