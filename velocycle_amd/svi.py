@@ -492,14 +492,16 @@ class SVIRunner:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(e.device))
         t0 = time.monotonic()
-        nap = 1e-4
         while not ev.query():
-            if time.monotonic() - t0 > limit:
+            waited = time.monotonic() - t0
+            if waited > limit:
                 from .engine import HipEngineError
                 raise HipEngineError(f"rank {e.rank} of {self.world}: the sharded run did not finish within {limit:.0f} s "
                                      f"(VC_RUN_DEADLINE_S) -- a collective or a peer is stuck (exchange: {self.exchange})")
-            time.sleep(nap)
-            nap = min(nap * 2, 0.01)
+            # the return must not lag the device by more than ~0.1 % of the run (callers time run_perf(sync=True)): spin for the
+            # first quarter second, then naps of a thousandth of what has been waited so far (at most 2 ms)
+            if waited > 0.25:
+                time.sleep(min(waited * 1e-3, 2e-3))
 
     _SENTINEL = -0x0007_2174_5EED_0001          # an int64 bit pattern no loss takes (a NaN with this payload)
 
