@@ -263,13 +263,16 @@ int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_d
  * Replaces, for `fit(loss=Trace_ELBO(num_particles=K))` (velocity_inference_model.py:79,111, phase_inference_model.py:128,162:
  * the user's ELBO object goes into SVI; K guide draws per step, loss and gradients averaged before the optimiser step), the
  * host loop  K x vc_elbo_grad + average + vc_clipped_adam:  n_steps steps are enqueued from this one call, per step
- *   for k < K:  K_pre (Philox stream (seed, t K + k), t read from step_dev) -> K_main -> K_post -> K_fin -> the gradient of
- *               particle k joins the running sum in grad_acc (DEVICE float[total], caller-owned scratch)
- *   the last particle leaves the average in `grad` (header: the averaged loss, hi / lo) and in loss_dev[t % loss_slots];
- *   ClippedAdam (step_dev = t + 1).
- * The same kernels, streams and arithmetic as the host loop -- the same numbers.  step0 = the value step_dev holds when the
- * call is made (the host's mirror: used for the non-finite-loss latch).  Cells sharded: VC_ERR_STATE (the average has to
- * cross the all-reduce before the optimiser; the host loop does that). */
+ *   particle k < K:  K_pre (Philox stream (seed, t K + k), t read from step_dev) -> K_main -> K_post -> K_fin, with its own
+ *               per-step workspaces and gradient buffer and, for k >= 1, on a HIP stream of the engine's (created at the first
+ *               call; the parameters do not change between particles, so every K_pre starts at once, the likelihood kernels
+ *               follow one another, K_post / K_fin of particle k run beside K_main of particle k + 1);
+ *   hip_stream joins them: the K gradients and losses are added in particle order and multiplied by 1 / K -- left in `grad`
+ *   (header: the averaged loss, hi / lo) and in loss_dev[t % loss_slots]; step_dev := t + 1; ClippedAdam.
+ * The same kernels and arithmetic as the host loop -- the same numbers.  step0 = the value step_dev holds when the call is made
+ * (the host's mirror: used for the non-finite-loss latch).  grad_acc: DEVICE float[total], caller-owned (kept in the signature;
+ * not written since the particles have buffers of their own).  At most 16 particles (VC_ERR_UNSUPPORTED beyond).  Cells sharded:
+ * VC_ERR_STATE (the average has to cross the all-reduce before the optimiser; the host loop does that). */
 int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, int64_t* step_dev, int64_t step0, float* grad,
                          float* grad_acc, double* loss_dev, int64_t loss_slots, float* exp_avg, float* exp_avg_sq, double lr,
                          double lrd, double beta1, double beta2, double adam_eps, double clip_norm, int num_particles,

@@ -117,3 +117,19 @@ def test_four_process_p2p_exchange():
     assert got["distributed"]["exchange"] == "p2p" and got["distributed"]["world_size"] == 4 and got["nonfinite_loss_steps"] == 0
     for (a, b), tol in zip(zip(ref["loss_first_last"], got["loss_first_last"]), (2e-6, 2e-4)):      # first step | 34 steps on
         assert abs(a - b) <= tol * abs(a), (ref["loss_first_last"], got["loss_first_last"])
+
+
+def test_p2p_exchange_survives_a_peer_that_stops():
+    """A rank that stops publishing must not hang its peers' device: the exchange kernel's wait is bounded (VC_P2P_TIMEOUT_S),
+    the step is poisoned (NaN loss -- never a partial sum) and vc_get_status reports VC_ERR_STATE (tests/p2p_dead_peer_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_P2P_TIMEOUT_S="1", VC_TEST_PEER_SLEEP_S="8")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "tests/p2p_dead_peer_worker.py"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("DEAD_PEER ")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    got = eval(lines[0][len("DEAD_PEER "):])
+    assert got["nan"] == [True, True], got                 # both lonely steps poisoned
+    assert 1.5 <= got["waited_s"] < 7.0, got               # two bounded waits of 1 s, not the peer's 8 s
+    assert "peer-to-peer exchange" in got["status"] and "did not publish" in got["status"], got

@@ -23,7 +23,7 @@ def test_profile_tool_compiles(src, tmp_path):
 @pytest.mark.parametrize("flag", ["-DVC_STREAM_ONLY", "-DVC_DBG_TIMES", "-DVC_PF=1", "-DVC_PF_SINGLE=2", "-DVC_EPI_ROWS=1", "-DVC_RCP_MERGE=0",
                                   "-DVC_LDS_REDUCE=0", "-DVC_LB_SINGLE=3", "-DVC_NO_LOADS", "-DVC_ISSUE_PIN=0", "-DVC_NT_LOADS=0 -DVC_RCP_MERGE=1",
                                   "-DVC_WT_STORES=1 -DVC_RCP_MERGE=1", "-DVC_FOLD_LOGBETA=0", "-DVC_PW_INLINE=0 -DVC_RCP_MERGE=1",
-                                  "-DVC_FOLD_LOG2E=0 -DVC_OMEGA_CS=0 -DVC_HOIST_LB=0 -DVC_NR_MERGE=0 -DVC_REC_TOUCH=0 -DVC_TILE_TABLE=0 -DVC_RCP_MERGE=1"])
+                                  "-DVC_FOLD_LOG2E=0 -DVC_OMEGA_CS=0 -DVC_HOIST_LB=0 -DVC_NR_MERGE=0 -DVC_REC_TOUCH=0 -DVC_RCP_MERGE=1"])
 def test_measurement_aid_builds(flag, tmp_path):
     """One translation unit of the likelihood kernel per macro (the full library takes too long for the CPU suite)."""
     src = os.path.join(ROOT, "velocycle_amd", "csrc", "vc_main_vfull_poisson_u16.hip" if "REDUCE" in flag or "RCP" in flag

@@ -30,9 +30,6 @@
                             // 4 floats (pw_inline = 4) or 8 (pw_inline = 8: e.g. two samples x three harmonics of omega)
 // (the staged W rows live in DYNAMIC shared memory: d.pw_slots float4 per wave, + 32 float4 of accumulators per wave for the
 // S+U kernel; vc_main_dyn_lds() is what the launch asks for -- 0 bytes when pw_inline is off)
-#ifndef VC_TILE_TABLE
-#define VC_TILE_TABLE 1     // likelihood kernel: a wave's cell range from the table vc_finalize wrote (one scalar load) instead of
-#endif                      // evaluating the tiling function itself
 #ifndef VC_REC_PAD
 #define VC_REC_PAD 2        // cell records are padded to a multiple of this many {x, x} pairs (2 = 16 bytes: the S+U kernel's record
                             // of 6 pairs at H = 1 then strides 48 bytes, not 64; measured 113.8 vs 114.1-116.7 us, profiles/r03_kmain.md)
@@ -572,8 +569,10 @@ vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gp
 vc_main_launch_fn vc_find_generic_main_kernel(int kind, int noise, const void** kernel);
 void vc_launch_pre_generic(const VcDims& d, const VcBufs& b, const float* params, const float* eps, uint64_t seed, long long step,
                            const long long* step_dev, int cond_only, int with_hist, hipStream_t st, int particles, int particle);
-void vc_launch_particle_acc(float* acc, float* g, long long n, int K, int k, double* lsum, double* loss_ring, long long loss_slots,
-                            long long step, hipStream_t st);
+#define VC_MAX_PARTICLES 16
+struct VcParticleGrads { float* g[VC_MAX_PARTICLES]; int K; };      // gradient buffers of the particles of one step (g[0]: the caller's)
+void vc_launch_particle_avg(const VcParticleGrads& pg, long long n, double* loss_ring, long long loss_slots, long long step,
+                            long long* step_dev, hipStream_t st);
 void vc_launch_post_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev, hipStream_t st);
 void vc_launch_fin_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev, long long loss_slots,
                            long long step, const long long* step_dev, hipStream_t st);

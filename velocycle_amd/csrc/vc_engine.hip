@@ -52,7 +52,13 @@ static VcRccl g_rccl;
 struct vc_engine {
   vc_config cfg{};
   VcNcclComm comm = nullptr;          // the engine's own communicator (vc_comm_init_rccl), or null
-  double* particle_lsum = nullptr;    // vc_svi_run_particles: [0] running sum of the particles' losses, [1] scratch slot of K_fin
+  double* particle_lsum = nullptr;    // vc_svi_run_particles: scratch slots of the particles' K_fin launches
+  // vc_svi_run_particles: particle k >= 1 has its own per-step workspaces, gradient buffer and stream (particle 0: e->b, the
+  // caller's gradient buffer and stream), so that the small launches of one particle run beside the likelihood kernel of another
+  struct Particle { VcBufs b; float* grad = nullptr; hipStream_t st = nullptr; hipEvent_t main_done = nullptr, done = nullptr; };
+  std::vector<Particle> particles;
+  hipEvent_t ev_params = nullptr, ev_main0 = nullptr;
+  std::vector<size_t> alloc_bytes;    // parallel to `allocs`
   float* sis = nullptr;               // phase A's snapshot of shape_inv {parameter, exp_avg, exp_avg_sq} [3][Ng_pad]
   int xb_pw_off = 0, xb_pw_cap = 0, xb_loss_off = 0;
   long long xb_total = 0;
@@ -135,7 +141,24 @@ struct vc_engine {
   }
   void dfree(const void* p) {           // release one tracked allocation before vc_destroy
     for (size_t i = 0; i < allocs.size(); ++i)
-      if (allocs[i] == p) { (void)hipFree(allocs[i]); allocs.erase(allocs.begin() + i); return; }
+      if (allocs[i] == p) { (void)hipFree(allocs[i]); allocs.erase(allocs.begin() + i); alloc_bytes.erase(alloc_bytes.begin() + i); return; }
+  }
+  size_t bytes_of(const void* p) const {
+    for (size_t i = 0; i < allocs.size(); ++i) if (allocs[i] == p) return alloc_bytes[i];
+    return 0;
+  }
+  // a second buffer of the same size and content (particle workspaces); *pp may be null (a buffer this model does not have)
+  template <class T>
+  int dclone(T** pp) {
+    if (!*pp) return VC_OK;
+    const size_t nbytes = bytes_of(*pp);
+    if (!nbytes) return fail(VC_ERR_STATE, "dclone: not an engine allocation");
+    char* q = nullptr;
+    int rc = dalloc(&q, nbytes);
+    if (rc != VC_OK) return rc;
+    if (hipMemcpy(q, *pp, nbytes, hipMemcpyDeviceToDevice) != hipSuccess) return fail(VC_ERR_HIP, "dclone: copy failed");
+    *pp = (T*)q;
+    return VC_OK;
   }
   template <class T>
   int dalloc(T** out, size_t n) {
@@ -144,6 +167,7 @@ struct vc_engine {
     hipError_t e = hipMalloc(&p, n * sizeof(T));
     if (e != hipSuccess) return fail(VC_ERR_HIP, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
     allocs.push_back(p);
+    alloc_bytes.push_back(n * sizeof(T));
     *out = (T*)p;
     return VC_OK;
   }
@@ -340,6 +364,13 @@ extern "C" void vc_destroy(vc_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   for (auto& c : e->src) c.release();
   for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& pt : e->particles) {
+    if (pt.st) (void)hipStreamDestroy(pt.st);
+    if (pt.main_done) (void)hipEventDestroy(pt.main_done);
+    if (pt.done) (void)hipEventDestroy(pt.done);
+  }
+  if (e->ev_params) (void)hipEventDestroy(e->ev_params);
+  if (e->ev_main0) (void)hipEventDestroy(e->ev_main0);
   delete e;
 }
 
@@ -1249,30 +1280,71 @@ extern "C" int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, 
   if (!params || !grad || !grad_acc || !exp_avg || !exp_avg_sq || !step_dev) return e->fail(VC_ERR_ARG, "vc_svi_run_particles: null buffer");
   if (num_particles < 1 || n_steps < 0) return e->fail(VC_ERR_ARG, "vc_svi_run_particles: num_particles >= 1, n_steps >= 0");
   hipStream_t st = (hipStream_t)hip_stream;
-  if (!e->particle_lsum) {
-    TRY(e->dalloc(&e->particle_lsum, 2));
-    HIPCHK(e, hipMemsetAsync(e->particle_lsum, 0, 2 * sizeof(double), st));
-  }
   const int K = num_particles;
+  if (K > VC_MAX_PARTICLES) return e->fail(VC_ERR_UNSUPPORTED, "vc_svi_run_particles: at most %d particles", VC_MAX_PARTICLES);
   const long long total = e->layout.total, header = e->layout.header;
+  if (!e->particle_lsum) TRY(e->dalloc(&e->particle_lsum, VC_MAX_PARTICLES));
+  // workspaces, gradient buffer, stream and events of the particles beyond the first (created once, at the first call that
+  // needs them; the copies start from the first particle's content: what vc_finalize left there for good is in them too)
+  while ((int)e->particles.size() < K - 1) {
+    vc_engine::Particle pt;
+    pt.b = e->b;
+    VcBufs& b = pt.b;
+    for (int sidx = 0; sidx < VC_SITE_COUNT; ++sidx) TRY(e->dclone(&b.lat[sidx]));
+    TRY(e->dclone(&b.eps_used)); TRY(e->dclone(&b.GT)); TRY(e->dclone(&b.CT));
+    TRY(e->dclone(&b.lat_delta)); TRY(e->dclone(&b.lat_sgam)); TRY(e->dclone(&b.lat_phi)); TRY(e->dclone(&b.lat_omega));
+    TRY(e->dclone(&b.lat_domega)); TRY(e->dclone(&b.GO)); TRY(e->dclone(&b.CO)); TRY(e->dclone(&b.LO)); TRY(e->dclone(&b.LP));
+    TRY(e->dclone(&b.PW)); TRY(e->dclone(&b.PWM)); TRY(e->dclone(&b.WT)); TRY(e->dclone(&b.HL)); TRY(e->dclone(&b.HD));
+    TRY(e->dalloc(&pt.grad, (size_t)total));
+    HIPCHK(e, hipMemset(pt.grad, 0, sizeof(float) * (size_t)total));
+    HIPCHK(e, hipStreamCreateWithFlags(&pt.st, hipStreamNonBlocking));
+    HIPCHK(e, hipEventCreateWithFlags(&pt.main_done, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&pt.done, hipEventDisableTiming));
+    e->particles.push_back(pt);
+  }
+  if (!e->ev_params) {
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_params, hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_main0, hipEventDisableTiming));
+  }
+  HIPCHK(e, hipDeviceSynchronize());          // (the clones above were copied on the null stream; once per engine)
+  VcParticleGrads pg;
+  pg.K = K;
+  for (int k = 0; k < VC_MAX_PARTICLES; ++k) pg.g[k] = k == 0 ? grad : (k < K ? e->particles[k - 1].grad : nullptr);
+  const bool serial = getenv("VC_PARTICLES_ONE_STREAM") && atoi(getenv("VC_PARTICLES_ONE_STREAM")) == 1;     // A/B: everything on the caller's stream
   for (int64_t i = 0; i < n_steps; ++i) {
+    // Particle k runs the unfused sequence K_pre -> K_main -> K_post -> K_fin on the Philox stream (seed, t K + k), t read from
+    // the device counter, on its own HIP stream and workspaces.  The parameters are the same for all of them (the optimiser
+    // runs once, behind the average), so K_pre of every particle starts at once; the likelihood kernels are chained one behind
+    // the other (each fills the chip; side by side they would only share it), and K_post / K_fin of particle k run beside
+    // K_main of particle k + 1.
+    if (K > 1 && !serial) {
+      HIPCHK(e, hipEventRecord(e->ev_params, st));
+      for (int k = 1; k < K; ++k) HIPCHK(e, hipStreamWaitEvent(e->particles[k - 1].st, e->ev_params, 0));
+    }
     for (int k = 0; k < K; ++k) {
-      // the unfused sequence of particle k on the Philox stream (seed, t K + k), t read from the device counter
-      vc_launch_pre(e->d, e->b, params, nullptr, seed, 0, (const long long*)step_dev, 0, e->hist_each_step ? 1 : 0, st, K, k);
+      const VcBufs& b = k == 0 ? e->b : e->particles[k - 1].b;
+      hipStream_t sk = (k == 0 || serial) ? st : e->particles[k - 1].st;
+      vc_launch_pre(e->d, b, params, nullptr, seed, 0, (const long long*)step_dev, 0, e->hist_each_step ? 1 : 0, sk, K, k);
+      if (k > 0 && !serial) HIPCHK(e, hipStreamWaitEvent(sk, k == 1 ? e->ev_main0 : e->particles[k - 2].main_done, 0));
       if (e->timing) {
         if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
         auto& pr = e->ev_pool[e->ev_used++];
-        HIPCHK(e, hipEventRecord(pr.first, st));
-        e->main_fn(e->d, e->b, st);
-        HIPCHK(e, hipEventRecord(pr.second, st));
+        HIPCHK(e, hipEventRecord(pr.first, sk));
+        e->main_fn(e->d, b, sk);
+        HIPCHK(e, hipEventRecord(pr.second, sk));
       } else {
-        e->main_fn(e->d, e->b, st);
+        e->main_fn(e->d, b, sk);
       }
-      // (the step counter advances once per step: with the last particle)
-      vc_launch_post(e->d, e->b, params, grad, k == K - 1 ? (long long*)step_dev : nullptr, st);
-      vc_launch_fin(e->d, e->b, params, grad, e->particle_lsum + 1, 1, (long long)(step0 + i), nullptr, st);
-      vc_launch_particle_acc(grad_acc, grad, total, K, k, e->particle_lsum, loss_dev, (long long)loss_slots, (long long)(step0 + i), st);
+      if (k + 1 < K && !serial) HIPCHK(e, hipEventRecord(k == 0 ? e->ev_main0 : e->particles[k - 1].main_done, sk));
+      // (the step counter advances once per step, behind the average: no K_post touches it)
+      vc_launch_post(e->d, b, params, pg.g[k], nullptr, sk);
+      vc_launch_fin(e->d, b, params, pg.g[k], e->particle_lsum + k, 1, (long long)(step0 + i), nullptr, sk);
+      if (k > 0 && !serial) HIPCHK(e, hipEventRecord(e->particles[k - 1].done, sk));
     }
+    if (!serial) for (int k = 1; k < K; ++k) HIPCHK(e, hipStreamWaitEvent(st, e->particles[k - 1].done, 0));
+    // average of the K gradients and losses in particle order (what a host loop's g_0 + g_1 + ... and its division by K give),
+    // left in the first particle's buffer; advances the step counter
+    vc_launch_particle_avg(pg, total, loss_dev, (long long)loss_slots, (long long)(step0 + i), (long long*)step_dev, st);
     vc_launch_adam(params + header, grad + header, exp_avg, exp_avg_sq, total - header, lr, lrd, beta1, beta2, (float)adam_eps,
                    (float)clip_norm, 0, (const long long*)step_dev, nullptr, nullptr, 0, st);
   }

@@ -16,14 +16,10 @@
 //     lane per cell and flushed as a coalesced 256-B store every 64 cells;
 //   * gene-level partials of the 4 waves are combined through LDS (up to 6 output rows per barrier pair) and
 //     written once per workgroup; the second (deterministic) reduction stage is K_post.  No float atomics.
-//
-// Bound: HBM by design (algorithmic bytes: 4*Ng*Nc per matrix read; S and U for VFULL, one matrix otherwise); measured,
-// the S+U kernel sits within 10 % of both that memory-side bound and its own arithmetic bound, the one-matrix kernels
-// at 95 % of their arithmetic (profiles/r01_d_kmain_bound.md).
+// Bound: DESIGN.md section 5 (algorithmic bytes 4*Ng*Nc per matrix; measured: VALU issue binds first on uint16 counts).
 #pragma once
 #include <type_traits>
 #include "vc_common.h"
-#include "vc_host_logic.h"   // vc_wave_first_cell: the cell tiling, shared with the host (and its CPU sanitizer test)
 #include "vc_main_math.h"
 
 // build-time knobs (the defaults are the measured best).  Variants that were measured and rejected in
@@ -85,14 +81,11 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   constexpr bool L2 = VC_FOLD_LOG2E && !LN;          // eta, dd, e2 in log2 units (coefficients scaled once per gene)
   constexpr bool OCS = VC_OMEGA_CS && FULL;          // k omega cos / sin from the record
   constexpr bool HLB = VC_HOIST_LB && FULL && !LN;   // -log beta sum_c k_U added once per gene (epilogue)
-  // U-only kernel on one rank (pw_inline): per-workgroup partials of d loglik / d nu_omega[j] = sum_c A3_c W_cj, formed where
-  // the per-cell sums are stored (lane = cell, 64 cells per flush).  The W rows of the wave's cells are copied into the LDS
-  // before the loop: a compiler-visible VECTOR load inside the loop body would bring hipcc's conservative vmcnt waits back
-  // into every trip; an LDS read in the (rare) flush branch costs a lgkmcnt wait there and nothing elsewhere.
-  // Since round 4 the S+U kernel does the same at its LDS-tile flush (lane = (row, cell) of a 16-cell tile: the lanes of row
-  // A3 multiply), with the accumulators in the LDS as well -- it has no registers to spare.  With those partials at hand the
-  // nu_omega chain no longer depends on the cell blocks of the launch that follows, which is what lets the whole rest of
-  // the step go out as ONE launch (vc_fused_kernels.hip: vc_tail2_kernel).
+  // pw_inline (one rank): per-workgroup partials of d loglik / d nu_omega[j] = sum_c A3_c W_cj, formed where the per-cell sums
+  // are stored.  U-only kernel: lane = cell, 64 cells per flush; S+U kernel (round 4): at its LDS-tile flush, lane = (row, cell)
+  // of a 16-cell tile, accumulators in the LDS (no registers to spare).  The W rows of the wave's cells are copied into the
+  // LDS before the loop: a compiler-visible VECTOR load in the loop body would bring hipcc's conservative vmcnt waits back.
+  // With these partials the nu_omega chain needs nothing from the next launch's cell blocks (vc_fused_kernels.hip: vc_tail2_kernel).
   constexpr bool PWI = VC_PW_INLINE && (KIND == VC_KIND_VU || KIND == VC_KIND_VFULL);
   const bool pw_on = PWI && d.pw_inline != 0;
   float pwacc[VC_PWQ];
@@ -107,8 +100,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 #define VC_STAMP(k) do {} while (0)
 #endif
   const int lane = threadIdx.x & 63;
-  // wave index as an SGPR value, so that everything derived from it (cell range, cell-record
-  // addresses) is provably wave-uniform and the records are fetched with scalar loads
+  // wave index as an SGPR value: the cell range and the record addresses derived from it are provably wave-uniform (scalar loads)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gb = blockIdx.x % d.nGB;
   const int chunk = blockIdx.x / d.nGB;
@@ -122,13 +114,11 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // (pass_cw[p] cells per wave in pass p), so that the waves of a SIMD end together (vc_host_logic.h: vc_tile_cells).
   int my_cw;
   long long cbeg;
-  if (VC_TILE_TABLE) {
-    typedef const __attribute__((address_space(4))) int* ciptr;       // constant address space: a scalar load
+  {   // from the table vc_finalize wrote with vc_host_logic.h's vc_wave_first_cell: one scalar load (constant address space)
+    typedef const __attribute__((address_space(4))) int* ciptr;
     ciptr tl = (ciptr)(const void*)(b.wg_tile + 2 * (size_t)blockIdx.x);
     my_cw = tl[1];
     cbeg = (long long)tl[0] + (long long)wave * my_cw;
-  } else {
-    cbeg = vc_wave_first_cell(chunk, gb, wave, d.nGB, d.pass_wgs, d.pass_cw, VC_WAVES, &my_cw);
   }
   long long cend = cbeg + my_cw;
   if (cbeg > d.Nc) cbeg = d.Nc;

@@ -430,33 +430,34 @@ void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const 
                      params, eps, seed, step, step_dev, cond_only, particles, particle);
 }
 
-// K-particle step (vc_svi_run_particles): the gradient of one particle joins the running sum; the last one leaves the average
-// in `g` (sum / K, as the reference's Trace_ELBO averages loss and gradients over its particles: velocity_inference_model.py:79,111)
-// together with the averaged loss (header hi / lo, loss ring slot)
-__global__ __launch_bounds__(256) void vc_particle_acc_kernel(float* __restrict__ acc, float* __restrict__ g, long long n, int K,
-                                                             int k, double* __restrict__ lsum, double* __restrict__ loss_ring,
-                                                             long long loss_slots, long long step) {
+// K-particle step (vc_svi_run_particles): the average of the particles' gradients and losses, added up in particle order and
+// multiplied by 1 / K (as the reference's Trace_ELBO averages loss and gradients over its particles:
+// velocity_inference_model.py:79,111; x * (1 / K) is what a PyTorch division by a scalar computes), left in particle 0's buffer
+// (header hi / lo = the averaged loss, also filed in the loss ring); advances the device step counter.
+__global__ __launch_bounds__(256) void vc_particle_avg_kernel(const VcParticleGrads pg, long long n, double* __restrict__ loss_ring,
+                                                             long long loss_slots, long long step, long long* __restrict__ step_dev) {
+  const int K = pg.K;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const double l = (k == 0 ? 0.0 : lsum[0]) + ((double)g[0] + (double)g[1]);
-    lsum[0] = l;
-    if (k == K - 1) {
-      const double avg = l * (1.0 / (double)K);          // (x * (1 / K): what the host loop's PyTorch division by a scalar computes)
-      const float hi = (float)avg, lo = (float)(avg - (double)hi);
-      g[0] = hi; g[1] = lo;
-      if (loss_ring) loss_ring[loss_slots > 1 ? (step % loss_slots) : 0] = (double)hi + (double)lo;
-    }
+    double l = 0.0;
+    for (int k = 0; k < K; ++k) l += (double)pg.g[k][0] + (double)pg.g[k][1];
+    const double avg = l * (1.0 / (double)K);
+    const float hi = (float)avg, lo = (float)(avg - (double)hi);
+    pg.g[0][0] = hi; pg.g[0][1] = lo;
+    if (loss_ring) loss_ring[loss_slots > 1 ? (step % loss_slots) : 0] = (double)hi + (double)lo;
+    if (step_dev) step_dev[0] += 1;
   }
+  const float inv = 1.0f / (float)K;
   for (long long i = 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float a = (k == 0 ? 0.f : acc[i]) + g[i];
-    acc[i] = a;
-    if (k == K - 1) g[i] = a * (1.0f / (float)K);
+    float a = 0.f + pg.g[0][i];
+    for (int k = 1; k < K; ++k) a += pg.g[k][i];
+    pg.g[0][i] = a * inv;
   }
 }
-void vc_launch_particle_acc(float* acc, float* g, long long n, int K, int k, double* lsum, double* loss_ring, long long loss_slots,
-                            long long step, hipStream_t st) {
+void vc_launch_particle_avg(const VcParticleGrads& pg, long long n, double* loss_ring, long long loss_slots, long long step,
+                            long long* step_dev, hipStream_t st) {
   long long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(vc_particle_acc_kernel, dim3((unsigned)nb), dim3(256), 0, st, acc, g, n, K, k, lsum, loss_ring, loss_slots, step);
+  hipLaunchKernelGGL(vc_particle_avg_kernel, dim3((unsigned)nb), dim3(256), 0, st, pg, n, loss_ring, loss_slots, step, step_dev);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -354,17 +354,21 @@ class SVIRunner:
             if (self.exchange == "engine" and (self.world > 1 or (self.do_reduce and os.environ.get("VC_EXCHANGE_CHECK") == "1"))
                     and not getattr(self, "_exchange_checked", False) and n_steps > 0):
                 # The first step of the engine-owned exchange is cut open once: phase A -> the buffer summed by the engine's
-                # communicator AND, on a copy, by torch.distributed -> compared (the loss pieces are exact sums on fixed
-                # grids: equal bit for bit; gradient partials: the order of the ranks' adds may differ) -> phase B.  If any
+                # communicator AND, on a copy, by torch.distributed -> compared -> phase B.  If any
                 # rank sees a difference every rank falls back to the torch exchange (MIN all-reduce of the verdict).
                 import torch.distributed as dist
                 self._exchange_checked = True
                 e.svi_run_sharded(self.xbuf, o.m, o.v, o.lr0, o.lrd, o.b1, o.b2, o.eps, o.clip, prime=prime,
                                   phase=_lib.VC_PHASE_A, **kw)
                 ref = self.xbuf.clone()
+                mag = self.xbuf.abs()
                 dist.all_reduce(ref, group=self.pg)
+                dist.all_reduce(mag, group=self.pg)
                 e.comm_allreduce(self.xbuf)
-                same = torch.allclose(self.xbuf, ref, rtol=1e-5, atol=1e-6, equal_nan=True)
+                # tolerance relative to the sum of the ranks' MAGNITUDES: two correct all-reduces may add the ranks in different
+                # orders, and a gradient whose terms cancel differs by ~1e-7 of those terms, not of the result
+                diff = (self.xbuf - ref).abs()
+                same = bool(((diff <= 1e-5 * mag + 1e-30) | (torch.isnan(self.xbuf) & torch.isnan(ref))).all().item())
                 flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=e.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
                 self.exchange_check = "ok" if int(flag.item()) else "mismatch"
