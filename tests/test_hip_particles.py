@@ -73,8 +73,11 @@ def test_particles_from_one_c_call_equal_the_host_loop(case, monkeypatch):
     z = H.load_fixture(f"{H.GOLDEN}/ref_fitK3_{case}.npz")
     spec = H.spec_from_fixture(z)
     out = []
-    for host in ("0", "1"):
+    # the C call in its three launch layouts (csrc/vc_engine.hip: all particles' K_pre / K_post as one launch each and K_fin +
+    # average + ClippedAdam as one = the default; per particle on one stream; per particle on streams of their own), then the host loop
+    for host, layout in (("0", "batched"), ("0", "serial"), ("0", "streams"), ("1", "batched")):
         monkeypatch.setenv("VC_PARTICLES_HOST_LOOP", host)
+        monkeypatch.setenv("VC_PARTICLES_LAYOUT", layout)
         eng = HipEngine(spec)
         run = SVIRunner(eng, _opt(z), mode="perf", seed=5, num_particles=3)
         run.run_perf(4)
@@ -83,9 +86,10 @@ def test_particles_from_one_c_call_equal_the_host_loop(case, monkeypatch):
                     int(run.step_dev.item()), run.opt.t, eng.status()))
         eng.close()
     nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
-    a, b = out
-    assert torch.equal(nz(a[0]), nz(b[0])) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    assert a[3] == b[3] and len(a[3]) == 9 and a[4] == b[4] == 9 and a[5] == b[5] == 9 and a[6] == b[6] == (True, -1, 0)
+    b = out[-1]
+    for a in out[:-1]:
+        assert torch.equal(nz(a[0]), nz(b[0])) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert a[3] == b[3] and len(a[3]) == 9 and a[4] == b[4] == 9 and a[5] == b[5] == 9 and a[6] == b[6] == (True, -1, 0)
 
 
 def test_fit_reads_num_particles_from_the_loss_object():

@@ -573,6 +573,14 @@ void vc_launch_pre_generic(const VcDims& d, const VcBufs& b, const float* params
 struct VcParticleGrads { float* g[VC_MAX_PARTICLES]; int K; };      // gradient buffers of the particles of one step (g[0]: the caller's)
 void vc_launch_particle_avg(const VcParticleGrads& pg, long long n, double* loss_ring, long long loss_slots, long long step,
                             long long* step_dev, hipStream_t st);
+void vc_launch_pre_particles(const VcDims& d, const VcBufs& b, const VcBufs* bs_dev, const float* params, uint64_t seed,
+                             const long long* step_dev, int with_hist, int K, hipStream_t st);
+void vc_launch_post_particles(const VcDims& d, const VcBufs& b, const VcBufs* bs_dev, const VcParticleGrads& pg, const float* params,
+                              hipStream_t st);
+void vc_launch_particle_fin_adam(const VcDims& d, const VcBufs* bs_dev, const VcParticleGrads& pg, float* params, double* loss_dev,
+                                 long long loss_slots, long long step, long long* step_dev, double* scratch, float* m, float* v,
+                                 double lr0, double lrd, double b1, double b2, float eps, float clip, int header, long long total,
+                                 hipStream_t st);
 void vc_launch_post_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev, hipStream_t st);
 void vc_launch_fin_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev, long long loss_slots,
                            long long step, const long long* step_dev, hipStream_t st);

@@ -58,6 +58,8 @@ struct vc_engine {
   struct Particle { VcBufs b; float* grad = nullptr; hipStream_t st = nullptr; hipEvent_t main_done = nullptr, done = nullptr; };
   std::vector<Particle> particles;
   hipEvent_t ev_params = nullptr, ev_main0 = nullptr;
+  VcBufs* particle_bufs_dev = nullptr;   // [VC_MAX_PARTICLES] the particles' VcBufs on the device (entry 0 = b): the one-launch K_pre / K_post
+  int particle_bufs_n = 0;               // entries of it that are filled
   std::vector<size_t> alloc_bytes;    // parallel to `allocs`
   float* sis = nullptr;               // phase A's snapshot of shape_inv {parameter, exp_avg, exp_avg_sq} [3][Ng_pad]
   int xb_pw_off = 0, xb_pw_cap = 0, xb_loss_off = 0;
@@ -1306,12 +1308,47 @@ extern "C" int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, 
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_params, hipEventDisableTiming));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_main0, hipEventDisableTiming));
   }
-  HIPCHK(e, hipDeviceSynchronize());          // (the clones above were copied on the null stream; once per engine)
+  if (e->particle_bufs_n < K) {
+    if (!e->particle_bufs_dev) TRY(e->dalloc(&e->particle_bufs_dev, VC_MAX_PARTICLES));
+    std::vector<VcBufs> hb((size_t)K);
+    for (int k = 0; k < K; ++k) hb[(size_t)k] = k == 0 ? e->b : e->particles[(size_t)k - 1].b;
+    HIPCHK(e, hipMemcpy(e->particle_bufs_dev, hb.data(), sizeof(VcBufs) * (size_t)K, hipMemcpyHostToDevice));
+    e->particle_bufs_n = K;
+    HIPCHK(e, hipDeviceSynchronize());        // (the clones above were copied on the null stream; once per engine and K)
+  }
   VcParticleGrads pg;
   pg.K = K;
   for (int k = 0; k < VC_MAX_PARTICLES; ++k) pg.g[k] = k == 0 ? grad : (k < K ? e->particles[k - 1].grad : nullptr);
-  const bool serial = getenv("VC_PARTICLES_ONE_STREAM") && atoi(getenv("VC_PARTICLES_ONE_STREAM")) == 1;     // A/B: everything on the caller's stream
-  for (int64_t i = 0; i < n_steps; ++i) {
+  // How the particles of a step are laid out in launches (VC_PARTICLES_LAYOUT, measured at 50k x 2k, K = 3, profiles/r04_particles.md):
+  //   "batched" (default; fast kernel set): K_pre of all particles as ONE launch, the K likelihood kernels, K_post of all particles
+  //             as one launch, K_fin of each + average + ClippedAdam as one launch = K + 3 launches per step
+  //   "serial":  K_pre, K_main, K_post, K_fin per particle on the caller's stream, then average, ClippedAdam = 4 K + 2 launches
+  //   "streams": as "serial" with particle k >= 1 on a stream of its own (the small launches of one particle beside the
+  //             likelihood kernel of another): the event records and cross-stream waits cost what the overlap gains
+  const char* lay = getenv("VC_PARTICLES_LAYOUT");
+  const bool streams = lay && !strcmp(lay, "streams");
+  const bool batched = !e->d.generic && !(lay && (!strcmp(lay, "serial") || streams));
+  const bool serial = !streams;
+  for (int64_t i = 0; i < n_steps && batched; ++i) {
+    vc_launch_pre_particles(e->d, e->b, e->particle_bufs_dev, params, seed, (const long long*)step_dev, e->hist_each_step ? 1 : 0, K, st);
+    for (int k = 0; k < K; ++k) {
+      const VcBufs& b = k == 0 ? e->b : e->particles[(size_t)k - 1].b;
+      if (e->timing) {
+        if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
+        auto& pr = e->ev_pool[e->ev_used++];
+        HIPCHK(e, hipEventRecord(pr.first, st));
+        e->main_fn(e->d, b, st);
+        HIPCHK(e, hipEventRecord(pr.second, st));
+      } else {
+        e->main_fn(e->d, b, st);
+      }
+    }
+    vc_launch_post_particles(e->d, e->b, e->particle_bufs_dev, pg, params, st);
+    vc_launch_particle_fin_adam(e->d, e->particle_bufs_dev, pg, params, loss_dev, (long long)loss_slots, (long long)(step0 + i),
+                                (long long*)step_dev, e->particle_lsum, exp_avg, exp_avg_sq, lr, lrd, beta1, beta2, (float)adam_eps,
+                                (float)clip_norm, (int)header, total, st);
+  }
+  for (int64_t i = 0; i < n_steps && !batched; ++i) {
     // Particle k runs the unfused sequence K_pre -> K_main -> K_post -> K_fin on the Philox stream (seed, t K + k), t read from
     // the device counter, on its own HIP stream and workspaces.  The parameters are the same for all of them (the optimiser
     // runs once, behind the average), so K_pre of every particle starts at once; the likelihood kernels are chained one behind

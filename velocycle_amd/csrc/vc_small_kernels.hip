@@ -153,14 +153,21 @@ void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int c
 // ---------------------------------------------------------------------------------------------
 // K_pre
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBufs b,
+// MULTI (vc_svi_run_particles): ONE launch draws the samples of all K particles of a step -- blockIdx.y = particle, whose
+// workspaces are entry blockIdx.y of `bs` (device array; the parameters are the same for all of them)
+template <bool MULTI>
+__global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBufs b0, const VcBufs* __restrict__ bs,
                                                      const float* __restrict__ P,
                                                      const float* __restrict__ eps_in, uint64_t seed,
                                                      long long step_host,
                                                      const long long* __restrict__ step_dev,
-                                                     int cond_only, int particles, int particle) {
+                                                     int cond_only, int particles, int particle_in) {
   __shared__ double sm_red[16];
   __shared__ float s_nuw[VC_MAX_NW];
+  VcBufs bm;
+  if (MULTI) bm = bs[blockIdx.y];
+  const VcBufs& b = MULTI ? bm : b0;
+  const int particle = MULTI ? (int)blockIdx.y : particle_in;
   VC_KSTAMP(0, 0);
   // Philox stream of this draw: (seed, step); with K particles per step the k-th draw of step t is stream t K + k
   const long long step = (step_dev ? *step_dev : step_host) * particles + particle;
@@ -426,8 +433,15 @@ void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const 
                    hipStream_t st, int particles, int particle) {
   if (d.generic) { vc_launch_pre_generic(d, b, params, eps, seed, step, step_dev, cond_only, with_hist, st, particles, particle); return; }
   const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
-  hipLaunchKernelGGL(vc_pre_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st, d, b,
-                     params, eps, seed, step, step_dev, cond_only, particles, particle);
+  hipLaunchKernelGGL(vc_pre_kernel<false>, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st, d, b,
+                     (const VcBufs*)nullptr, params, eps, seed, step, step_dev, cond_only, particles, particle);
+}
+// the K particles of a step in one launch (fast kernel set only; b = the first particle's buffers: sizes and tables are common)
+void vc_launch_pre_particles(const VcDims& d, const VcBufs& b, const VcBufs* bs_dev, const float* params, uint64_t seed,
+                             const long long* step_dev, int with_hist, int K, hipStream_t st) {
+  const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
+  hipLaunchKernelGGL(vc_pre_kernel<true>, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist, K), dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st,
+                     d, b, bs_dev, params, (const float*)nullptr, seed, 0LL, step_dev, 0, K, 0);
 }
 
 // K-particle step (vc_svi_run_particles): the average of the particles' gradients and losses, added up in particle order and
@@ -750,11 +764,17 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
 }
 
 // one launch for both second-stage reductions: blocks [0, nb_post_gene) gene level, the rest cell level
-template <int MQ>
-__global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcBufs b, const float* __restrict__ P,
-                                                       float* __restrict__ G, long long* __restrict__ step_dev) {
+template <int MQ, bool MULTI = false>
+__global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcBufs b0, const float* __restrict__ P,
+                                                       float* __restrict__ G0, long long* __restrict__ step_dev,
+                                                       const VcBufs* __restrict__ bs, const VcParticleGrads pg) {
   // every reader of this step's counter (K_pre) has finished and nothing in this launch reads it:
   // advance it here, so that K_fin / the optimiser (which only read it) see step + 1 = the 1-based Adam step
+  // (MULTI: blockIdx.y = particle, its workspaces bs[blockIdx.y], its gradient buffer pg.g[blockIdx.y]; step_dev is null)
+  VcBufs bm;
+  if (MULTI) bm = bs[blockIdx.y];
+  const VcBufs& b = MULTI ? bm : b0;
+  float* __restrict__ G = MULTI ? pg.g[blockIdx.y] : G0;
   VC_KSTAMP(1, 0);
   if (blockIdx.x == 0 && threadIdx.x == 0 && step_dev) *step_dev += 1;
   if ((int)blockIdx.x < d.nb_post_gene) vc_post_gene_block<MQ>(d, b, P, G, blockIdx.x);
@@ -976,6 +996,85 @@ __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const 
   VC_KSTAMP(2, 3);
 }
 
+// K-particle step, last launch: block 0 finishes every particle's loss and angular-speed gradients (K_fin of particle k on its
+// workspaces and gradient buffer, one after the other), all blocks then average the K gradients in particle order --
+// (g_0 + g_1 + ...) * (1 / K), what a host loop's sum and PyTorch's division by a scalar give; left in particle 0's buffer --
+// and apply ClippedAdam to the average; block 0 files the averaged loss and sets the step counter to t + 1.
+__global__ __launch_bounds__(256) void vc_particle_fin_adam_kernel(const VcDims d, const VcBufs* __restrict__ bs, const VcParticleGrads pg,
+                                                                   float* P, double* loss_dev, long long loss_slots, long long step_host,
+                                                                   long long* step_dev, double* __restrict__ scratch, float* __restrict__ m,
+                                                                   float* __restrict__ v, double lr0, double lrd /* log */, double b1,
+                                                                   double b2, double b1l, double b2l, float eps, float clip, int header,
+                                                                   long long total) {
+  __shared__ float s_step;
+  const int K = pg.K;
+  const long long t1 = step_host + 1;        // 1-based optimiser step (the host's mirror of the device counter: nothing here reads it)
+  if (threadIdx.x == 0) {
+    const double td = (double)t1;
+    s_step = (float)(lr0 * exp(td * lrd) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));   // lrd, b1l, b2l: logs
+  }
+  long long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};      // parameters whose gradient K_fin produces (vc_fin_adam_kernel)
+  if (d.model == VC_MODEL_VELOCITY) {
+    if (d.guide != VC_GUIDE_LRMN) {
+      lo[0] = d.poff[VC_P_NUOMEGA_LOCS]; hi[0] = lo[0] + d.NW;
+      lo[1] = d.poff[VC_P_NUOMEGA_USCALES]; hi[1] = lo[1] + d.NW;
+    } else {
+      lo[0] = d.poff[VC_P_LRMN_LOC] + d.Ng; hi[0] = d.poff[VC_P_LRMN_LOC] + d.M;
+      lo[1] = d.poff[VC_P_LRMN_UCOV_DIAG] + d.Ng; hi[1] = d.poff[VC_P_LRMN_UCOV_DIAG] + d.M;
+      lo[2] = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)d.Ng * d.R; hi[2] = d.poff[VC_P_LRMN_UCOV_FACTOR] + (long long)d.M * d.R;
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int k = 0; k < K; ++k) {
+      const VcBufs bk = bs[k];
+      vc_fin_block(d, bk, P, pg.g[k], scratch + k, 1, step_host);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      double l = 0.0;
+      for (int k = 0; k < K; ++k) l += (double)pg.g[k][0] + (double)pg.g[k][1];
+      const double avg = l * (1.0 / (double)K);
+      const float h = (float)avg, lw = (float)(avg - (double)h);
+      pg.g[0][0] = h; pg.g[0][1] = lw;
+      if (loss_dev) loss_dev[loss_slots > 1 ? (step_host % loss_slots) : 0] = (double)h + (double)lw;
+      if (step_dev) step_dev[0] = t1;
+    }
+  }
+  __syncthreads();
+  const float step_size = s_step;
+  const float fb1 = (float)b1, fb2 = (float)b2, inv = 1.0f / (float)K;
+  auto upd = [&](long long idx) {
+    const long long j = idx - header;
+    float a = 0.f + pg.g[0][idx];
+    for (int k = 1; k < K; ++k) a += pg.g[k][idx];
+    const float ga = a * inv;
+    pg.g[0][idx] = ga;
+    const float gi = fminf(fmaxf(ga, -clip), clip);
+    const float mi = fb1 * m[j] + (1.f - fb1) * gi;
+    const float vi = fb2 * v[j] + (1.f - fb2) * gi * gi;
+    m[j] = mi;
+    v[j] = vi;
+    P[idx] = P[idx] - step_size * (mi / (sqrtf(vi) + eps));
+  };
+  for (long long idx = header + (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const bool tail = (idx >= lo[0] && idx < hi[0]) || (idx >= lo[1] && idx < hi[1]) || (idx >= lo[2] && idx < hi[2]);
+    if (!tail) upd(idx);
+  }
+  if (blockIdx.x == 0)
+    for (int q = 0; q < 3; ++q)
+      for (long long idx = lo[q] + threadIdx.x; idx < hi[q]; idx += 256) upd(idx);
+}
+void vc_launch_particle_fin_adam(const VcDims& d, const VcBufs* bs_dev, const VcParticleGrads& pg, float* params, double* loss_dev,
+                                 long long loss_slots, long long step, long long* step_dev, double* scratch, float* m, float* v,
+                                 double lr0, double lrd, double b1, double b2, float eps, float clip, int header, long long total,
+                                 hipStream_t st) {
+  long long nb = (total - header + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(vc_particle_fin_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, d, bs_dev, pg, params, loss_dev, loss_slots, step,
+                     step_dev, scratch, m, v, lr0, log(lrd), b1, b2, log(b1), log(b2), eps, clip, header, total);
+}
+
 void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* grad, double* loss_dev,
                         long long loss_slots, long long step, long long* step_dev, float* m, float* v, double lr0,
                         double lrd, double b1, double b2, float eps, float clip, int header, long long total,
@@ -1001,10 +1100,20 @@ void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float
                     hipStream_t st) {
   if (d.generic) { vc_launch_post_generic(d, b, params, grad, step_dev, st); return; }
   const dim3 grid(d.nb_post_gene + d.nb_post_cell), block(1024);
-  if (d.nq <= 2) hipLaunchKernelGGL(vc_post_kernel<2>, grid, block, 0, st, d, b, params, grad, step_dev);
-  else if (d.nq <= 6) hipLaunchKernelGGL(vc_post_kernel<6>, grid, block, 0, st, d, b, params, grad, step_dev);
-  else hipLaunchKernelGGL(vc_post_kernel<VC_MAXQ>, grid, block, 0, st, d, b, params, grad, step_dev);
+  if (d.nq <= 2) hipLaunchKernelGGL((vc_post_kernel<2, false>), grid, block, 0, st, d, b, params, grad, step_dev, (const VcBufs*)nullptr, VcParticleGrads());
+  else if (d.nq <= 6) hipLaunchKernelGGL((vc_post_kernel<6, false>), grid, block, 0, st, d, b, params, grad, step_dev, (const VcBufs*)nullptr, VcParticleGrads());
+  else hipLaunchKernelGGL((vc_post_kernel<VC_MAXQ, false>), grid, block, 0, st, d, b, params, grad, step_dev, (const VcBufs*)nullptr, VcParticleGrads());
 }
+void vc_launch_post_particles(const VcDims& d, const VcBufs& b, const VcBufs* bs_dev, const VcParticleGrads& pg, const float* params,
+                              hipStream_t st) {
+  const dim3 grid(d.nb_post_gene + d.nb_post_cell, pg.K), block(1024);
+  long long* no_ctr = nullptr;
+  float* no_g = nullptr;
+  if (d.nq <= 2) hipLaunchKernelGGL((vc_post_kernel<2, true>), grid, block, 0, st, d, b, params, no_g, no_ctr, bs_dev, pg);
+  else if (d.nq <= 6) hipLaunchKernelGGL((vc_post_kernel<6, true>), grid, block, 0, st, d, b, params, no_g, no_ctr, bs_dev, pg);
+  else hipLaunchKernelGGL((vc_post_kernel<VC_MAXQ, true>), grid, block, 0, st, d, b, params, no_g, no_ctr, bs_dev, pg);
+}
+
 void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev,
                    long long loss_slots, long long step, const long long* step_dev, hipStream_t st) {
   if (d.generic) { vc_launch_fin_generic(d, b, params, grad, loss_dev, loss_slots, step, step_dev, st); return; }
