@@ -176,7 +176,9 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
           // the other half)
           const double* __restrict__ HLs = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
           const double* __restrict__ HDs = b.HD + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
-          const int t0 = b.h_tptr[g], t1 = b.h_tptr[g + 1];
+          // (dense tables: one task per matrix and gene, no table of first tasks to wait for)
+          const int nmat = vel ? 2 : 1;
+          const int t0 = d.hist_dense ? nmat * g : b.h_tptr[g], t1 = d.hist_dense ? nmat * (g + 1) : b.h_tptr[g + 1];
           for (int tb = t0; tb < t1; tb += 4) {
             double hl[4], hd[4];
 #pragma unroll
@@ -587,8 +589,30 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
         xy = *reinterpret_cast<const float2*>(b.lat[VC_SITE_PHIXY] + 2 * (size_t)c);
         if (d.kind == VC_KIND_VFULL) { om = b.lat_omega[c]; dom = b.lat_domega[c]; }
       }
-      for (int gb = 0; gb < d.nGB; ++gb)
-        for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + c];
+      // K_main's per-cell partial rows, four gene blocks requested per trip before the first is added (an `A += load` loop with
+      // run-time bounds is one dependent round trip per row: 12 of them for the S+U kernel's three rows -- 6 us of this block's
+      // chain, profiles/r04_two_launch.md); every A[j] still adds its rows in gene-block order
+      for (int gb0 = 0; gb0 < d.nGB; gb0 += 4) {
+        float v[4][3];
+        if (d.nco == 3) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[u][j] = b.CO[((size_t)(gb0 + u < d.nGB ? gb0 + u : gb0) * 3 + j) * d.Nc + c];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v[u][0] = b.CO[(size_t)(gb0 + u < d.nGB ? gb0 + u : gb0) * d.Nc + c];
+            v[u][1] = 0.f; v[u][2] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (gb0 + u < d.nGB) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (j < d.nco) A[j] += v[u][j];
+          }
+      }
       if (!cxy) {
         float dphi = A[0];
         if (d.kind == VC_KIND_VFULL) dphi += om * A[1] + A[2] * dom;
