@@ -14,11 +14,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc_fetch -- $CMD --no-graph > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc_write -- $CMD --no-graph > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_pmc_sq -- $CMD --no-graph > /dev/null 2>&1
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 python3 profiles/summarize.py gpurun_out/${tag}_stats $out/kernel_stats_graph.txt "$tag: $CMD (hipGraph replay)" > /dev/null
 python3 profiles/summarize.py gpurun_out/${tag}_stats_eager $out/kernel_stats_eager.txt "$tag: $CMD --no-graph" > /dev/null
 for p in fetch write sq; do python3 profiles/summarize.py gpurun_out/${tag}_pmc_$p $out/pmc_$p.txt "$tag: --pmc pass ($p) of $CMD --no-graph" > /dev/null; done
 cat $out/pmc_fetch.txt $out/pmc_write.txt $out/pmc_sq.txt > $out/pmc.txt
 python3 profiles/tools/pmc_to_traffic.py $out/pmc.txt $out/latest_traffic.json $tag
+# the plain run last, with the traffic file of THIS library in place (bench.py takes `roofline.traffic` from
+# profiles/latest_traffic.json only if its csrc hash matches the library it runs)
+cp $out/latest_traffic.json profiles/latest_traffic.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 head -30 $out/kernel_stats_eager.txt
 tail -c 600 $out/bench.json
