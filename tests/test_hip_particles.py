@@ -92,6 +92,30 @@ def test_particles_from_one_c_call_equal_the_host_loop(case, monkeypatch):
         assert a[3] == b[3] and len(a[3]) == 9 and a[4] == b[4] == 9 and a[5] == b[5] == 9 and a[6] == b[6] == (True, -1, 0)
 
 
+def test_particles_on_the_run_time_sized_kernel_set(monkeypatch):
+    """The C call on a generic engine (VC_FORCE_GENERIC=1 on a fast-set fixture): the per-particle launch layout on the generic
+    kernels, again bit for bit the host loop -- and a change of K on the same engine (the particle workspaces grow)."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fitK3_vel_mf_joint.npz")
+    spec = H.spec_from_fixture(z)
+    monkeypatch.setenv("VC_FORCE_GENERIC", "1")
+    out = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("VC_PARTICLES_HOST_LOOP", host)
+        eng = HipEngine(spec)
+        assert eng.stats["generic"]
+        run = SVIRunner(eng, _opt(z), mode="perf", seed=5, num_particles=2)
+        run.run_perf(3)
+        run.K = 4
+        run.run_perf(3)
+        out.append((eng.params.clone().cpu(), run.opt.m.clone().cpu(), run.perf_losses(), eng.status()))
+        eng.close()
+    nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+    assert torch.equal(nz(out[0][0]), nz(out[1][0])) and torch.equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2] and len(out[0][2]) == 6 and out[0][3] == out[1][3] == (True, -1, 0)
+
+
 def test_fit_reads_num_particles_from_the_loss_object():
     """The drop-in API: PhaseFitModel.fit(optimizer, loss=Trace_ELBO(num_particles=3)) reproduces the reference's fit with
     the same object; an object asking for vectorised particles is refused by name."""

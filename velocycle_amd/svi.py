@@ -364,7 +364,11 @@ class SVIRunner:
                 mag = self.xbuf.abs()
                 dist.all_reduce(ref, group=self.pg)
                 dist.all_reduce(mag, group=self.pg)
+                # two communicators never have a collective in flight at the same time (their kernels could be scheduled in
+                # different orders on different ranks): torch's are complete on every rank before the engine's is enqueued
+                torch.cuda.synchronize(e.device)
                 e.comm_allreduce(self.xbuf)
+                torch.cuda.synchronize(e.device)
                 # tolerance relative to the sum of the ranks' MAGNITUDES: two correct all-reduces may add the ranks in different
                 # orders, and a gradient whose terms cancel differs by ~1e-7 of those terms, not of the result
                 diff = (self.xbuf - ref).abs()
