@@ -47,7 +47,8 @@ def main():
         eng.status()
     except HipEngineError as ex:
         msg = str(ex)
-    print("DEAD_PEER " + repr({"waited_s": round(waited, 2), "nan": [x != x for x in alone], "status": msg}), flush=True)
+    import json
+    print("DEAD_PEER " + json.dumps({"waited_s": round(waited, 2), "nan": [x != x for x in alone], "status": msg}), flush=True)
     dist.barrier()
 
 

@@ -129,7 +129,7 @@ def test_p2p_exchange_survives_a_peer_that_stops():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("DEAD_PEER ")]
     assert len(lines) == 1, r.stdout[-2000:]
-    got = eval(lines[0][len("DEAD_PEER "):])
+    got = json.loads(lines[0][len("DEAD_PEER "):])
     assert got["nan"] == [True, True], got                 # both lonely steps poisoned
     assert 1.5 <= got["waited_s"] < 7.0, got               # two bounded waits of 1 s, not the peer's 8 s
     assert "peer-to-peer exchange" in got["status"] and "did not publish" in got["status"], got
