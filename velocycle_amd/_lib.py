@@ -88,6 +88,7 @@ EXPORTS = {
     "vc_svi_run_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_int, C.c_int64, C.c_void_p]),
+    "vc_set_loss_every": (C.c_int, [C.c_void_p, C.c_int32]),
     "vc_exchange_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "vc_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vc_svi_run_particles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -105,6 +105,12 @@ struct vc_engine {
   size_t setup_transient_bytes = 0;     // peak device memory held only during vc_finalize
   int hist_on_device = 0;
   vc_main_launch_fn main_fn = nullptr;
+  // vc_set_loss_every: the gradient-only instantiation of the U-only kernel (null: none for this configuration), the period and
+  // the count of likelihood launches of the fused single-rank runs since it was set (launch n evaluates the loss iff n % k == 0)
+  vc_main_launch_fn main_fn_nl = nullptr;
+  const char* main_name_nl = "";
+  int loss_every = 1;
+  long long loss_ctr = 0;
   vc_main_launch_fn phase_fn = nullptr;  // S-only kernel used once to hoist the S term (VU kind)
   const char* main_name = "";
   long long gs = 0, cs = 0;          // strides of the host copies hS / hU
@@ -854,6 +860,15 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       if (!d.pw_inline) tile(bpc0);     // off: the tiling of the plain kernel
     }
   }
+  if (!d.generic && d.kind == VC_KIND_VU && d.noise == VC_NOISE_NB) {
+    // the gradient-only twin of the selected kernel (same tiling, same dynamic LDS); used only after vc_set_loss_every(k > 1)
+    const void* knl = nullptr;
+    e->main_fn_nl = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, d.c16 | 2, &e->main_name_nl, &knl);
+    hipFuncAttributes fa;
+    if (e->main_fn_nl && knl && (hipFuncGetAttributes(&fa, knl) != hipSuccess || fa.localSizeBytes > 0)) e->main_fn_nl = nullptr;
+    const unsigned dyn = vc_main_dyn_lds(d);
+    if (e->main_fn_nl && dyn > 0) (void)hipFuncSetAttribute(knl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  }
   {
     // the tiling as a table: {first cell of wave 0, cells per wave} of every workgroup of the likelihood kernel, evaluated
     // HERE by the function the kernel used to run itself (vc_host_logic.h; 64-bit divisions = ~700 scalar instructions in
@@ -1246,14 +1261,17 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
   const int tail_kind = fused_tail_kind(e);
   const bool merged = tail_kind == 1, tail2 = tail_kind == 2;
   for (int64_t i = 0; i < n_steps; ++i) {
+    // vc_set_loss_every(k > 1): the gradient-only kernel except at every k-th likelihood launch
+    const vc_main_launch_fn fn = (e->loss_every > 1 && e->main_fn_nl && (e->loss_ctr % e->loss_every) != 0) ? e->main_fn_nl : e->main_fn;
+    ++e->loss_ctr;
     if (e->timing) {
       if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
       auto& pr = e->ev_pool[e->ev_used++];
       HIPCHK(e, hipEventRecord(pr.first, st));
-      e->main_fn(e->d, b2, st);
+      fn(e->d, b2, st);
       HIPCHK(e, hipEventRecord(pr.second, st));
     } else {
-      e->main_fn(e->d, b2, st);
+      fn(e->d, b2, st);
     }
     if (merged && e->plain_steps >= 2) {
       vc_launch_tail_merged(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, st);
@@ -1387,6 +1405,18 @@ extern "C" int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, 
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
+extern "C" int vc_set_loss_every(vc_engine* e, int32_t k) {
+  if (!e) return VC_ERR_ARG;
+  if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_set_loss_every before vc_finalize");
+  if (k < 1) return e->fail(VC_ERR_ARG, "vc_set_loss_every: k >= 1");
+  if (k > 1 && !e->main_fn_nl)
+    return e->fail(VC_ERR_UNSUPPORTED, "vc_set_loss_every: no gradient-only likelihood kernel for this configuration (it exists for the "
+                                       "velocity model with phi_xy, nu, delta nu and shape_inv conditioned, negative-binomial noise, fast kernel set)");
+  e->loss_every = k;
+  e->loss_ctr = 0;
   return VC_OK;
 }
 

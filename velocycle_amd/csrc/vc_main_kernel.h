@@ -64,11 +64,18 @@
 // GPL = genes per lane (4 or 8): 8 amortises the per-cell work (DPP reductions, staging, loop) over twice
 // the genes and is faster whenever its accumulators still fit 2 waves per SIMD (launch bound) -- the host
 // picks GPL per (kind, K); the HBM layout [gene block][cell][64*GPL] follows it.
-// C16: the counts are stored as uint16 (every count of the matrix is an integer <= 65535: decided by vc_finalize from the
+// C16 (bit 0 of CS): the counts are stored as uint16 (every count of the matrix is an integer <= 65535: decided by vc_finalize from the
 // histograms) -- half the HBM bytes of the reference's float32 storage, one v_cvt_f32_u32 with a WORD_n source select per
 // element; C16 = 0 reads the float32 layout (Lognormal noise stores log(k+1); non-integer or huge counts).
-template <int H, int NB, int KIND, int NOISE, int GPL, int C16>
+// CS = C16 | 2 NOLOSS.  NOLOSS (U-only kernel, negative-binomial noise; opt-in through vc_set_loss_every): the gradient alone -- with
+// shape_inv conditioned both v_log_f32 per element serve only the loss VALUE, and mu = 2^eta_S * zp needs no log of zp either:
+// 4 of 8 transcendentals and 4 of 21 packed operations per gene pair less (68 -> 52 us at 50k x 2k, profiles/r04_vcond.md);
+// the likelihood part of that step's loss is not formed (the host reports NaN for it).
+template <int H, int NB, int KIND, int NOISE, int GPL, int CS>
 __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB_SINGLE) : 1)) void vc_main_kernel(const VcDims d, const VcBufs b) {
+  constexpr int C16 = CS & 1;
+  constexpr bool NOLOSS = (CS & 2) != 0;
+  static_assert(!NOLOSS || (KIND == VC_KIND_VU && NOISE == VC_NOISE_NB && VC_RCP_MERGE), "gradient-only: U-only kernel, NB noise");
   constexpr int GBW = 64 * GPL;
   constexpr int NH = 2 * H + 1;
   constexpr int K = NH + NB;
@@ -309,13 +316,14 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         v2f m;      // one packed multiply with the clamp output modifier (hipcc does not fold fmed3 into v_pk_mul)
         asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(m) : "v"(z), "v"(v2(1.2676506e30f)));
         const v2f zp = v2_fma(z, m, v2(1e-5f));
-        const v2f eu2 = ((VC_FOLD_LOGBETA && KIND == VC_KIND_VU) || HLB) ? es2 + v2_log2(zp) : (es2 - lb2[p]) + v2_log2(zp);
+        const v2f ez2 = ((VC_FOLD_LOGBETA && KIND == VC_KIND_VU) || HLB) ? es2 : es2 - lb2[p];
+        const v2f eu2 = NOLOSS ? ez2 : ez2 + v2_log2(zp);
         v2f aU;
         if (VC_RCP_MERGE && NOISE == VC_NOISE_NB) {
           // one reciprocal for 1/t_U and 1/zp: R = 1/(t_U zp), a_U = r (k - mu) zp R, w = a_U m / zp = r (k - mu) m R
-          const v2f muU = FULL ? muS * (ib[p] * zp) : v2_exp2(eu2);
+          const v2f muU = FULL ? muS * (ib[p] * zp) : (NOLOSS ? v2_exp2(eu2) * zp : v2_exp2(eu2));
           const v2f t = rr[p] + muU;
-          const v2f lt2 = v2_log2(t);
+          const v2f lt2 = NOLOSS ? v2(0.f) : v2_log2(t);
           const v2f R = v2_rcp(t * zp);
           const v2f num = rr[p] * (uv[p] - muU);
           if (VC_NR_MERGE) {
@@ -326,8 +334,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
             aU = num * (R * zp);
             w = num * (R * m);
           }
-          ll[p] = v2_fma(uv[p], eu2 - lt2, ll[p]);
-          lt[p] += lt2;
+          if (!NOLOSS) { ll[p] = v2_fma(uv[p], eu2 - lt2, ll[p]); lt[p] += lt2; }
         } else {
           const v2f iz = v2_rcp(zp);
           const v2f q = iz * m;                                                 // torch.relu': 0 at z <= 0
@@ -615,36 +622,4 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 #endif
 }
 
-template <int H, int NB, int KIND, int NOISE, int GPL, int C16>
-static void vc_main_launch(const VcDims& d, const VcBufs& b, hipStream_t st) {
-  hipLaunchKernelGGL((vc_main_kernel<H, NB, KIND, NOISE, GPL, C16>), dim3(d.n_main_wg), dim3(256), vc_main_dyn_lds(d), st, d, b);
-}
-
-struct VcMainEntry { int H, NB, kind, noise, gpl, c16; vc_main_launch_fn fn; const void* kernel; };
-
-// Explicit kernel instantiations are needed in both compilation passes; the launcher table is host-only.
-// The uint16 variants exist for the count noise models only (Lognormal stores log(k + 1)).
-#define VC_INST_1(KIND, NOISE, H, NB, GPL, C16) \
-  template __global__ void vc_main_kernel<H, NB, KIND, NOISE, GPL, C16>(const VcDims, const VcBufs);
-#define VC_ENT_1(KIND, NOISE, H, NB, GPL, C16)                                   \
-  {H, NB, KIND, NOISE, GPL, C16, &vc_main_launch<H, NB, KIND, NOISE, GPL, C16>, \
-   (const void*)&vc_main_kernel<H, NB, KIND, NOISE, GPL, C16>},
-#define VC_FOR_NB(M, KIND, NOISE, H, GPL, C16)                                                                  \
-  M(KIND, NOISE, H, 0, GPL, C16) M(KIND, NOISE, H, 1, GPL, C16) M(KIND, NOISE, H, 2, GPL, C16) M(KIND, NOISE, H, 3, GPL, C16) \
-  M(KIND, NOISE, H, 4, GPL, C16)
-#define VC_FOR_H(M, KIND, NOISE, GPL, C16) \
-  VC_FOR_NB(M, KIND, NOISE, 1, GPL, C16) VC_FOR_NB(M, KIND, NOISE, 2, GPL, C16) VC_FOR_NB(M, KIND, NOISE, 3, GPL, C16)
-#define VC_FOR_ALL_F32(M, KIND, NOISE) VC_FOR_H(M, KIND, NOISE, 4, 0) VC_FOR_H(M, KIND, NOISE, 8, 0)
-#define VC_FOR_ALL_U16(M, KIND, NOISE) VC_FOR_H(M, KIND, NOISE, 4, 1) VC_FOR_H(M, KIND, NOISE, 8, 1)
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define VC_DEFINE_TABLE(NAME, KIND, NOISE) VC_FOR_ALL_F32(VC_INST_1, KIND, NOISE)
-#define VC_DEFINE_TABLE_U16(NAME, KIND, NOISE) VC_FOR_ALL_U16(VC_INST_1, KIND, NOISE)
-#else
-#define VC_DEFINE_TABLE(NAME, KIND, NOISE)      \
-  VC_FOR_ALL_F32(VC_INST_1, KIND, NOISE)        \
-  extern const VcMainEntry NAME[30] = {VC_FOR_ALL_F32(VC_ENT_1, KIND, NOISE)};
-#define VC_DEFINE_TABLE_U16(NAME, KIND, NOISE)  \
-  VC_FOR_ALL_U16(VC_INST_1, KIND, NOISE)        \
-  extern const VcMainEntry NAME[30] = {VC_FOR_ALL_U16(VC_ENT_1, KIND, NOISE)};
-#endif
+#include "vc_main_tables.h"   // launcher + the tables of instantiations (VC_DEFINE_TABLE*)

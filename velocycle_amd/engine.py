@@ -282,6 +282,12 @@ class HipEngine:
             C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), lr, lrd, b1, b2, adam_eps, clip, int(bool(prime)),
             C.c_int64(n_steps), self._stream()))
 
+    def set_loss_every(self, k: int):
+        """Opt-in (vc_set_loss_every): the fused single-rank runs form the loss at every k-th step only and run the gradient-only
+        likelihood kernel in between (tutorial-flow velocity stage: phases, nu, shape_inv conditioned, NB noise).  k = 1 restores
+        the default.  Raises HipEngineError (VC_ERR_UNSUPPORTED) when the configuration has no gradient-only kernel."""
+        self._check(self.lib.vc_set_loss_every(self._h, C.c_int32(int(k))))
+
     def svi_run_particles(self, grad_acc, m, v, lr, lrd, b1, b2, adam_eps, clip, seed, step_dev, step0, num_particles, n_steps,
                           loss_buf=None):
         """n_steps steps of Trace_ELBO(num_particles=K) enqueued from one call (vc_svi_run_particles): per step K x the unfused

@@ -74,7 +74,11 @@ class _FitBase:
         pass
 
     def fit(self, optimizer, loss=None, num_steps=1000, intermediate_output_step_size=100, store_output=False,
-            verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None, process_group=None):
+            verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None, process_group=None, loss_every: int = 1):
+        """The reference's fit() (velocity_inference_model.py:77-160, phase_inference_model.py:126-214) + mode / seed / device /
+        process_group of this engine.  loss_every = k > 1 is an opt-in that is NOT in the reference: only every k-th step forms
+        the loss (`losses` holds NaN in between), the others run a gradient-only likelihood kernel -- available for the velocity
+        stage of the tutorial flow (phases, nu, delta nu, shape_inv conditioned, NB noise) in perf mode on one rank."""
         self._warn_sizes()
         import time
         t_start = time.perf_counter()
@@ -97,6 +101,9 @@ class _FitBase:
         if loss is not None and getattr(loss, "vectorize_particles", False):
             raise NotImplementedError("Trace_ELBO(vectorize_particles=True) is not supported by the HIP engine")
         exact = mode == "parity" or self.early_exit or store_output
+        if int(loss_every) > 1 and (exact or particles > 1 or self._world > 1):
+            raise ValueError("loss_every > 1 needs mode='perf' on one rank without early_exit / store_output / particles "
+                             "(they read the loss of every step)")
         # continue-from-store (pyro_compat): parameters the store still holds are the starting values, and an optimizer OBJECT
         # that stepped on them before carries its moments / step counts on
         plan = self._continuation_plan(optimizer)
@@ -120,9 +127,11 @@ class _FitBase:
             s = int(torch.initial_seed() % (2 ** 63)) if seed is None else int(seed)
             s = broadcast_int(s, self._pg, eng.device)
             run = SVIRunner(eng, args, mode="perf", seed=s, process_group=self._pg, num_particles=particles,
-                            adam_impl="torch" if plan["mixed"] else None)
+                            adam_impl="torch" if plan["mixed"] else None, loss_every=int(loss_every))
         self._runner = run
         t_first = self._apply_continuation(run, plan)
+        if int(loss_every) > 1:
+            run._arm_loss_every()            # (the continuation moved the step counter: the period starts at THIS fit's first step)
         losses, intermediate_output = [], []
         if mode == "perf" and not exact:
             run.run_perf(num_steps)
@@ -147,7 +156,8 @@ class _FitBase:
         torch.cuda.synchronize(eng.device)
         t_svi = time.perf_counter()
         ok, first_bad, n_bad = eng.status()                                     # device-side latch of the C ABI
-        if not ok or not np.all(np.isfinite(np.asarray(losses, dtype=np.float64))):   # pyro.util.warn_if_nan(loss, "loss")
+        formed = np.asarray(losses, dtype=np.float64)[:: max(1, int(loss_every))]        # (loss_every > 1: NaN in between by design)
+        if not ok or not np.all(np.isfinite(formed)):   # pyro.util.warn_if_nan(loss, "loss")
             import warnings
             warnings.warn("Encountered NaN/Inf: loss" + ("" if ok else f" (first at step {first_bad}, {n_bad} steps)"),
                           UserWarning)

@@ -126,8 +126,15 @@ class SVIRunner:
     def __init__(self, engine: HipEngine, optim_args: dict, mode: str = "parity", seed: Optional[int] = None,
                  process_group=None, use_graph: Optional[bool] = None, warmup_draw: bool = True,
                  init: bool = True, adam_impl: Optional[str] = None, force_reduce: bool = False,
-                 exchange: Optional[str] = None, num_particles: int = 1):
+                 exchange: Optional[str] = None, num_particles: int = 1, loss_every: int = 1):
         assert mode in ("parity", "perf")
+        # loss_every = k > 1 (opt-in, SURVEY.md section 5 "or every k steps in perf mode"): only every k-th step of a fused
+        # single-rank run forms the loss, the others run the gradient-only likelihood kernel (engine.set_loss_every: exists for
+        # the tutorial flow's velocity stage); perf_losses() reports NaN for the steps in between.  The reference reads the
+        # loss of EVERY step (velocity_inference_model.py:118-121): that is k = 1, the default.
+        self.loss_every = int(loss_every)
+        if self.loss_every < 1:
+            raise ValueError("loss_every must be >= 1")
         # Trace_ELBO(num_particles=K): K guide draws per step, loss and gradients averaged before the optimiser step.  K > 1
         # runs the unfused kernel sequence once per particle (the fused steps draw the NEXT step's single sample inside
         # the optimiser kernel); parity mode draws K host eps sets per step, perf mode uses the Philox streams
@@ -244,6 +251,7 @@ class SVIRunner:
         if mode == "perf":
             self.step_dev = torch.zeros(1, dtype=torch.int64, device=engine.device)
             self.loss_hist = None
+        self._arm_loss_every()
 
     # ------------------------------------------------------------------------------------------
     def _reduce(self):
@@ -519,6 +527,8 @@ class SVIRunner:
         device writes directly (K_omega's loss block), and the host spins on the slot of this step.  Single-rank fused
         path only; every other configuration runs the step and copies the loss back."""
         e = self.e
+        if self.loss_every > 1:
+            raise ValueError("step_with_loss hands over the loss of every step: not with loss_every > 1")
         if self.mode != "perf" or self.adam_impl != "fused3" or self._graph is not None or self.use_graph:
             self.run_perf(1, sync=False)
             return float(self.loss_hist[self.step_idx - 1].item())
@@ -552,7 +562,21 @@ class SVIRunner:
             torch.cuda.synchronize(self.e.device)
         if self.loss_hist is None:
             return []
-        return self.loss_hist[: self.step_idx].cpu().tolist()
+        out = self.loss_hist[: self.step_idx].cpu().tolist()
+        if self.loss_every > 1:          # steps that ran the gradient-only kernel have no loss
+            base = getattr(self, "_loss_base", 0)
+            out = [x if i < base or (i - base) % self.loss_every == 0 else float("nan") for i, x in enumerate(out)]
+        return out
+
+    def _arm_loss_every(self):
+        """(Re)starts the engine's count of likelihood launches at the runner's current step: step base + j k forms the loss."""
+        if self.loss_every > 1:
+            if self.mode != "perf" or self.adam_impl != "fused3" or self.K != 1:
+                raise ValueError("loss_every > 1 needs the fused single-rank perf-mode step (one particle)")
+            self.e.set_loss_every(self.loss_every)
+            self._loss_base = self.step_idx
+        elif hasattr(self.e, "set_loss_every") and self.mode == "perf" and self.adam_impl == "fused3":
+            self.e.set_loss_every(1)        # the engine outlives its runners: an earlier runner's period must not linger
 
     # ------------------------------------------------------------------------------------------
     # checkpoint / resume of a fit (the reference's analogue: pyro.get_param_store().get_state()/set_state(),
@@ -587,6 +611,7 @@ class SVIRunner:
         self.step_idx, self.seed = int(sd["step_idx"]), int(sd["seed"])
         losses = torch.as_tensor(sd["losses"], dtype=torch.float64)
         self._primed = False
+        self._arm_loss_every()
         if self.mode == "perf":
             self.step_dev.fill_(self.step_idx)
             n = max(2 * self.step_idx, 16384)
