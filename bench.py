@@ -567,7 +567,26 @@ def main():
         del run_w, eng_w, spec_w
         torch.cuda.empty_cache()
         run = eng = spec = None
+    def loss_every_demo(engine):
+        # OPT-IN, never the headline and not what the reference does (it reads the loss of every step): the loss formed at every
+        # 10th step only -- the other steps run the gradient-only instantiation of the likelihood kernel (vc_set_loss_every;
+        # DESIGN.md section 8).  Reported under its own name next to the default numbers of the same model.
+        try:
+            r3 = SVIRunner(engine, optim, mode="perf", seed=0, loss_every=10)
+            ts3 = time_steps(r3, args.steps, args.warmup, False, device, max(5, args.repeats // 2))
+            rf3 = kernel_roofline(engine, r3, args.roofline_launches, median(ts3) / args.steps)
+            res = {"steps_per_s": round(args.steps / median(ts3), 2), "ms_per_step": round(1e3 * median(ts3) / args.steps, 4),
+                   "kernel_avg_us_mix": rf3["kernel_avg_us"], "step_overhead_us": rf3["step_overhead_us"],
+                   "note": "losses hold NaN at 9 of 10 steps; 9 of 10 likelihood launches are the gradient-only instantiation "
+                           "(kernel_avg_us_mix averages both)"}
+            SVIRunner(engine, optim, mode="perf", seed=0, init=False)      # (restores the engine's default: every loss)
+            return res
+        except Exception as ex:            # (a configuration without such a kernel: say so, do not fail the line)
+            return {"error": str(ex)[:200]}
+
     extra = {}
+    if not dist_on and not solo_group and not args.no_loss_every_demo and rank == 0:
+        out["opt_in_loss_every_10"] = loss_every_demo(eng)
     if not args.no_extra_modes and not dist_on:
         del run, eng, spec
         torch.cuda.empty_cache()
@@ -581,22 +600,8 @@ def main():
                         "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"],
                         "hbm_frac": rf["frac"], "step_frac": rf["step_frac"], "step_overhead_us": rf["step_overhead_us"], "hbm_pipe_frac": rf["hbm_pipe_frac"], "valu_frac": (rf["valu"] or {}).get("frac"),
                         "valu_frac_at_in_loop_clock": (rf["valu"] or {}).get("frac_at_in_loop_clock")}
-            if m == "vcond" and not args.no_loss_every_demo:
-                # OPT-IN, never the headline and not what the reference does (it reads the loss of every step): the tutorial flow's
-                # velocity stage with the loss formed at every 10th step only -- the other steps run the gradient-only likelihood
-                # kernel (vc_set_loss_every).  Reported under its own name next to the default above.
-                try:
-                    r3 = SVIRunner(e2, optim, mode="perf", seed=0, loss_every=10)
-                    ts3 = time_steps(r3, args.steps, args.warmup, False, device, max(5, args.repeats // 2))
-                    rf3 = kernel_roofline(e2, r3, args.roofline_launches, median(ts3) / args.steps)
-                    extra[m]["opt_in_loss_every_10"] = {
-                        "steps_per_s": round(args.steps / median(ts3), 2), "ms_per_step": round(1e3 * median(ts3) / args.steps, 4),
-                        "kernel_avg_us_mix": rf3["kernel_avg_us"], "step_overhead_us": rf3["step_overhead_us"],
-                        "note": "losses hold NaN at 9 of 10 steps; 9 of 10 likelihood launches are the gradient-only instantiation "
-                                "(kernel_avg_us_mix averages both)"}
-                    del r3
-                except Exception as ex:            # (a configuration without such a kernel: say so, do not fail the line)
-                    extra[m]["opt_in_loss_every_10"] = {"error": str(ex)[:200]}
+            if not args.no_loss_every_demo:
+                extra[m]["opt_in_loss_every_10"] = loss_every_demo(e2)
             del s2, e2, r2
             torch.cuda.empty_cache()
         out["modes"] = extra

@@ -261,13 +261,14 @@ int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int64_t* step_d
 
 /* --- opt-in: the loss every k-th step only ("or every k steps in perf mode") -----------------------------
  * The reference's loop takes the loss of EVERY step from `svi.step` (velocity_inference_model.py:118-121); that stays the default
- * (k = 1).  With phi_xy, nu, delta nu and shape_inv conditioned (the tutorials' velocity stage) the likelihood kernel's two
- * logarithms per element serve the loss VALUE only: vc_set_loss_every(e, k > 1) lets the launches of vc_svi_run_fused run the
- * gradient-only instantiation except at every k-th one (counted from this call: launches 0, k, 2k, ... form the loss).  The loss
- * slots of the other steps hold the prior / guide terms without the likelihood -- the caller must not read them as losses
- * (velocycle_amd reports NaN there).  Gradients of the two instantiations agree to float32 rounding (mu = 2^eta * z instead of
- * 2^(eta + log2 z)), not bit for bit.  VC_ERR_UNSUPPORTED when the configuration has no such instantiation.  vc_svi_step_fused,
- * vc_svi_run_sharded, vc_elbo_grad and vc_svi_run_particles always form the loss. */
+ * (k = 1).  vc_set_loss_every(e, k > 1) lets the launches of vc_svi_run_fused run a gradient-only instantiation of the likelihood
+ * kernel except at every k-th one (counted from this call: launches 0, k, 2k, ... form the loss).  What that instantiation leaves
+ * out is what serves the loss VALUE only: with phi_xy, nu, delta nu and shape_inv conditioned (the tutorials' velocity stage)
+ * both logarithms per element (the gradients then agree with the full kernel's to float32 rounding: mu = 2^eta * z instead of
+ * 2^(eta + log2 z)); with shape_inv learned only log2(z) and the loss accumulations (the same gradient bits).  The loss slots of
+ * the other steps hold the prior / guide terms without the likelihood -- the caller must not read them as losses (velocycle_amd
+ * reports NaN there).  Negative-binomial noise on the compiled fast kernel set; VC_ERR_UNSUPPORTED otherwise.
+ * vc_svi_step_fused, vc_svi_run_sharded, vc_elbo_grad and vc_svi_run_particles always form the loss. */
 int vc_set_loss_every(vc_engine* e, int32_t k);
 
 /* --- Trace_ELBO(num_particles = K) from one call (single rank) -----------------------------------------------------------

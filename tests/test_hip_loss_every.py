@@ -1,8 +1,8 @@
 """GPU: the opt-in `loss_every = k` (vc_set_loss_every; SURVEY.md section 5 "or every k steps in perf mode").  Default k = 1 is the
 reference's behaviour (velocity_inference_model.py:118-121 reads the loss of every step) and everything else in the suite; here:
 the gradient-only instantiation of the U-only kernel steps like the full one (same gradients to float32 rounding: mu is formed
-as 2^eta * z instead of 2^(eta + log2 z)), the loss appears at every k-th step and is NaN in between, and configurations
-without such an instantiation refuse by name."""
+as 2^eta * z instead of 2^(eta + log2 z)), those of the S+U / S-only kernels give the full kernels' gradient bits, the loss
+appears at every k-th step and is NaN in between, and configurations without such an instantiation refuse by name."""
 import math
 
 import numpy as np
@@ -46,18 +46,34 @@ def test_tutorial_flow_with_the_loss_every_kth_step(cells, genes, k):
     assert float(d.median()) <= 1e-5 and float((d <= 2e-3).float().mean()) >= 0.99, (float(d.median()), float(d.max()))
 
 
-def test_loss_every_is_refused_where_no_gradient_only_kernel_exists():
+@pytest.mark.parametrize("mode", ["vjoint", "phase"])
+def test_models_that_learn_shape_inv_keep_their_gradient_bits(mode):
+    """S+U / S-only kernels: log2(r + mu) feeds d / d shape_inv and stays in the gradient-only instantiation; what goes is the
+    loss-only log2(zp) and the two loss accumulations per element -- parameters bit for bit the default run's, losses at every
+    k-th step equal, NaN in between."""
+    from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
+    spec = make_phase_spec(4000, 300, seed=2, device="cuda") if mode == "phase" else make_velocity_spec(4000, 300, "vjoint", 1, 1, seed=2, device="cuda")
+    p1, l1, st1, name = _run(spec, 1, 14)
+    pk, lk, stk, _ = _run(spec, 4, 14)
+    nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+    assert torch.equal(nz(p1), nz(pk)) and st1 == stk == (True, -1, 0)
+    for i, (a, b) in enumerate(zip(l1, lk)):
+        assert (a == b) if i % 4 == 0 else math.isnan(b), (i, a, b)
+
+
+def test_loss_every_is_refused_where_no_gradient_only_kernel_exists(monkeypatch):
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
-    from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
-    for spec in (make_velocity_spec(2000, 200, "vjoint", 1, 1, seed=1, device="cuda"), make_phase_spec(2000, 200, seed=1, device="cuda")):
-        eng = HipEngine(spec)
-        with pytest.raises(NotImplementedError, match="gradient-only"):
-            SVIRunner(eng, OPT, mode="perf", seed=1, loss_every=5)
-        run = SVIRunner(eng, OPT, mode="perf", seed=1)          # the default is untouched
-        run.run_perf(3)
-        assert all(math.isfinite(x) for x in run.perf_losses())
-        eng.close()
+    from velocycle_amd.workloads import make_velocity_spec
+    import dataclasses
+    base = make_velocity_spec(2000, 200, "vjoint", 1, 1, seed=1, device="cuda")
+    eng = HipEngine(dataclasses.replace(base, noisemodel="Poisson"))          # count noise without a dispersion: no such kernel
+    with pytest.raises(NotImplementedError, match="gradient-only"):
+        SVIRunner(eng, OPT, mode="perf", seed=1, loss_every=5)
+    run = SVIRunner(eng, OPT, mode="perf", seed=1)          # the default is untouched
+    run.run_perf(3)
+    assert all(math.isfinite(x) for x in run.perf_losses())
+    eng.close()
     spec = make_velocity_spec(2000, 200, "vcond", 1, 1, seed=1, device="cuda")
     eng = HipEngine(spec)
     run = SVIRunner(eng, OPT, mode="perf", seed=1, loss_every=3)

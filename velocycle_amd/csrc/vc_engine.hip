@@ -860,7 +860,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       if (!d.pw_inline) tile(bpc0);     // off: the tiling of the plain kernel
     }
   }
-  if (!d.generic && d.kind == VC_KIND_VU && d.noise == VC_NOISE_NB) {
+  if (!d.generic && d.noise == VC_NOISE_NB) {
     // the gradient-only twin of the selected kernel (same tiling, same dynamic LDS); used only after vc_set_loss_every(k > 1)
     const void* knl = nullptr;
     e->main_fn_nl = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, d.c16 | 2, &e->main_name_nl, &knl);
@@ -1413,8 +1413,8 @@ extern "C" int vc_set_loss_every(vc_engine* e, int32_t k) {
   if (!e->finalized) return e->fail(VC_ERR_STATE, "vc_set_loss_every before vc_finalize");
   if (k < 1) return e->fail(VC_ERR_ARG, "vc_set_loss_every: k >= 1");
   if (k > 1 && !e->main_fn_nl)
-    return e->fail(VC_ERR_UNSUPPORTED, "vc_set_loss_every: no gradient-only likelihood kernel for this configuration (it exists for the "
-                                       "velocity model with phi_xy, nu, delta nu and shape_inv conditioned, negative-binomial noise, fast kernel set)");
+    return e->fail(VC_ERR_UNSUPPORTED, "vc_set_loss_every: no gradient-only likelihood kernel for this configuration (it exists for "
+                                       "negative-binomial noise on the compiled fast kernel set)");
   e->loss_every = k;
   e->loss_ctr = 0;
   return VC_OK;

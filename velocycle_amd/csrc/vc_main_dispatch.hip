@@ -17,6 +17,10 @@ extern const VcMainEntry vc_tab_vu_nb_u16[30];
 extern const VcMainEntry vc_tab_vu_poisson_u16[30];
 extern const VcMainEntry vc_tab_vu_nb_nl[30];          // gradient-only (c16 | 2)
 extern const VcMainEntry vc_tab_vu_nb_u16_nl[30];
+extern const VcMainEntry vc_tab_vfull_nb_nl[30];
+extern const VcMainEntry vc_tab_vfull_nb_u16_nl[30];
+extern const VcMainEntry vc_tab_phase_nb_nl[30];
+extern const VcMainEntry vc_tab_phase_nb_u16_nl[30];
 
 vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, int c16, const char** name,
                                       const void** kernel) {
@@ -24,10 +28,12 @@ vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gp
                                       vc_tab_vfull_poisson, vc_tab_vfull_lognormal, vc_tab_vu_nb, vc_tab_vu_poisson,
                                       vc_tab_vu_lognormal, vc_tab_phase_nb_u16, vc_tab_phase_poisson_u16,
                                       vc_tab_vfull_nb_u16, vc_tab_vfull_poisson_u16, vc_tab_vu_nb_u16, vc_tab_vu_poisson_u16,
-                                      vc_tab_vu_nb_nl, vc_tab_vu_nb_u16_nl};
+                                      vc_tab_vu_nb_nl, vc_tab_vu_nb_u16_nl, vc_tab_vfull_nb_nl, vc_tab_vfull_nb_u16_nl,
+                                      vc_tab_phase_nb_nl, vc_tab_phase_nb_u16_nl};
   static const char* tab_names[] = {"phase_nb", "phase_poisson", "phase_lognormal", "vfull_nb", "vfull_poisson",
                                     "vfull_lognormal", "vu_nb", "vu_poisson", "vu_lognormal", "phase_nb", "phase_poisson",
-                                    "vfull_nb", "vfull_poisson", "vu_nb", "vu_poisson", "vu_nb_gradonly", "vu_nb_gradonly"};
+                                    "vfull_nb", "vfull_poisson", "vu_nb", "vu_poisson", "vu_nb_gradonly", "vu_nb_gradonly",
+                                    "vfull_nb_gradonly", "vfull_nb_gradonly", "phase_nb_gradonly", "phase_nb_gradonly"};
   for (unsigned t = 0; t < sizeof(tabs) / sizeof(tabs[0]); ++t)
     for (int i = 0; i < 30; ++i) {
       const VcMainEntry& e = tabs[t][i];

@@ -67,15 +67,17 @@
 // C16 (bit 0 of CS): the counts are stored as uint16 (every count of the matrix is an integer <= 65535: decided by vc_finalize from the
 // histograms) -- half the HBM bytes of the reference's float32 storage, one v_cvt_f32_u32 with a WORD_n source select per
 // element; C16 = 0 reads the float32 layout (Lognormal noise stores log(k+1); non-integer or huge counts).
-// CS = C16 | 2 NOLOSS.  NOLOSS (U-only kernel, negative-binomial noise; opt-in through vc_set_loss_every): the gradient alone -- with
+// CS = C16 | 2 NOLOSS.  NOLOSS (negative-binomial noise; opt-in through vc_set_loss_every): the gradient alone.  U-only kernel: with
 // shape_inv conditioned both v_log_f32 per element serve only the loss VALUE, and mu = 2^eta_S * zp needs no log of zp either:
-// 4 of 8 transcendentals and 4 of 21 packed operations per gene pair less (68 -> 52 us at 50k x 2k, profiles/r04_vcond.md);
-// the likelihood part of that step's loss is not formed (the host reports NaN for it).
+// 4 of 8 transcendentals and 4 of 21 packed operations per gene pair less (68 -> 52 us at 50k x 2k, profiles/r04_vcond.md).
+// S+U / S-only kernels (shape_inv learned: log2(r + mu) feeds d / d shape_inv and stays): log2(zp) and the two loss
+// accumulations per element go -- the same gradient bits as the full kernel.  The likelihood part of that step's loss is not
+// formed (the host reports NaN for it).
 template <int H, int NB, int KIND, int NOISE, int GPL, int CS>
 __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB_SINGLE) : 1)) void vc_main_kernel(const VcDims d, const VcBufs b) {
   constexpr int C16 = CS & 1;
   constexpr bool NOLOSS = (CS & 2) != 0;
-  static_assert(!NOLOSS || (KIND == VC_KIND_VU && NOISE == VC_NOISE_NB && VC_RCP_MERGE), "gradient-only: U-only kernel, NB noise");
+  static_assert(!NOLOSS || (NOISE == VC_NOISE_NB && VC_RCP_MERGE), "gradient-only: negative-binomial noise");
   constexpr int GBW = 64 * GPL;
   constexpr int NH = 2 * H + 1;
   constexpr int K = NH + NB;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         if (LN) vc_obs_lognormal(sv[p], es, inv_s2_s, aS, ll[p]);
         else {
           muS = v2_exp2(es2);
-          vc_obs_counts<NOISE>(sv[p], es2, muS, rr[p], aS, ll[p], lt[p]);
+          vc_obs_counts<NOISE, NOLOSS>(sv[p], es2, muS, rr[p], aS, ll[p], lt[p]);
         }
         a += aS;
       }
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           // one reciprocal for 1/t_U and 1/zp: R = 1/(t_U zp), a_U = r (k - mu) zp R, w = a_U m / zp = r (k - mu) m R
           const v2f muU = FULL ? muS * (ib[p] * zp) : (NOLOSS ? v2_exp2(eu2) * zp : v2_exp2(eu2));
           const v2f t = rr[p] + muU;
-          const v2f lt2 = NOLOSS ? v2(0.f) : v2_log2(t);
+          const v2f lt2 = (NOLOSS && !FULL) ? v2(0.f) : v2_log2(t);      // (S+U kernel: sum of log2 t feeds d / d shape_inv)
           const v2f R = v2_rcp(t * zp);
           const v2f num = rr[p] * (uv[p] - muU);
           if (VC_NR_MERGE) {
@@ -334,7 +336,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
             aU = num * (R * zp);
             w = num * (R * m);
           }
-          if (!NOLOSS) { ll[p] = v2_fma(uv[p], eu2 - lt2, ll[p]); lt[p] += lt2; }
+          if (!NOLOSS) ll[p] = v2_fma(uv[p], eu2 - lt2, ll[p]);
+          if (!NOLOSS || FULL) lt[p] += lt2;
         } else {
           const v2f iz = v2_rcp(zp);
           const v2f q = iz * m;                                                 // torch.relu': 0 at z <= 0

@@ -77,14 +77,15 @@ __device__ __forceinline__ v2f v2_rcp(v2f x) { return v2f{__builtin_amdgcn_rcpf(
 //   lt += log2 t              [NB]: sum_c log(r+mu) enters the loss (times r) and d/dr.
 // Nothing else of the NB needs per-element work: sum_c (r+k)/(r+mu) = n + (sum_c a)/r, and the r-only
 // terms (r log r, lgamma) come from the per-gene count histograms (K_pre / K_post).
-template <int NOISE>
+// NOLOSS (gradient-only instantiations, vc_set_loss_every): the terms that enter the loss VALUE only are not formed
+template <int NOISE, bool NOLOSS = false>
 __device__ __forceinline__ void vc_obs_counts(v2f k, v2f eta2, v2f mu, v2f r, v2f& a, v2f& ll, v2f& lt) {
   if (NOISE == VC_NOISE_NB) {
     const v2f t = r + mu;
     const v2f lt2 = v2_log2(t);
     const v2f it = v2_rcp(t);
     a = (r * (k - mu)) * it;
-    ll = v2_fma(k, eta2 - lt2, ll);
+    if (!NOLOSS) ll = v2_fma(k, eta2 - lt2, ll);
     lt += lt2;
   } else {
     a = k - mu;

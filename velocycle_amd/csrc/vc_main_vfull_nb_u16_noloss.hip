@@ -1,0 +1,3 @@
+// Gradient-only instantiations of the likelihood kernel (vc_set_loss_every), uint16 count storage: kind=vfull, noise=nb, H in 1..3, NB in 0..4.
+#include "vc_main_kernel.h"
+VC_DEFINE_TABLE_CS(vc_tab_vfull_nb_u16_nl, VC_KIND_VFULL, VC_NOISE_NB, 3)

