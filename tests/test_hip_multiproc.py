@@ -42,6 +42,11 @@ def test_two_process_bench_matches_single_process():
     assert two.returncode == 0, two.stderr[-2000:]
     j2 = _json_line(two.stdout)
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["steps"] == 30 and j2["scaling"] == "strong"
+    # the fields round 4 added to the line: the step-level fraction next to the kernel-level one, and the OPT-IN measurement under
+    # its own name (never `value`)
+    r1 = j1["roofline"]
+    assert 0 < r1["step_frac"] < r1["frac"] and r1["step_overhead_us"] > 0 and j1["config"]["launches_per_step"] in (2, 3)
+    assert j1["opt_in_loss_every_10"]["steps_per_s"] > 0 and "opt_in_loss_every_10" not in j2
     assert "all-reduce" in j2["config"]["step"] and "cpu_baseline" not in j2
     assert j2["roofline"]["algorithmic_bytes_per_launch"] * 2 == j1["roofline"]["algorithmic_bytes_per_launch"]
     # first loss: the same parameters on both sides, only the order of the cell sums differs; the loss 34 steps later: two
