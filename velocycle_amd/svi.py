@@ -572,8 +572,9 @@ class SVIRunner:
     def _arm_loss_every(self):
         """(Re)starts the engine's count of likelihood launches at the runner's current step: step base + j k forms the loss."""
         if self.loss_every > 1:
-            if self.mode != "perf" or self.adam_impl != "fused3" or self.K != 1:
-                raise ValueError("loss_every > 1 needs the fused single-rank perf-mode step (one particle)")
+            if self.mode != "perf" or self.adam_impl != "fused3" or self.K != 1 or self.use_graph:
+                # (a captured graph would replay whichever kernel its one captured step chose)
+                raise ValueError("loss_every > 1 needs the fused single-rank perf-mode step (one particle, no hipGraph replay)")
             self.e.set_loss_every(self.loss_every)
             self._loss_base = self.step_idx
         elif hasattr(self.e, "set_loss_every") and self.mode == "perf" and self.adam_impl == "fused3":
