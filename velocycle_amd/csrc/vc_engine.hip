@@ -630,7 +630,25 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         const int shard_cells = world > 1 ? (int)((ncg + world - 1) / world) : d.Nc;
         const VcTiling t8 = vc_tile_cells(shard_cells, ngb8, n_cu, bpc8, VC_WAVES, 0, nullptr, 12);
         const int small_cw = d.kind == VC_KIND_VFULL ? 52 : 10;
-        if (t8.cw <= small_cw) d.gpl = 4;
+        // Round 4, S+U kernel on ONE rank: the 8-genes-per-lane kernel can emit the nu_omega partials itself (room in the LDS),
+        // which makes the step two launches instead of three; the 4-genes-per-lane kernel can do that only where a wave has
+        // <= 12 cells (its reduction tiles fill the LDS: profiles/r04_small_shard.md).  Measured at 2 000 genes, 6 250 ... 20 000
+        // cells: K_main + 4-5 us, the step - 1.3 ... - 3.4 us (- 3 ... - 7 %); equal at 25 000.  So: 4 genes per lane only where
+        // that kernel keeps the step at two launches as well.
+        bool two_launch8 = false;
+        if (d.kind == VC_KIND_VFULL && world == 1 && VC_PW_INLINE && d.NW >= 1 && d.NW <= VC_PWQ) {
+          const char* pwe = getenv("VC_PW_INLINE");
+          const char* t2e = getenv("VC_TAIL2");
+          const void* k4 = nullptr;
+          int bpc4 = 0;
+          if (!(pwe && atoi(pwe) == 0) && !(t2e && atoi(t2e) == 0) &&
+              vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 4, 0, nullptr, &k4) && k4 &&
+              hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc4, k4, 256, 0) == hipSuccess && bpc4 >= 1) {
+            const VcTiling t4 = vc_tile_cells(shard_cells, (d.Ng + 255) / 256, n_cu, bpc4, VC_WAVES, 0, nullptr, 12);
+            two_launch8 = t4.cw > 12;
+          }
+        }
+        if (t8.cw <= small_cw && !two_launch8) d.gpl = 4;
       }
     }
   }
