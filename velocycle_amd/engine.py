@@ -286,6 +286,8 @@ class HipEngine:
         """Opt-in (vc_set_loss_every): the fused single-rank runs form the loss at every k-th step only and run the gradient-only
         likelihood kernel in between (NB noise on the fast kernel set; the tutorial flow's velocity stage gains most).  k = 1 restores
         the default.  Raises HipEngineError (VC_ERR_UNSUPPORTED) when the configuration has no gradient-only kernel."""
+        if int(k) == 1 and not hasattr(self.lib, "vc_set_loss_every"):
+            return                       # (an older build of the ABI selected with VC_LIB_PATH + VC_LIB_OLDER=1: it has no period to reset)
         self._check(self.lib.vc_set_loss_every(self._h, C.c_int32(int(k))))
 
     def svi_run_particles(self, grad_acc, m, v, lr, lrd, b1, b2, adam_eps, clip, seed, step_dev, step0, num_particles, n_steps,
