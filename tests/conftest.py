@@ -29,3 +29,16 @@ def _fresh_param_store():
     except Exception:
         pass
     yield
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How often the gradient-block check of tests/helpers.py passed only through its `4 x float32 oracle` clause."""
+    try:
+        from tests import helpers as H
+    except Exception:
+        return
+    st = H.CLAUSE_STATS
+    if st["blocks"]:
+        terminalreporter.write_line(f"assert_step_matches_oracle: {st['blocks']} gradient blocks checked, "
+                                    f"{len(st['by_ref32_clause'])} passed through the 4 x float32-oracle clause only"
+                                    + ("" if not st["by_ref32_clause"] else ": " + ", ".join(f"{n} (err {e:.1e} / float32 oracle {r:.1e} of the block max)" for n, e, r in st["by_ref32_clause"][:12])))

@@ -89,12 +89,17 @@ def problem_arrays(p, prefix="in_"):
     return out
 
 
-def check(a, b, what, rtol=2e-4, atol=2e-4):
+def check(a, b, what, rtol=2e-4, atol=2e-4, block_rtol=0.0):
+    """block_rtol > 0 (medium-size cases): the absolute tolerance is at least block_rtol x the block's largest element -- two
+    float32 evaluations of a sum over hundreds of cells differ by rounding that scales with the sum's terms, not with each
+    (possibly cancelling) result."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     fin = np.isfinite(a) & np.isfinite(b)
+    if block_rtol > 0 and fin.any():
+        atol = max(atol, block_rtol * np.abs(b[fin]).max())
     if not np.array_equal(np.isfinite(a), np.isfinite(b)) or not np.allclose(a[fin], b[fin], rtol=rtol, atol=atol):
         err = np.abs(a[fin] - b[fin]).max() if fin.any() else float("nan")
-        raise SystemExit(f"ORACLE != REFERENCE for {what}: max abs err {err}")
+        raise SystemExit(f"ORACLE != REFERENCE for {what}: max abs err {err} (block max {np.abs(b[fin]).max() if fin.any() else float('nan')})")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -120,6 +125,10 @@ CASES = {
                             model_type="normal", wdn=False),
     "vel_mf_lognormal": dict(kind="velocity", Nc=29, Ng=7, H=1, Hw=1, nb=1, noise="Lognormal",
                              model_type="normal", wdn=False),
+    # a MEDIUM single step: two gene blocks of the 4-genes-per-lane layout, several ragged cell tiles,
+    # two harmonics, two batches with learned offsets, the default LRMN guide -- the toy cases above fit one block and one tile
+    "vel_lrmn_joint_dnu2_med": dict(kind="velocity", Nc=700, Ng=300, H=2, Hw=1, nb=2, noise="NegativeBinomial",
+                                    model_type="lrmn", wdn=True),
 }
 FIT_CASES = {"phase_nb": 25, "vel_mf_joint": 25, "vel_lrmn_cond": 25, "vel_mf_cond": 15}
 
@@ -181,7 +190,7 @@ def make_case(name, c, seed=11):
     o_loss, o_grad, o_val, o_det = orc.loss_and_grads(p32, par32, eps)
     check(o_loss, ref_loss, f"{name}: loss", 1e-5, 1e-3)
     for k in ref_grad:
-        check(o_grad[k], ref_grad[k], f"{name}: grad {k}", 2e-3, 2e-3)
+        check(o_grad[k], ref_grad[k], f"{name}: grad {k}", 2e-3, 2e-3, block_rtol=(2e-5 if c["Nc"] >= 200 else 0.0))
     # float64 oracle values = what the HIP path is compared with
     par64 = {k: v.double() for k, v in par32.items()}
     eps64 = {k: v.double() for k, v in eps.items()}
@@ -503,11 +512,12 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["--particles"]:
         make_particles()
         sys.exit(0)
-    make_basis()
-    make_tutorial_flow()
-    make_preprocess()
-    make_phase_prior()
     only = sys.argv[1:]
+    if not only:
+        make_basis()
+        make_tutorial_flow()
+        make_preprocess()
+        make_phase_prior()
     for nm, c in CASES.items():
         if only and nm not in only:
             continue

@@ -90,5 +90,91 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"oracle_fit_{name}.npz"), **out)
 
 
+def reference_metaparams(name, vc):
+    """The workload of `make_spec(name)` handed to the REFERENCE's own preprocess_for_* through its own containers (tutorial
+    cells 19-21, 38-41): returns (metaparams, condition dict, fit class, kind).  main_reference() proves field by field that
+    the reference's container describes the same problem as the spec the oracle / the HIP engine run on."""
+    from velocycle_amd.anndata_lite import AnnDataLite
+    key, kw, _ = CASES[name]
+    sp = make_spec(name)
+    ad = AnnDataLite(sp.S.t().numpy(), (sp.U if sp.U is not None else sp.S).t().numpy())
+    batch = sp.truth["batch"]
+    ad.obs["batch"] = [f"s{int(b)}" for b in batch]
+    genes = list(ad.var.index)
+    cyc = vc.cycle.Cycle.trivial_prior(gene_names=genes, harmonics=sp.H)
+    cyc.set_means(sp.mu_nu.T.double().numpy())
+    cyc.set_stds(sp.sd_nu.T.double().numpy())
+    ph = vc.phases.Phases.from_array(sp.phixy_prior.T.double().numpy(), cell_names=list(ad.obs.index))
+    Db = vc.preprocessing.make_design_matrix(ad, ids="batch")
+    if name.startswith("phase"):
+        mp = vc.preprocessing.preprocess_for_phase_estimation(ad, cyc, ph, Db, n_harmonics=sp.H, with_delta_nu=False)
+        return mp, {}, vc.phase_inference_model.PhaseFitModel, "phase"
+    nb = sp.Nx
+    spd = vc.angularspeed.AngularSpeed.trivial_prior(condition_names=[f"s{i}" for i in range(nb)], harmonics=sp.Hw)
+    if sp.Hw == 1:
+        spd.stds.loc["nu1_cos"] = [0.05] * nb
+        spd.stds.loc["nu1_sin"] = [0.05] * nb
+    cond = {}
+    if kw["mode"].startswith("vcond"):
+        c = sp.condition_on
+        cond = {"ϕxy": c["ϕxy"].float(), "ν": c["ν"].float().unsqueeze(-2), "shape_inv": c["shape_inv"].float().unsqueeze(-1)}
+        if "Δν" in c:
+            cond["Δν"] = c["Δν"].float().reshape(nb, 1, 1, sp.Ng, 1)
+    cf = sp.count_factor.float()[None, None, :]
+    mp = vc.preprocessing.preprocess_for_velocity_estimation(
+        ad, cyc, ph, spd, Db.float(), Db.float(), n_harmonics=sp.H, ω_n_harmonics=sp.Hw, count_factor=cf,
+        with_delta_nu=sp.with_delta_nu, condition_on=cond, model_type=("lrmn" if sp.guide == "lrmn" else "normal"))
+    return mp, cond, vc.velocity_inference_model.VelocityFitModel, "velocity"
+
+
+def main_reference():
+    """`python tests/golden/make_oracle_fits.py --reference` (build container only: needs /root/reference): the SAME 1 500-step fits
+    run by the reference's own `PhaseFitModel.fit` / `VelocityFitModel.fit` (velocity_inference_model.py:111-187,
+    phase_inference_model.py:162-201; unmodified files from build/lib on oracle/pyro_shim), float32 as the reference computes,
+    `torch.manual_seed(seed)` = the eps stream of the oracle fits -> ref_fitlong_<case>.npz (losses + fitted unconstrained
+    parameters in canonical shapes).  Aborts unless the reference's container and the workload spec describe the same problem."""
+    from oracle.ref_loader import load_reference
+    vc = load_reference()
+    import pyro
+    from tests.golden.make_golden import CANON
+    for name, (key, kw, seed) in CASES.items():
+        mp, cond, FitCls, kind = reference_metaparams(name, vc)
+        spec = make_spec(name)
+        pr = orc.problem_from_metaparams(mp, kind, cond, dtype=torch.float32)
+        ps = H.problem_from_spec(spec, torch.float32)
+        for k, v in ps.__dict__.items():
+            w = getattr(pr, k)
+            if isinstance(v, torch.Tensor):
+                if not torch.allclose(w.reshape(v.shape), v, rtol=1e-6, atol=1e-6):
+                    raise SystemExit(f"{name}: the reference's container differs from the workload spec in {k}: {float((w.reshape(v.shape) - v).abs().max())}")
+            elif k == "condition_on":
+                assert set(v) == set(w), (name, set(v), set(w))
+                for a in v:
+                    assert torch.allclose(pr.cond(a), ps.cond(a), rtol=1e-6, atol=1e-6), (name, a)
+            elif k == "sd_dnu":
+                assert kind == "phase" or float(w) == float(v), (name, k, v, w)
+            elif isinstance(v, float):
+                assert abs(float(w) - v) <= 1e-6 * max(1.0, abs(v)), (name, k, v, w)
+            else:
+                assert w == v, (name, k, v, w)
+        t0 = time.time()
+        fitm = FitCls(mp, condition_on=cond, num_samples=4, n_per_bin=2)
+        pyro.clear_param_store()
+        torch.manual_seed(seed)
+        fitm.fit(pyro.optim.ClippedAdam(dict(OPT)), loss=pyro.infer.Trace_ELBO(num_particles=1), num_steps=N_STEPS, verbose=False)
+        store = pyro.get_param_store()
+        out = {"digest": digest(spec), "seed": seed, "n_steps": N_STEPS, "ref_losses": np.array(fitm.losses, dtype=np.float64)}
+        for pn in store.keys():
+            out["reffit_" + pn] = store.unconstrained(pn).detach().reshape(CANON[pn](pr)).double().numpy()
+        np.savez_compressed(os.path.join(HERE, f"ref_fitlong_{name}.npz"), **out)
+        z = np.load(os.path.join(HERE, f"oracle_fit_{name}.npz"))
+        l32, l64, lr = z["loss32"], z["loss64"], out["ref_losses"]
+        print(name, f"{time.time() - t0:.0f}s", "reference loss", lr[0], "->", lr[-1], "| vs oracle32: first 5", np.abs(lr[:5] / l32[:5] - 1).max(),
+              "max", np.abs(lr / l32 - 1).max(), "median", np.median(np.abs(lr / l32 - 1)), "| oracle32 vs 64 max", np.abs(l32 / l64 - 1).max(), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["--reference"]:
+        main_reference()
+    else:
+        main()

@@ -97,8 +97,21 @@ def assert_step_matches_oracle(eng, spec, eps, loss_rtol=1e-5, grad_rtol=2e-3):
         fin = np.isfinite(want)
         err = np.abs(got.cpu().numpy()[fin] - want[fin]).max()
         ref32 = np.abs(g32[name].numpy().astype(np.float64)[fin] - want[fin]).max()
-        assert err <= max(grad_rtol * max(np.abs(want[fin]).max(), 1e-3), 4 * ref32), (name, err, ref32)
+        strict = grad_rtol * max(np.abs(want[fin]).max(), 1e-3)
+        assert err <= max(strict, 4 * ref32), (name, err, ref32)
+        CLAUSE_STATS["blocks"] += 1
+        if err > strict:
+            # the block passed only because the float32 oracle itself is this far from float64 (the 1 / (z + 1e-5) relu kink):
+            # counted and printed, so that a suite that leans on this clause says so (pytest -s / the summary line of conftest.py)
+            CLAUSE_STATS["by_ref32_clause"].append((name, float(err / max(np.abs(want[fin]).max(), 1e-3)), float(ref32 / max(np.abs(want[fin]).max(), 1e-3))))
+            print(f"[assert_step_matches_oracle] block {name!r} passed through the 4 x float32-oracle clause only: err {err:.3e} "
+                  f"(strict bar {strict:.3e}), float32 oracle's own error {ref32:.3e}")
     return l64, g64
+
+
+# how often assert_step_matches_oracle's second clause (<= 4 x the float32 oracle's own error) was what let a gradient block pass;
+# tests/conftest.py prints the tally at the end of a run
+CLAUSE_STATS = {"blocks": 0, "by_ref32_clause": []}
 
 
 def assert_trajectory_within_float32_spread(spec, opt, n, seed, losses, named_params, snapshots=None):

@@ -50,6 +50,20 @@ def test_converged_parity_fit_matches_the_fp64_oracle_trajectory(name):
     got = {k: v.detach().cpu().numpy() for k, v in eng.named().items()}
     H.assert_params_track_oracle(got, {k: z["par64_" + k] for k in got}, {k: z["par32_" + k] for k in got},
                                  report=f"{name}: final loss rel err {rel_hip[-1]:.2e} (float32 oracle {rel_32[-1]:.2e})")
+    # ... and against the REFERENCE'S OWN fit() of the same problem, seed and optimiser (ref_fitlong_<name>.npz: the unmodified
+    # PhaseFitModel.fit / VelocityFitModel.fit of /root/reference run on oracle/pyro_shim by `make_oracle_fits.py --reference`;
+    # velocity_inference_model.py:111-187, phase_inference_model.py:162-201) -- north_star: "posterior means within 1e-3 rel of
+    # reference".  The reference computes in float32 like the engine; the yardstick for two float32 trajectories is the distance
+    # the reference itself keeps from the float64 trajectory.
+    zr = np.load(os.path.join(H.GOLDEN, f"ref_fitlong_{name}.npz"))
+    assert str(zr["digest"]) == str(z["digest"]) and int(zr["seed"]) == seed and int(zr["n_steps"]) == n
+    lref = zr["ref_losses"]
+    rel_ref, ref_64 = np.abs(losses - lref) / np.abs(lref), np.abs(lref - l64) / np.abs(l64)
+    assert rel_ref[:5].max() <= 1e-5, rel_ref[:5]
+    assert rel_ref.max() <= max(1e-5, 4 * ref_64.max()), (rel_ref.max(), ref_64.max())
+    assert np.median(rel_ref) <= max(1e-6, 4 * np.median(ref_64)), (np.median(rel_ref), np.median(ref_64))
+    H.assert_params_track_oracle(got, {k: zr["reffit_" + k] for k in got}, {k: z["par64_" + k] for k in got},
+                                 report=f"{name} vs the reference's own fit(): final loss rel err {rel_ref[-1]:.2e} (reference vs float64 oracle {ref_64[-1]:.2e})")
     eng.close()
 
 

@@ -93,9 +93,24 @@ def test_two_sample_split_over_two_ranks_equals_single_engine(two_sample):
         # one sum than the shards' cell blocks -- and a gene on the relu kink of ElogU turns such a 1e-7 into per cent of ITS
         # gradient within ten steps: 9e-8 / 9e-8 / 4e-6 / 9e-6 / 4e-6 / 6e-5 / 1e-3 / 1e-4 / 2e-5 / 6e-3 of the largest element
         # were measured step by step; the sharded STEP itself is held against the single-rank step in test_hip_sharded_step.py)
-        tol = 2e-4 if step == 0 else (1e-3 if step <= 5 else 2e-2)
-        scale = float(ref[4:].abs().max())
-        assert float((tot[4:] - ref[4:]).abs().max()) <= tol * max(scale, 1e-3), step
+        # The bar is 5e-3 of the largest element at every step after the first (it had been widened to 2e-2 from
+        # step 6 on).  What exceeds it late in the run is NOT the gradient evaluation but single genes on the relu kink of ElogU
+        # whose parameters have separated between the two float32 trajectories: those elements are named, must be fewer than
+        # 0.1 % of the buffer, and must stay below 2e-2 -- everything else holds 5e-3 (1e-3 up to step 5, 2e-4 at step 0).
+        tol = 2e-4 if step == 0 else (1e-3 if step <= 5 else 5e-3)
+        scale = max(float(ref[4:].abs().max()), 1e-3)
+        dev = (tot[4:] - ref[4:]).abs() / scale
+        over = (dev > tol).nonzero().reshape(-1)
+        if over.numel():
+            assert step > 5, (step, float(dev.max()))
+            where = []
+            for i in over.tolist()[:8]:
+                off = i + 4
+                name = next((n for n, (o, sz) in full.param_slices.items() if o <= off < o + sz), "?")
+                where.append((name, off - full.param_slices[name][0] if name != "?" else off, float(dev[i])))
+            print(f"[two-sample split] step {step}: {over.numel()} of {dev.numel()} gradient elements beyond {tol:g} of the largest "
+                  f"(relu-kink genes of two separated float32 trajectories): {where}")
+            assert over.numel() <= max(1, dev.numel() // 1000) and float(dev.max()) <= 2e-2, (step, over.numel(), float(dev.max()))
         xy = torch.cat([s.view(s.grad, "ϕxy_locs") for s in shards])
         xyf = full.view(full.grad, "ϕxy_locs")
         assert float((xy - xyf).abs().max()) <= tol * max(float(xyf.abs().max()), 1.0), step

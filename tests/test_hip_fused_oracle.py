@@ -81,3 +81,55 @@ def test_fused_philox_run_matches_oracle_on_a_slice_of_the_benchmark_data(mode, 
     spec.condition_on = {k: (v[:n] if k == "ϕxy" else v) for k, v in full.condition_on.items()}
     del full
     _fused_vs_oracle(spec, n=6, seed=0)
+
+
+def test_sharded_sequence_matches_oracle_on_a_slice_of_the_benchmark_data():
+    """The sharded sequence (K_main -> phase A -> exchange -> phase B, world = 2, in-process ranks) on the first 2 000 cells of
+    the 50 000 x 2 000 V-joint benchmark data, replayed step by step by the float64 oracle on the Philox draws it used
+    (the path SCALE runs had only been held against the single-rank step, never against the oracle)."""
+    import copy
+    from velocycle_amd import _lib
+    from velocycle_amd.workloads import make_velocity_spec
+    from tests.test_hip_sharded_step import _Rank, OPT as SOPT
+    full = make_velocity_spec(50000, 2000, "vjoint", 1, 1, seed=0, device="cuda")
+    nc = 2000
+    spec = copy.copy(full)
+    spec.S, spec.U = full.S[:, :nc].contiguous(), full.U[:, :nc].contiguous()
+    spec.count_factor, spec.Db, spec.D = full.count_factor[:nc], full.Db[:, :nc], full.D[:, :nc]
+    spec.phixy_prior = full.phixy_prior[:nc]
+    del full
+    world, n, seed = 2, 6, 0
+    ranks = [_Rank(spec, r, world, seed) for r in range(world)]
+    par0 = {k: v.detach().cpu().clone() for k, v in ranks[0].e.named().items()}
+    par0["ϕxy_locs"] = torch.cat([r.e.view(r.e.params, "ϕxy_locs").detach().cpu() for r in ranks])
+    for t in range(n):
+        for r in ranks:
+            r.call(seed, _lib.VC_PHASE_A, prime=(t == 0))
+        torch.cuda.synchronize()
+        tot = ranks[0].x + ranks[1].x
+        for r in ranks:
+            r.x.copy_(tot)
+            r.call(seed, _lib.VC_PHASE_B)
+    torch.cuda.synchronize()
+    losses = ranks[0].ring[:n].cpu().numpy()
+    got = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in ranks[0].e.named().items()}
+    got["ϕxy_locs"] = torch.cat([r.e.view(r.e.params, "ϕxy_locs").detach().cpu() for r in ranks]).numpy().astype(np.float64)
+    for r in ranks:
+        assert r.e.status() == (True, -1, 0)
+        r.e.close()
+    # the single-engine layout of the same parameters for the independent eps rebuild
+    from velocycle_amd.engine import HipEngine
+    e0 = HipEngine(spec)
+    e0.set_params(par0)
+    flat0 = e0.params.detach().clone()
+    e0.close()
+    opt = {"lr": SOPT["lr"], "lrd": SOPT["lrd"], "betas": (SOPT["b1"], SOPT["b2"])}
+    eps = H.philox_eps_list(spec, flat0, seed, n)
+    l64, par64 = H.oracle_replay(spec, opt, par0, eps, torch.float64)
+    l32, par32 = H.oracle_replay(spec, opt, par0, eps, torch.float32)
+    l64, l32 = np.array(l64), np.array(l32)
+    rel_hip, rel_32 = np.abs(losses - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
+    assert rel_hip[:5].max() <= 1e-5, rel_hip[:5]
+    assert (rel_hip <= np.maximum(1e-5, 4 * np.maximum.accumulate(rel_32))).all(), (rel_hip.max(), rel_32.max())
+    H.assert_params_track_oracle(got, {k: v.numpy() for k, v in par64.items()}, {k: v.double().numpy() for k, v in par32.items()},
+                                 report="sharded world=2, 2000-cell slice")

@@ -127,3 +127,55 @@ def test_sharded_fused_step_medium(mode, ncond, world, monkeypatch):
     for r in ranks:
         r.e.close()
     e1.close()
+
+
+def test_configs3_as_scale_will_run_it_eight_ranks_at_full_size():
+    """BASELINE configs[3] the way the driver's SCALE run executes it: 50 000 cells x 2 000 genes, V-joint,
+    EIGHT ranks of 6 250 cells through vc_svi_run_sharded (K_main -> phase A -> the exchange buffers added in rank order ->
+    phase B), three steps, eight in-process engines on one GPU.  Asserted: the kernel a rank of that run selects (4 genes per
+    lane: the shard-size rule is rank-invariant), three launches per step, replicated parameters / moments / losses
+    bit-identical on all ranks, losses against the single-rank two-launch step to 1e-6, the summed gradient of step 1 against
+    the single rank's (same parameters, same draws: only the association of the per-shard sums differs)."""
+    from velocycle_amd import _lib
+    from velocycle_amd.workloads import make_velocity_spec
+    spec = make_velocity_spec(50000, 2000, "vjoint", n_conditions=1, Hw=1, seed=0, device="cuda")
+    world, n, seed = 8, 3, 11
+    ranks = [_Rank(spec, r, world, seed) for r in range(world)]
+    for r in ranks:
+        assert r.e.Nc_local == 6250 and "gpl4" in r.e.stats["main_kernel"] and "vfull_nb" in r.e.stats["main_kernel"], r.e.stats
+        assert r.e.stats["count_storage"] == "u16" and r.e.stats["pw_inline"] == 0
+        assert r.x.numel() == ranks[0].x.numel()
+    grad1 = None
+    for t in range(n):
+        for r in ranks:
+            r.call(seed, _lib.VC_PHASE_A, prime=(t == 0))
+        torch.cuda.synchronize()
+        tot = ranks[0].x.clone()
+        for r in ranks[1:]:
+            tot += r.x
+        for r in ranks:
+            r.x.copy_(tot)
+            r.call(seed, _lib.VC_PHASE_B)
+        if t == 0:
+            torch.cuda.synchronize()
+            grad1 = ranks[0].e.grad.clone()
+    torch.cuda.synchronize()
+    e1, r1 = _single(spec, n, seed)
+    assert e1.stats["launches_per_step"] == 2 and "gpl8" in e1.stats["main_kernel"]
+    ng = e1.header + e1.n_global
+    for r in ranks[1:]:
+        assert torch.equal(r.e.params[:ng], ranks[0].e.params[:ng])
+        assert torch.equal(r.m[: ng - 4], ranks[0].m[: ng - 4]) and torch.equal(r.v[: ng - 4], ranks[0].v[: ng - 4])
+        assert torch.equal(r.ring[:n], ranks[0].ring[:n]) and int(r.sd.item()) == n
+    l1, lw = np.array(r1.perf_losses()), ranks[0].ring[:n].cpu().numpy()
+    assert np.allclose(lw, l1, rtol=1e-6), np.abs(lw / l1 - 1).max()
+    # the gradient of step 1: a second single engine stopped after one step
+    e2, r2 = _single(spec, 1, seed)
+    _close(grad1[4:ng], e2.grad[4:ng], "summed gradient of step 1 (8 shards vs one rank)", 2e-4, 2e-4 * float(e2.grad[4:ng].abs().max()))
+    xy = torch.cat([r.e.view(r.e.params, "ϕxy_locs") for r in ranks])
+    _close(xy, e1.view(e1.params, "ϕxy_locs"), "phi_xy after 3 steps", 2e-3, 2e-3)
+    _close(ranks[0].e.params[4:ng], e1.params[4:ng], "replicated params after 3 steps", 2e-3, 2e-3)
+    for r in ranks:
+        assert r.e.status() == (True, -1, 0)
+        r.e.close()
+    e1.close(); e2.close()

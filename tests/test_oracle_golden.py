@@ -68,6 +68,32 @@ def test_oracle_continued_fit_matches_reference_fixture(case, scen):
         assert np.allclose(v.numpy()[fin], want[fin], rtol=2e-3, atol=2e-3), k
 
 
+@pytest.mark.parametrize("name", ["vjoint_3000x200", "vcond_3000x200", "vjoint2_1500x200", "phase_3000x200"])
+def test_oracle_long_fit_is_the_references_long_fit(name):
+    """1 500 steps at 3 000 x 200: the float32 oracle trajectory stored in oracle_fit_<name>.npz against the
+    trajectory of the REFERENCE'S OWN fit() on the same data, seed and optimiser (ref_fitlong_<name>.npz, written by
+    `make_oracle_fits.py --reference` from /root/reference's unmodified PhaseFitModel.fit / VelocityFitModel.fit,
+    velocity_inference_model.py:111-187, phase_inference_model.py:162-201).  Both are float32 runs of the same algorithm with
+    differently associated sums: identical to 1e-6 over the first steps, 1e-4 in the typical step; a gene that crosses the relu
+    kink of ElogU makes single steps of EITHER run jump, so the worst step is held to the distance the
+    float32 oracle itself keeps from the float64 one."""
+    import os
+    zo = np.load(os.path.join(H.GOLDEN, f"oracle_fit_{name}.npz"))
+    zr = np.load(os.path.join(H.GOLDEN, f"ref_fitlong_{name}.npz"))
+    assert str(zo["digest"]) == str(zr["digest"]) and int(zo["seed"]) == int(zr["seed"]) and int(zo["n_steps"]) == int(zr["n_steps"])
+    l32, l64, lr = zo["loss32"], zo["loss64"], zr["ref_losses"]
+    rel = np.abs(lr / l32 - 1)
+    assert rel[:5].max() <= 5e-7 and rel[:20].max() <= 1e-5, (rel[:5].max(), rel[:20].max())
+    assert np.median(rel) <= 1e-4, np.median(rel)
+    spread = np.abs(l32 / l64 - 1).max()
+    assert rel.max() <= max(1e-4, 2 * spread), (rel.max(), spread)
+    assert abs(lr[-100:].mean() / l32[-100:].mean() - 1) <= max(1e-5, 2 * abs(l32[-100:].mean() / l64[-100:].mean() - 1))
+    # the reference's fitted posterior means against the float32 oracle's: within the oracle's own float32-vs-float64 spread
+    ref = {k[len("reffit_"):]: zr[k] for k in zr.files if k.startswith("reffit_")}
+    H.assert_params_track_oracle(ref, {k: zo["par64_" + k] for k in ref}, {k: zo["par32_" + k] for k in ref},
+                                 report=f"{name}: reference fit() vs float64 oracle (yardstick: float32 oracle)")
+
+
 def test_oracle_rejects_unknown_noise_model():
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_phase_nb.npz")
     p = H.problem_from_fixture(z)

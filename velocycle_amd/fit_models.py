@@ -32,6 +32,20 @@ from .svi import SVIRunner, optim_args_of
 from .utils import torch_basis, torch_fourier_basis
 
 
+def _perf_seed(seed: int, drawn: int, counter_continues: bool, continues_store: bool) -> int:
+    """Philox key of a perf-mode fit.  The step counter of the runner is Philox step, loss slot and ClippedAdam step in one: a fit
+    that continues from the param store with the SAME optimizer object carries that counter on (a fresh part of the stream
+    (seed, t0 ...): fit(n) + fit(n) == fit(2n)); a continued fit whose counter restarts at 0 -- a new optimizer object, a dict,
+    mixed per-parameter step counts -- would draw (seed, 0 ...) again, the very noise of the fit it continues, whereas Pyro's
+    global RNG keeps advancing.  Such a fit takes a key derived from (seed, perf steps drawn since the store was cleared)."""
+    if counter_continues or not continues_store or drawn <= 0:
+        return int(seed)
+    x = (int(seed) ^ ((int(drawn) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF            # splitmix64 finaliser
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return int((x ^ (x >> 31)) % (2 ** 63))
+
+
 class _FitBase:
     _kind = None
     # The reference's default `loss=Trace_ELBO(...)` object is created once per class and shared by later
@@ -126,7 +140,13 @@ class _FitBase:
                     pass
         else:
             s = int(torch.initial_seed() % (2 ** 63)) if seed is None else int(seed)
+            # (a continued fit whose step counter restarts must not replay the first fit's eps sequence)
+            s = _perf_seed(s, pyro_compat.perf_steps_drawn(), (not plan["mixed"]) and int(plan["t0"]) > 0, bool(plan["values"]))
             s = broadcast_int(s, self._pg, eng.device)
+            if int(loss_every) > 1 and plan["mixed"]:
+                raise ValueError("loss_every > 1 cannot be combined with a fit that continues parameters of DIFFERENT step counts "
+                                 "(the same optimizer object after a phase fit and a velocity fit): that continuation runs the "
+                                 "per-element-step ClippedAdam, not the fused step that has the gradient-only kernel")
             run = SVIRunner(eng, args, mode="perf", seed=s, process_group=self._pg, num_particles=particles,
                             adam_impl="torch" if plan["mixed"] else None, loss_every=int(loss_every))
         self._runner = run
@@ -154,6 +174,8 @@ class _FitBase:
                 elif step > 200 and self.early_exit:
                     early = True
         self.losses = losses
+        if mode == "perf":
+            pyro_compat.add_perf_steps(len(losses))
         torch.cuda.synchronize(eng.device)
         t_svi = time.perf_counter()
         ok, first_bad, n_bad = eng.status()                                     # device-side latch of the C ABI

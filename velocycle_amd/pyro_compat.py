@@ -16,12 +16,27 @@ _RAW: Dict[str, dict] = {}
 _GENERATION = [0]
 
 
+# perf-mode (Philox) SVI steps drawn by fit() calls since the store was last cleared: a fit() that CONTINUES from the store but
+# whose step counter starts at 0 again (a new optimizer object, a dict, mixed step counts) must not replay the noise of the
+# fit it continues -- Pyro draws from a global RNG that keeps advancing (fit_models._perf_seed)
+_PERF_DRAWS = [0]
+
+
 def clear_param_store():
     """`pyro.clear_param_store()`: the next fit() starts from the guides' initial values again, and optimizer objects that
     stepped on the old parameters start afresh on the new ones."""
     _STORE.clear()
     _RAW.clear()
     _GENERATION[0] += 1
+    _PERF_DRAWS[0] = 0
+
+
+def perf_steps_drawn() -> int:
+    return _PERF_DRAWS[0]
+
+
+def add_perf_steps(n: int):
+    _PERF_DRAWS[0] += int(n)
 
 
 def get_param_store():
