@@ -257,7 +257,8 @@ def cpu_baseline(args, mode, device=None):
     def hip_loss(spec, params, eps):
         """-ELBO of the HIP engine (unfused kernel sequence, host eps) on exactly these parameters and draws."""
         from velocycle_amd.engine import HipEngine
-        eng = HipEngine(spec, device=device)
+        from velocycle_amd.tuning import Tuning
+        eng = HipEngine(spec, device=device, tuning=Tuning.from_env())
         eng.set_params({k: v.float() for k, v in params.items()})
         eng.elbo_grad(eps=eng.pack_eps({k: v.float() for k, v in eps.items() if not k.startswith("_")}))
         torch.cuda.synchronize(device)
@@ -450,7 +451,7 @@ def main():
             spec = make_velocity_spec(cells // args.conditions, args.genes, mode, args.conditions, 1, seed=0, device=device)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
-        eng = HipEngine(spec, device=device, rank=rank, world_size=world)
+        eng = HipEngine(spec, device=device, rank=rank, world_size=world, tuning=Tuning.from_env())
         torch.cuda.synchronize(device)
         t2 = time.perf_counter()
         # N > 1: the fused step cut at its one exchange (K_main -> phase A -> sum over ranks -> phase B).  On the nccl backend

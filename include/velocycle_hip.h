@@ -142,6 +142,32 @@ typedef struct vc_config {
   float reserved0;
 } vc_config;
 
+/* Tuning of the engine: DATA handed over by the caller, never ambient state (the library reads no environment variable).
+ * All-zero = the measured defaults of DESIGN.md.  The reference has no counterpart (its "tuning" is the kwargs of
+ * preprocess_for_* and the dict given to ClippedAdam: preprocessing.py:103-122, 207-240); SURVEY.md section 5 asks for "engine
+ * config = plain C struct mirrored by a Python dataclass": this is it (velocycle_amd.tuning.Tuning).  Every rank of a sharded
+ * run must pass the same values (the exchange buffer's layout follows genes_per_lane); the host side checks that. */
+typedef struct vc_tuning {
+  int32_t genes_per_lane;    /* 0: the rule of vc_finalize | 4 | 8 (8 is honoured only where that kernel has no scratch) */
+  int32_t blocks_per_cu;     /* 0: the occupancy the code object reports | n: tile the likelihood kernel for n resident workgroups per CU */
+  int32_t cells_per_wave;    /* 0: one balanced resident round | n: fixed cells per wave (ragged tiles in tests; no pass shares) */
+  int32_t pass_min_cw;       /* cells per wave below which the dispatch passes take equal shares; 0 = 12 */
+  int32_t n_pass_shares;     /* 0: measured defaults | 1: equal shares | 2..4: pass_shares[0..n) (later passes continue the last ratio) */
+  float pass_shares[4];
+  int32_t tail_cells;        /* cells per cell block of the second launch: 0 auto | 256 | 512 | 1024 */
+  int32_t count_storage;     /* 0: uint16 whenever every count is an integer <= 65535 | 1: keep float32 */
+  int32_t host_hist;         /* 1: per-gene count histograms by the host pass (the checker of the device pass) */
+  int32_t hist_dense;        /* histogram form of the negative binomial's lgamma terms: 0 auto | 1 (value, multiplicity) lists | 2 dense tables */
+  int32_t pw_inline;         /* the likelihood kernel's own d loglik / d nu_omega partials: 0 auto | 1 never | 2 even where they cost a resident workgroup */
+  int32_t no_tail2;          /* 1: three launches per single-rank step where two (vc_tail2_kernel) are the default */
+  int32_t no_tail_merged;    /* 1: the tutorial flow without its merged second launch */
+  int32_t force_generic;     /* 1: the run-time-sized kernel set on a configuration the compiled fast set covers */
+  int32_t particles_layout;  /* vc_svi_run_particles: 0 batched (K + 3 launches) | 1 serial | 2 streams */
+  int32_t dense_batches;     /* 1: batch offsets as the dense Db contraction even when Db is one-hot (A/B, tests) */
+  float p2p_timeout_s;       /* bound of the peer-to-peer exchange's wait; 0 = 2 s */
+  int32_t reserved[7];
+} vc_tuning;
+
 typedef struct vc_layout {
   int64_t header;                 /* floats reserved at the front of params/grad (grad[0..1] = loss hi/lo) */
   int64_t n_global;               /* floats of replicated parameters (after the header) */
@@ -178,6 +204,15 @@ int vc_create(const vc_config* cfg, vc_engine** out);
 void vc_destroy(vc_engine* e);
 /* message of the last failing call on `e` (or of the last failing vc_create when e == NULL) */
 const char* vc_last_error(const vc_engine* e);
+
+/* Tuning (optional): after vc_create and before the first vc_set_counts* call; NULL or never calling it = all defaults.
+ * VC_ERR_ARG for a value outside the ranges documented at vc_tuning, VC_ERR_STATE once counts have been handed over. */
+int vc_set_tuning(vc_engine* e, const vc_tuning* t);
+/* The tuning in effect (what vc_set_tuning stored; all-zero if it was never called). */
+int vc_get_tuning(const vc_engine* e, vc_tuning* out);
+/* Builds of the library with -DVC_DBG_TIMES only (profiles/tools): writes the per-wave / per-block time stamps of the last
+ * launches to `path`; VC_ERR_UNSUPPORTED in the product build. */
+int vc_dbg_dump_times(vc_engine* e, const char* path);
 
 /* inputs (call before vc_finalize) ---------------------------------------------------------- */
 /* Count matrices, element (g, c) at ptr[g*gene_stride + c*cell_stride] (so both the reference's
@@ -336,7 +371,7 @@ int vc_comm_allreduce(vc_engine* e, float* buf, int64_t n, void* hip_stream);
  * bits on every rank, no float atomics).  vc_p2p_alloc creates this rank's region and returns its 64-byte hipIpcMemHandle_t;
  * the host side gathers the handles of all ranks in rank order (any transport) and hands the world_size x 64 bytes to
  * vc_p2p_connect (collective in effect: every rank must do it before the first step).  When connected, VC_PHASE_AB uses
- * this exchange instead of RCCL.  A peer that never publishes is detected by a bounded wait (VC_P2P_TIMEOUT_S, default 2 s):
+ * this exchange instead of RCCL.  A peer that never publishes is detected by a bounded wait (vc_tuning.p2p_timeout_s, default 2 s):
  * vc_get_status then returns VC_ERR_STATE.  Opt-in: it has run across processes on one device only. */
 int vc_p2p_alloc(vc_engine* e, void* ipc_handle_out_64_bytes);
 int vc_p2p_connect(vc_engine* e, const void* all_handles_world_x_64_bytes);
@@ -377,7 +412,7 @@ int vc_get_stats(const vc_engine* e, vc_stats* out);
 /* The per-gene count histograms vc_finalize built (CSR over [S genes..., U genes...]: ptr int32[2*Ng + 1], distinct
  * non-zero count values and their multiplicities) -- the sufficient statistic of the negative binomial's lgamma /
  * digamma terms.  Pass NULL arrays to query *n_entries first.  Lets tests hold the device-built histograms against the
- * host pass (VC_HOST_HIST=1). */
+ * host pass (vc_tuning.host_hist). */
 int vc_get_histogram(const vc_engine* e, int64_t* n_entries, int32_t* ptr_out, float* val_out, float* cnt_out);
 /* Failure detection (the reference's counterpart: pyro.util.warn_if_nan(loss, "loss") inside SVI.step, call sites
  * phase_inference_model.py:169 / velocity_inference_model.py:120).  The last kernel of every step checks this rank's

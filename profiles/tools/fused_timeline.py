@@ -8,8 +8,8 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.getcwd())
-os.environ["VC_DBG_TIMES_OUT"] = "/tmp/vc_times.bin"
 from velocycle_amd.engine import HipEngine
+from velocycle_amd.tuning import Tuning
 from velocycle_amd.svi import SVIRunner
 from velocycle_amd.workloads import make_velocity_spec
 
@@ -17,12 +17,13 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "vjoint"
 NC = int(sys.argv[2]) if len(sys.argv) > 2 else 6250
 dev = torch.device("cuda:0")
 spec = make_velocity_spec(NC, 2000, mode, 1, 1, seed=0, device=dev)
-eng = HipEngine(spec, device=dev)
+eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
 nwg = eng.stats["main_grid"]
 run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=0, use_graph=False)
 run.run_perf(30, sync=True)
 ng_blocks = (2000 + 63) // 64 if eng.stats["main_kernel"].endswith("gpl8>") or True else 0
 del run
+eng.dump_dbg_times("/tmp/vc_times.bin")      # (a -DVC_DBG_TIMES build of the library: VC_LIB_PATH)
 eng.close()
 del eng
 raw = np.fromfile("/tmp/vc_times.bin", dtype=np.uint64).astype(np.int64)

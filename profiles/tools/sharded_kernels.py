@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from velocycle_amd.engine import HipEngine  # noqa: E402
+from velocycle_amd.tuning import Tuning
 from velocycle_amd.svi import SVIRunner  # noqa: E402
 from velocycle_amd.workloads import make_velocity_spec  # noqa: E402
 
@@ -18,7 +19,7 @@ dev = torch.device("cuda:0")
 spec = make_velocity_spec(nc, 2000, mode, 1, 1, seed=0, device=dev)
 OPT = {"lr": 0.03, "lrd": 0.9999, "betas": (0.8, 0.99)}
 for kw in (dict(adam_impl="fused3"), dict(adam_impl="sharded", exchange="none", force_reduce=True)):
-    eng = HipEngine(spec, device=dev)
+    eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
     run = SVIRunner(eng, OPT, mode="perf", seed=0, use_graph=False, **kw)
     run.run_perf(1500, sync=True)
     eng.close()

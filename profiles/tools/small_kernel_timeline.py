@@ -1,18 +1,19 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
-os.environ["VC_DBG_TIMES_OUT"] = "/tmp/vc_times.bin"
 from velocycle_amd.engine import HipEngine
+from velocycle_amd.tuning import Tuning
 from velocycle_amd.svi import SVIRunner
 from velocycle_amd.workloads import make_velocity_spec
 mode = sys.argv[1] if len(sys.argv) > 1 else "vcond"
 NC = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 dev = torch.device("cuda:0")
 spec = make_velocity_spec(NC, 2000, mode, 1, 1, seed=0, device=dev)
-eng = HipEngine(spec, device=dev)
+eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
 st = eng.stats
 run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=0, use_graph=False)
 run.run_perf(20, sync=True)
 nwg = st["main_grid"]
+eng.dump_dbg_times("/tmp/vc_times.bin")      # (a -DVC_DBG_TIMES build of the library: VC_LIB_PATH)
 del run; eng.close(); del eng
 raw = np.fromfile("/tmp/vc_times.bin", dtype=np.uint64).astype(np.int64)
 main = raw[: nwg * 32].reshape(-1, 8)

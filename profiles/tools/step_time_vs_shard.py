@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from velocycle_amd.engine import HipEngine  # noqa: E402
+from velocycle_amd.tuning import Tuning
 from velocycle_amd.svi import SVIRunner  # noqa: E402
 from velocycle_amd.workloads import make_velocity_spec  # noqa: E402
 
@@ -62,7 +63,7 @@ for n_ranks, nc in ((8, 6250), (4, 12500), (2, 25000), (1, 50000)):
                      ("sharded_fused_engine_rccl", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="engine")),
                      ("sharded_fused_no_exchange", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="none"))]
     for name, kw in variants:
-        eng = HipEngine(spec, device=dev)
+        eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
         run = SVIRunner(eng, OPT, mode="perf", seed=0, **kw)
         row[name] = round(timed(run), 2)
         if name == "fused_3_launches":

@@ -10,8 +10,8 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.getcwd())
-os.environ["VC_DBG_TIMES_OUT"] = "/tmp/vc_times.bin"
 from velocycle_amd.engine import HipEngine
+from velocycle_amd.tuning import Tuning
 from velocycle_amd.svi import SVIRunner
 from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
 
@@ -20,12 +20,13 @@ NC = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 NG = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 dev = torch.device("cuda:0")
 spec = make_phase_spec(NC, NG, seed=0, device=dev) if mode == "phase" else make_velocity_spec(NC, NG, mode, 1, 1, seed=0, device=dev)
-eng = HipEngine(spec, device=dev)
+eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
 nwg = eng.stats["main_grid"]
 print(mode, NC, NG, eng.stats["main_kernel"], "launches per step", eng.stats["launches_per_step"], "pw_inline", eng.stats["pw_inline"])
 run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=0, use_graph=False)
 run.run_perf(60, sync=True)
 del run
+eng.dump_dbg_times("/tmp/vc_times.bin")      # (a -DVC_DBG_TIMES build of the library: VC_LIB_PATH)
 eng.close()
 del eng
 raw = np.fromfile("/tmp/vc_times.bin", dtype=np.uint64).astype(np.int64)

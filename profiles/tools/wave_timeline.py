@@ -6,21 +6,22 @@ after the epilogue, plus HW_ID / XCC_ID; this prints the distributions and their
 (The tick is nominally 10 ns; on the boxes used it ran ~16 % fast against rocprofv3 durations.)"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
-os.environ["VC_DBG_TIMES_OUT"] = "/tmp/vc_times.bin"
 from velocycle_amd.engine import HipEngine
+from velocycle_amd.tuning import Tuning
 from velocycle_amd.svi import SVIRunner
 from velocycle_amd.workloads import make_velocity_spec
 mode = sys.argv[1] if len(sys.argv) > 1 else "vjoint"
 dev = torch.device("cuda:0")
 NC = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
 spec = make_velocity_spec(NC, 2000, mode, 1, 1, seed=0, device=dev)
-eng = HipEngine(spec, device=dev)
+eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
 run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=0, use_graph=False)
 run.run_perf(int(os.environ.get("VC_TIMELINE_STEPS", "600")), sync=True)      # long enough for the clocks to settle (the first ~30 ms run slower)
 grid = int(eng.stats["main_grid"])
 print("kernel", eng.stats["main_kernel"], "grid", grid)
 del run
-eng.close() if hasattr(eng, "close") else None
+eng.dump_dbg_times("/tmp/vc_times.bin")      # (a -DVC_DBG_TIMES build of the library: VC_LIB_PATH)
+eng.close()
 del eng
 import gc; gc.collect()
 raw = np.fromfile("/tmp/vc_times.bin", dtype=np.uint64)[: grid * 32].reshape(-1, 8).astype(np.int64)   # the small kernels' stamps follow

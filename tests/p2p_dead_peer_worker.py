@@ -22,11 +22,12 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend="gloo")
     from velocycle_amd.engine import HipEngine, HipEngineError
+    from velocycle_amd.tuning import Tuning
     from velocycle_amd.svi import SVIRunner
     from velocycle_amd.workloads import make_velocity_spec
 
     spec = make_velocity_spec(3000, 200, "vjoint", 1, 1, seed=3, device=device)
-    eng = HipEngine(spec, device=device, rank=rank, world_size=world)
+    eng = HipEngine(spec, device=device, rank=rank, world_size=world, tuning=Tuning.from_env())
     run = SVIRunner(eng, {"lr": 0.03, "lrd": 0.9999, "betas": (0.8, 0.99)}, mode="perf", seed=5, exchange="p2p")
     assert run.exchange == "p2p"
     run.run_perf(6, sync=True)

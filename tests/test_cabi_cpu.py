@@ -89,3 +89,42 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
+
+
+def test_tuning_is_data_not_environment(monkeypatch):
+    """the library reads no environment variable (no getenv in csrc/), the package reads none for tuning outside
+    Tuning.from_env(), the ctypes mirror of vc_tuning has the header's layout, and the defaults are all-zero."""
+    import ctypes as C
+    import glob
+    import re
+    from velocycle_amd import _lib
+    from velocycle_amd.tuning import Tuning
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, "velocycle_amd", "csrc", "*.h*")):
+        assert "getenv" not in open(f).read(), f
+    for f in glob.glob(os.path.join(root, "velocycle_amd", "*.py")):
+        src = open(f).read()
+        if os.path.basename(f) in ("tuning.py", "_lib.py"):
+            continue
+        assert "os.environ" not in src and "getenv" not in src, f
+    hdr = open(os.path.join(root, "include", "velocycle_hip.h")).read()
+    body = hdr[hdr.index("typedef struct vc_tuning {"):hdr.index("} vc_tuning;")]
+    names = re.findall(r"^\s*(?:int32_t|float)\s+(\w+)(?:\[\d+\])?;", body, flags=re.M)
+    assert names == [n for n, _ in _lib.vc_tuning._fields_], (names, [n for n, _ in _lib.vc_tuning._fields_])
+    assert C.sizeof(_lib.vc_tuning) == 4 * (5 + 4 + 10 + 1 + 7)
+    assert bytes(Tuning().to_c()) == bytes(C.sizeof(_lib.vc_tuning))
+    # from_env is explicit and complete: every knob the A/B scripts used to export
+    env = {"VC_GPL": "4", "VC_PASS_SHARES": "0.5:0.3:0.2", "VC_TAIL_TC": "512", "VC_COUNT_STORAGE": "f32", "VC_HIST_DENSE": "0",
+           "VC_PW_INLINE": "2", "VC_TAIL2": "0", "VC_FORCE_GENERIC": "1", "VC_PARTICLES_LAYOUT": "streams", "VC_EXCHANGE": "p2p",
+           "VC_RUN_DEADLINE_S": "3", "VC_ADAM_IMPL_DIST": "hip", "VC_P2P_TIMEOUT_S": "1.5", "VC_DENSE_BATCHES": "1"}
+    t = Tuning.from_env(env)
+    assert (t.genes_per_lane, t.pass_shares, t.tail_cells, t.count_storage, t.hist_dense, t.pw_inline, t.tail2, t.force_generic,
+            t.particles_layout, t.exchange, t.run_deadline_s, t.adam_impl_dist, t.p2p_timeout_s, t.dense_batches) == \
+        (4, (0.5, 0.3, 0.2), 512, "f32", "lists", "force", False, True, "streams", "p2p", 3.0, "hip", 1.5, True)
+    c = t.to_c()
+    assert (c.genes_per_lane, c.n_pass_shares, c.tail_cells, c.count_storage, c.hist_dense, c.pw_inline, c.no_tail2, c.force_generic,
+            c.particles_layout, c.dense_batches) == (4, 3, 512, 1, 1, 2, 1, 1, 2, 1)
+    assert Tuning.from_env({}) == Tuning() and Tuning().digest() != t.digest() and t.digest() == Tuning.from_env(env).digest()
+    # an ambient variable changes nothing by itself
+    monkeypatch.setenv("VC_GPL", "4")
+    assert Tuning() == Tuning.from_env({})

@@ -18,7 +18,7 @@ def spec():
     return make_velocity_spec(NC, NG, "vjoint", n_conditions=1, Hw=1, seed=0, device="cuda")
 
 
-def _run(spec, seed=5, step=2, **kw):
+def _run(spec, seed=5, step=2, **kw):      # kw: rank / world_size / tuning of the engine
     from velocycle_amd.engine import HipEngine
     e = HipEngine(spec, **kw)
     e.init_params()
@@ -50,11 +50,11 @@ def test_full_size_shard_additivity_and_determinism(spec):
     full.close()
 
 
-def test_full_size_layout_invariance(spec, monkeypatch):
+def test_full_size_layout_invariance(spec):
+    from velocycle_amd.tuning import Tuning
     res = []
     for gpl in (4, 8):
-        monkeypatch.setenv("VC_GPL", str(gpl))
-        e = _run(spec)
+        e = _run(spec, tuning=Tuning(genes_per_lane=gpl))
         assert f"gpl{gpl}" in e.stats["main_kernel"]
         res.append((e.loss(), e.grad.double().cpu()))
         e.close()

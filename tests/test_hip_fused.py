@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 OPT = {"lr": 0.03, "lrd": 0.995, "betas": (0.8, 0.99)}
 
 
-def _run(spec, impl, n, use_graph, seed=7):
+def _run(spec, impl, n, use_graph, seed=7, tuning=None):
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
-    e = HipEngine(spec)
+    e = HipEngine(spec, tuning=tuning)
     r = SVIRunner(e, OPT, mode="perf", seed=seed, use_graph=use_graph, adam_impl=impl)
     r.run_perf(n)
     out = dict(p=e.params.clone().cpu(), l=np.array(r.perf_losses()), m=r.opt.m.clone().cpu(), v=r.opt.v.clone().cpu(),
@@ -55,49 +55,47 @@ def test_fused_step_equals_unfused_sequence(case):
 
 
 @pytest.mark.parametrize("mode,ncond", [("vcond", 1), ("vcond", 2), ("vcond_mf", 1)])
-def test_tutorial_flow_two_launch_step_equals_the_three_launch_step(mode, ncond, monkeypatch):
+def test_tutorial_flow_two_launch_step_equals_the_three_launch_step(mode, ncond):
     """Tutorial flow on one rank (U-only kernel, phases / nu / shape_inv conditioned): from the third step of a run on, K_tail's
     gene blocks and K_omega's blocks go out as ONE launch (vc_launch_tail_merged) and K_tail's cell blocks not at all -- the
     partials of d loglik / d nu_omega come from K_main (pw_inline).  The launch structure changes nothing: bit-identical
-    parameters, moments and losses after 25 steps (VC_TAIL_MERGED=0: three launches).  Against the cell blocks' own partial
-    sums (VC_PW_INLINE=0) only the association of one sum over the cells differs: equal to float32 rounding after 2 steps."""
+    parameters, moments and losses after 25 steps (Tuning(tail_merged=False): three launches).  Against the cell blocks' own partial
+    sums (Tuning(pw_inline="off")) only the association of one sum over the cells differs: equal to float32 rounding after 2 steps."""
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.workloads import make_velocity_spec
     spec = make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5)
     e = HipEngine(spec)
     assert e.stats["main_kernel"].startswith("vc_main_kernel<1,") and "vu_" in e.stats["main_kernel"]
     e.close()
+    from velocycle_amd.tuning import Tuning
     two = _run(spec, "fused3", 25, False)
-    monkeypatch.setenv("VC_TAIL_MERGED", "0")
-    three = _run(spec, "fused3", 25, False)
+    three = _run(spec, "fused3", 25, False, tuning=Tuning(tail_merged=False))
     nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
     assert np.array_equal(two["l"], three["l"]) and torch.equal(nz(two["p"]), nz(three["p"]))
     assert torch.equal(nz(two["m"]), nz(three["m"])) and torch.equal(nz(two["v"]), nz(three["v"]))
     assert two["sd"] == 25 and two["status"][0]
-    monkeypatch.delenv("VC_TAIL_MERGED")
     a = _run(spec, "fused3", 2, False)
-    monkeypatch.setenv("VC_PW_INLINE", "0")
-    b = _run(spec, "fused3", 2, False)
+    b = _run(spec, "fused3", 2, False, tuning=Tuning(pw_inline="off"))
     assert np.allclose(a["l"], b["l"], rtol=2e-7, atol=0)
     _same(a["p"], b["p"], "params after 2 steps", rtol=2e-6, atol=2e-7)
     _same(a["g"][4:], b["g"][4:], "gradient of step 2", rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("mode,ncond,cw", [("vjoint", 1, "37"), ("vcond", 2, None), ("vjoint", 2, "29"), ("vcond_mf", 1, None)])
-def test_fused_step_medium_sizes(mode, ncond, cw, monkeypatch):
+def test_fused_step_medium_sizes(mode, ncond, cw):
     """3001 (x n_conditions) cells x 300 genes: several gene blocks, many cell blocks, ragged tails, Nx = Nb = 2."""
+    from velocycle_amd.tuning import Tuning
     from velocycle_amd.workloads import make_velocity_spec
-    if cw:
-        monkeypatch.setenv("VC_CELLS_PER_WAVE", cw)
+    tun = Tuning(cells_per_wave=int(cw)) if cw else None
     spec = make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5)
     # two steps: nothing but reassociation can differ yet -> tight; twelve steps: the optimiser has amplified that rounding
     # where gradients pass through zero (same yardstick as the float32-vs-float64 trajectory tests) -> loose
-    ref, got = _run(spec, "hip", 2, False), _run(spec, "fused3", 2, False)
+    ref, got = _run(spec, "hip", 2, False, tuning=tun), _run(spec, "fused3", 2, False, tuning=tun)
     assert np.allclose(got["l"], ref["l"], rtol=2e-7, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
     _same(got["p"], ref["p"], "params after 2 steps", rtol=2e-6, atol=2e-7)
     _same(got["m"], ref["m"], "exp_avg after 2 steps", rtol=1e-5, atol=1e-6)
     _same(got["g"][4:], ref["g"][4:], "gradient of step 2", rtol=1e-5, atol=1e-5)
-    ref, got = _run(spec, "hip", 12, False), _run(spec, "fused3", 12, True)
+    ref, got = _run(spec, "hip", 12, False, tuning=tun), _run(spec, "fused3", 12, True, tuning=tun)
     assert np.allclose(got["l"], ref["l"], rtol=1e-6, atol=0), np.abs(got["l"] / ref["l"] - 1).max()
     _same(got["p"], ref["p"], "params", rtol=1e-3, atol=1e-4)
     _same(got["m"], ref["m"], "exp_avg", rtol=2e-3, atol=2e-3)
@@ -216,14 +214,13 @@ def test_step_with_loss_equals_the_device_ring(mode):
 
 
 @pytest.mark.parametrize("mode", ["vjoint", "vcond"])
-def test_fused_step_with_large_shard_cell_blocks(mode, monkeypatch):
+def test_fused_step_with_large_shard_cell_blocks(mode):
     """K_tail's cell blocks take 1024 instead of 256 cells on shards above 160 000 cells (all 16 waves of the block busy);
     forced here at a small size: same steps as the unfused sequence."""
+    from velocycle_amd.tuning import Tuning
     from velocycle_amd.workloads import make_velocity_spec
-    monkeypatch.setenv("VC_TAIL_TC", "1024")
     spec = make_velocity_spec(2600, 200, mode, 2, 1, seed=9)
-    a = _run(spec, "fused3", 6, False)
-    monkeypatch.delenv("VC_TAIL_TC")
+    a = _run(spec, "fused3", 6, False, tuning=Tuning(tail_cells=1024))
     b = _run(spec, "fused", 6, False)
     assert a["sd"] == b["sd"] == 6 and a["status"][0] and b["status"][0]
     assert np.allclose(a["l"], b["l"], rtol=2e-7, atol=0)
@@ -240,64 +237,57 @@ def _bits_equal(a, b, what):
 
 
 @pytest.mark.parametrize("case", H.STEP_CASES)
-def test_two_launch_step_equals_three_launch_step_on_the_fixtures(case, monkeypatch):
+def test_two_launch_step_equals_three_launch_step_on_the_fixtures(case):
     """Round 4: every single-rank step in TWO launches (vc_launch_tail2: K_tail's gene blocks, its cell blocks with the nu_omega
     chain inside on K_main's own partials, the loss block, the histogram blocks re-deriving the shape_inv update, the eps
     blocks -- side by side).  The launch structure changes nothing: parameters, moments, gradients AND losses bit for bit equal
-    to the three-launch step (VC_TAIL2=0) after 15 steps, on every model / guide / noise / conditioning of the step fixtures."""
+    to the three-launch step (Tuning(tail2=False)) after 15 steps, on every model / guide / noise / conditioning of the step fixtures."""
     from velocycle_amd.engine import HipEngine
+    from velocycle_amd.tuning import Tuning
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
     spec = H.spec_from_fixture(z)
     # like with like: the dense histogram tables are the default only where the one-launch tail runs; here both launch
     # structures evaluate them (the four-wave and the sixteen-wave blocks add the same slices in the same order)
-    monkeypatch.setenv("VC_HIST_DENSE", "1")
-    e = HipEngine(spec)
+    t2 = Tuning(hist_dense="dense")
+    t3 = t2.replace(tail2=False, tail_merged=False)
+    e = HipEngine(spec, tuning=t2)
     assert e.stats["launches_per_step"] == 2, e.stats          # every fixture is small enough for K_main's own partials
     e.close()
-    two = _run(spec, "fused3", 15, False)
-    monkeypatch.setenv("VC_TAIL2", "0")
-    monkeypatch.setenv("VC_TAIL_MERGED", "0")
-    e = HipEngine(spec)
+    two = _run(spec, "fused3", 15, False, tuning=t2)
+    e = HipEngine(spec, tuning=t3)
     assert e.stats["launches_per_step"] == 3
     e.close()
-    three = _run(spec, "fused3", 15, False)
+    three = _run(spec, "fused3", 15, False, tuning=t3)
     _bits_equal(two, three, case)
 
 
 @pytest.mark.parametrize("mode,ncond,cw,tc", [("vjoint", 1, "37", None), ("vjoint", 2, "29", None), ("phase", 1, "41", None),
                                               ("vjoint", 1, None, "1024"), ("phase", 1, None, "1024"), ("vjoint", 2, None, None)])
-def test_two_launch_step_medium_sizes(mode, ncond, cw, tc, monkeypatch):
+def test_two_launch_step_medium_sizes(mode, ncond, cw, tc):
     """The same at 3001 (x n_conditions) cells x 300 genes -- several gene blocks, many cell blocks, ragged tiles, two samples
     (6 angular-speed coefficients: rows of 8 floats), 1024-cell blocks -- over 25 steps, and through a hipGraph replay."""
     from velocycle_amd.engine import HipEngine
+    from velocycle_amd.tuning import Tuning
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
-    if cw:
-        monkeypatch.setenv("VC_CELLS_PER_WAVE", cw)
-    if tc:
-        monkeypatch.setenv("VC_TAIL_TC", tc)
     # K_main's own nu_omega partials even where they cost the 4-genes-per-lane S+U kernel a resident workgroup (the engine
     # declines that trade above 12 cells per wave: profiles/r04_small_shard.md), and the dense histogram tables on both sides
-    monkeypatch.setenv("VC_PW_INLINE", "2")
-    monkeypatch.setenv("VC_HIST_DENSE", "1")
+    t2 = Tuning(cells_per_wave=int(cw) if cw else 0, tail_cells=int(tc) if tc else 0, pw_inline="force", hist_dense="dense")
     spec = make_phase_spec(3001, 300, seed=5) if mode == "phase" else make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5)
-    e = HipEngine(spec)
+    e = HipEngine(spec, tuning=t2)
     assert e.stats["launches_per_step"] == 2 and (mode == "phase" or e.stats["pw_inline"] == (4 if ncond == 1 else 8)), e.stats
     e.close()
-    two = _run(spec, "fused3", 25, False)
-    two_g = _run(spec, "fused3", 25, True)
-    monkeypatch.setenv("VC_TAIL2", "0")
-    three = _run(spec, "fused3", 25, False)
+    two = _run(spec, "fused3", 25, False, tuning=t2)
+    two_g = _run(spec, "fused3", 25, True, tuning=t2)
+    three = _run(spec, "fused3", 25, False, tuning=t2.replace(tail2=False))
     _bits_equal(two, three, f"{mode} x{ncond}")
     _bits_equal(two_g, three, f"{mode} x{ncond} (graph)")
     if mode != "phase":
-        # ... and against the cell blocks' own partial sums of d loglik / d nu_omega (VC_PW_INLINE=0: three launches, nothing
+        # ... and against the cell blocks' own partial sums of d loglik / d nu_omega (pw_inline="off": three launches, nothing
         # from K_main): only the association of one sum over the cells differs -- float32 rounding after 2 steps
-        monkeypatch.delenv("VC_TAIL2")
-        a = _run(spec, "fused3", 2, False)
-        monkeypatch.setenv("VC_PW_INLINE", "0")
-        b = _run(spec, "fused3", 2, False)
-        monkeypatch.setenv("VC_HIST_DENSE", "0")      # ... and with the (value, multiplicity) lists instead of the dense tables
-        c = _run(spec, "fused3", 2, False)
+        a = _run(spec, "fused3", 2, False, tuning=t2)
+        b = _run(spec, "fused3", 2, False, tuning=t2.replace(pw_inline="off"))
+        # ... and with the (value, multiplicity) lists instead of the dense tables
+        c = _run(spec, "fused3", 2, False, tuning=t2.replace(pw_inline="off", hist_dense="lists"))
         assert np.allclose(c["l"], b["l"], rtol=5e-7, atol=0)
         _same(c["p"], b["p"], "params after 2 steps, lists vs dense tables", rtol=2e-5, atol=2e-6)
         assert np.allclose(a["l"], b["l"], rtol=2e-7, atol=0)
@@ -312,25 +302,21 @@ def test_two_launch_step_resumes_and_mixes_with_step_with_loss():
     from velocycle_amd.svi import SVIRunner
     from velocycle_amd.workloads import make_velocity_spec
     spec = make_velocity_spec(3001, 300, "vjoint", n_conditions=1, Hw=1, seed=6)
-    import os
-    os.environ["VC_PW_INLINE"] = "2"
-    try:
-        _resume_body(spec)
-    finally:
-        del os.environ["VC_PW_INLINE"]
+    from velocycle_amd.tuning import Tuning
+    _resume_body(spec, Tuning(pw_inline="force"))
 
 
-def _resume_body(spec):
+def _resume_body(spec, tun):
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
-    ref = _run(spec, "fused3", 13, False)
-    e1 = HipEngine(spec)
+    ref = _run(spec, "fused3", 13, False, tuning=tun)
+    e1 = HipEngine(spec, tuning=tun)
     assert e1.stats["launches_per_step"] == 2
     r1 = SVIRunner(e1, OPT, mode="perf", seed=7)
     r1.run_perf(4)
     l = r1.perf_losses() + [r1.step_with_loss() for _ in range(3)]
     sd = r1.state_dict()
-    e2 = HipEngine(spec)
+    e2 = HipEngine(spec, tuning=tun)
     r2 = SVIRunner(e2, OPT, mode="perf", seed=7)
     r2.load_state_dict(sd)
     r2.run_perf(6)

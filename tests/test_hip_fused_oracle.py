@@ -19,10 +19,10 @@ pytestmark = pytest.mark.gpu
 OPT = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / 1000), "betas": (0.80, 0.99)}
 
 
-def _fused_vs_oracle(spec, n, seed, check_params=True, report=None):
+def _fused_vs_oracle(spec, n, seed, check_params=True, report=None, tuning=None):
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
-    eng = HipEngine(spec)
+    eng = HipEngine(spec, tuning=tuning)
     run = SVIRunner(eng, OPT, mode="perf", seed=seed)
     assert run.adam_impl == "fused3" and not run.use_graph          # the path bench.py times
     flat0 = eng.params.detach().clone()
@@ -52,12 +52,13 @@ def test_fused_philox_run_matches_oracle_replay_on_fixtures(case):
 
 
 @pytest.mark.parametrize("mode,ncond,gpl", [("vjoint", 1, 8), ("vjoint", 1, 4), ("vcond", 2, 8), ("vjoint", 2, 4)])
-def test_fused_philox_run_matches_oracle_replay_medium(mode, ncond, gpl, monkeypatch):
+def test_fused_philox_run_matches_oracle_replay_medium(mode, ncond, gpl):
     """3001 (x conditions) cells x 300 genes: two gene blocks, ragged cell tiles, Nx = Nb = 2 with per-batch offsets; the
     8-genes-per-lane kernels (what the full-size benchmark runs; shards this small default to 4) and the 4-genes-per-lane ones."""
+    from velocycle_amd.tuning import Tuning
     from velocycle_amd.workloads import make_velocity_spec
-    monkeypatch.setenv("VC_GPL", str(gpl))
-    _fused_vs_oracle(make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5), n=12, seed=77, report=f"{mode} x{ncond}")
+    _fused_vs_oracle(make_velocity_spec(3001, 300, mode, n_conditions=ncond, Hw=1, seed=5), n=12, seed=77, report=f"{mode} x{ncond}",
+                     tuning=Tuning(genes_per_lane=gpl))
 
 
 def test_fused_philox_run_matches_oracle_replay_phase_medium():
@@ -66,12 +67,13 @@ def test_fused_philox_run_matches_oracle_replay_phase_medium():
 
 
 @pytest.mark.parametrize("mode", ["vjoint", "vcond"])
-def test_fused_philox_run_matches_oracle_on_a_slice_of_the_benchmark_data(mode, monkeypatch):
+def test_fused_philox_run_matches_oracle_on_a_slice_of_the_benchmark_data(mode):
     """The first 2 000 cells of the 50 000 x 2 000 benchmark workload (bench.py's generator and seed): every gene block of
     the full-size launch, the oracle finishes in seconds."""
     import copy
+    from velocycle_amd.tuning import Tuning
     from velocycle_amd.workloads import make_velocity_spec
-    monkeypatch.setenv("VC_GPL", "8")            # the kernel of the full-size launch (a 2 000-cell shard alone would take 4)
+    gpl8 = Tuning(genes_per_lane=8)              # the kernel of the full-size launch (a 2 000-cell shard alone would take 4)
     full = make_velocity_spec(50000, 2000, mode, 1, 1, seed=0, device="cuda")
     n = 2000
     spec = copy.copy(full)
@@ -80,7 +82,7 @@ def test_fused_philox_run_matches_oracle_on_a_slice_of_the_benchmark_data(mode, 
     spec.phixy_prior = full.phixy_prior[:n]
     spec.condition_on = {k: (v[:n] if k == "ϕxy" else v) for k, v in full.condition_on.items()}
     del full
-    _fused_vs_oracle(spec, n=6, seed=0)
+    _fused_vs_oracle(spec, n=6, seed=0, tuning=gpl8)
 
 
 def test_sharded_sequence_matches_oracle_on_a_slice_of_the_benchmark_data():

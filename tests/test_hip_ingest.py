@@ -25,22 +25,22 @@ def _hist_equal(a, b):
     return all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-def _host_checker(spec, monkeypatch, **kw):
-    monkeypatch.setenv("VC_HOST_HIST", "1")
-    e = _mk(spec, **kw)
-    monkeypatch.delenv("VC_HOST_HIST")
+def _host_checker(spec, tuning=None, **kw):
+    from velocycle_amd.tuning import Tuning
+    e = _mk(spec, tuning=(tuning or Tuning()).replace(host_hist=True), **kw)
     assert not e.stats["hist_on_device"]
     return e
 
 
 @pytest.mark.parametrize("case", ["vel_mf_joint", "phase_nb", "vel_lrmn_cond_dnu2", "vel_mf_poisson"])
-def test_device_histograms_equal_host_pass_on_fixtures(case, monkeypatch):
+def test_device_histograms_equal_host_pass_on_fixtures(case):
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
     spec = H.spec_from_fixture(z)
     # like with like: the (value, multiplicity) lists on both sides (the S+U models evaluate the histogram sums from dense
     # tail-count tables by default since round 4 -- another formula for the same numbers: checked at the end)
-    monkeypatch.setenv("VC_HIST_DENSE", "0")
-    dev, host = _mk(spec), _host_checker(spec, monkeypatch)
+    from velocycle_amd.tuning import Tuning
+    lists = Tuning(hist_dense="lists")
+    dev, host = _mk(spec, tuning=lists), _host_checker(spec, lists)
     assert dev.stats["hist_on_device"]
     assert _hist_equal(dev.histogram(), host.histogram())
     for e in (dev, host):
@@ -52,8 +52,7 @@ def test_device_histograms_equal_host_pass_on_fixtures(case, monkeypatch):
     assert torch.equal(torch.nan_to_num(dev.grad[4:]), torch.nan_to_num(host.grad[4:]))
     # dense tail-count tables (sum_j C_j log(r + j), hardware log2 / reciprocal) against the lists (Stirling differences): the
     # same sums to float32 rounding of their terms
-    monkeypatch.setenv("VC_HIST_DENSE", "1")
-    dense = _mk(spec)
+    dense = _mk(spec, tuning=Tuning(hist_dense="dense"))
     dense.init_params() if spec.guide != "lrmn" else dense.init_params(torch.zeros(spec.Ng + spec.Nx * spec.Nhw, spec.rho_rank))
     dense.elbo_grad(eps=None, seed=3, step=1)
     torch.cuda.synchronize()
@@ -78,26 +77,26 @@ def _spiky_spec(on_device):
 
 
 @pytest.mark.parametrize("on_device", [False, True])
-def test_device_histograms_with_overflow_values(on_device, monkeypatch):
+def test_device_histograms_with_overflow_values(on_device):
     spec = _spiky_spec(on_device)
-    dev, host = _mk(spec), _host_checker(spec, monkeypatch)
+    dev, host = _mk(spec), _host_checker(spec)
     hd, hh = dev.histogram(), host.histogram()
     assert _hist_equal(hd, hh) and hd[1].max() >= 2048 and (hd[1] != np.floor(hd[1])).any()
     # two shards: each rank's histograms come from its own cells only
-    a, b = _mk(spec, rank=1, world_size=2), _host_checker(spec, monkeypatch, rank=1, world_size=2)
+    a, b = _mk(spec, rank=1, world_size=2), _host_checker(spec, rank=1, world_size=2)
     assert _hist_equal(a.histogram(), b.histogram()) and not _hist_equal(a.histogram(), hd)
     for e in (dev, host, a, b):
         e.close()
 
 
-def test_device_histograms_full_size(monkeypatch):
+def test_device_histograms_full_size():
     from velocycle_amd.workloads import make_velocity_spec
     spec = make_velocity_spec(50000, 2000, "vjoint", 1, 1, seed=0, device="cuda")
     dev = _mk(spec)
     hd = dev.histogram()
     transient = dev.stats["setup_transient_bytes"]
     dev.close()
-    host = _host_checker(spec, monkeypatch)
+    host = _host_checker(spec)
     assert _hist_equal(hd, host.histogram())
     # histogram tables + overflow lists (+ the float32 layout while its uint16 copy is made): never a copy of the matrix
     # in the caller's layout, never a byte of it back on the host
@@ -176,8 +175,8 @@ def test_invalid_counts_are_refused(bad):
 
 
 @pytest.mark.parametrize("mode", ["vjoint", "vcond", "phase"])
-def test_uint16_count_storage_equals_float32(mode, monkeypatch):
-    """Counts that are integers <= 65535 are stored as uint16 in HBM (half the bytes K_main streams); VC_COUNT_STORAGE=f32
+def test_uint16_count_storage_equals_float32(mode):
+    """Counts that are integers <= 65535 are stored as uint16 in HBM (half the bytes K_main streams); Tuning(count_storage="f32")
     keeps the reference's float32.  Same arithmetic on the same values: loss and every gradient agree to float32 rounding
     of re-scheduled FMAs (observed bit-identical); a matrix with one count > 65535 falls back to float32 by itself."""
     from velocycle_amd.rng import draw_eps
@@ -187,17 +186,15 @@ def test_uint16_count_storage_equals_float32(mode, monkeypatch):
     first = draw_eps(spec, g)
     eps = draw_eps(spec, g)
     res = {}
+    from velocycle_amd.tuning import Tuning
     for storage in ("u16", "f32"):
-        if storage == "f32":
-            monkeypatch.setenv("VC_COUNT_STORAGE", "f32")
-        e = _mk(spec)
+        e = _mk(spec, tuning=Tuning(count_storage="f32" if storage == "f32" else None))
         assert e.stats["count_storage"] == storage and ("u16" in e.stats["main_kernel"]) == (storage == "u16")
         e.init_params(first.get("_cov_factor_draw"))
         e.elbo_grad(eps=e.pack_eps(eps))
         torch.cuda.synchronize()
         res[storage] = (e.loss(), e.grad.clone().cpu(), e.stats["streamed_bytes"])
         e.close()
-    monkeypatch.delenv("VC_COUNT_STORAGE")
     assert res["u16"][2] * 2 == res["f32"][2]
     assert abs(res["u16"][0] - res["f32"][0]) <= 1e-9 * abs(res["f32"][0])
     a, b = torch.nan_to_num(res["u16"][1][4:]).double(), torch.nan_to_num(res["f32"][1][4:]).double()

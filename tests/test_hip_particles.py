@@ -64,10 +64,10 @@ def test_perf_mode_particles_average_the_philox_streams(case):
 
 
 @pytest.mark.parametrize("case", ["vel_mf_joint", "phase_nb", "vel_lrmn_cond"])
-def test_particles_from_one_c_call_equal_the_host_loop(case, monkeypatch):
+def test_particles_from_one_c_call_equal_the_host_loop(case):
     """vc_svi_run_particles (every launch of an n-step, K-particle run enqueued from one C call; the particles' gradients averaged
     by a kernel) against the host loop of K x vc_elbo_grad + PyTorch averaging + vc_clipped_adam it replaces
-    (VC_PARTICLES_HOST_LOOP=1): the same kernels on the same Philox streams -- parameters, moments and losses bit for bit."""
+    (Tuning(particles_host_loop=True)): the same kernels on the same Philox streams -- parameters, moments and losses bit for bit."""
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
     z = H.load_fixture(f"{H.GOLDEN}/ref_fitK3_{case}.npz")
@@ -75,10 +75,9 @@ def test_particles_from_one_c_call_equal_the_host_loop(case, monkeypatch):
     out = []
     # the C call in its three launch layouts (csrc/vc_engine.hip: all particles' K_pre / K_post as one launch each and K_fin +
     # average + ClippedAdam as one = the default; per particle on one stream; per particle on streams of their own), then the host loop
-    for host, layout in (("0", "batched"), ("0", "serial"), ("0", "streams"), ("1", "batched")):
-        monkeypatch.setenv("VC_PARTICLES_HOST_LOOP", host)
-        monkeypatch.setenv("VC_PARTICLES_LAYOUT", layout)
-        eng = HipEngine(spec)
+    from velocycle_amd.tuning import Tuning
+    for host, layout in ((False, "batched"), (False, "serial"), (False, "streams"), (True, "batched")):
+        eng = HipEngine(spec, tuning=Tuning(particles_host_loop=host, particles_layout=layout))
         run = SVIRunner(eng, _opt(z), mode="perf", seed=5, num_particles=3)
         run.run_perf(4)
         run.run_perf(5)
@@ -92,18 +91,17 @@ def test_particles_from_one_c_call_equal_the_host_loop(case, monkeypatch):
         assert a[3] == b[3] and len(a[3]) == 9 and a[4] == b[4] == 9 and a[5] == b[5] == 9 and a[6] == b[6] == (True, -1, 0)
 
 
-def test_particles_on_the_run_time_sized_kernel_set(monkeypatch):
-    """The C call on a generic engine (VC_FORCE_GENERIC=1 on a fast-set fixture): the per-particle launch layout on the generic
+def test_particles_on_the_run_time_sized_kernel_set():
+    """The C call on a generic engine (Tuning(force_generic=True) on a fast-set fixture): the per-particle launch layout on the generic
     kernels, again bit for bit the host loop -- and a change of K on the same engine (the particle workspaces grow)."""
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import SVIRunner
     z = H.load_fixture(f"{H.GOLDEN}/ref_fitK3_vel_mf_joint.npz")
     spec = H.spec_from_fixture(z)
-    monkeypatch.setenv("VC_FORCE_GENERIC", "1")
+    from velocycle_amd.tuning import Tuning
     out = []
-    for host in ("0", "1"):
-        monkeypatch.setenv("VC_PARTICLES_HOST_LOOP", host)
-        eng = HipEngine(spec)
+    for host in (False, True):
+        eng = HipEngine(spec, tuning=Tuning(force_generic=True, particles_host_loop=host))
         assert eng.stats["generic"]
         run = SVIRunner(eng, _opt(z), mode="perf", seed=5, num_particles=2)
         run.run_perf(3)

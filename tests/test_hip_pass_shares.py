@@ -15,21 +15,11 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _evaluate(spec, eps_seed, shares):
+def _evaluate(spec, eps_seed, shares, **tun):
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.rng import draw_eps
-    old = os.environ.get("VC_PASS_SHARES")
-    try:
-        if shares is None:
-            os.environ.pop("VC_PASS_SHARES", None)
-        else:
-            os.environ["VC_PASS_SHARES"] = shares
-        eng = HipEngine(spec)          # the tiling is fixed at vc_finalize
-    finally:
-        if old is None:
-            os.environ.pop("VC_PASS_SHARES", None)
-        else:
-            os.environ["VC_PASS_SHARES"] = old
+    from velocycle_amd.tuning import Tuning
+    eng = HipEngine(spec, tuning=Tuning(pass_shares=shares, **tun))          # the tiling is fixed at vc_finalize
     g = torch.Generator().manual_seed(eps_seed)
     first = draw_eps(spec, g)
     eng.init_params(first.get("_cov_factor_draw"))
@@ -40,14 +30,14 @@ def _evaluate(spec, eps_seed, shares):
 
 
 @pytest.mark.parametrize("mode", ["vjoint", "vcond", "phase"])
-def test_pass_shares_leave_the_result_alone(mode, monkeypatch):
+def test_pass_shares_leave_the_result_alone(mode):
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
-    monkeypatch.setenv("VC_GPL", "8")          # the multi-pass kernels of the full-size problems (a shard this narrow defaults to 4)
+    gpl8 = dict(genes_per_lane=8)              # the multi-pass kernels of the full-size problems (a shard this narrow defaults to 4)
     if mode == "phase":
         spec = make_phase_spec(40000, 128, seed=21)
     else:
         spec = make_velocity_spec(40000, 128, mode, 1, 1, seed=21)
-    ref, eps = _evaluate(spec, 5, None)
+    ref, eps = _evaluate(spec, 5, None, **gpl8)
     st = ref.stats
     assert st["main_grid"] > 256, st                      # more than one dispatch pass
     pc = st["pass_cells"]
@@ -57,10 +47,10 @@ def test_pass_shares_leave_the_result_alone(mode, monkeypatch):
     H.assert_step_matches_oracle(ref, spec, eps)
     g_ref = {k: v.double().cpu().clone() for k, v in ref.named(ref.grad).items()}
     loss_ref = float(ref.loss())
-    for shares in ("1:1", "0.85:0.15", "0.5:0.3:0.2", "4:3:2:1"):
-        eng, _ = _evaluate(spec, 5, shares)
+    for shares in ((1.0, 1.0), (0.85, 0.15), (0.5, 0.3, 0.2), (4.0, 3.0, 2.0, 1.0)):
+        eng, _ = _evaluate(spec, 5, shares, **gpl8)
         pcs = eng.stats["pass_cells"]
-        assert (pcs[0] == pcs[1]) == (shares == "1:1") and pcs != pc, (shares, pcs)
+        assert (pcs[0] == pcs[1]) == (shares == (1.0, 1.0)) and pcs != pc, (shares, pcs)
         assert abs(float(eng.loss()) - loss_ref) <= 2e-6 * abs(loss_ref), (shares, float(eng.loss()), loss_ref)
         for name, got in eng.named(eng.grad).items():
             want = g_ref[name]
@@ -71,10 +61,10 @@ def test_pass_shares_leave_the_result_alone(mode, monkeypatch):
     ref.close()
 
 
-def test_pass_shares_with_gene_blocks_that_do_not_divide_the_cus(monkeypatch):
+def test_pass_shares_with_gene_blocks_that_do_not_divide_the_cus():
     """1 100 genes = 3 gene blocks: the boundary between two dispatch passes then falls inside a row of chunks (chunk c of
     gene block gb runs in pass (3 c + gb) / CUs), so the gene blocks have different numbers of chunks per pass.  One
-    evaluation against the float64 oracle, and against the balanced tiling selected the old way (VC_CELLS_PER_WAVE), which
+    evaluation against the float64 oracle, and against the balanced tiling selected the old way (Tuning.cells_per_wave), which
     does not go through the share arithmetic at all."""
     from velocycle_amd.workloads import make_velocity_spec
     spec = make_velocity_spec(9000, 1100, "vjoint", 1, 1, seed=23)
@@ -84,9 +74,7 @@ def test_pass_shares_with_gene_blocks_that_do_not_divide_the_cus(monkeypatch):
     H.assert_step_matches_oracle(ref, spec, eps)
     g_ref = {k: v.double().cpu().clone() for k, v in ref.named(ref.grad).items()}
     loss_ref = float(ref.loss())
-    monkeypatch.setenv("VC_CELLS_PER_WAVE", "14")
-    old, _ = _evaluate(spec, 6, None)
-    monkeypatch.delenv("VC_CELLS_PER_WAVE")
+    old, _ = _evaluate(spec, 6, None, cells_per_wave=14)
     assert len(set(old.stats["pass_cells"])) == 1
     assert abs(float(old.loss()) - loss_ref) <= 2e-6 * abs(loss_ref)
     for name, got in old.named(old.grad).items():

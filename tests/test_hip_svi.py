@@ -100,14 +100,13 @@ def test_hip_adam_equals_torch_ops():
 
 @pytest.mark.parametrize("gpl", [4, 8])
 @pytest.mark.parametrize("mode", ["vjoint", "vcond", "vcond_mf"])
-def test_medium_problem_against_oracle(mode, gpl, monkeypatch):
+def test_medium_problem_against_oracle(mode, gpl):
     """3000 cells x 300 genes (two gene blocks, many cell chunks, ragged tails) vs the float64 oracle, on the 4- and on the
     8-genes-per-lane kernels (the engine picks 4 by itself for shards this small, 8 for the full-size benchmark)."""
     from velocycle_amd.workloads import make_velocity_spec
     spec = make_velocity_spec(3001, 300, mode, n_conditions=2, Hw=1, seed=5)
-    monkeypatch.setenv("VC_CELLS_PER_WAVE", "37")
-    monkeypatch.setenv("VC_GPL", str(gpl))
-    eng = _mk(spec)
+    from velocycle_amd.tuning import Tuning
+    eng = _mk(spec, tuning=Tuning(cells_per_wave=37, genes_per_lane=gpl))
     g = torch.Generator().manual_seed(0)
     from velocycle_amd.rng import draw_eps
     first = draw_eps(spec, g)
@@ -278,15 +277,15 @@ def test_trajectory_at_3k_x_200_stays_within_float32_spread_of_the_oracle(mode):
 
 def test_bounded_sync_gives_up_instead_of_hanging(monkeypatch):
     """SVIRunner._bounded_sync (what run_perf / fit() wait with when cells are sharded): a stream that never drains -- here an
-    event whose query is made to say "not yet" forever -- ends in a HipEngineError after VC_RUN_DEADLINE_S, not in a hang."""
+    event whose query is made to say "not yet" forever -- ends in a HipEngineError after Tuning.run_deadline_s, not in a hang."""
     from velocycle_amd.engine import HipEngineError
     from velocycle_amd.svi import SVIRunner
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_vel_mf_joint.npz")
-    e = _mk(H.spec_from_fixture(z))
+    from velocycle_amd.tuning import Tuning
+    e = _mk(H.spec_from_fixture(z), tuning=Tuning(run_deadline_s=0.3))
     r = SVIRunner(e, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=1, adam_impl="sharded", exchange="none")
     r.run_perf(3)                                  # one rank, nothing to wait for: plain synchronise
     r.do_reduce = True                             # ... as a rank of a sharded run waits
-    monkeypatch.setenv("VC_RUN_DEADLINE_S", "0.3")
     monkeypatch.setattr(torch.cuda.Event, "query", lambda self: False)
     import time
     t0 = time.time()
@@ -333,17 +332,14 @@ def test_engine_owned_rccl_exchange_single_rank():
         # the one-time self-check of the engine-owned exchange (first step cut open: phase A -> the buffer summed by the engine's
         # communicator and, on a copy, by torch.distributed -> compared -> phase B), forced on the 1-rank
         # group: verdict "ok", and the run equals the unchecked one bit for bit
-        os.environ["VC_EXCHANGE_CHECK"] = "1"
-        try:
-            e = _mk(spec)
-            r = SVIRunner(e, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=11, force_reduce=True, exchange="engine")
-            r.run_perf(10)
-            assert r.exchange_check == "ok" and r.exchange == "engine"
-            nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
-            assert torch.equal(nz(e.params.cpu()), nz(outs[0][0])) and r.perf_losses() == outs[0][1]
-            e.close()
-        finally:
-            del os.environ["VC_EXCHANGE_CHECK"]
+        from velocycle_amd.tuning import Tuning
+        e = _mk(spec, tuning=Tuning(exchange_check=True))
+        r = SVIRunner(e, {"lr": 0.03, "lrd": 0.999, "betas": (0.8, 0.99)}, mode="perf", seed=11, force_reduce=True, exchange="engine")
+        r.run_perf(10)
+        assert r.exchange_check == "ok" and r.exchange == "engine"
+        nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+        assert torch.equal(nz(e.params.cpu()), nz(outs[0][0])) and r.perf_losses() == outs[0][1]
+        e.close()
         a, b = outs[0][0].double().numpy(), outs[1][0].double().numpy()
         fin = np.isfinite(b)
         assert np.array_equal(np.isfinite(a), fin) and np.allclose(a[fin], b[fin], rtol=2e-5, atol=2e-6), np.abs(a[fin] - b[fin]).max()

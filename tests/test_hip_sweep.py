@@ -46,11 +46,11 @@ def _problem(kind, guide, noise, H, Hw, Nb, Nx, cond_sites, Nc, Ng, seed):
     return p
 
 
-def _check(p, gpl=None, monkeypatch=None):
+def _check(p, gpl=None, tuning=None):
     from tests.helpers import spec_from_problem
     from velocycle_amd.engine import HipEngine
-    if gpl is not None:
-        monkeypatch.setenv("VC_GPL", str(gpl))
+    from velocycle_amd.tuning import Tuning
+    tuning = (tuning or Tuning()).replace(genes_per_lane=gpl or 0)
     gen = torch.Generator().manual_seed(1)
     first = orc.draw_eps(p, gen)
     eps = orc.draw_eps(p, gen)
@@ -58,7 +58,7 @@ def _check(p, gpl=None, monkeypatch=None):
     for k in par:                                   # move off the prior means so that every term is exercised
         if torch.isfinite(par[k]).all():
             par[k] = par[k] + 0.05 * torch.randn(par[k].shape, generator=gen, dtype=torch.float64)
-    eng = HipEngine(spec_from_problem(p))
+    eng = HipEngine(spec_from_problem(p), tuning=tuning)
     eng.set_params({k: v.float() for k, v in par.items()})
     eng.elbo_grad(eps=eng.pack_eps({k: v.float() for k, v in eps.items() if not k.startswith("_")}))
     torch.cuda.synchronize()
@@ -77,65 +77,65 @@ def _check(p, gpl=None, monkeypatch=None):
 
 
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 1, 2, 3, 4))))
-def test_phase_kernels(H, Nb, monkeypatch):
+def test_phase_kernels(H, Nb):
     for noise, gpl in (("NegativeBinomial", 8), ("Poisson", 4), ("Lognormal", None)):
         p = _problem("phase", "meanfield", noise, H, 0, Nb, 0, [], Nc=70 + 13 * H, Ng=9 + Nb, seed=H * 10 + Nb)
-        _check(p, gpl, monkeypatch)
+        _check(p, gpl)
 
 
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 1, 2, 4))))
-def test_velocity_joint_kernels(H, Nb, monkeypatch):
+def test_velocity_joint_kernels(H, Nb):
     for noise, guide, Hw, Nx, gpl in (("NegativeBinomial", "meanfield", 1, 2, 8), ("Poisson", "lrmn", 0, 1, 4),
                                       ("Lognormal", "meanfield", 2, 3, None)):
         p = _problem("velocity", guide, noise, H, Hw, Nb, Nx, [], Nc=90 + 7 * Nb, Ng=7 + H, seed=100 + H * 10 + Nb)
-        k = _check(p, gpl, monkeypatch)
+        k = _check(p, gpl)
         assert "vfull" in k
 
 
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 2, 3))))
-def test_velocity_conditioned_kernels(H, Nb, monkeypatch):
+def test_velocity_conditioned_kernels(H, Nb):
     full = ["ϕxy", "ν", "shape_inv"] + (["Δν"] if Nb else [])
     for noise, guide, Hw, gpl in (("NegativeBinomial", "lrmn", 1, 8), ("NegativeBinomial", "meanfield", 3, 4),
                                   ("Poisson", "lrmn", 0, None), ("Lognormal", "meanfield", 1, None)):
         sites = [s for s in full if not (s == "shape_inv" and noise != "NegativeBinomial")]
         p = _problem("velocity", guide, noise, H, Hw, Nb, 2, sites, Nc=130, Ng=11, seed=200 + H * 10 + Nb)
-        k = _check(p, gpl, monkeypatch)
+        k = _check(p, gpl)
         assert "vu_" in k          # S term hoisted
 
 
 @pytest.mark.parametrize("sites", [["ϕxy"], ["ν"], ["shape_inv"], ["ν", "ϕxy"], ["logγg"], ["logβg", "νω"],
                                    ["rho_real"], ["Δν", "logγg", "logβg", "νω", "rho_real"]])
-def test_partial_conditioning(sites, monkeypatch):
+def test_partial_conditioning(sites):
     for guide in ("meanfield", "lrmn"):
         s = [x for x in sites if not (x == "rho_real" and guide != "lrmn")]
         p = _problem("velocity", guide, "NegativeBinomial", 1, 1, 2, 2, s, Nc=101, Ng=10, seed=7)
-        k = _check(p, None, monkeypatch)
+        k = _check(p, None)
         assert "vfull" in k
 
 
 @pytest.mark.parametrize("Nc,Ng", [(1, 1), (3, 300), (65, 2), (64, 256), (257, 513), (700, 5)])
-def test_ragged_and_tiny_shapes(Nc, Ng, monkeypatch):
+def test_ragged_and_tiny_shapes(Nc, Ng):
     for gpl in (4, 8):
         p = _problem("velocity", "meanfield", "NegativeBinomial", 1, 1, 1, 1, [], Nc=Nc, Ng=Ng, seed=Nc + Ng)
-        _check(p, gpl, monkeypatch)
+        _check(p, gpl)
 
 
 @pytest.mark.parametrize("rank,Nx,Hw", [(1, 1, 0), (3, 2, 1), (8, 3, 2), (8, 9, 3)])
-def test_lrmn_ranks_and_many_speed_coefficients(rank, Nx, Hw, monkeypatch):
+def test_lrmn_ranks_and_many_speed_coefficients(rank, Nx, Hw):
     """LRMN guide with rank 1 / 3 / 8 (the compiled maximum) and up to Nx (2 Hw + 1) = 63 angular-speed coefficients:
     the loops over the low-rank factors and over the nu_omega outputs in K_pre, K_post and K_fin."""
     for sites in ([], ["ϕxy", "ν", "shape_inv"]):
         p = _problem("velocity", "lrmn", "NegativeBinomial", 1, Hw, 0, Nx, sites, Nc=150, Ng=70, seed=300 + rank + Nx)
         p.rho_rank = rank
-        _check(p, None, monkeypatch)
+        _check(p, None)
 
 
 @pytest.mark.parametrize("Ng", [1, 3, 65, 66, 129])
-def test_lrmn_with_a_nearly_empty_last_gene_block(Ng, monkeypatch):
+def test_lrmn_with_a_nearly_empty_last_gene_block(Ng):
     """Fewer real genes in the last 64-gene block than low-rank factors: the eps_W broadcast of K_pre must not depend
     on lanes that belong to padded genes (a cross-lane read after divergence did, caught at rank >= 7 with Ng = 70)."""
     p = _problem("velocity", "lrmn", "NegativeBinomial", 1, 1, 0, 2, [], Nc=90, Ng=Ng, seed=400 + Ng)
-    _check(p, None, monkeypatch)
+    _check(p, None)
 
 
 # ---- outside the compiled fast set: the run-time-sized kernel set (csrc/vc_generic_kernels.hip) -------------------------------
@@ -144,57 +144,57 @@ def test_lrmn_with_a_nearly_empty_last_gene_block(Ng, monkeypatch):
 # velocity_inference_guide.py:91-92); round 3 refused H > 3, > 4 batches, rank > 8 with VC_ERR_UNSUPPORTED.
 
 @pytest.mark.parametrize("H,Nb", [(4, 0), (5, 2), (4, 5), (2, 8), (7, 9)])
-def test_generic_phase_kernels(H, Nb, monkeypatch):
+def test_generic_phase_kernels(H, Nb):
     for noise in ("NegativeBinomial", "Poisson", "Lognormal"):
         p = _problem("phase", "meanfield", noise, H, 0, Nb, 0, [], Nc=70 + 13 * H, Ng=9 + Nb, seed=H * 10 + Nb)
-        k = _check(p, None, monkeypatch)
+        k = _check(p, None)
         assert "generic_phase" in k and "gpl2" in k, k
 
 
 @pytest.mark.parametrize("H,Nb", [(4, 0), (5, 5), (1, 8), (3, 6)])
-def test_generic_velocity_joint_kernels(H, Nb, monkeypatch):
+def test_generic_velocity_joint_kernels(H, Nb):
     for noise, guide, Hw, Nx in (("NegativeBinomial", "meanfield", 1, 2), ("Poisson", "lrmn", 0, 1), ("Lognormal", "meanfield", 4, 3),
                                  ("NegativeBinomial", "lrmn", 2, 2)):
         p = _problem("velocity", guide, noise, H, Hw, Nb, Nx, [], Nc=90 + 7 * Nb, Ng=7 + H, seed=100 + H * 10 + Nb)
-        k = _check(p, None, monkeypatch)
+        k = _check(p, None)
         assert "generic_vfull" in k, k
 
 
 @pytest.mark.parametrize("H,Nb", [(4, 0), (2, 5), (5, 8)])
-def test_generic_velocity_conditioned_kernels(H, Nb, monkeypatch):
+def test_generic_velocity_conditioned_kernels(H, Nb):
     full = ["ϕxy", "ν", "shape_inv"] + (["Δν"] if Nb else [])
     for noise, guide, Hw in (("NegativeBinomial", "lrmn", 1), ("NegativeBinomial", "meanfield", 5), ("Poisson", "lrmn", 0),
                              ("Lognormal", "meanfield", 1)):
         sites = [s for s in full if not (s == "shape_inv" and noise != "NegativeBinomial")]
         p = _problem("velocity", guide, noise, H, Hw, Nb, 2, sites, Nc=130, Ng=11, seed=200 + H * 10 + Nb)
-        k = _check(p, None, monkeypatch)
+        k = _check(p, None)
         assert "generic_vu" in k, k          # S term hoisted by the generic S-only kernel
 
 
 @pytest.mark.parametrize("rank,Nx,Hw", [(12, 2, 1), (9, 1, 0), (16, 3, 2), (5, 10, 3), (12, 13, 3)])
-def test_generic_lrmn_rank_and_speed_coefficients(rank, Nx, Hw, monkeypatch):
+def test_generic_lrmn_rank_and_speed_coefficients(rank, Nx, Hw):
     """LRMN rank above the compiled 8 (the verdict's rank 12), and more than 64 angular-speed coefficients (10 x 7 = 70, 13 x 7 = 91)."""
     for sites in ([], ["ϕxy", "ν", "shape_inv"]):
         p = _problem("velocity", "lrmn", "NegativeBinomial", 1, Hw, 0, Nx, sites, Nc=150, Ng=70, seed=300 + rank + Nx)
         p.rho_rank = rank
-        k = _check(p, None, monkeypatch)
+        k = _check(p, None)
         assert "generic" in k, k
 
 
 @pytest.mark.parametrize("Nc,Ng", [(1, 1), (3, 300), (65, 2), (257, 513)])
-def test_generic_set_on_fast_set_sizes_equals_the_fast_set(Nc, Ng, monkeypatch):
-    """VC_FORCE_GENERIC=1: the run-time-sized kernels on a configuration the fast set covers -- same oracle, same tolerances,
+def test_generic_set_on_fast_set_sizes_equals_the_fast_set(Nc, Ng):
+    """Tuning(force_generic=True): the run-time-sized kernels on a configuration the fast set covers -- same oracle, same tolerances,
     ragged and tiny shapes -- and the two kernel sets against each other."""
     from tests.helpers import spec_from_problem
     from velocycle_amd.engine import HipEngine
     p = _problem("velocity", "lrmn", "NegativeBinomial", 2, 1, 2, 2, [], Nc=Nc, Ng=Ng, seed=Nc + Ng)
-    fast = _check(p, None, monkeypatch)
-    monkeypatch.setenv("VC_FORCE_GENERIC", "1")
-    gen = _check(p, None, monkeypatch)
+    from velocycle_amd.tuning import Tuning
+    fast = _check(p, None)
+    gen = _check(p, None, Tuning(force_generic=True))
     assert "generic" in gen and "generic" not in fast
 
 
-def test_the_fast_instantiations_stay_selected_where_they_exist(monkeypatch):
+def test_the_fast_instantiations_stay_selected_where_they_exist():
     from tests.helpers import spec_from_problem
     from velocycle_amd.engine import HipEngine
     for H, Nb, rank in ((3, 4, 8), (1, 0, 5)):
@@ -205,7 +205,7 @@ def test_the_fast_instantiations_stay_selected_where_they_exist(monkeypatch):
         e.close()
 
 
-def test_generic_set_runs_whole_fits(monkeypatch):
+def test_generic_set_runs_whole_fits():
     """SVIRunner on a generic engine: perf mode picks the unfused kernel sequence by itself (the fused steps exist for the fast
     set only and say so), parity mode follows the float64 oracle's trajectory."""
     from tests.helpers import spec_from_problem

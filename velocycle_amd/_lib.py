@@ -48,6 +48,15 @@ class vc_config(C.Structure):
                 ("reserved0", C.c_float)]
 
 
+class vc_tuning(C.Structure):
+    _fields_ = [("genes_per_lane", C.c_int32), ("blocks_per_cu", C.c_int32), ("cells_per_wave", C.c_int32),
+                ("pass_min_cw", C.c_int32), ("n_pass_shares", C.c_int32), ("pass_shares", C.c_float * 4),
+                ("tail_cells", C.c_int32), ("count_storage", C.c_int32), ("host_hist", C.c_int32),
+                ("hist_dense", C.c_int32), ("pw_inline", C.c_int32), ("no_tail2", C.c_int32),
+                ("no_tail_merged", C.c_int32), ("force_generic", C.c_int32), ("particles_layout", C.c_int32),
+                ("dense_batches", C.c_int32), ("p2p_timeout_s", C.c_float), ("reserved", C.c_int32 * 7)]
+
+
 class vc_layout(C.Structure):
     _fields_ = [("header", C.c_int64), ("n_global", C.c_int64), ("n_local", C.c_int64),
                 ("total", C.c_int64), ("offset", C.c_int64 * VC_P_COUNT), ("size", C.c_int64 * VC_P_COUNT),
@@ -69,6 +78,9 @@ EXPORTS = {
     "vc_create": (C.c_int, [C.POINTER(vc_config), C.POINTER(C.c_void_p)]),
     "vc_destroy": (None, [C.c_void_p]),
     "vc_last_error": (C.c_char_p, [C.c_void_p]),
+    "vc_set_tuning": (C.c_int, [C.c_void_p, C.POINTER(vc_tuning)]),
+    "vc_get_tuning": (C.c_int, [C.c_void_p, C.POINTER(vc_tuning)]),
+    "vc_dbg_dump_times": (C.c_int, [C.c_void_p, C.c_char_p]),
     "vc_set_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
     "vc_set_counts_csr": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "vc_get_histogram": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]),

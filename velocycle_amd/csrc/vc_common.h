@@ -638,7 +638,7 @@ void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, floa
 void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, hipStream_t st);
 void vc_launch_p2p_xchg(const VcP2p& p, long long step, float* out, long long n, long long* status, double timeout_s,
-                        hipStream_t st);
+                        unsigned long long* verdict, hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
                     double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
                     const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st);

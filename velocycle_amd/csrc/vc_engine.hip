@@ -51,6 +51,7 @@ static VcRccl g_rccl;
 
 struct vc_engine {
   vc_config cfg{};
+  vc_tuning tun{};                    // vc_set_tuning: all-zero = defaults (the library reads no environment variable)
   VcNcclComm comm = nullptr;          // the engine's own communicator (vc_comm_init_rccl), or null
   double* particle_lsum = nullptr;    // vc_svi_run_particles: scratch slots of the particles' K_fin launches
   // vc_svi_run_particles: particle k >= 1 has its own per-step workspaces, gradient buffer and stream (particle 0: e->b, the
@@ -71,16 +72,18 @@ struct vc_engine {
   int p2p_mem_kind = -1;              // 0 fine-grained, 1 uncached, 2 plain hipMalloc (vc_p2p_alloc)
   long long p2p_step = 0;             // steps exchanged so far: slot parity and flag value, identical on every rank
   double p2p_timeout_s = 2.0;
+  unsigned long long* p2p_verdict = nullptr;   // {step + 1, dead}: the one verdict of an exchange launch (vc_p2p_exchange.hip)
   VcDims d{};
   VcBufs b{};
   vc_layout layout{};
   std::string err;
   std::vector<void*> allocs;
   bool finalized = false;
+  bool generic_needed = false;        // the configuration lies outside the compiled fast set (vc_create)
   bool have_counts = false, have_cells = false;
   bool prior_set[VC_PRIOR_COUNT] = {};
   // host copies needed at finalize
-  std::vector<float> hS, hU;            // VC_HOST_HIST=1 only (the host histogram pass kept as the checker of the device one)
+  std::vector<float> hS, hU;            // tuning.host_hist only (the host histogram pass kept as the checker of the device one)
   bool host_hist = false;
   std::vector<float> h_prior[VC_PRIOR_COUNT];
   std::vector<float> h_cond[VC_SITE_COUNT];
@@ -312,7 +315,6 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
       return VC_ERR_UNSUPPORTED;
     }
   }
-  if (const char* env = getenv("VC_FORCE_GENERIC")) generic = generic || atoi(env) != 0;      // tests: the generic set on fast-set sizes
   if (2 * c->n_harmonics + 1 + (c->with_delta_nu ? c->Nb : 0) > 150) {
     g_create_error = "2 n_harmonics + 1 + Nb > 150: the per-gene state of one wave no longer fits the LDS";
     return VC_ERR_UNSUPPORTED;
@@ -323,6 +325,7 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   e->cfg = *c;
   VcDims& d = e->d;
   d.generic = generic ? 1 : 0;
+  e->generic_needed = generic;
   d.Ng = (int)c->Ng;
   d.gpl = 4; d.gbw = 256;
   d.nGB = (d.Ng + d.gbw - 1) / d.gbw;
@@ -355,15 +358,6 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
 
 extern "C" void vc_destroy(vc_engine* e) {
   if (!e) return;
-#ifdef VC_DBG_TIMES
-  if (e->b.dbg && getenv("VC_DBG_TIMES_OUT")) {
-    (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(VC_DBG_WORDS(e->d.n_main_wg));
-    (void)hipMemcpy(h.data(), e->b.dbg, h.size() * 8, hipMemcpyDeviceToHost);
-    FILE* f = fopen(getenv("VC_DBG_TIMES_OUT"), "wb");
-    if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-  }
-#endif
   if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
   if (e->p2p_connected)
     for (int q = 0; q < e->p2p.world; ++q)
@@ -388,6 +382,53 @@ extern "C" int vc_get_layout(const vc_engine* e, vc_layout* out) {
   return VC_OK;
 }
 
+extern "C" int vc_set_tuning(vc_engine* e, const vc_tuning* t) {
+  if (!e) return VC_ERR_ARG;
+  if (e->finalized || e->have_counts) return e->fail(VC_ERR_STATE, "vc_set_tuning after the counts were handed over");
+  vc_tuning z{};
+  if (t) z = *t;
+  auto in = [](int v, std::initializer_list<int> ok) { for (int o : ok) if (v == o) return true; return false; };
+  if (!in(z.genes_per_lane, {0, 4, 8})) return e->fail(VC_ERR_ARG, "vc_set_tuning: genes_per_lane must be 0, 4 or 8");
+  if (z.blocks_per_cu < 0 || z.cells_per_wave < 0 || z.pass_min_cw < 0) return e->fail(VC_ERR_ARG, "vc_set_tuning: negative value");
+  if (z.n_pass_shares < 0 || z.n_pass_shares > 4) return e->fail(VC_ERR_ARG, "vc_set_tuning: n_pass_shares must be 0..4");
+  for (int p = 0; p < z.n_pass_shares && z.n_pass_shares >= 2; ++p)
+    if (!(z.pass_shares[p] > 0.f)) return e->fail(VC_ERR_ARG, "vc_set_tuning: pass_shares must be positive");
+  if (!in(z.tail_cells, {0, 256, 512, 1024})) return e->fail(VC_ERR_ARG, "vc_set_tuning: tail_cells must be 0, 256, 512 or 1024");
+  if (!in(z.count_storage, {0, 1}) || !in(z.host_hist, {0, 1}) || !in(z.hist_dense, {0, 1, 2}) || !in(z.pw_inline, {0, 1, 2}) ||
+      !in(z.no_tail2, {0, 1}) || !in(z.no_tail_merged, {0, 1}) || !in(z.force_generic, {0, 1}) || !in(z.particles_layout, {0, 1, 2}) ||
+      !in(z.dense_batches, {0, 1}))
+    return e->fail(VC_ERR_ARG, "vc_set_tuning: a switch is outside its documented values");
+  if (z.p2p_timeout_s < 0.f) return e->fail(VC_ERR_ARG, "vc_set_tuning: negative p2p_timeout_s");
+  e->tun = z;
+  if (z.force_generic) e->d.generic = 1;
+  else e->d.generic = e->generic_needed ? 1 : 0;
+  if (z.p2p_timeout_s > 0.f) e->p2p_timeout_s = z.p2p_timeout_s;
+  return VC_OK;
+}
+
+extern "C" int vc_get_tuning(const vc_engine* e, vc_tuning* out) {
+  if (!e || !out) return VC_ERR_ARG;
+  *out = e->tun;
+  return VC_OK;
+}
+
+extern "C" int vc_dbg_dump_times(vc_engine* e, const char* path) {
+  if (!e || !path) return VC_ERR_ARG;
+#ifdef VC_DBG_TIMES
+  if (!e->b.dbg) return e->fail(VC_ERR_STATE, "vc_dbg_dump_times before vc_finalize");
+  (void)hipDeviceSynchronize();
+  std::vector<unsigned long long> h(VC_DBG_WORDS(e->d.n_main_wg));
+  HIPCHK(e, hipMemcpy(h.data(), e->b.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+  FILE* f = fopen(path, "wb");
+  if (!f) return e->fail(VC_ERR_ARG, "vc_dbg_dump_times: cannot open %s", path);
+  fwrite(h.data(), 8, h.size(), f);
+  fclose(f);
+  return VC_OK;
+#else
+  return e->fail(VC_ERR_UNSUPPORTED, "vc_dbg_dump_times: this build of the library carries no time stamps (-DVC_DBG_TIMES)");
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" int vc_set_counts(vc_engine* e, const float* S, const float* U, int64_t gs, int64_t cs, int on_device) {
   if (!e) return VC_ERR_ARG;
@@ -400,7 +441,7 @@ extern "C" int vc_set_counts(vc_engine* e, const float* S, const float* U, int64
   const size_t span = (size_t)(d.Ng - 1) * gs + (size_t)(d.Nc - 1) * cs + 1;
   const float* src[2] = {S, vel ? U : nullptr};
   std::vector<float>* hcopy[2] = {&e->hS, &e->hU};
-  e->host_hist = getenv("VC_HOST_HIST") && atoi(getenv("VC_HOST_HIST")) != 0;
+  e->host_hist = e->tun.host_hist != 0;
   long long ngs = gs, ncs = cs;
   for (int m = 0; m < 2; ++m) {
     e->src[m].release();
@@ -603,9 +644,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // per-gene state (latents + accumulators) fits 2 waves per SIMD without scratch, which the code object itself
   // tells (private segment size 0); else 4.
   d.gpl = d.generic ? 2 : 4;
-  size_t max_scratch = 0;      // VC_MAX_SCRATCH (bytes per lane, measurement aid): accept an 8-genes-per-lane kernel that spills this little
-  if (const char* env = getenv("VC_MAX_SCRATCH")) max_scratch = (size_t)atoi(env);
-  max_scratch = 0;             // asm-issued count loads: a spilled destination tuple would be stored before its data has landed
+  const size_t max_scratch = 0;      // asm-issued count loads: a spilled destination tuple would be stored before its data has landed
   if (!d.generic) {
     const void* k8 = nullptr;
     hipFuncAttributes fa;
@@ -637,11 +676,9 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         // that kernel keeps the step at two launches as well.
         bool two_launch8 = false;
         if (d.kind == VC_KIND_VFULL && world == 1 && VC_PW_INLINE && d.NW >= 1 && d.NW <= VC_PWQ) {
-          const char* pwe = getenv("VC_PW_INLINE");
-          const char* t2e = getenv("VC_TAIL2");
           const void* k4 = nullptr;
           int bpc4 = 0;
-          if (!(pwe && atoi(pwe) == 0) && !(t2e && atoi(t2e) == 0) &&
+          if (e->tun.pw_inline != 1 && !e->tun.no_tail2 &&
               vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 4, 0, nullptr, &k4) && k4 &&
               hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc4, k4, 256, 0) == hipSuccess && bpc4 >= 1) {
             const VcTiling t4 = vc_tile_cells(shard_cells, (d.Ng + 255) / 256, n_cu, bpc4, VC_WAVES, 0, nullptr, 12);
@@ -652,9 +689,9 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       }
     }
   }
-  if (const char* env = d.generic ? nullptr : getenv("VC_GPL")) {
-    if (atoi(env) == 4) d.gpl = 4;
-    if (atoi(env) == 8) {       // honoured only where the 8-genes-per-lane kernel may run at all (no scratch: see above)
+  if (!d.generic && e->tun.genes_per_lane) {
+    if (e->tun.genes_per_lane == 4) d.gpl = 4;
+    if (e->tun.genes_per_lane == 8) {       // honoured only where the 8-genes-per-lane kernel may run at all (no scratch: see above)
       const void* k8 = nullptr;
       hipFuncAttributes fa;
       if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
@@ -753,10 +790,9 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     if (hbad[1]) { free_transients(); return e->fail(VC_ERR_ARG, "vc_set_counts_csr: gene index outside [0, Ng)"); }
     if (hbad[0]) { free_transients(); return e->fail(VC_ERR_ARG, "count matrices must be finite and >= 0 (NaN / Inf / negative value found)"); }
     // Count storage: when every count of this rank's matrices is an integer <= 65535 (checked by the pass above) the
-    // blocked layout is narrowed to uint16 -- half the bytes K_main streams per step; exact.  VC_COUNT_STORAGE=f32 keeps
+    // blocked layout is narrowed to uint16 -- half the bytes K_main streams per step; exact.  tuning.count_storage = 1 keeps
     // the reference's float32 (A/B measurements, tests); Lognormal noise stores log(k + 1) and stays float32.
-    const char* cs_env = getenv("VC_COUNT_STORAGE");
-    const bool want16 = !(cs_env && strcmp(cs_env, "f32") == 0) && d.noise != VC_NOISE_LOGNORMAL && !hbad[2] && !d.generic;
+    const bool want16 = e->tun.count_storage != 1 && d.noise != VC_NOISE_LOGNORMAL && !hbad[2] && !d.generic;
     if (want16) {
       const void* k16 = nullptr;
       const char* nm = nullptr;
@@ -802,8 +838,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       if (dyn_bytes > 0) (void)hipFuncSetAttribute(main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes);
       HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, main_kernel, 64 * wg_waves, dyn_bytes));
       if (d.generic && bpc > 8) bpc = 8;      // (one wave each: two per SIMD hide the LDS latency, more only shorten the runs of cells)
-      const char* env = getenv("VC_BLOCKS_PER_CU");
-      if (env && atoi(env) > 0) bpc = atoi(env);
+      if (e->tun.blocks_per_cu > 0) bpc = e->tun.blocks_per_cu;
       *out = bpc;
       return VC_OK;
     };
@@ -811,7 +846,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     // p + 1 and the SIMD arbiter issues the oldest ready wave first: with equal shares the first pass ends its cells at
     // ~60 % of the kernel and the last pass then runs alone, one wave per SIMD (profiles/tools/wave_timeline.py).  Measured
     // (profiles/r02_pass_shares.md): shares falling by 1/2 per pass (2 passes 0.67 : 0.33, 3 passes 0.57 : 0.29 : 0.14) cut the
-    // kernel by 5-9 %; that is the default for a full multi-pass grid.  VC_PASS_SHARES="a:b[:c[:d]]" overrides ("1:1" = the
+    // kernel by 5-9 %; that is the default for a full multi-pass grid.  tuning.pass_shares overrides (n_pass_shares = 1: the
     // balanced tiling).  The tiling (vc_host_logic.h, also what the kernel evaluates per wave) stays a pure function of
     // (Nc, Ng, occupancy, CUs): results are reproducible.
     auto tile = [&](int blocks_per_cu) {
@@ -828,16 +863,15 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         share[1] = 0.42; share[2] = 0.19; share[3] = 0.09;
       }
       bool want = true;
-      if (const char* se = getenv("VC_PASS_SHARES")) {
-        int n = sscanf(se, "%lf%*[,:]%lf%*[,:]%lf%*[,:]%lf", &share[0], &share[1], &share[2], &share[3]);
-        want = n >= 2;
-        for (int p = (n > 0 ? n : 1); p < 4; ++p) share[p] = share[p - 1] * (n >= 2 ? share[n - 1] / share[n - 2] : 1.0);
+      if (e->tun.n_pass_shares == 1) want = false;                  // equal shares: the balanced tiling
+      else if (e->tun.n_pass_shares >= 2) {
+        const int n = e->tun.n_pass_shares;
+        for (int p = 0; p < n; ++p) share[p] = (double)e->tun.pass_shares[p];
+        for (int p = n; p < 4; ++p) share[p] = share[p - 1] * (share[n - 1] / share[n - 2]);
       }
-      const char* cwe = getenv("VC_CELLS_PER_WAVE");
-      const char* mce = getenv("VC_PASS_MIN_CW");
       // below 12 cells per wave the passes' fixed prologue / epilogue dominate (measured at the 6 250-cell shard)
-      const VcTiling t = vc_tile_cells(d.Nc, d.nGB, n_cu, blocks_per_cu, wg_waves, cwe && atoi(cwe) > 0 ? atoi(cwe) : 0,
-                                       (want && !d.generic) ? share : nullptr, mce && atoi(mce) > 0 ? atoi(mce) : 12);
+      const VcTiling t = vc_tile_cells(d.Nc, d.nGB, n_cu, blocks_per_cu, wg_waves, e->tun.cells_per_wave,
+                                       (want && !d.generic) ? share : nullptr, e->tun.pass_min_cw > 0 ? e->tun.pass_min_cw : 12);
       d.cw = t.cw;
       d.n_chunks = t.n_chunks;
       d.pass_wgs = n_cu;
@@ -854,8 +888,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     d.pw_slots = 0;
     const bool pw_kind = VC_PW_INLINE && (d.kind == VC_KIND_VU || d.kind == VC_KIND_VFULL) && d.NW >= 1 && d.NW <= VC_PWQ &&
                          e->cfg.world_size == 1 && !d.generic;
-    const char* pwe = getenv("VC_PW_INLINE");
-    if (pw_kind && !(pwe && atoi(pwe) == 0)) {
+    if (pw_kind && e->tun.pw_inline != 1) {
       const int row = d.NW <= 4 ? 4 : 8;
       int bpc = bpc0;
       for (int attempt = 0; attempt < 2; ++attempt) {
@@ -871,7 +904,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         // 52 KB of LDS, three workgroups just fit).  Measured at 2 000 genes (profiles/r04_small_shard.md): K_main 58.9 -> 70.8 us
         // at 25 000 cells, 33.6 -> 40.1 at 12 500, 23.0 -> 24.6 at 6 250 -- more than the launch it saves, except where a wave
         // has so few cells that the kernel is prologue and epilogue anyway: accepted only there.
-        if (d.cw > 12 && !(pwe && atoi(pwe) == 2)) break;      // (VC_PW_INLINE=2: accept the loss anyway -- tests, A/B)
+        if (d.cw > 12 && e->tun.pw_inline != 2) break;      // (tuning.pw_inline = 2: accept the loss anyway -- tests, A/B)
         bpc = got;                      // tile for the occupancy that is left and look again
         tile(bpc);
       }
@@ -967,7 +1000,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // wait a round (50k x 2k: phase 17.5 -> 13.0 us outside K_main with 1024-cell blocks, V-joint 25 -> 22.5)
   // -- and with the dense histogram tables (S+U kernel) 512: its cell blocks carry the longest chain of that launch (nu_omega inside)
   if (fused_tail_kind(e) == 2 && d.Nc > 16384) d.tail_tc = d.kind == VC_KIND_VFULL ? 512 : 1024;
-  if (const char* env = getenv("VC_TAIL_TC")) { if (atoi(env) == 256 || atoi(env) == 512 || atoi(env) == 1024) d.tail_tc = atoi(env); }
+  if (e->tun.tail_cells) d.tail_tc = e->tun.tail_cells;
   d.nb_tail_cell = (d.Nc + d.tail_tc - 1) / d.tail_tc;
   d.nlpf = d.nb_post_gene + d.nb_tail_cell + 1;
   d.lgamma_alpha = lgammaf(d.gamma_alpha);
@@ -1025,14 +1058,13 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         // dense tail-count tables (vc_host_logic.h: vc_build_dense_hist) when every non-zero count of the matrices is an integer
         // below VC_HIST_CAP (no overflow entries): the histogram sums then cost a logarithm and a reciprocal per (gene, count
         // level) and are evaluated per gene block.
-        const char* hde = getenv("VC_HIST_DENSE");
         // Default: the S+U kernel's models only -- 4 000+ task waves there (two matrices) against 32 blocks; measured at 50k x 2k
         // (profiles/r04_two_launch.md) V-joint 21-24 -> 17.5-19 us outside K_main, phase (one matrix, nothing to hide the blocks
-        // of its few outlier genes behind) 13.4 -> 15.5: the phase model keeps the lists.  VC_HIST_DENSE=1 / 0 forces either.
+        // of its few outlier genes behind) 13.4 -> 15.5: the phase model keeps the lists.  tuning.hist_dense = 2 / 1 forces either.
         // Only where the one-launch tail runs (single rank with K_main's own nu_omega partials): through K_omega's / K_pre's
         // 4-wave blocks the dense evaluation is slower than the lists (6 250-cell shard: sharded step 41.6 -> 44.2 us).
         dense_ok = nb && novf[0] == 0 && novf[1] == 0 && d.Nc <= (1 << 24) &&
-                   (hde ? atoi(hde) != 0 : (d.kind == VC_KIND_VFULL && fused_tail_kind(e) == 2));
+                   (e->tun.hist_dense ? e->tun.hist_dense == 2 : (d.kind == VC_KIND_VFULL && fused_tail_kind(e) == 2));
         for (int m = 0; m < (vel ? 2 : 1); ++m) {
           HIPCHK(e, hipMemcpy(htab.data(), tab[m], htab.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
           if (dense_ok) vc_build_dense_hist(htab.data(), d.Ng, d.Ng_pad, hc, hc_off, hc_rows);
@@ -1050,7 +1082,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         if (!vel) for (int g = 0; g < d.Ng; ++g) ptr.push_back((int)val.size());
         e->hist_on_device = 1;
       } else {
-        // checker path (VC_HOST_HIST=1) or fallback: histograms from a host copy of the raw counts
+        // checker path (tuning.host_hist) or fallback: histograms from a host copy of the raw counts
         if (e->hS.empty()) {
           if (e->src[0].kind != 1) { free_transients(); return e->fail(VC_ERR_UNSUPPORTED, "CSR input with more than %u non-integer / large counts per matrix", OVF_CAP); }
           const size_t span = (size_t)(d.Ng - 1) * e->dgs + (size_t)(d.Nc - 1) * e->dcs + 1;
@@ -1231,13 +1263,13 @@ static int fused_tail_kind(const vc_engine* e) {
   if (e->d.generic) return 0;
   const bool with_hist = e->hist_each_step;
   bool merged = e->d.pw_inline && e->d.kind == VC_KIND_VU && !with_hist && (e->d.cond >> VC_SITE_PHIXY & 1u);
-  if (const char* env = getenv("VC_TAIL_MERGED")) merged = merged && atoi(env) != 0;
+  if (e->tun.no_tail_merged) merged = false;
   if (merged) return 1;
   // Round 4: every other single-rank step in TWO launches as well -- the phase model (no nu_omega chain), and the velocity
   // models whenever K_main supplies the partials of d loglik / d nu_omega itself (pw_inline), so that the chain runs inside the
-  // cell blocks.  VC_TAIL2=0 keeps the three-launch step (A/B, tests: the same bits).
+  // cell blocks.  tuning.no_tail2 keeps the three-launch step (A/B, tests: the same bits).
   bool tail2 = e->cfg.world_size == 1 && (e->d.model == VC_MODEL_PHASE || e->d.pw_inline != 0);
-  if (const char* env = getenv("VC_TAIL2")) tail2 = tail2 && atoi(env) != 0;
+  if (e->tun.no_tail2) tail2 = false;
   return tail2 ? 2 : 0;
 }
 static int fused_launches_per_step(const vc_engine* e) { return fused_tail_kind(e) ? 2 : 3; }
@@ -1355,15 +1387,14 @@ extern "C" int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, 
   VcParticleGrads pg;
   pg.K = K;
   for (int k = 0; k < VC_MAX_PARTICLES; ++k) pg.g[k] = k == 0 ? grad : (k < K ? e->particles[k - 1].grad : nullptr);
-  // How the particles of a step are laid out in launches (VC_PARTICLES_LAYOUT, measured at 50k x 2k, K = 3, profiles/r04_particles.md):
+  // How the particles of a step are laid out in launches (tuning.particles_layout, measured at 50k x 2k, K = 3, profiles/r04_particles.md):
   //   "batched" (default; fast kernel set): K_pre of all particles as ONE launch, the K likelihood kernels, K_post of all particles
   //             as one launch, K_fin of each + average + ClippedAdam as one launch = K + 3 launches per step
   //   "serial":  K_pre, K_main, K_post, K_fin per particle on the caller's stream, then average, ClippedAdam = 4 K + 2 launches
   //   "streams": as "serial" with particle k >= 1 on a stream of its own (the small launches of one particle beside the
   //             likelihood kernel of another): the event records and cross-stream waits cost what the overlap gains
-  const char* lay = getenv("VC_PARTICLES_LAYOUT");
-  const bool streams = lay && !strcmp(lay, "streams");
-  const bool batched = !e->d.generic && !(lay && (!strcmp(lay, "serial") || streams));
+  const bool streams = e->tun.particles_layout == 2;
+  const bool batched = !e->d.generic && e->tun.particles_layout == 0;
   const bool serial = !streams;
   for (int64_t i = 0; i < n_steps && batched; ++i) {
     vc_launch_pre_particles(e->d, e->b, e->particle_bufs_dev, params, seed, (const long long*)step_dev, e->hist_each_step ? 1 : 0, K, st);
@@ -1516,7 +1547,6 @@ extern "C" int vc_p2p_alloc(vc_engine* e, void* ipc_handle_out) {
   }
   if (!e->p2p_own) return e->fail(VC_ERR_HIP, "vc_p2p_alloc: no IPC-exportable region: %s", hipGetErrorString(last));
   memcpy(ipc_handle_out, &h, sizeof h);
-  if (const char* env = getenv("VC_P2P_TIMEOUT_S")) { if (atof(env) > 0.0) e->p2p_timeout_s = atof(env); }
   return VC_OK;
   VC_GUARD_END(e)
 }
@@ -1539,6 +1569,10 @@ extern "C" int vc_p2p_connect(vc_engine* e, const void* all_handles) {
       return e->fail(VC_ERR_HIP, "hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(er));
     }
     p.region[q] = ptr;
+  }
+  if (!e->p2p_verdict) {
+    TRY(e->dalloc(&e->p2p_verdict, 1));
+    HIPCHK(e, hipMemset(e->p2p_verdict, 0, sizeof(unsigned long long)));
   }
   e->p2p_connected = true;
   e->p2p_step = 0;
@@ -1596,7 +1630,7 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
       vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 1, xa, st);
     }
     if (use_p2p) {
-      vc_launch_p2p_xchg(e->p2p, e->p2p_step, xbuf, (long long)e->xb_total, e->b.status, e->p2p_timeout_s, st);
+      vc_launch_p2p_xchg(e->p2p, e->p2p_step, xbuf, (long long)e->xb_total, e->b.status, e->p2p_timeout_s, e->p2p_verdict, st);
       e->p2p_step++;
     } else if (phase == VC_PHASE_AB && e->comm) {      // (a 1-rank communicator is summed too: the single-GPU measurement of this path)
       const int rc = g_rccl.AllReduce(xbuf, xbuf, (size_t)e->xb_total, /*ncclFloat32*/ 7, /*ncclSum*/ 0, e->comm, st);

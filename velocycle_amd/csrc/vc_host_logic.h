@@ -51,7 +51,7 @@ static inline double vc_compact_hist(const unsigned* tab, int Ng, const std::vec
 }
 
 // The same histograms straight from a host copy of the matrix (element (g, c) at M[g * gs + c * cs]): the checker of the
-// device path (VC_HOST_HIST=1) and the reference for tests.  *bad is set when a value is negative / NaN / infinite.
+// device path (tuning.host_hist) and the reference for tests.  *bad is set when a value is negative / NaN / infinite.
 static inline double vc_build_hist_host(const float* M, long long gs, long long cs, int Ng, int Nc, std::vector<int>& ptr_out,
                                         std::vector<float>& val, std::vector<float>& cnt, bool* bad) {
   std::vector<std::vector<std::pair<float, float>>> per_gene(Ng);

@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from .spec import ModelSpec
+from .tuning import Tuning
 
 
 class HipEngineError(RuntimeError):
@@ -34,8 +35,9 @@ def _f32c(t, device="cpu"):
 
 class HipEngine:
     def __init__(self, spec: ModelSpec, device: Optional[torch.device] = None, rank: int = 0,
-                 world_size: int = 1):
+                 world_size: int = 1, tuning: Optional[Tuning] = None):
         self.lib = _lib.load()
+        self.tuning = tuning if tuning is not None else Tuning()
         if not torch.cuda.is_available():
             raise HipEngineError("velocycle_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
@@ -64,6 +66,10 @@ class HipEngine:
                 raise NotImplementedError(msg)
             raise ValueError(msg)
         try:
+            if hasattr(self.lib, "vc_set_tuning"):       # (absent only from an older build selected with VC_LIB_PATH + VC_LIB_OLDER)
+                self._check(self.lib.vc_set_tuning(self._h, C.byref(self.tuning.to_c())))
+            elif self.tuning != Tuning():
+                raise HipEngineError("this build of the library has no vc_set_tuning: only the default Tuning can run on it")
             self._setup()
         except Exception:
             self.close()
@@ -334,7 +340,12 @@ class HipEngine:
         import torch.distributed as dist
         # idempotent: the engine is kept across fit() calls and every fit() builds a new SVIRunner; the communicator made
         # by the first one is the engine's for its lifetime.  (Every rank made it together, so every rank returns here together.)
+        ranks = self._group_ranks(process_group)
         if getattr(self, "_rccl_ready", False):
+            if ranks != self._rccl_group:
+                raise HipEngineError(f"this engine's RCCL communicator was created for the ranks {self._rccl_group}; a run over "
+                                     f"the group {ranks} needs an engine of its own (ADVICE r4: a communicator is not silently reused "
+                                     "for another group)")
             return True
         path = self.rccl_path().encode()
         ok = 1
@@ -368,7 +379,17 @@ class HipEngine:
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
         self._rccl_ready = bool(int(flag.item()))
+        self._rccl_group = ranks
         return self._rccl_ready
+
+    @staticmethod
+    def _group_ranks(process_group):
+        """Global ranks of a torch.distributed group (the identity a communicator / IPC mapping was built for)."""
+        import torch.distributed as dist
+        try:
+            return tuple(dist.get_process_group_ranks(process_group if process_group is not None else dist.group.WORLD))
+        except Exception:
+            return tuple(range(dist.get_world_size(process_group)))
 
     def comm_allreduce(self, buf: torch.Tensor):
         """Sum of a float32 device buffer over the ranks of the engine's own RCCL communicator, in place, on the current
@@ -380,7 +401,11 @@ class HipEngine:
         the 64-byte IPC handles of all ranks are gathered in rank order with torch.distributed (any backend), the peers'
         regions are mapped.  Returns True when EVERY rank is connected (MIN all-reduce), else False on every rank."""
         import torch.distributed as dist
+        ranks = self._group_ranks(process_group)
         if getattr(self, "_p2p_ready", False):       # idempotent, like init_rccl_comm: one region per engine
+            if ranks != self._p2p_group:
+                raise HipEngineError(f"this engine's peer-to-peer region is mapped for the ranks {self._p2p_group}; a run over the "
+                                     f"group {ranks} needs an engine of its own")
             return True
         buf = (C.c_char * 64)()
         rc = self.lib.vc_p2p_alloc(self._h, buf)
@@ -399,6 +424,7 @@ class HipEngine:
                             device=self.device if dist.get_backend(process_group) == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
         self._p2p_ready = bool(int(flag.item()))
+        self._p2p_group = ranks
         return self._p2p_ready
 
     def clipped_adam(self, p, g, m, v, lr, lrd, b1, b2, eps, clip, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
@@ -503,6 +529,10 @@ class HipEngine:
         self._check(self.lib.vc_get_histogram(self._h, C.byref(n), ptr.ctypes.data_as(C.c_void_p),
                                               val.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
         return ptr, val, cnt
+
+    def dump_dbg_times(self, path: str):
+        """profiles/tools: the time stamps of a -DVC_DBG_TIMES build of the library (vc_dbg_dump_times)."""
+        self._check(self.lib.vc_dbg_dump_times(self._h, path.encode()))
 
     def set_timing(self, enable: bool):
         self._check(self.lib.vc_set_timing(self._h, int(enable)))

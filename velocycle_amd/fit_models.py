@@ -68,7 +68,7 @@ class _FitBase:
         self.engine: Optional[HipEngine] = None
 
     # ------------------------------------------------------------------------------------------
-    def _make_engine(self, device=None, process_group=None):
+    def _make_engine(self, device=None, process_group=None, tuning=None):
         spec = spec_from_metaparams(self.metaparams, self._kind, self.condition)
         dev = device if device is not None else getattr(self.metaparams, "device", None)
         if dev is None or torch.device(dev).type != "cuda":
@@ -77,7 +77,7 @@ class _FitBase:
         self._rank, self._world, self._pg = dist_context(process_group)
         self._shard_sizes = [b - a for a, b in (shard_bounds(spec.Nc, r, self._world) for r in range(self._world))]
         # raises without a GPU: no CPU fallback
-        self.engine = HipEngine(spec, device=dev, rank=self._rank, world_size=self._world)
+        self.engine = HipEngine(spec, device=dev, rank=self._rank, world_size=self._world, tuning=tuning)
         return self.engine
 
     def _gather(self, local: torch.Tensor, dim: int) -> torch.Tensor:
@@ -88,7 +88,8 @@ class _FitBase:
         pass
 
     def fit(self, optimizer, loss=None, num_steps=1000, intermediate_output_step_size=100, store_output=False,
-            verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None, process_group=None, loss_every: int = 1):
+            verbose=True, mode: str = "perf", seed: Optional[int] = None, device=None, process_group=None, loss_every: int = 1,
+            tuning=None):
         """The reference's fit() (velocity_inference_model.py:77-160, phase_inference_model.py:126-214) + mode / seed / device /
         process_group of this engine.  loss_every = k > 1 is an opt-in that is NOT in the reference: only every k-th step forms
         the loss (`losses` holds NaN in between), the others run a gradient-only likelihood kernel -- NB noise, perf mode, one
@@ -98,7 +99,10 @@ class _FitBase:
         import time
         t_start = time.perf_counter()
         if self.engine is None:
-            self._make_engine(device, process_group)
+            self._make_engine(device, process_group, tuning)
+        elif tuning is not None and tuning != self.engine.tuning:
+            raise ValueError("this model's engine was built with another Tuning (the engine is kept across fit() calls); "
+                             "make a new model object for a new tuning")
         eng = self.engine
         eng.clear_status()           # the engine is kept across fit() calls: the NaN / Inf latch must describe THIS fit only
         if eng.stats["count_storage"] != "u16" and self.spec.noisemodel != "Lognormal":

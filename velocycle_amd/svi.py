@@ -65,6 +65,9 @@ class FlatClippedAdam:
 
     def step(self, p: torch.Tensor, g: torch.Tensor, t_dev: Optional[torch.Tensor] = None, loss_hdr=None,
              loss_ring=None):
+        if getattr(self, "t_vec", None) is not None and (self.impl != "torch" or self.capturable):
+            raise RuntimeError("per-parameter step counts (a 'mixed' continued fit) run on the PyTorch-op ClippedAdam only "
+                               f"(impl={self.impl!r}, capturable={self.capturable})")
         if self.impl == "hip":
             self.t += 1
             self.engine.clipped_adam(p, g, self.m, self.v, self.lr0, self.lrd, self.b1, self.b2, self.eps,
@@ -107,12 +110,16 @@ class FlatClippedAdam:
         return self.t
 
     def state_dict(self, step_dev: Optional[torch.Tensor] = None):
-        return dict(m=self.m.detach().cpu().clone(), v=self.v.detach().cpu().clone(), t=self.steps_done(step_dev))
+        sd = dict(m=self.m.detach().cpu().clone(), v=self.v.detach().cpu().clone(), t=self.steps_done(step_dev))
+        if getattr(self, "t_vec", None) is not None:      # per-element step counts of a 'mixed' continued fit
+            sd["t_vec"] = self.t_vec.detach().cpu().clone()
+        return sd
 
     def load_state_dict(self, sd):
         self.m.copy_(torch.as_tensor(sd["m"]).to(self.m.device))
         self.v.copy_(torch.as_tensor(sd["v"]).to(self.v.device))
         self.t = int(sd["t"])
+        self.t_vec = torch.as_tensor(sd["t_vec"]).to(device=self.m.device, dtype=torch.float64).clone() if sd.get("t_vec") is not None else None
         if self.impl == "torch" and self.capturable:
             self.t_dev.fill_(float(self.t))
 
@@ -165,8 +172,12 @@ class SVIRunner:
         # (4 launches per step); "fused3": the three-launch step of vc_svi_step_fused (reductions + chain rule + optimiser +
         # the NEXT step's guide sample in one kernel) -- the single-rank default; "sharded": the same step cut at its one
         # exchange (K_main -> phase A -> sum over ranks -> phase B: vc_svi_run_sharded) -- the default when cells are sharded
-        # (VC_ADAM_IMPL / VC_ADAM_IMPL_DIST override the perf defaults for A/B measurements, e.g. the unfused "hip" sequence)
-        import os
+        # (engine.tuning.adam_impl / adam_impl_dist override the perf defaults for A/B measurements, e.g. the unfused "hip" sequence)
+        tun = getattr(engine, "tuning", None)
+        if tun is None:
+            from .tuning import Tuning
+            tun = Tuning()
+        self.tuning = tun
         if adam_impl is None and self.K > 1 and mode == "perf":
             adam_impl = "hip"
         if adam_impl is None and mode == "perf" and (getattr(engine, "stats", None) or {}).get("generic"):
@@ -179,9 +190,9 @@ class SVIRunner:
             if mode != "perf":
                 adam_impl = "torch"
             elif self.do_reduce:
-                adam_impl = os.environ.get("VC_ADAM_IMPL_DIST", "sharded")
+                adam_impl = tun.adam_impl_dist or "sharded"
             else:
-                adam_impl = os.environ.get("VC_ADAM_IMPL", "fused3")
+                adam_impl = tun.adam_impl or "fused3"
         self.adam_impl = adam_impl
         if self.adam_impl in ("fused", "fused3") and (self.do_reduce or mode != "perf"):
             raise ValueError(f"adam_impl={self.adam_impl!r} needs mode='perf' on a single rank")
@@ -195,7 +206,7 @@ class SVIRunner:
         self.xbuf = None
         if self.adam_impl == "sharded":
             import torch.distributed as dist
-            want = exchange or os.environ.get("VC_EXCHANGE")
+            want = exchange or tun.exchange
             if want is None:
                 if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
                     want = "none"              # one rank, no process group: nothing to sum, nobody to call all_reduce on
@@ -222,6 +233,8 @@ class SVIRunner:
                 raise ValueError(f"unknown exchange {want!r}")
             self.exchange = want
             self.xbuf = torch.zeros(engine.exchange_size(), dtype=torch.float32, device=engine.device)
+        if self.world > 1:
+            self._assert_same_tuning_on_every_rank()
         self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
                                    capturable=self.use_graph,
                                    impl=("hip" if self.adam_impl in ("fused", "fused3", "sharded") else self.adam_impl), engine=engine)
@@ -253,6 +266,27 @@ class SVIRunner:
             self.step_dev = torch.zeros(1, dtype=torch.int64, device=engine.device)
             self.loss_hist = None
         self._arm_loss_every()
+
+    def _assert_same_tuning_on_every_rank(self):
+        """Every rank of a sharded run must hold the same Tuning and have derived the same layout from it (one rank with another
+        genes_per_lane would pad the genes differently: another exchange buffer, a hang or garbage in the first all-reduce):
+        a MIN and a MAX all-reduce of a digest of (tuning, gradient layout, exchange size, kernel), compared on every rank."""
+        import hashlib
+        import torch.distributed as dist
+        e = self.e
+        stats = getattr(e, "stats", None) or {}
+        desc = repr((self.tuning.digest(), e.header, e.n_global, stats.get("main_kernel", "").split("gpl")[-1],
+                     e.exchange_size() if self.adam_impl == "sharded" else 0))
+        h = int.from_bytes(hashlib.sha256(desc.encode()).digest()[:8], "little") >> 2
+        dev = e.device if dist.get_backend(self.pg) == "nccl" else "cpu"
+        lo = torch.tensor([h], dtype=torch.int64, device=dev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        if int(lo.item()) != int(hi.item()):
+            from .engine import HipEngineError
+            raise HipEngineError(f"rank {e.rank}: the ranks of this sharded run do not share one Tuning / layout "
+                                 f"(this rank: {self.tuning}, kernel {stats.get('main_kernel')}, layout {desc})")
 
     # ------------------------------------------------------------------------------------------
     def _reduce(self):
@@ -320,8 +354,7 @@ class SVIRunner:
         """perf mode with K particles: per step the unfused kernel sequence on the Philox streams (seed, step * K + k),
         averaged on the device; losses stay in the device ring."""
         e, K = self.e, self.K
-        import os
-        if not self.do_reduce and self.opt.impl == "hip" and os.environ.get("VC_PARTICLES_HOST_LOOP", "0") != "1":
+        if not self.do_reduce and self.opt.impl == "hip" and not self.tuning.particles_host_loop:
             # single rank: every launch of the run from one C call (vc_svi_run_particles) -- the same kernels on the same
             # streams, the gradients averaged by a kernel instead of PyTorch ops: the same numbers
             if getattr(self, "_gacc", None) is None:
@@ -359,8 +392,7 @@ class SVIRunner:
             from . import _lib
             o = self.opt
             kw = dict(seed=self.seed, step_dev=self.step_dev, loss_buf=self.loss_hist)
-            import os
-            if (self.exchange == "engine" and (self.world > 1 or (self.do_reduce and os.environ.get("VC_EXCHANGE_CHECK") == "1"))
+            if (self.exchange == "engine" and (self.world > 1 or (self.do_reduce and self.tuning.exchange_check))
                     and not getattr(self, "_exchange_checked", False) and n_steps > 0):
                 # The first step of the engine-owned exchange is cut open once: phase A -> the buffer summed by the engine's
                 # communicator AND, on a copy, by torch.distributed -> compared -> phase B.  If any
@@ -503,9 +535,8 @@ class SVIRunner:
         if self.world <= 1 and not self.do_reduce:
             torch.cuda.synchronize(e.device)
             return
-        import os
         import time
-        limit = float(os.environ.get("VC_RUN_DEADLINE_S", "900"))
+        limit = float(self.tuning.run_deadline_s)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(e.device))
         t0 = time.monotonic()
@@ -514,7 +545,7 @@ class SVIRunner:
             if waited > limit:
                 from .engine import HipEngineError
                 raise HipEngineError(f"rank {e.rank} of {self.world}: the sharded run did not finish within {limit:.0f} s "
-                                     f"(VC_RUN_DEADLINE_S) -- a collective or a peer is stuck (exchange: {self.exchange})")
+                                     f"(Tuning.run_deadline_s) -- a collective or a peer is stuck (exchange: {self.exchange})")
             # the return must not lag the device by more than ~0.1 % of the run (callers time run_perf(sync=True)): spin for the
             # first quarter second, then naps of a thousandth of what has been waited so far (at most 2 ms)
             if waited > 0.25:
@@ -596,7 +627,7 @@ class SVIRunner:
         torch.cuda.synchronize(e.device)
         opt = self.opt.state_dict(self.step_dev if self.mode == "perf" else None)
         sd = dict(layout=self._layout_key(), mode=self.mode, seed=self.seed, step_idx=self.step_idx,
-                  params=e.params.detach().cpu().clone(), m=opt["m"], v=opt["v"], t=opt["t"],
+                  params=e.params.detach().cpu().clone(), m=opt["m"], v=opt["v"], t=opt["t"], **({"t_vec": opt["t_vec"]} if "t_vec" in opt else {}),
                   losses=torch.tensor(self.perf_losses() if self.mode == "perf" else self.losses, dtype=torch.float64))
         if self.gen is not None:
             sd["gen_state"] = self.gen.get_state()
@@ -609,7 +640,7 @@ class SVIRunner:
         if sd["mode"] != self.mode:
             raise ValueError(f"checkpoint was written in mode={sd['mode']!r}, this runner is mode={self.mode!r}")
         e.params.copy_(torch.as_tensor(sd["params"]).to(e.device))
-        self.opt.load_state_dict(dict(m=sd["m"], v=sd["v"], t=sd["t"]))
+        self.opt.load_state_dict(dict(m=sd["m"], v=sd["v"], t=sd["t"], t_vec=sd.get("t_vec")))
         self.step_idx, self.seed = int(sd["step_idx"]), int(sd["seed"])
         losses = torch.as_tensor(sd["losses"], dtype=torch.float64)
         self._primed = False
@@ -642,7 +673,7 @@ class SVIRunner:
             sd[k] = str(sd[k])
         for k in ("seed", "step_idx", "t"):
             sd[k] = int(sd[k])
-        for k in ("params", "m", "v", "losses", "gen_state"):
+        for k in ("params", "m", "v", "losses", "gen_state", "t_vec"):
             if k in sd:
                 sd[k] = torch.from_numpy(np.array(sd[k]))
         self.load_state_dict(sd)
