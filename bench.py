@@ -442,13 +442,14 @@ def main():
 
     optim = {"lr": 0.03, "lrd": (0.005 / 0.03) ** (1.0 / 10000), "betas": (0.80, 0.99)}
 
-    def build(mode, cells=None):
+    def build(mode, cells=None, conditions=None):
         cells = args.cells if cells is None else cells
+        conditions = args.conditions if conditions is None else conditions
         t0 = time.perf_counter()
         if mode == "phase":
             spec = make_phase_spec(cells, args.genes, seed=0, device=device)
         else:
-            spec = make_velocity_spec(cells // args.conditions, args.genes, mode, args.conditions, 1, seed=0, device=device)
+            spec = make_velocity_spec(cells // conditions, args.genes, mode, conditions, 1, seed=0, device=device)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
         eng = HipEngine(spec, device=device, rank=rank, world_size=world, tuning=Tuning.from_env())
@@ -603,6 +604,20 @@ def main():
                         "valu_frac_at_in_loop_clock": (rf["valu"] or {}).get("frac_at_in_loop_clock")}
             if not args.no_loss_every_demo:
                 extra[m]["opt_in_loss_every_10"] = loss_every_demo(e2)
+            del s2, e2, r2
+            torch.cuda.empty_cache()
+        # BASELINE configs[4]: two samples (Nx = Nb = 2, one angular speed and one batch offset per sample) at the same total size --
+        # the one-hot batch design is folded per workgroup of the likelihood kernel (NB = 0 instantiation: nothing per cell)
+        for m in ("vjoint", "vcond"):
+            s2, e2, r2, _ = build(m, conditions=2)
+            ts2 = time_steps(r2, args.steps, args.warmup, False, device, max(5, args.repeats // 2))
+            rf = kernel_roofline(e2, r2, args.roofline_launches, median(ts2) / args.steps)
+            extra[m + "_2sample"] = {"steps_per_s": round(args.steps / median(ts2), 2), "ms_per_step": round(1e3 * median(ts2) / args.steps, 4),
+                                     "launches_per_step": e2.stats.get("launches_per_step"), "kernel": rf["kernel"],
+                                     "onehot_batches": e2.stats.get("onehot_batches"),
+                                     "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"], "hbm_frac": rf["frac"],
+                                     "step_frac": rf["step_frac"], "step_overhead_us": rf["step_overhead_us"],
+                                     "hbm_pipe_frac": rf["hbm_pipe_frac"], "valu_frac": (rf["valu"] or {}).get("frac")}
             del s2, e2, r2
             torch.cuda.empty_cache()
         out["modes"] = extra

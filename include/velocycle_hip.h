@@ -195,7 +195,8 @@ typedef struct vc_stats {
   int32_t pw_inline;              /* floats per row of the likelihood kernel's own d loglik / d nu_omega partials (4 | 8), 0: off */
   int32_t generic;                /* 1: the run-time-sized (slower) kernel set is in use: a configuration outside the compiled
                                      fast set (H > 3, > 4 batches, LRMN rank > 8, > 64 angular-speed coefficients) */
-  int32_t reserved1;
+  int32_t onehot_batches;         /* n > 0: the batch design matrix Db is one-hot, its n batch offsets are folded into the constant
+                                     harmonic per workgroup of the likelihood kernel (the kernel's NB is 0: nothing per cell) */
 } vc_stats;
 
 /* lifecycle ------------------------------------------------------------------------------- */

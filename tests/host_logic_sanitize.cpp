@@ -106,7 +106,80 @@ static void tiling_case(long long Nc, int nGB, int n_cu, int bpc, const double* 
   }
 }
 
+// one-hot batches: order by batch, batch-aligned workgroup table -- every position of every gene block is covered exactly once,
+// every workgroup lies inside the batch the table names, the batches' chunk ranges are consecutive and complete
+static void batch_case(long long Nc, int Nb, int nGB, int n_cu, int bpc, bool shuffled, unsigned seed) {
+  std::mt19937 rng(seed);
+  std::vector<float> Db((size_t)Nb * Nc, 0.f);
+  std::vector<int> want((size_t)Nc);
+  for (long long c = 0; c < Nc; ++c) {
+    int q = shuffled ? (int)(rng() % Nb) : (int)((c * Nb) / Nc);
+    if (Nb > 2 && q == 1) q = 0;                 // an empty batch
+    want[(size_t)c] = q;
+    Db[(size_t)q * Nc + c] = 1.f;
+  }
+  std::vector<int> bid, pos, ord, len;
+  CHECK(vc_onehot_batches(Db.data(), Nb, Nc, bid));
+  CHECK(bid == want);
+  const bool sorted = vc_order_by_batch(bid, Nb, pos, ord, len);
+  if (!shuffled) CHECK(sorted);
+  long long tot = 0;
+  for (int q = 0; q < Nb; ++q) tot += len[(size_t)q];
+  CHECK(tot == Nc);
+  for (long long c = 0; c < Nc; ++c) CHECK(ord[(size_t)pos[(size_t)c]] == (int)c);
+  for (long long p = 1; p < Nc; ++p) {
+    CHECK(bid[(size_t)ord[(size_t)p]] >= bid[(size_t)ord[(size_t)p - 1]]);
+    if (bid[(size_t)ord[(size_t)p]] == bid[(size_t)ord[(size_t)p - 1]]) CHECK(ord[(size_t)p] > ord[(size_t)p - 1]);      // stable
+  }
+  const double half[4] = {1.0, 0.5, 0.25, 0.125};
+  VcTiling t = vc_tile_cells(Nc, nGB, n_cu, bpc, 4, 0, half, 12);
+  int nonempty = 0;
+  for (int v : len) nonempty += v > 0;
+  if (t.n_chunks < nonempty) t.n_chunks = nonempty;
+  std::vector<int> tile, bc;
+  const int cwm = vc_tile_batches(Nc, nGB, t.n_chunks, n_cu, t.pass_cw, 4, len, tile, bc);
+  std::vector<long long> start((size_t)Nb + 1, 0);
+  for (int q = 0; q < Nb; ++q) start[(size_t)q + 1] = start[(size_t)q] + len[(size_t)q];
+  for (int gb = 0; gb < nGB; ++gb) {
+    long long next = 0;
+    for (int k = 0; k < t.n_chunks; ++k) {
+      const int* w = &tile[4 * ((size_t)k * nGB + gb)];
+      const int q = w[2];
+      CHECK(q >= 0 && q < Nb && w[1] <= cwm && w[1] >= 0);
+      CHECK(k >= bc[(size_t)gb * (Nb + 1) + q] && k < bc[(size_t)gb * (Nb + 1) + q + 1]);
+      CHECK(w[0] >= start[(size_t)q] && w[3] <= start[(size_t)q + 1] && w[0] <= w[3]);
+      CHECK(w[0] == next || w[0] == w[3]);
+      CHECK((long long)w[1] * 4 >= w[3] - w[0]);            // four waves of cw cells reach the end
+      if (w[3] > w[0]) next = w[3];
+    }
+    CHECK(next == Nc);
+    CHECK(bc[(size_t)gb * (Nb + 1)] == 0 && bc[(size_t)gb * (Nb + 1) + Nb] == t.n_chunks);
+    for (int q = 0; q < Nb; ++q) CHECK(bc[(size_t)gb * (Nb + 1) + q] <= bc[(size_t)gb * (Nb + 1) + q + 1]);
+  }
+  // not one-hot: a fractional entry, two entries in one column, an empty column
+  if (Nc >= 2) {
+    std::vector<float> bad = Db;
+    bad[0] = bad[0] == 1.f ? 0.5f : bad[0];
+    for (int q = 0; q < Nb; ++q) if (bad[(size_t)q * Nc] == 1.f) bad[(size_t)q * Nc] = 0.5f;
+    CHECK(!vc_onehot_batches(bad.data(), Nb, Nc, bid));
+    bad = Db;
+    for (int q = 0; q < Nb; ++q) bad[(size_t)q * Nc + 1] = 0.f;
+    CHECK(!vc_onehot_batches(bad.data(), Nb, Nc, bid));
+    if (Nb >= 2) { bad = Db; bad[1] = 1.f; bad[(size_t)Nc + 1] = 1.f; CHECK(!vc_onehot_batches(bad.data(), Nb, Nc, bid)); }
+  }
+}
+
 int main() {
+  {
+    std::mt19937 rng(5);
+    for (int it = 0; it < 120; ++it)
+      batch_case(1 + (long long)(rng() % 60000), 1 + (int)(rng() % 13), 1 + (int)(rng() % 8), (it % 4 == 0) ? 1 + (int)(rng() % 300) : 256,
+                 1 + (int)(rng() % 4), it % 2 == 1, 100 + it);
+    batch_case(50000, 2, 4, 256, 2, false, 1);
+    batch_case(50000, 8, 4, 256, 2, true, 2);
+    batch_case(23, 2, 1, 256, 2, false, 3);
+    batch_case(5, 5, 1, 256, 3, true, 4);
+  }
   {
     const double half[4] = {1.0, 0.5, 0.25, 0.125}, flat[4] = {1, 1, 1, 1}, odd[4] = {0.5, 0.3, 0.2, 0.2}, steep[4] = {0.85, 0.15, 0.15, 0.15};
     std::mt19937 rng(11);

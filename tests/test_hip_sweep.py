@@ -72,34 +72,56 @@ def _check(p, gpl=None, tuning=None):
         err = np.abs(got.cpu().numpy()[fin] - want[fin]).max() if fin.any() else 0.0
         assert err <= 3e-3 * max(np.abs(want[fin]).max() if fin.any() else 0, 1e-2), (name, err)
     kind = eng.stats["main_kernel"]
+    # batch offsets: a one-hot design matrix is folded per workgroup (the kernel's NB is 0 for any number of batches) unless the
+    # tuning asks for the dense contraction; anything else keeps NB = Nb (or the run-time-sized set beyond 4 batches)
+    if p.with_delta_nu and not eng.stats["generic"]:
+        onehot = bool(((p.Db == 0) | (p.Db == 1)).all() and (p.Db.sum(0) == 1).all()) and not tuning.dense_batches
+        assert eng.stats["onehot_batches"] == (p.Nb if onehot else 0), eng.stats
+        assert kind.startswith(f"vc_main_kernel<{p.H},{0 if onehot else p.Nb},"), kind
     eng.close()
     return kind
 
 
+def _dense(dense):
+    from velocycle_amd.tuning import Tuning
+    return Tuning(dense_batches=True) if dense else None
+
+
+@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 1, 2, 3, 4))))
-def test_phase_kernels(H, Nb):
+def test_phase_kernels(H, Nb, dense):
+    """dense = True: the compiled NB = 1..4 instantiations (batch offsets as a dense contraction per cell: what a design matrix
+    that is not one-hot runs); False: one-hot batches folded per workgroup, in the shuffled cell order `_problem` draws."""
+    if dense and Nb == 0:
+        pytest.skip("no batches")
     for noise, gpl in (("NegativeBinomial", 8), ("Poisson", 4), ("Lognormal", None)):
         p = _problem("phase", "meanfield", noise, H, 0, Nb, 0, [], Nc=70 + 13 * H, Ng=9 + Nb, seed=H * 10 + Nb)
-        _check(p, gpl)
+        _check(p, gpl, _dense(dense))
 
 
+@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 1, 2, 4))))
-def test_velocity_joint_kernels(H, Nb):
+def test_velocity_joint_kernels(H, Nb, dense):
+    if dense and Nb == 0:
+        pytest.skip("no batches")
     for noise, guide, Hw, Nx, gpl in (("NegativeBinomial", "meanfield", 1, 2, 8), ("Poisson", "lrmn", 0, 1, 4),
                                       ("Lognormal", "meanfield", 2, 3, None)):
         p = _problem("velocity", guide, noise, H, Hw, Nb, Nx, [], Nc=90 + 7 * Nb, Ng=7 + H, seed=100 + H * 10 + Nb)
-        k = _check(p, gpl)
+        k = _check(p, gpl, _dense(dense))
         assert "vfull" in k
 
 
+@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("H,Nb", list(itertools.product((1, 2, 3), (0, 2, 3))))
-def test_velocity_conditioned_kernels(H, Nb):
+def test_velocity_conditioned_kernels(H, Nb, dense):
+    if dense and Nb == 0:
+        pytest.skip("no batches")
     full = ["ϕxy", "ν", "shape_inv"] + (["Δν"] if Nb else [])
     for noise, guide, Hw, gpl in (("NegativeBinomial", "lrmn", 1, 8), ("NegativeBinomial", "meanfield", 3, 4),
                                   ("Poisson", "lrmn", 0, None), ("Lognormal", "meanfield", 1, None)):
         sites = [s for s in full if not (s == "shape_inv" and noise != "NegativeBinomial")]
         p = _problem("velocity", guide, noise, H, Hw, Nb, 2, sites, Nc=130, Ng=11, seed=200 + H * 10 + Nb)
-        k = _check(p, gpl)
+        k = _check(p, gpl, _dense(dense))
         assert "vu_" in k          # S term hoisted
 
 
@@ -147,7 +169,7 @@ def test_lrmn_with_a_nearly_empty_last_gene_block(Ng):
 def test_generic_phase_kernels(H, Nb):
     for noise in ("NegativeBinomial", "Poisson", "Lognormal"):
         p = _problem("phase", "meanfield", noise, H, 0, Nb, 0, [], Nc=70 + 13 * H, Ng=9 + Nb, seed=H * 10 + Nb)
-        k = _check(p, None)
+        k = _check(p, None, _dense(True))          # (a one-hot design with H <= 3 now runs on the fast set: test_onehot_*)
         assert "generic_phase" in k and "gpl2" in k, k
 
 
@@ -156,7 +178,7 @@ def test_generic_velocity_joint_kernels(H, Nb):
     for noise, guide, Hw, Nx in (("NegativeBinomial", "meanfield", 1, 2), ("Poisson", "lrmn", 0, 1), ("Lognormal", "meanfield", 4, 3),
                                  ("NegativeBinomial", "lrmn", 2, 2)):
         p = _problem("velocity", guide, noise, H, Hw, Nb, Nx, [], Nc=90 + 7 * Nb, Ng=7 + H, seed=100 + H * 10 + Nb)
-        k = _check(p, None)
+        k = _check(p, None, _dense(True) if Hw <= 3 else None)      # (Hw = 4 is generic by itself: there with the one-hot design as it is)
         assert "generic_vfull" in k, k
 
 
@@ -167,7 +189,7 @@ def test_generic_velocity_conditioned_kernels(H, Nb):
                              ("Lognormal", "meanfield", 1)):
         sites = [s for s in full if not (s == "shape_inv" and noise != "NegativeBinomial")]
         p = _problem("velocity", guide, noise, H, Hw, Nb, 2, sites, Nc=130, Ng=11, seed=200 + H * 10 + Nb)
-        k = _check(p, None)
+        k = _check(p, None, _dense(True) if Hw <= 3 else None)
         assert "generic_vu" in k, k          # S term hoisted by the generic S-only kernel
 
 
@@ -254,3 +276,58 @@ def test_unsupported_configurations_raise():
     sp4.condition_on = {"nonsense": torch.zeros(3)}
     with pytest.raises(ValueError):
         HipEngine(sp4)
+
+
+# ---- one-hot batch designs: any number of batches on the fast kernel set, at no cost per cell ---------------
+# The reference's make_design_matrix builds one indicator column per unique id (preprocessing.py:65-93), used as
+# einsum("bgc,bgc->gc", Db, dnu) (phase_inference_model.py:374-377) / its velocity form (velocity_inference_model.py:360).
+
+@pytest.mark.parametrize("order", ["contiguous", "shuffled"])
+@pytest.mark.parametrize("Nb", [2, 5, 8, 12])
+def test_onehot_batches_any_number_on_the_fast_set(Nb, order):
+    """Nb in {2, 5, 8, 12} batches, contiguous (anndata.concat(..., label="batch")) and interleaved (cells re-ordered by batch inside
+    the engine, results in the caller's order): phase, velocity joint (delta nu learned: its gradient is a sum over the batch's
+    workgroups) and the tutorials' conditioned velocity stage, against the float64 oracle; the kernel asserted NB = 0."""
+    for kind, guide, noise, sites, H in (("phase", "meanfield", "NegativeBinomial", [], 2),
+                                         ("velocity", "meanfield", "NegativeBinomial", [], 1),
+                                         ("velocity", "lrmn", "Poisson", [], 1),
+                                         ("velocity", "lrmn", "NegativeBinomial", ["ϕxy", "ν", "Δν", "shape_inv"], 1)):
+        p = _problem(kind, guide, noise, H, 1, Nb, 2, sites, Nc=400 + 31 * Nb, Ng=70, seed=500 + Nb)
+        if order == "contiguous":
+            idx = torch.argsort(p.Db.argmax(0), stable=True)
+            p.Db = p.Db[:, idx].contiguous()
+        for gpl in (4, 8):
+            k = _check(p, gpl)
+            assert k.startswith(f"vc_main_kernel<{H},0,") and "generic" not in k, k
+
+
+def test_a_design_matrix_that_is_not_onehot_keeps_the_dense_contraction():
+    """Soft batch memberships (columns 0.3 / 0.7) and a cell that belongs to two batches: the reference's einsum takes any matrix;
+    the engine then runs the dense NB = Nb kernels (<= 4 batches) or the run-time-sized set (more) -- same oracle, same bars."""
+    for Nb, soft in ((2, True), (3, False), (6, True)):
+        p = _problem("velocity", "meanfield", "NegativeBinomial", 1, 1, Nb, 2, [], Nc=300, Ng=40, seed=600 + Nb)
+        if soft:
+            p.Db = 0.3 * p.Db + 0.7 * p.Db.roll(1, 0)
+        else:
+            p.Db[1, 5] = 1.0
+            p.Db[0, 5] = 1.0
+        k = _check(p, None)
+        assert ("generic" in k) == (Nb > 4), k
+        if Nb <= 4:
+            assert k.startswith(f"vc_main_kernel<1,{Nb},"), k
+
+
+def test_onehot_batches_on_ragged_tilings_and_an_empty_batch():
+    """A batch without cells on this rank, a batch of three cells, tiles forced ragged: every workgroup still lies inside one batch
+    (vc_host_logic.h: vc_tile_batches) and every cell is evaluated exactly once."""
+    from velocycle_amd.tuning import Tuning
+    p = _problem("velocity", "meanfield", "NegativeBinomial", 1, 1, 5, 2, [], Nc=1500, Ng=300, seed=77)
+    b = torch.zeros(1500, dtype=torch.long)
+    b[700:703] = 3
+    b[703:] = 4
+    b[100:400] = 2                                   # batch 1 is empty
+    p.Db = torch.stack([(b == q).double() for q in range(5)])
+    for cw in (0, 7, 29):
+        k = _check(p, None, Tuning(cells_per_wave=cw))
+        assert k.startswith("vc_main_kernel<1,0,"), k
+

@@ -70,7 +70,7 @@ class vc_stats(C.Structure):
                 ("hist_on_device", C.c_int32), ("main_kernel_name", C.c_char * 96),
                 ("setup_transient_bytes", C.c_int64), ("count_storage_bytes", C.c_int64),
                 ("pass_cells", C.c_int32 * 4), ("launches_per_step", C.c_int32), ("pw_inline", C.c_int32),
-                ("generic", C.c_int32), ("reserved1", C.c_int32)]
+                ("generic", C.c_int32), ("onehot_batches", C.c_int32)]
 
 
 EXPORTS = {

@@ -54,7 +54,14 @@ struct VcDims {
   int Nc;                 // cells on this rank
   long long cell_offset;  // global index of the first local cell
   int H, Nh, Hw, Nhw, Nb, Nx, R, M, NW;   // M = Ng + Nx*Nhw, NW = Nx*Nhw
-  int K;                  // Nh + Nb : expression-map coefficients per gene (harmonics, then batch offsets)
+  int K;                  // Nh + Nb : expression-map coefficients per gene (harmonics, then batch offsets) = rows of the gene table in front of log beta
+  int onehot;             // 1: the batch design matrix Db is one-hot (preprocessing.py:65-93 builds it so) and every workgroup of the
+                          // likelihood kernel lies inside ONE batch: sum_b Db[b,c] dnu[b,g] = dnu[b(c),g] is added to the constant
+                          // harmonic when the wave loads its latents -- the NB = 0 instantiation runs for ANY number of batches, at no
+                          // cost per cell; d loglik / d dnu[b,g] = the sum of the constant harmonic's partial rows over the batch's
+                          // workgroups (vc_dnu_range_sum)
+  int Kq;                 // coefficient rows the likelihood kernel emits (K, or Nh when the batches are folded: onehot)
+  int nbk;                // batch entries of a cell record (Nb, or 0: onehot / no batch offsets)
   int pw_inline;          // 4 | 8: K_main (U-only and S+U kernels) writes PWM rows of that many floats, K_omega / K_fin read them
                           // instead of the cell blocks' PW; 0: off
   int pw_slots;           // float4 slots per wave of K_main's staged W rows (>= cells per wave x float4 per row)
@@ -134,7 +141,12 @@ struct VcBufs {
   const float* HC;                          // rows of 64 floats
   const int* hc_off;                        // [2][Ng_pad / 64] first row of a gene block (matrix S, then U)
   const int* hc_rows;                       // [2][Ng_pad / 64] rows of a gene block = 1 + its largest count
-  const int *wg_tile;                       // [n_main_wg][2] {first cell of wave 0, cells per wave} of the likelihood kernel's workgroups
+  const int *wg_tile;                       // [n_main_wg][4] {first cell of wave 0, cells per wave, batch, end of the workgroup's cells} of the
+                                            // likelihood kernel's workgroups (cells = POSITIONS of the blocked layout: cell_pos)
+  const int *bat_chunk;                     // onehot: [nGB][Nb + 1] first chunk of batch q among the chunks of a gene block (chunks of a batch are
+                                            // consecutive); entry Nb = n_chunks
+  const int *cell_pos;                      // position of cell c in the blocked counts / cell table / per-cell partial rows (cells ordered by
+                                            // batch when the batches are not contiguous); nullptr: the identity
   const float *gene_sum_u;                  // [Ng_pad] sum over this rank's cells of the unspliced counts of every gene (count noise)
   // per-step workspaces
   float *eps_used;
@@ -185,7 +197,7 @@ struct VcBufs {
 // The omega entries of a cell record (every value twice {x, x}: an SGPR pair is a packed operand of the likelihood kernel);
 // sk / ck = sin, cos of k phi, k = 1..H
 __device__ __forceinline__ void vc_rec_put_omega(float2* ct, const VcDims& d, float omega, const float* sk, const float* ck) {
-  const int nbk = d.with_dnu ? d.Nb : 0;
+  const int nbk = d.nbk;
   const float oz = omega * vc_rec_omega_scale(d.noise);
   ct[2 * d.H + nbk] = make_float2(oz, oz);
   if (VC_OMEGA_CS && d.kind == VC_KIND_VFULL) {          // read by the S+U kernel only; the other kinds keep the short record
@@ -198,8 +210,10 @@ __device__ __forceinline__ void vc_rec_put_omega(float2* ct, const VcDims& d, fl
       }
   }
 }
-// Row c of the W table of the U-only kernel (pw_inline): sk / ck = sin, cos of k phi_c up to Hw
-__device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c, const float* sk, const float* ck) {
+// position of cell c in the likelihood kernel's layout (blocked counts, cell table, per-cell partial rows, W table)
+__device__ __forceinline__ int vc_pos(const VcBufs& b, int c) { return b.cell_pos ? b.cell_pos[c] : c; }
+// Row of cell c (at position cp) of the W table of the U-only / S+U kernels (pw_inline): sk / ck = sin, cos of k phi_c up to Hw
+__device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c, int cp, const float* sk, const float* ck) {
   if (!(d.pw_inline && (d.kind == VC_KIND_VU || d.kind == VC_KIND_VFULL))) return;
   for (int xq = 0; xq < d.Nx; ++xq) {
     const float dx = b.Dm[(size_t)xq * d.Nc + c];
@@ -207,9 +221,28 @@ __device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c
     for (int h = 0; h < 2 * VC_MAXH + 1; ++h)
       if (h < d.Nhw) {
         const float z = (h == 0) ? 1.f : ((h & 1) ? sk[(h - 1) >> 1] : ck[(h - 1) >> 1]);
-        b.WT[(size_t)c * d.pw_inline + xq * d.Nhw + h] = dx * z;
+        b.WT[(size_t)cp * d.pw_inline + xq * d.Nhw + h] = dx * z;
       }
   }
+}
+// onehot: d loglik / d dnu[q, g] = the sum of the constant harmonic's partial row (GO row 0) over the workgroups of batch q of the
+// likelihood kernel's gene block that holds gene g -- chunks [c0, c1) of that gene block, added in chunk order (one fixed
+// association for every caller: K_post, K_tail, phase A), 16 chunks requested per trip
+__device__ __forceinline__ float vc_dnu_range_sum(const VcDims& d, const VcBufs& b, int g, int q) {
+  const int gbm = g / d.gbw;
+  const int c0 = b.bat_chunk[gbm * (d.Nb + 1) + q], c1 = b.bat_chunk[gbm * (d.Nb + 1) + q + 1];
+  const float* __restrict__ go = b.GO + g;
+  const size_t stride = (size_t)d.nq * d.Ng_pad;
+  float acc = 0.f;
+  constexpr int UB = 16;
+  for (int ch0 = c0; ch0 < c1; ch0 += UB) {
+    float v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) v[u] = go[(size_t)(ch0 + u < c1 ? ch0 + u : ch0) * stride];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) if (ch0 + u < c1) acc += v[u];
+  }
+  return acc;
 }
 // ---------------------------------------------------------------------------------------------
 // wave64 reductions with DPP row operations; the total lands in lane 63.
@@ -591,10 +624,10 @@ void vc_launch_clock_probe(unsigned long long wall_ticks, unsigned long long* ou
 // per-gene count histogram is built on the device in the same pass (vc_small_kernels.hip)
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
                            int Ng, int Nc, int nGB, int gbw, int log1p_transform, unsigned* tab, float* ovf_val,
-                           int* ovf_gene, unsigned* ovf_n, unsigned ovf_cap, int* bad, hipStream_t st);
+                           int* ovf_gene, unsigned* ovf_n, unsigned ovf_cap, int* bad, const int* ord, hipStream_t st);
 void vc_launch_scatter_csr(const long long* indptr, const int* indices, const float* data, float* dst, int Ng, int Nc,
                            int gbw, int log1p_transform, unsigned* tab, float* ovf_val, int* ovf_gene, unsigned* ovf_n,
-                           unsigned ovf_cap, int* bad, hipStream_t st);
+                           unsigned ovf_cap, int* bad, const int* pos, hipStream_t st);
 void vc_launch_expected_logs(const VcDims& d, const VcBufs& b, const float* nu, const float* dnu, const float* phi,
                              const float* omega, const float* logbeta, const float* gamma, float cf_avg, float* out_S,
                              float* out_S2, float* out_U, float* out_U2, hipStream_t st);

@@ -79,7 +79,9 @@ struct vc_engine {
   std::string err;
   std::vector<void*> allocs;
   bool finalized = false;
-  bool generic_needed = false;        // the configuration lies outside the compiled fast set (vc_create)
+  bool generic_needed = false;        // the configuration lies outside the compiled fast set for a reason other than its batches (vc_create)
+  bool generic_nb = false;            // ... because it has more than VC_MAXNB batches: generic only if their design matrix is not one-hot
+  std::vector<float> hDb;             // host copy of the batch design matrix (vc_finalize: is it one-hot?)
   bool have_counts = false, have_cells = false;
   bool prior_set[VC_PRIOR_COUNT] = {};
   // host copies needed at finalize
@@ -303,7 +305,8 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   // kernel keeps 2 K rows of per-gene state in the LDS of one wave (K = 2 H + 1 + Nb <= 150: 150 KB of the CU's 160).
   if (c->n_harmonics < 1) return bad("vc_create: n_harmonics must be >= 1");
   if (c->with_delta_nu && c->Nb < 1) return bad("vc_create: with_delta_nu needs Nb >= 1");
-  bool generic = c->n_harmonics > VC_MAXH || (c->with_delta_nu && c->Nb > VC_MAXNB);
+  bool generic = c->n_harmonics > VC_MAXH;
+  const bool generic_nb = c->with_delta_nu && c->Nb > VC_MAXNB;      // (not with a one-hot design matrix: vc_finalize decides)
   if (vel) {
     if (c->n_harmonics_w < 0) return bad("vc_create: negative omega harmonics");
     if (c->Nx < 1) return bad("vc_create: bad Nx");
@@ -324,8 +327,9 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   if (!e) return bad("vc_create: out of host memory");
   e->cfg = *c;
   VcDims& d = e->d;
-  d.generic = generic ? 1 : 0;
+  d.generic = (generic || generic_nb) ? 1 : 0;      // provisional: vc_finalize
   e->generic_needed = generic;
+  e->generic_nb = generic_nb;
   d.Ng = (int)c->Ng;
   d.gpl = 4; d.gbw = 256;
   d.nGB = (d.Ng + d.gbw - 1) / d.gbw;
@@ -344,6 +348,7 @@ extern "C" int vc_create(const vc_config* c, vc_engine** out) {
   d.R = (vel && d.guide == VC_GUIDE_LRMN) ? c->lrmn_rank : 0;
   d.M = d.Ng + d.NW;
   d.K = d.Nh + d.Nb;
+  d.Kq = d.K; d.nbk = d.Nb; d.onehot = 0;      // provisional: vc_finalize
   d.ctw = 2 * ((vc_rec_pairs(d.H, d.Nb, false) + VC_REC_PAD - 1) / VC_REC_PAD * VC_REC_PAD);   // provisional (vc_finalize: the S+U kernel's record is longer)
   d.pw_inline = 0;
   d.cond = 0;
@@ -400,8 +405,7 @@ extern "C" int vc_set_tuning(vc_engine* e, const vc_tuning* t) {
     return e->fail(VC_ERR_ARG, "vc_set_tuning: a switch is outside its documented values");
   if (z.p2p_timeout_s < 0.f) return e->fail(VC_ERR_ARG, "vc_set_tuning: negative p2p_timeout_s");
   e->tun = z;
-  if (z.force_generic) e->d.generic = 1;
-  else e->d.generic = e->generic_needed ? 1 : 0;
+  e->d.generic = (z.force_generic || e->generic_needed || e->generic_nb) ? 1 : 0;      // provisional: vc_finalize
   if (z.p2p_timeout_s > 0.f) e->p2p_timeout_s = z.p2p_timeout_s;
   return VC_OK;
 }
@@ -546,6 +550,9 @@ extern "C" int vc_set_cell_data(vc_engine* e, const float* count_factor, const f
     HIPCHK(e, hipMemcpy(dbm, Db, sizeof(float) * d.Nb * d.Nc, hipMemcpyHostToDevice));
   }
   e->b.cf = cf; e->b.Dm = dm; e->b.Dbm = dbm; e->b.pxy = pxy;
+  if (d.Nb > 0) {
+    try { e->hDb.assign(Db, Db + (size_t)d.Nb * d.Nc); } catch (...) { return e->fail(VC_ERR_ARG, "out of host memory"); }
+  }
   e->have_cells = true;
   return VC_OK;
 }
@@ -629,6 +636,24 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   if (!vel && d.with_dnu && !e->prior_set[VC_PRIOR_SD_DNU])
     return e->fail(VC_ERR_STATE, "vc_finalize: sd_dnu prior not set");
 
+  // Batch offsets.  The reference's design matrix is one-hot by construction (make_design_matrix, preprocessing.py:65-93): then the
+  // offset of a cell's batch is folded into the constant harmonic per workgroup of the likelihood kernel (cells ordered by batch,
+  // workgroups aligned to the batch boundaries), the kernel without batch terms runs for ANY number of batches and the gradient
+  // of an offset is a sum over its batch's workgroups.  Any other matrix keeps the dense contraction (<= VC_MAXNB batches on the
+  // fast kernel set, the run-time-sized set beyond).
+  std::vector<int> bat_id, bat_pos, bat_ord, bat_len;
+  bool bat_sorted = true;
+  d.onehot = 0;
+  if (d.with_dnu && d.Nb >= 1 && !e->tun.dense_batches && !e->tun.force_generic && !e->generic_needed &&
+      vc_onehot_batches(e->hDb.data(), d.Nb, d.Nc, bat_id)) {
+    d.onehot = 1;
+    bat_sorted = vc_order_by_batch(bat_id, d.Nb, bat_pos, bat_ord, bat_len);
+  }
+  std::vector<float>().swap(e->hDb);
+  d.generic = (e->tun.force_generic || e->generic_needed || (e->generic_nb && !d.onehot)) ? 1 : 0;
+  d.Kq = d.onehot ? d.Nh : d.K;
+  d.nbk = d.onehot ? 0 : d.Nb;
+  const int knb = d.nbk;            // the NB template argument of the likelihood kernel
   // kernel kind
   if (!vel) d.kind = VC_KIND_PHASE;
   else {
@@ -636,7 +661,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
                     (!nb || cond(e, VC_SITE_SHAPE_INV));
     d.kind = vu ? VC_KIND_VU : VC_KIND_VFULL;
   }
-  auto nq_of = [&](int kind) { return kind == VC_KIND_PHASE ? d.K + 1 : (kind == VC_KIND_VFULL ? d.K + 3 : 2); };
+  auto nq_of = [&](int kind) { return kind == VC_KIND_PHASE ? d.Kq + 1 : (kind == VC_KIND_VFULL ? d.Kq + 3 : 2); };
   auto nco_of = [&](int kind) { return kind == VC_KIND_VFULL ? 3 : 1; };
   d.nq = nq_of(d.kind);
   d.nco = nco_of(d.kind);
@@ -648,7 +673,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   if (!d.generic) {
     const void* k8 = nullptr;
     hipFuncAttributes fa;
-    if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
+    if (vc_find_main_kernel(d.H, knb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
         hipFuncGetAttributes(&fa, k8) == hipSuccess && fa.localSizeBytes <= max_scratch)
       d.gpl = 8;
     if (d.gpl == 8) {
@@ -679,7 +704,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
           const void* k4 = nullptr;
           int bpc4 = 0;
           if (e->tun.pw_inline != 1 && !e->tun.no_tail2 &&
-              vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 4, 0, nullptr, &k4) && k4 &&
+              vc_find_main_kernel(d.H, knb, d.kind, d.noise, 4, 0, nullptr, &k4) && k4 &&
               hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc4, k4, 256, 0) == hipSuccess && bpc4 >= 1) {
             const VcTiling t4 = vc_tile_cells(shard_cells, (d.Ng + 255) / 256, n_cu, bpc4, VC_WAVES, 0, nullptr, 12);
             two_launch8 = t4.cw > 12;
@@ -694,7 +719,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     if (e->tun.genes_per_lane == 8) {       // honoured only where the 8-genes-per-lane kernel may run at all (no scratch: see above)
       const void* k8 = nullptr;
       hipFuncAttributes fa;
-      if (vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
+      if (vc_find_main_kernel(d.H, knb, d.kind, d.noise, 8, 0, nullptr, &k8) && k8 &&
           hipFuncGetAttributes(&fa, k8) == hipSuccess && fa.localSizeBytes <= max_scratch)
         d.gpl = 8;
     }
@@ -713,11 +738,11 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     e->main_name = gen_names[d.kind][d.noise];
     if (d.kind == VC_KIND_VU) e->phase_fn = vc_find_generic_main_kernel(VC_KIND_PHASE, d.noise, nullptr);
   } else {
-    e->main_fn = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, 0, &e->main_name, &main_kernel);
+    e->main_fn = vc_find_main_kernel(d.H, knb, d.kind, d.noise, d.gpl, 0, &e->main_name, &main_kernel);
   }
-  if (!e->main_fn) return e->fail(VC_ERR_UNSUPPORTED, "no likelihood kernel for H=%d Nb=%d kind=%d noise=%d", d.H, d.Nb, d.kind, d.noise);
+  if (!e->main_fn) return e->fail(VC_ERR_UNSUPPORTED, "no likelihood kernel for H=%d Nb=%d kind=%d noise=%d", d.H, knb, d.kind, d.noise);
   if (d.kind == VC_KIND_VU && !d.generic) {
-    e->phase_fn = vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, 0, nullptr, nullptr);
+    e->phase_fn = vc_find_main_kernel(d.H, knb, VC_KIND_PHASE, d.noise, d.gpl, 0, nullptr, nullptr);
     if (!e->phase_fn) return e->fail(VC_ERR_UNSUPPORTED, "no S-only kernel for the hoisted term");
   }
   // HBM layout of the counts: [gene block][cell][gbw], zero padded in genes; the per-gene count histograms are built on
@@ -748,6 +773,14 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     if (bad) (void)hipFree(bad);
     ovf_n = nullptr; bad = nullptr;
   };
+  // cells ordered by batch (one-hot batches that are not contiguous): the blocked counts, the cell table and the per-cell partial
+  // rows live in that order; every per-cell kernel maps its cell through cell_pos (vc_common.h: vc_pos)
+  const int* dev_ord = nullptr;
+  b.cell_pos = nullptr;
+  if (d.onehot && !bat_sorted) {
+    TRY(upload(e, bat_pos, &b.cell_pos));
+    TRY(upload(e, bat_ord, &dev_ord));
+  }
   TRY(tmalloc((void**)&ovf_n, 2 * sizeof(unsigned)));
   TRY(tmalloc((void**)&bad, 4 * sizeof(int)));
   HIPCHK(e, hipMemsetAsync(ovf_n, 0, 2 * sizeof(unsigned), st));
@@ -772,11 +805,11 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       const int ln = d.noise == VC_NOISE_LOGNORMAL;
       if (c.kind == 1) {
         vc_launch_pack_counts(c.dense, packed, e->dgs, e->dcs, d.Ng, d.Nc, d.nGB, d.gbw, ln, tab[m], ovf_val[m], ovf_gene[m],
-                              ovf_n + m, OVF_CAP, bad, st);
+                              ovf_n + m, OVF_CAP, bad, dev_ord, st);
       } else {
         HIPCHK(e, hipMemsetAsync(packed, 0, blocked * sizeof(float), st));
         vc_launch_scatter_csr(c.indptr, c.indices, c.data, packed, d.Ng, d.Nc, d.gbw, ln, tab[m], ovf_val[m], ovf_gene[m],
-                              ovf_n + m, OVF_CAP, bad, st);
+                              ovf_n + m, OVF_CAP, bad, b.cell_pos, st);
       }
       HIPCHK(e, hipStreamSynchronize(st));
       HIPCHK(e, hipGetLastError());
@@ -797,8 +830,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       const void* k16 = nullptr;
       const char* nm = nullptr;
       hipFuncAttributes fa;
-      vc_main_launch_fn f16 = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, 1, &nm, &k16);
-      vc_main_launch_fn p16 = d.kind == VC_KIND_VU ? vc_find_main_kernel(d.H, d.Nb, VC_KIND_PHASE, d.noise, d.gpl, 1, nullptr, nullptr) : nullptr;
+      vc_main_launch_fn f16 = vc_find_main_kernel(d.H, knb, d.kind, d.noise, d.gpl, 1, &nm, &k16);
+      vc_main_launch_fn p16 = d.kind == VC_KIND_VU ? vc_find_main_kernel(d.H, knb, VC_KIND_PHASE, d.noise, d.gpl, 1, nullptr, nullptr) : nullptr;
       if (f16 && k16 && (d.kind != VC_KIND_VU || p16) && hipFuncGetAttributes(&fa, k16) == hipSuccess && fa.localSizeBytes <= max_scratch) {
         const size_t blocked = (size_t)d.nGB * d.Nc * d.gbw;
         const float** dstp[2] = {&b.S, &b.U};
@@ -820,6 +853,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       }
     }
   }
+  std::vector<int> tile_host, bat_chunk_host;      // the workgroup table / the batches' chunk ranges (one-hot batches: built with the tiling)
   // tiling: one balanced round.  The grid is sized to the workgroups the chip holds at once for
   // this kernel (occupancy x 256 CUs); each wave gets an equal share of the cells of its gene block,
   // so no partially filled last round is left over (a 2.04-round grid costs 3 rounds).
@@ -851,6 +885,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     // (Nc, Ng, occupancy, CUs): results are reproducible.
     auto tile = [&](int blocks_per_cu) {
       if (blocks_per_cu < 1) blocks_per_cu = 1;
+      tile_host.clear(); bat_chunk_host.clear();
       double share[4] = {1.0, 0.5, 0.25, 0.125};
       if (d.kind == VC_KIND_VFULL && blocks_per_cu == 2) {
         // round 3: with two cells of the S+U kernel's counts in flight (hand-placed waits) the older wave of a SIMD stalls less
@@ -876,6 +911,15 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       d.n_chunks = t.n_chunks;
       d.pass_wgs = n_cu;
       for (int p = 0; p < 4; ++p) d.pass_cw[p] = t.pass_cw[p];
+      if (d.onehot) {
+        // every workgroup inside one batch: the chunks of a gene block are dealt out to the batches in proportion to their cells
+        // (vc_host_logic.h: vc_tile_batches); a non-empty batch needs at least one chunk
+        int nonempty = 0;
+        for (int v : bat_len) nonempty += v > 0;
+        if (d.n_chunks < nonempty) d.n_chunks = nonempty;
+        const int cwm = vc_tile_batches(d.Nc, d.nGB, d.n_chunks, d.pass_wgs, d.pass_cw, wg_waves, bat_len, tile_host, bat_chunk_host);
+        if (cwm > d.cw) d.cw = cwm;
+      }
       d.n_main_wg = d.nGB * d.n_chunks;
     };
     int bpc0 = 0;
@@ -914,7 +958,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   if (!d.generic && d.noise == VC_NOISE_NB) {
     // the gradient-only twin of the selected kernel (same tiling, same dynamic LDS); used only after vc_set_loss_every(k > 1)
     const void* knl = nullptr;
-    e->main_fn_nl = vc_find_main_kernel(d.H, d.Nb, d.kind, d.noise, d.gpl, d.c16 | 2, &e->main_name_nl, &knl);
+    e->main_fn_nl = vc_find_main_kernel(d.H, knb, d.kind, d.noise, d.gpl, d.c16 | 2, &e->main_name_nl, &knl);
     hipFuncAttributes fa;
     if (e->main_fn_nl && knl && (hipFuncGetAttributes(&fa, knl) != hipSuccess || fa.localSizeBytes > 0)) e->main_fn_nl = nullptr;
     const unsigned dyn = vc_main_dyn_lds(d);
@@ -924,15 +968,24 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     // the tiling as a table: {first cell of wave 0, cells per wave} of every workgroup of the likelihood kernel, evaluated
     // HERE by the function the kernel used to run itself (vc_host_logic.h; 64-bit divisions = ~700 scalar instructions in
     // front of every wave's first load)
-    std::vector<int> tile(2 * (size_t)d.n_main_wg);
-    for (int w = 0; w < d.n_main_wg; ++w) {
-      int cw = 0;
-      const long long first = vc_wave_first_cell(w / d.nGB, w % d.nGB, 0, d.nGB, d.pass_wgs, d.pass_cw, d.generic ? 1 : VC_WAVES, &cw);
-      tile[2 * (size_t)w] = (int)std::min<long long>(first, 0x7fffffff);
-      tile[2 * (size_t)w + 1] = cw;
+    // {first cell, cells per wave, batch, end of the workgroup's cells}; one-hot batches: the batch-aligned table built with the tiling
+    if (!d.onehot) {
+      tile_host.assign(4 * (size_t)d.n_main_wg, 0);
+      for (int w = 0; w < d.n_main_wg; ++w) {
+        int cw = 0;
+        const long long first = vc_wave_first_cell(w / d.nGB, w % d.nGB, 0, d.nGB, d.pass_wgs, d.pass_cw, d.generic ? 1 : VC_WAVES, &cw);
+        tile_host[4 * (size_t)w] = (int)std::min<long long>(first, (long long)d.Nc);
+        tile_host[4 * (size_t)w + 1] = cw;
+        tile_host[4 * (size_t)w + 3] = d.Nc;
+      }
+      b.bat_chunk = nullptr;
+    } else {
+      if (tile_host.size() != 4 * (size_t)d.n_main_wg) return e->fail(VC_ERR_STATE, "internal: batch-aligned tile table of the wrong size");
+      TRY(upload(e, bat_chunk_host, &b.bat_chunk));
     }
-    TRY(upload(e, tile, &b.wg_tile));
+    TRY(upload(e, tile_host, &b.wg_tile));
   }
+  if (dev_ord) { e->dfree(dev_ord); dev_ord = nullptr; }
   d.nb_pre_gene = d.Ng_pad / 64;       // 64 genes per block, the sites of a gene spread over its 4 waves
   d.nb_pre_cell = (d.Nc + 255) / 256;
   d.nb_post_gene = d.Ng_pad / 64;
@@ -968,7 +1021,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.eps_used, (size_t)e->layout.eps_total));
   HIPCHK(e, hipMemset(b.eps_used, 0, sizeof(float) * e->layout.eps_total));
   TRY(e->dalloc(&b.GT, (size_t)(d.K + 3) * d.Ng_pad));
-  d.ctw = 2 * ((vc_rec_pairs(d.H, d.Nb, d.kind == VC_KIND_VFULL) + VC_REC_PAD - 1) / VC_REC_PAD * VC_REC_PAD);   // values duplicated {x,x}, record padded to VC_REC_PAD pairs
+  d.ctw = 2 * ((vc_rec_pairs(d.H, d.nbk, d.kind == VC_KIND_VFULL) + VC_REC_PAD - 1) / VC_REC_PAD * VC_REC_PAD);   // values duplicated {x,x}, record padded to VC_REC_PAD pairs
   TRY(e->dalloc(&b.CT, (size_t)d.Nc * d.ctw));
   HIPCHK(e, hipMemset(b.CT, 0, sizeof(float) * (size_t)d.Nc * d.ctw));
   TRY(e->dalloc(&b.lat_delta, (size_t)d.M));
@@ -1751,8 +1804,9 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   out->launches_per_step = fused_launches_per_step(e);
   out->pw_inline = d.pw_inline;
   out->generic = d.generic;
-  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.Nb, e->main_name, d.gpl,
+  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.nbk, e->main_name, d.gpl,
            d.c16 ? ",u16" : "");
+  out->onehot_batches = d.onehot ? d.Nb : 0;
   return VC_OK;
 }
 

@@ -106,13 +106,16 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   const float* __restrict__ eps_old = b.EPS + (size_t)((s + 2) % 3) * d.eps_total;
   auto draw_new = [&](long long idx) { return boot ? vc_philox_normal(seed, s, idx) : eps_new[idx]; };
   const bool nb = d.noise == VC_NOISE_NB;
-  const int K = d.K, Nh = d.Nh;
+  const int K = d.Kq, KT = d.K, Nh = d.Nh;      // K: coefficient rows of K_main's partials; KT: rows of the gene table in front of log beta
   const float rw = d.root_w;
   const size_t NP = d.Ng_pad;
   const bool live = g < d.Ng;
   // role kinds
   const bool r_nu = role < Nh;
-  const bool r_dnu = !r_nu && role < Nh + d.Nb && d.with_dnu;
+  const bool r_dnu = !r_nu && role < Nh + d.Nb && d.with_dnu && !d.onehot;
+  // one-hot batches: the waves of roles Nh .. 11 take the batch offsets q = role - Nh, + (12 - Nh), ... in a loop of their own
+  // (vc_tail_dnu_onehot: any number of batches); the role machinery below sees no delta-nu role then
+  const bool r_dnu1 = !r_nu && role < 12 && d.with_dnu && d.onehot;
   const bool r_si = role == 12 && nb;
   const bool r_mf = (role == 13 || role == 14) && vel && !lrmn;      // mean-field: role 13 log gamma, role 14 log beta
   const bool r_core = role == 13 && lrmn;
@@ -167,7 +170,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     } else if (r_si) {
       off[0] = (int)(d.poff[VC_P_SHAPE_INV_ULOCS] + g); nown = 1;
       if (chain) {
-        in[0] = b.GT[(size_t)(K + 2) * NP + g];
+        in[0] = b.GT[(size_t)(KT + 2) * NP + g];
         if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
         {
           // the gene's histogram terms (usually 2..4 tasks): four requested per trip instead of one (a dependent round trip
@@ -191,7 +194,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     } else if (r_mf || r_core || r_cov) {
       in[2] = b.sd_g[g]; in[3] = b.mu_g[g]; in[5] = b.sd_b[g]; in[6] = b.mu_b[g];
       if (chain) {
-        in[0] = b.GT[(size_t)(K + 1) * NP + g];
+        in[0] = b.GT[(size_t)(KT + 1) * NP + g];
         if (!CND(VC_SITE_LOGGAMMA)) in[1] = b.lat[VC_SITE_LOGGAMMA][g];
         if (!CND(VC_SITE_LOGBETA)) in[4] = b.lat[VC_SITE_LOGBETA][g];
       }
@@ -363,6 +366,35 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       }
     }
   }
+  // ---- one-hot batches: delta nu[q, g] of this wave's batches, start to end (gradient from the batch's workgroups -> phase A's
+  // partial / ClippedAdam -> the value of the next sample, its prior term, gene-table row) -------------------------------
+  float logp_dnu = 0.f;
+  if (r_dnu1 && live) {
+    for (int q = role - Nh; q < d.Nb; q += 12 - Nh) {
+      const long long jq = (long long)q * d.Ng + g;
+      const int po = (int)(d.poff[VC_P_DNU_LOCS] + jq);
+      const float sd = vel ? 0.01f : b.sd_dnu[jq];
+      float p = P[po];
+      if (!boot) {
+        float gq = 0.f;
+        if (phase == VC_PH_B) gq = xb.x[po];                           // the gradient summed over ranks
+        else if (!CND(VC_SITE_DNU)) gq = -(vc_dnu_range_sum(d, b, g, q) - rw * b.lat[VC_SITE_DNU][jq] / (sd * sd));
+        if (phase == VC_PH_A) xb.x[po] = gq;
+        else {
+          G[po] = gq;
+          float mm = Mm[po - header], vv = Vv[po - header];
+          p = vc_adam_elem(p, gq, mm, vv, o.step_size, o.b1, o.b2, o.eps, o.clip);
+          Mm[po - header] = mm; Vv[po - header] = vv; P[po] = p;
+        }
+      }
+      if (samp) {
+        const float x = CND(VC_SITE_DNU) ? b.cnd[VC_SITE_DNU][jq] : p;
+        logp_dnu += vc_normal_lp(x, 0.f, sd);
+        b.lat[VC_SITE_DNU][jq] = x;
+        b.GT[(size_t)(Nh + q) * NP + g] = x;
+      }
+    }
+  }
   // ---- gradient out, ClippedAdam on the owned parameters (phase B: gg is the sum over ranks) -------------------------
   if (upd && live) {
 #pragma unroll
@@ -380,13 +412,13 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 
   VC_WSTAMP(0, 4);
   // ---- the guide sample of step s from the fresh parameters (statement by statement vc_pre_kernel) ---------------
-  float logp = 0.f, logq = 0.f;
+  float logp = logp_dnu, logq = 0.f;
   double lpr = 0.0;
   if (g < d.Ng_pad && !live) {
     if (boot && wave == 0) {       // padded gene: nu~ = 0 (never reaches a per-cell sum), loss masked in K_main
       float* GT = b.GT + g;
-      for (int k = 0; k < K; ++k) GT[k * NP] = 0.f;
-      GT[K * NP] = 0.f; GT[(K + 1) * NP] = 1.f; GT[(K + 2) * NP] = 1.f;
+      for (int k = 0; k < KT; ++k) GT[k * NP] = 0.f;
+      GT[KT * NP] = 0.f; GT[(KT + 1) * NP] = 1.f; GT[(KT + 2) * NP] = 1.f;
     }
   }
   if (live) {
@@ -413,7 +445,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       logp += d.gamma_alpha * logf(d.gamma_beta) + (d.gamma_alpha - 1.f) * logf(si) - d.gamma_beta * si - d.lgamma_alpha;
       b.lat[VC_SITE_SHAPE_INV][g] = si;
       const float r = 1.0f / si;
-      GT[(K + 2) * NP] = r;
+      GT[(KT + 2) * NP] = r;
       // the r-only likelihood term of THIS sample, for the loss of the step it belongs to (half s & 1)
       if (d.nmat_r > 0) lpr = -((double)d.nmat_r * d.Nc * (double)r * (double)logf(r));
       if (!CND(VC_SITE_SHAPE_INV)) {      // what the histogram blocks of the next launch re-derive the update from
@@ -421,7 +453,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
         sis[0] = pp[0]; sis[NP] = pm[0]; sis[2 * NP] = pv[0]; sis[3 * NP] = si;
       }
     } else if (role == 12 && boot && !nb) {
-      GT[(K + 2) * NP] = 1.0f;
+      GT[(KT + 2) * NP] = 1.0f;
     } else if (r_mf && role == 13) {
       const float eg = e0;
       const float ug = pp[1];
@@ -430,7 +462,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       const float lg = CND(VC_SITE_LOGGAMMA) ? b.cnd[VC_SITE_LOGGAMMA][g] : lg_guide;
       logp += vc_normal_lp(lg, in[3], in[2]);
       b.lat[VC_SITE_LOGGAMMA][g] = lg;
-      GT[(K + 1) * NP] = expf(lg);
+      GT[(KT + 1) * NP] = expf(lg);
     } else if (r_mf) {
       const float eb = e0;
       const float ub = pp[1];
@@ -439,7 +471,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       const float lbv = CND(VC_SITE_LOGBETA) ? b.cnd[VC_SITE_LOGBETA][g] : lb_guide;
       logp += vc_normal_lp(lbv, in[6], in[5]);
       b.lat[VC_SITE_LOGBETA][g] = lbv;
-      GT[K * NP] = lbv;
+      GT[KT * NP] = lbv;
     } else if (r_cov) {
       // LowRankMultivariateNormal.rsample, low-rank part: sum_k W[g,k] eps_W[k] and sum_k W[g,k]^2 -> role 13
       float dW = 0.f, w2 = 0.f;
@@ -484,16 +516,16 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     logp += vc_normal_lp(lg, in[3], in[2]) + vc_normal_lp(lbv, in[6], in[5]);
     b.lat[VC_SITE_LOGGAMMA][g] = lg;
     b.lat[VC_SITE_LOGBETA][g] = lbv;
-    GT[K * NP] = lbv;
-    GT[(K + 1) * NP] = expf(lg);
+    GT[KT * NP] = lbv;
+    GT[(KT + 1) * NP] = expf(lg);
   }
   if (role == 12) {                                // (every gene block has this wave; 0 without a negative binomial)
     const double tot = vc_wave_sum_d63(lpr);
     if (lane == 63) b.LPR[(size_t)(s & 1) * d.nb_post_gene + gblock] = tot;
   }
   if (live && !vel && role == 13 && boot) {      // phase model: the velocity rows of the gene table are constants
-    b.GT[(size_t)K * NP + g] = 0.f;
-    b.GT[(size_t)(K + 1) * NP + g] = 1.f;
+    b.GT[(size_t)KT * NP + g] = 0.f;
+    b.GT[(size_t)(KT + 1) * NP + g] = 1.f;
   }
   VC_WSTAMP(0, 5);
   // prior / guide terms of the step-s sample: fp64 block sum in fixed order
@@ -561,7 +593,8 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   float ex = 0.f, ey = 0.f;
   double loss = 0.0;
   const long long poff = d.poff[VC_P_PHIXY_LOCS] + 2LL * c;
-  const float2* ctr = reinterpret_cast<const float2*>(b.CT + (size_t)(in_range ? c : 0) * d.ctw);
+  const int cp = in_range ? vc_pos(b, c) : 0;      // the cell's place in the likelihood kernel's order (record, partial rows, W row)
+  const float2* ctr = reinterpret_cast<const float2*>(b.CT + (size_t)cp * d.ctw);
   if (in_range) {
     pxy = *reinterpret_cast<const float2*>(b.pxy + 2 * (size_t)c);
     if (!cxy) {
@@ -598,11 +631,11 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
 #pragma unroll
           for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) v[u][j] = b.CO[((size_t)(gb0 + u < d.nGB ? gb0 + u : gb0) * 3 + j) * d.Nc + c];
+            for (int j = 0; j < 3; ++j) v[u][j] = b.CO[((size_t)(gb0 + u < d.nGB ? gb0 + u : gb0) * 3 + j) * d.Nc + cp];
         } else {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            v[u][0] = b.CO[(size_t)(gb0 + u < d.nGB ? gb0 + u : gb0) * d.Nc + c];
+            v[u][0] = b.CO[(size_t)(gb0 + u < d.nGB ? gb0 + u : gb0) * d.Nc + cp];
             v[u][1] = 0.f; v[u][2] = 0.f;
           }
         }
@@ -708,15 +741,15 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
         ck[k] = ck[k - 1] * c1 - sk[k - 1] * s1;
       }
       s1_new = s1; c1_new = c1;
-      float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
+      float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)cp * d.ctw);
       for (int k = 0; k < d.H; ++k) { ct[2 * k] = make_float2(sk[k], sk[k]); ct[2 * k + 1] = make_float2(ck[k], ck[k]); }
-      if (vel) vc_put_w(d, b, c, sk, ck);      // the W row of K_main's nu_omega partials follows the phase
+      if (vel) vc_put_w(d, b, c, cp, sk, ck);      // the W row of K_main's nu_omega partials follows the phase
       if (boot) {              // step-invariant entries of the record
-        for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
+        for (int q = 0; q < d.nbk; ++q) {
           const float v = b.Dbm[(size_t)q * d.Nc + c];
           ct[2 * d.H + q] = make_float2(v, v);
         }
-        const int nbk = d.with_dnu ? d.Nb : 0;
+        const int nbk = d.nbk;
         if (!vel) ct[2 * d.H + nbk] = make_float2(0.f, 0.f);
         { const float cfs = b.cf[c] * vc_rec_cf_scale(d.noise); ct[2 * d.H + nbk + 1] = make_float2(cfs, cfs); }
         if (!vel) { b.lat_omega[c] = 0.f; b.lat_domega[c] = 0.f; }
@@ -868,7 +901,7 @@ __device__ __forceinline__ void vc_hist_rederive_block(const VcDims& d, const Vc
   __shared__ float sm_a[VC_PG_WAVES][VC_PG_WAVES];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t NP = d.Ng_pad;
-  const int q = d.kind == VC_KIND_PHASE ? d.K : d.K + 2;
+  const int q = d.kind == VC_KIND_PHASE ? d.Kq : d.Kq + 2;
   const int task = task0 + wv;
   const bool have = task < b.n_tasks;
   // everything that depends on the task table only, requested together
@@ -927,7 +960,7 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
   __shared__ float sm_a[VC_PG_WAVES][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t NP = d.Ng_pad;
-  const int q = d.kind == VC_KIND_PHASE ? d.K : d.K + 2;
+  const int q = d.kind == VC_KIND_PHASE ? d.Kq : d.Kq + 2;
   const int g = gb * 64 + lane;
   const bool live = g < d.Ng;
   VcHistPre hp;
@@ -1289,7 +1322,7 @@ __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, f
       omega += dx * om;
       domega += dx * dd;
     }
-    vc_rec_put_omega(reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw), d, omega, sk, ck);
+    vc_rec_put_omega(reinterpret_cast<float2*>(b.CT + (size_t)vc_pos(b, c) * d.ctw), d, omega, sk, ck);
     b.lat_omega[c] = omega;
     b.lat_domega[c] = domega;
   }
@@ -1313,7 +1346,7 @@ __device__ __forceinline__ void vc_omega_block(const VcDims& d, const VcBufs& b,
   const int c = oblk * 256 + (int)threadIdx.x;
   float s1 = 0.f, c1 = 1.f;
   if (c < d.Nc) {
-    const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)c * d.ctw);
+    const float2* ct = reinterpret_cast<const float2*>(b.CT + (size_t)vc_pos(b, c) * d.ctw);
     s1 = ct[0].x; c1 = ct[1].x;
   }
   vc_nuw_sums_direct(d, b, boot, phase, xb, 256, sh_nuw);

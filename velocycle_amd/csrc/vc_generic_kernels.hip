@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void vc_main_generic_kernel(const VcDims d, con
   long long cbeg;
   {
     typedef const __attribute__((address_space(4))) int* ciptr;
-    ciptr tl = (ciptr)(const void*)(b.wg_tile + 2 * (size_t)blockIdx.x);
+    ciptr tl = (ciptr)(const void*)(b.wg_tile + 4 * (size_t)blockIdx.x);
     my_cw = tl[1];
     cbeg = (long long)tl[0];
   }

@@ -241,3 +241,96 @@ static inline VcTiling vc_tile_cells(long long Nc, int nGB, int n_cu, int blocks
   t.n_chunks = (int)n_ch;
   return t;
 }
+
+// ---------------------------------------------------------------------------------------------
+// One-hot batch design ("batches"): the reference builds Db as one indicator column per unique id
+// (preprocessing.py:65-93), so sum_b Db[b,c] dnu[b,g] = dnu[b(c),g].  When every workgroup of the likelihood kernel lies inside one
+// batch, that offset joins the constant harmonic once per wave and the kernel without batch terms runs for any number of batches.
+// ---------------------------------------------------------------------------------------------
+// Batch id of every cell of a (Nb, Nc) row-major design matrix, or false when some cell does not have exactly one 1 and Nb - 1 zeros.
+static inline bool vc_onehot_batches(const float* Db, int Nb, long long Nc, std::vector<int>& bid) {
+  bid.assign((size_t)Nc, -1);
+  for (int q = 0; q < Nb; ++q) {
+    const float* row = Db + (size_t)q * Nc;
+    for (long long c = 0; c < Nc; ++c) {
+      const float v = row[c];
+      if (v == 0.f) continue;
+      if (v != 1.f || bid[(size_t)c] >= 0) return false;
+      bid[(size_t)c] = q;
+    }
+  }
+  for (long long c = 0; c < Nc; ++c) if (bid[(size_t)c] < 0) return false;
+  return true;
+}
+
+// Cells ordered by batch (stable): pos[c] = position of cell c, ord[p] = cell at position p, len[q] = cells of batch q.
+// Returns true when the cells are in that order already (pos is then the identity).
+static inline bool vc_order_by_batch(const std::vector<int>& bid, int Nb, std::vector<int>& pos, std::vector<int>& ord, std::vector<int>& len) {
+  const size_t n = bid.size();
+  len.assign((size_t)Nb, 0);
+  bool sorted = true;
+  for (size_t c = 0; c < n; ++c) { len[(size_t)bid[c]]++; if (c && bid[c] < bid[c - 1]) sorted = false; }
+  std::vector<long long> start((size_t)Nb + 1, 0);
+  for (int q = 0; q < Nb; ++q) start[(size_t)q + 1] = start[(size_t)q] + len[(size_t)q];
+  pos.resize(n); ord.resize(n);
+  std::vector<long long> cur(start.begin(), start.end() - 1);
+  for (size_t c = 0; c < n; ++c) { const long long p = cur[(size_t)bid[c]]++; pos[c] = (int)p; ord[(size_t)p] = (int)c; }
+  return sorted;
+}
+
+// The workgroup table of the likelihood kernel {first cell, cells per wave, batch, end} with every workgroup inside one batch
+// (cells = positions; batch q holds positions [sum len[<q], + len[q])).  The chunks of a gene block keep their nominal weights
+// (pass_cw of their dispatch pass: the unequal shares of vc_tile_cells); consecutive groups of chunks are given to the batches
+// in proportion to their cells, every non-empty batch at least one chunk, and inside a group the cells are split in proportion
+// to the weights -- exactly: the groups tile the batch without gaps or overlap.  bat_chunk[gb][q] = first chunk of batch q.
+// Needs n_chunks >= number of non-empty batches.  Returns the largest cells-per-wave of the table.
+static inline int vc_tile_batches(long long Nc, int nGB, int n_chunks, int pass_wgs, const int* pass_cw, int waves,
+                                  const std::vector<int>& len, std::vector<int>& tile, std::vector<int>& bat_chunk) {
+  const int Nb = (int)len.size();
+  tile.assign(4 * (size_t)nGB * n_chunks, 0);
+  bat_chunk.assign((size_t)nGB * (Nb + 1), 0);
+  int nonempty = 0;
+  for (int q = 0; q < Nb; ++q) nonempty += len[(size_t)q] > 0;
+  int cw_max = 0;
+  std::vector<double> pre((size_t)n_chunks + 1);
+  for (int gb = 0; gb < nGB; ++gb) {
+    pre[0] = 0.0;
+    for (int k = 0; k < n_chunks; ++k) {
+      long long pass = ((long long)k * nGB + gb) / (pass_wgs > 0 ? pass_wgs : 1);
+      if (pass > 3) pass = 3;
+      pre[(size_t)k + 1] = pre[(size_t)k] + (double)(pass_cw[pass] > 0 ? pass_cw[pass] : 1);
+    }
+    const double Wtot = pre[(size_t)n_chunks];
+    int k = 0, left = nonempty;
+    long long seg = 0, cum = 0;
+    for (int q = 0; q < Nb; ++q) {
+      bat_chunk[(size_t)gb * (Nb + 1) + q] = k;
+      const long long L = len[(size_t)q];
+      if (L == 0) continue;
+      --left;
+      cum += L;
+      int k_end = k + 1;
+      if (left == 0) k_end = n_chunks;
+      else {
+        const double target = Wtot * (double)cum / (double)Nc;
+        while (k_end < n_chunks - left && std::fabs(pre[(size_t)k_end + 1] - target) <= std::fabs(pre[(size_t)k_end] - target)) ++k_end;
+      }
+      const double W0 = pre[(size_t)k], Wg = pre[(size_t)k_end] - W0;
+      for (int j = k; j < k_end; ++j) {
+        const long long a = (long long)std::floor((double)L * ((pre[(size_t)j] - W0) / Wg));
+        const long long bnd = (j + 1 == k_end) ? L : (long long)std::floor((double)L * ((pre[(size_t)j + 1] - W0) / Wg));
+        const long long cells = bnd > a ? bnd - a : 0;
+        const int cw = (int)((cells + waves - 1) / waves);
+        int* t = &tile[4 * ((size_t)j * nGB + gb)];
+        t[0] = (int)(seg + a); t[1] = cw; t[2] = q; t[3] = (int)(seg + a + cells);
+        if (cw > cw_max) cw_max = cw;
+      }
+      k = k_end;
+      seg += L;
+    }
+    bat_chunk[(size_t)gb * (Nb + 1) + Nb] = n_chunks;
+    // (chunks behind the last non-empty batch do not exist: the last group ends at n_chunks)
+  }
+  return cw_max;
+}
+

@@ -121,17 +121,20 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // The workgroups of one dispatch pass (pass_wgs = one per CU) are co-resident with those of the other passes on every
   // CU, and the SIMD arbiter serves the oldest wave first; the passes may therefore take unequal shares of the cells
   // (pass_cw[p] cells per wave in pass p), so that the waves of a SIMD end together (vc_host_logic.h: vc_tile_cells).
-  int my_cw;
-  long long cbeg;
-  {   // from the table vc_finalize wrote with vc_host_logic.h's vc_wave_first_cell: one scalar load (constant address space)
+  int my_cw, my_batch;
+  long long cbeg, wg_end;
+  {   // from the table vc_finalize wrote (vc_host_logic.h: vc_wave_first_cell / vc_tile_batches): one scalar load (constant
+      // address space) of {first cell, cells per wave, batch, end of the workgroup's cells}
     typedef const __attribute__((address_space(4))) int* ciptr;
-    ciptr tl = (ciptr)(const void*)(b.wg_tile + 2 * (size_t)blockIdx.x);
+    ciptr tl = (ciptr)(const void*)(b.wg_tile + 4 * (size_t)blockIdx.x);
     my_cw = tl[1];
+    my_batch = tl[2];
+    wg_end = tl[3];
     cbeg = (long long)tl[0] + (long long)wave * my_cw;
   }
   long long cend = cbeg + my_cw;
-  if (cbeg > d.Nc) cbeg = d.Nc;
-  if (cend > d.Nc) cend = d.Nc;
+  if (cbeg > wg_end) cbeg = wg_end;      // (wg_end <= Nc: the cells of the rank, or of the workgroup's batch when the batches are folded)
+  if (cend > wg_end) cend = wg_end;
   const int ncell = (int)(cend - cbeg);
   constexpr int ESZ = C16 ? 2 : 4;       // bytes per count element
   constexpr int NP = GPL / 2;           // packed pairs per lane
@@ -214,6 +217,9 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 
   // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
   v2f nu[K][NP], lb2[NP], ib[NP], gam[NP], rr[NP];
+  // rows of the gene table in front of log beta: K, or Nh + Nb when the batch offsets are folded per workgroup (d.onehot: this
+  // NB = 0 instantiation serves any number of batches)
+  const int KT = d.K;
   {
     const float* gt = b.GT + g0;
     const size_t gt_stride = (size_t)d.Ng_pad;
@@ -224,9 +230,16 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)k * gt_stride + 4 * q4);
         nu[k][2 * q4] = v2f{v.x, v.y}; nu[k][2 * q4 + 1] = v2f{v.z, v.w};
       }
-      const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)K * gt_stride + 4 * q4);
-      const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(K + 1) * gt_stride + 4 * q4);
-      const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(K + 2) * gt_stride + 4 * q4);
+      if (NB == 0 && d.onehot) {
+        // one-hot batch design: every cell of this workgroup belongs to batch my_batch, so sum_b Db[b,c] dnu[b,g] = dnu[my_batch, g]
+        // joins the constant harmonic here, once per wave -- nothing per cell (phase_inference_model.py:374-377,
+        // velocity_inference_model.py:360)
+        const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)(NH + my_batch) * gt_stride + 4 * q4);
+        nu[0][2 * q4] += v2f{v.x, v.y}; nu[0][2 * q4 + 1] += v2f{v.z, v.w};
+      }
+      const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)KT * gt_stride + 4 * q4);
+      const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(KT + 1) * gt_stride + 4 * q4);
+      const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(KT + 2) * gt_stride + 4 * q4);
       if (!HLB) { lb2[2 * q4] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[2 * q4 + 1] = v2f{v0.z, v0.w} * VC_LOG2E; }
       else lb2[2 * q4] = lb2[2 * q4 + 1] = v2(0.f);      // not used in the loop (epilogue re-reads log beta)
       ib[2 * q4] = v2f{__expf(-v0.x), __expf(-v0.y)}; ib[2 * q4 + 1] = v2f{__expf(-v0.z), __expf(-v0.w)};   // 1/beta
@@ -538,7 +551,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     float l = 0.f;
     if (HLB && chunk == 0 && wave == 0) {
       // sum_c k_U * (-log2 beta) over ALL of this rank's cells, added once per gene by the first wave of the gene block
-      const float* lbp = b.GT + (size_t)K * d.Ng_pad + g0;
+      const float* lbp = b.GT + (size_t)KT * d.Ng_pad + g0;
       const float* sup = b.gene_sum_u + g0;
 #pragma unroll
       for (int q4 = 0; q4 < NV4; ++q4) {

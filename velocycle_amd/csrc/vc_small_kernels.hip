@@ -57,9 +57,10 @@ __device__ __forceinline__ void vc_hist_put(const VcHistDev& h, int g, float v) 
   }
 }
 
+// ord (or nullptr): the cell stored at position c of the blocked layout (cells ordered by batch: vc_order_by_batch)
 __global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                       long long gs, long long cs, int Ng, int Nc, int nGB, int gbw, int log1p_t,
-                                      VcHistDev h) {
+                                      VcHistDev h, const int* __restrict__ ord) {
   const long long total = (long long)nGB * Nc * gbw;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -70,7 +71,7 @@ __global__ void vc_pack_counts_kernel(const float* __restrict__ src, float* __re
     const int g = gb * gbw + gl;
     float v = 0.f;
     if (g < Ng) {
-      v = src[(long long)g * gs + (long long)c * cs];
+      v = src[(long long)g * gs + (long long)(ord ? ord[c] : c) * cs];
       vc_hist_put(h, g, v);
       if (log1p_t) v = (float)log((double)v + 1.0 + 1e-16);   // preprocessing.py:154 / :267
     }
@@ -93,9 +94,10 @@ void vc_launch_counts_to_u16(const float* src, unsigned short* dst, long long n,
 
 // CSR (cells x genes, canonical: no duplicate entries) -> the blocked layout, one wave per cell; dst is pre-zeroed.
 // Reference counterpart: the `.A` / `.toarray()` densification of preprocessing.py:141-147, 243-252.
+// pos (or nullptr): the position of cell c in the blocked layout
 __global__ __launch_bounds__(256) void vc_scatter_csr_kernel(const long long* __restrict__ indptr, const int* __restrict__ indices,
                                                              const float* __restrict__ data, float* __restrict__ dst, int Ng,
-                                                             int Nc, int gbw, int log1p_t, VcHistDev h) {
+                                                             int Nc, int gbw, int log1p_t, VcHistDev h, const int* __restrict__ pos) {
   const int lane = threadIdx.x & 63;
   for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c < Nc; c += (long long)gridDim.x * 4) {
     const long long beg = indptr[c], end = indptr[c + 1];
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void vc_scatter_csr_kernel(const long long* __
       float v = data[k];
       vc_hist_put(h, g, v);
       if (log1p_t) v = (float)log((double)v + 1.0 + 1e-16);
-      dst[((size_t)(g / gbw) * Nc + c) * gbw + (g % gbw)] = v;
+      dst[((size_t)(g / gbw) * Nc + (pos ? pos[c] : c)) * gbw + (g % gbw)] = v;
     }
   }
 }
@@ -118,18 +120,18 @@ static VcHistDev vc_hist_dev(unsigned* tab, float* ovf_val, int* ovf_gene, unsig
 
 void vc_launch_pack_counts(const float* src, float* dst, long long gene_stride, long long cell_stride,
                            int Ng, int Nc, int nGB, int gbw, int log1p_transform, unsigned* tab, float* ovf_val,
-                           int* ovf_gene, unsigned* ovf_n, unsigned ovf_cap, int* bad, hipStream_t st) {
+                           int* ovf_gene, unsigned* ovf_n, unsigned ovf_cap, int* bad, const int* ord, hipStream_t st) {
   hipLaunchKernelGGL(vc_pack_counts_kernel, dim3(2048), dim3(256), 0, st, src, dst, gene_stride,
-                     cell_stride, Ng, Nc, nGB, gbw, log1p_transform, vc_hist_dev(tab, ovf_val, ovf_gene, ovf_n, ovf_cap, bad));
+                     cell_stride, Ng, Nc, nGB, gbw, log1p_transform, vc_hist_dev(tab, ovf_val, ovf_gene, ovf_n, ovf_cap, bad), ord);
 }
 
 void vc_launch_scatter_csr(const long long* indptr, const int* indices, const float* data, float* dst, int Ng, int Nc,
                            int gbw, int log1p_transform, unsigned* tab, float* ovf_val, int* ovf_gene, unsigned* ovf_n,
-                           unsigned ovf_cap, int* bad, hipStream_t st) {
+                           unsigned ovf_cap, int* bad, const int* pos, hipStream_t st) {
   int nb = (Nc + 3) / 4;
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(vc_scatter_csr_kernel, dim3(nb), dim3(256), 0, st, indptr, indices, data, dst, Ng, Nc, gbw,
-                     log1p_transform, vc_hist_dev(tab, ovf_val, ovf_gene, ovf_n, ovf_cap, bad));
+                     log1p_transform, vc_hist_dev(tab, ovf_val, ovf_gene, ovf_n, ovf_cap, bad), pos);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,16 +409,17 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
         }
       }
       // every value stored twice {x, x}: K_main fetches it as an SGPR pair = packed-math operand
-      float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
+      const int cp = vc_pos(b, c);                     // the record's place in the likelihood kernel's cell order
+      float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)cp * d.ctw);
       for (int k = 0; k < d.H; ++k) { ct[2 * k] = make_float2(sk[k], sk[k]); ct[2 * k + 1] = make_float2(ck[k], ck[k]); }
-      for (int q = 0; q < d.Nb && d.with_dnu; ++q) {
+      for (int q = 0; q < d.nbk; ++q) {                // (none when the one-hot batch offsets are folded per workgroup)
         const float v = b.Dbm[(size_t)q * d.Nc + c];
         ct[2 * d.H + q] = make_float2(v, v);
       }
-      const int nbk = d.with_dnu ? d.Nb : 0;
+      const int nbk = d.nbk;
       vc_rec_put_omega(ct, d, omega, sk, ck);
       { const float cfs = b.cf[c] * vc_rec_cf_scale(d.noise); ct[2 * d.H + nbk + 1] = make_float2(cfs, cfs); }
-      vc_put_w(d, b, c, sk, ck);
+      vc_put_w(d, b, c, cp, sk, ck);
       b.lat_phi[c] = phi;
       b.lat_omega[c] = omega;
       b.lat_domega[c] = domega;
@@ -508,8 +511,11 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
   const bool vel = d.model == VC_MODEL_VELOCITY;
   const bool lrmn = vel && d.guide == VC_GUIDE_LRMN;
   const bool nb = d.noise == VC_NOISE_NB;
-  const int K = d.K, Nh = d.Nh;
+  const int K = d.Kq, KT = d.K, Nh = d.Nh;      // K: coefficient rows of K_main's partials; KT: rows of the gene table in front of log beta
   const float rw = d.root_w;
+  // one-hot batches (d.onehot): the delta-nu gradients come from vc_dnu_range_sum, by the waves of roles Nh .. 11 in a loop
+  // over their batches (any number of batches); the dense form keeps one role per batch
+  const bool dnu_dense = d.with_dnu && !d.onehot;
   constexpr int NIN = 11 + VC_MAX_RANK;   // role 13 uses in[0..13], role 14 in[0..10] + the R cov_factor entries
   float in[NIN];
   double HLg = 0.0, HDg = 0.0;            // histogram task sums of this gene, fixed order
@@ -522,17 +528,17 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
         in[0] = b.lat[VC_SITE_NU][j]; in[1] = b.sd_nu[j]; in[2] = b.mu_nu[j];
         in[3] = b.eps_used[d.eoff[VC_E_NU] + j]; in[4] = P[d.poff[VC_P_NU_USCALES] + j];
       }
-    } else if (role < Nh + d.Nb && d.with_dnu) {
+    } else if (role < Nh + d.Nb && dnu_dense) {
       if (!CND(VC_SITE_DNU)) {
         const long long j = (long long)(role - Nh) * d.Ng + g;
         in[0] = b.lat[VC_SITE_DNU][j]; in[1] = vel ? 0.01f : b.sd_dnu[j];
       }
     } else if (role == 12 && nb) {
-      in[0] = b.GT[(size_t)(K + 2) * d.Ng_pad + g];
+      in[0] = b.GT[(size_t)(KT + 2) * d.Ng_pad + g];
       if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
       for (int t = b.h_tptr[g]; t < b.h_tptr[g + 1]; ++t) { HLg += b.HL[t]; HDg += b.HD[t]; }
     } else if ((role == 13 || role == 14) && vel) {
-      in[0] = b.GT[(size_t)(K + 1) * d.Ng_pad + g];
+      in[0] = b.GT[(size_t)(KT + 1) * d.Ng_pad + g];
       if (!CND(VC_SITE_LOGGAMMA)) { in[1] = b.lat[VC_SITE_LOGGAMMA][g]; in[2] = b.sd_g[g]; in[3] = b.mu_g[g]; }
       if (!CND(VC_SITE_LOGBETA)) { in[4] = b.lat[VC_SITE_LOGBETA][g]; in[5] = b.sd_b[g]; in[6] = b.mu_b[g]; }
       if (!lrmn) {
@@ -602,7 +608,7 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
       }
       G[d.poff[VC_P_NU_LOCS] + j] = gl;
       G[d.poff[VC_P_NU_USCALES] + j] = gu;
-    } else if (role < Nh + d.Nb && d.with_dnu) {
+    } else if (role < Nh + d.Nb && dnu_dense) {
       // ---- delta nu[q] ----
       const int q = role - Nh;
       const long long j = (long long)q * d.Ng + g;
@@ -612,6 +618,18 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
         gl = -(T(Nh + q) - rw * x / (sd * sd));
       }
       G[d.poff[VC_P_DNU_LOCS] + j] = gl;
+    } else if (role >= Nh && role < 12 && d.onehot) {
+      // ---- delta nu[q], one-hot batches: q = role - Nh, + (12 - Nh), ... ; the likelihood part is the constant harmonic's
+      // partial row summed over the batch's workgroups
+      for (int q = role - Nh; q < d.Nb; q += 12 - Nh) {
+        const long long j = (long long)q * d.Ng + g;
+        float gl = 0.f;
+        if (!CND(VC_SITE_DNU)) {
+          const float x = b.lat[VC_SITE_DNU][j], sd = vel ? 0.01f : b.sd_dnu[j];
+          gl = -(vc_dnu_range_sum(d, b, g, q) - rw * x / (sd * sd));
+        }
+        G[d.poff[VC_P_DNU_LOCS] + j] = gl;
+      }
     } else if (role == 12 && nb) {
       // ---- shape_inv: r-only terms of sum_c NB(k; r, eta): nmat*Nc*r*log r + sum_hist cnt*(lgamma(r+k)-lgamma(r))
       const float r = in[0];
@@ -717,8 +735,9 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
       pxy = *reinterpret_cast<const float2*>(b.pxy + 2 * (size_t)c);
       if (d.kind == VC_KIND_VFULL) { om = b.lat_omega[c]; dom = b.lat_domega[c]; }
     }
+    const int cp = vc_pos(b, c);
     for (int gb = 0; gb < d.nGB; ++gb)
-      for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + c];
+      for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + cp];
     VC_KSTAMP(1, 1);
     if (d.poff[VC_P_PHIXY_LOCS] >= 0) {
       float gx = 0.f, gy = 0.f;

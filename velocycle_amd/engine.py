@@ -179,7 +179,7 @@ class HipEngine:
                           setup_transient_bytes=st.setup_transient_bytes,
                           count_storage="u16" if st.count_storage_bytes == 2 else "f32",
                           pass_cells=[int(x) for x in st.pass_cells], launches_per_step=int(st.launches_per_step),
-                          pw_inline=int(st.pw_inline), generic=bool(st.generic))
+                          pw_inline=int(st.pw_inline), generic=bool(st.generic), onehot_batches=int(st.onehot_batches))
 
     # ------------------------------------------------------------------------------------------
     def param_shape(self, name):
