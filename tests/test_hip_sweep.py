@@ -222,7 +222,12 @@ def test_the_fast_instantiations_stay_selected_where_they_exist():
     for H, Nb, rank in ((3, 4, 8), (1, 0, 5)):
         p = _problem("velocity", "lrmn", "NegativeBinomial", H, 3, Nb, 3, [], Nc=90, Ng=12, seed=5)
         p.rho_rank = rank
-        e = HipEngine(spec_from_problem(p))
+        from velocycle_amd.tuning import Tuning
+        e = HipEngine(spec_from_problem(p))          # one-hot batches: folded, the kernel without batch terms
+        assert not e.stats["generic"] and e.stats["main_kernel"].startswith(f"vc_main_kernel<{H},0,vfull_nb,gpl"), e.stats
+        assert e.stats["onehot_batches"] == Nb
+        e.close()
+        e = HipEngine(spec_from_problem(p), tuning=Tuning(dense_batches=True))
         assert not e.stats["generic"] and e.stats["main_kernel"].startswith(f"vc_main_kernel<{H},{Nb},vfull_nb,gpl"), e.stats
         e.close()
 
