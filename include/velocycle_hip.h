@@ -264,6 +264,22 @@ int vc_clipped_adam(float* params, const float* grad, float* exp_avg, float* exp
                     int64_t t, const int64_t* t_dev, const float* loss_hdr, double* loss_ring,
                     int64_t loss_slots, void* hip_stream);
 
+/* The optimisers fit() accepts.  The reference hands whatever PyroOptim object it is given to pyro.infer.SVI
+ * (velocity_inference_model.py:76-84,111; phase_inference_model.py:125-133,162): every package tutorial passes
+ * pyro.optim.ClippedAdam (cells 27/43/56), tutorials/1D_Pancreas_Analysis.ipynb cell 26 passes pyro.optim.Adam (= torch.optim.Adam).
+ *   VC_OPT_CLIPPED_ADAM  lr_t = lr * lrd^t, g = clamp(g, +-clip_norm), [g += weight_decay * p], m / v moments,
+ *                        p -= lr_t sqrt(1 - beta2^t) / (1 - beta1^t) * m / (sqrt(v) + eps)
+ *   VC_OPT_ADAM          [g += weight_decay * p], no clamp, no decay (lrd and clip_norm are ignored),
+ *                        p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)       (amsgrad / maximize: not supported)
+ * vc_set_optimizer selects what the step entry points of an engine apply (default: ClippedAdam, no weight decay);
+ * vc_adam_update is the optimiser as a call of its own (vc_clipped_adam = kind VC_OPT_CLIPPED_ADAM, weight_decay 0). */
+#define VC_OPT_CLIPPED_ADAM 0
+#define VC_OPT_ADAM 1
+int vc_set_optimizer(vc_engine* e, int kind, double weight_decay);
+int vc_adam_update(int kind, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double lrd,
+                   double beta1, double beta2, double eps, double clip_norm, double weight_decay, int64_t t, const int64_t* t_dev,
+                   const float* loss_hdr, double* loss_ring, int64_t loss_slots, void* hip_stream);
+
 /* One whole SVI step (single rank): vc_elbo_grad with pyro's ClippedAdam merged into its last kernel -- 4
  * launches instead of 5.  exp_avg / exp_avg_sq: device float[total - header], zero-initialised by the caller;
  * the optimiser step is step + 1.  Equivalent to vc_elbo_grad followed by vc_clipped_adam on params[header:].

@@ -40,4 +40,19 @@ class ClippedAdam:
             p.data.addcdiv_(st["m"], denom, value=-step_size)
 
 
-Adam = ClippedAdam  # not used by the reference; alias keeps `pyro.optim.Adam` importable
+class Adam:
+    """`pyro.optim.Adam` = PyroOptim(torch.optim.Adam): one torch optimiser per parameter tensor (created when the tensor is
+    first seen), stepped with the gradients SVI left on the parameters."""
+
+    def __init__(self, optim_args):
+        self.pt_optim_args = dict(optim_args)
+        self.pt_optim_constructor = torch.optim.Adam
+        self.state = {}
+
+    def __call__(self, params):
+        for p in params:
+            o = self.state.get(id(p))
+            if o is None:
+                o = self.state[id(p)] = (torch.optim.Adam([p], **self.pt_optim_args), p)
+            if p.grad is not None:
+                o[0].step()

@@ -422,6 +422,7 @@ class ClippedAdam:
         self.eps = a.get("eps", 1e-8)
         self.clip_norm = a.get("clip_norm", 10.0)
         self.lrd = a.get("lrd", 1.0)
+        self.weight_decay = a.get("weight_decay", 0.0)
         self.t = 0
         self.m: Dict[str, torch.Tensor] = {}
         self.v: Dict[str, torch.Tensor] = {}
@@ -433,12 +434,44 @@ class ClippedAdam:
         step_size = self.lr * math.sqrt(1 - b2 ** self.t) / (1 - b1 ** self.t)
         for k, g in grads.items():
             g = g.clamp(-self.clip_norm, self.clip_norm)
+            if self.weight_decay != 0:                       # pyro clipped_adam.py: grad.add(p.data, alpha=weight_decay), behind the clamp
+                g = g.add(par[k], alpha=self.weight_decay)
             m = self.m.setdefault(k, torch.zeros_like(g))
             v = self.v.setdefault(k, torch.zeros_like(g))
             m.mul_(b1).add_(g, alpha=1 - b1)
             v.mul_(b2).addcmul_(g, g, value=1 - b2)
             upd = m / (v.sqrt() + self.eps)
             par[k] = par[k] - step_size * torch.nan_to_num(upd, nan=0.0)
+        return par
+
+
+class Adam:
+    """pyro.optim.Adam = torch.optim.Adam restated for a dict of tensors (tutorials/1D_Pancreas_Analysis.ipynb cell 26 passes it to
+    the same SVI loop): no clamp, no decay, weight decay in front of the moments, eps INSIDE the second bias correction."""
+
+    def __init__(self, optim_args: dict):
+        a = dict(optim_args)
+        self.lr = a.get("lr", 1e-3)
+        self.betas = tuple(a.get("betas", (0.9, 0.999)))
+        self.eps = a.get("eps", 1e-8)
+        self.weight_decay = a.get("weight_decay", 0.0)
+        self.t = 0
+        self.m: Dict[str, torch.Tensor] = {}
+        self.v: Dict[str, torch.Tensor] = {}
+
+    def step(self, par: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor]):
+        self.t += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+        for k, g in grads.items():
+            if self.weight_decay != 0:
+                g = g.add(par[k], alpha=self.weight_decay)
+            m = self.m.setdefault(k, torch.zeros_like(g))
+            v = self.v.setdefault(k, torch.zeros_like(g))
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            upd = m / (v.sqrt() / math.sqrt(bc2) + self.eps)
+            par[k] = par[k] - (self.lr / bc1) * torch.nan_to_num(upd, nan=0.0)
         return par
 
 

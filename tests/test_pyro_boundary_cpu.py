@@ -207,6 +207,65 @@ def test_clipped_adam_documented_differences_in_closed_form():
     assert abs(float(pr["a"]) - want2) < 1e-14
 
 
+def test_adam_and_weight_decay_of_the_product_are_torchs_and_pyros():
+    """fit(optimizer=pyro.optim.Adam(...)) gets torch.optim.Adam's arithmetic (eps inside the second bias
+    correction, no clamp, no decay; tutorials/1D_Pancreas_Analysis.ipynb cell 26), not ClippedAdam's; weight_decay follows
+    pyro's clipped_adam.py (`grad.add(p, alpha=wd)` behind the clamp) / torch's Adam (in front of the moments).  50 steps of the
+    product's flat optimiser (float32) and of the oracle's (float64) against torch.optim.Adam itself and against the shim's
+    ClippedAdam (pyro's published source restated)."""
+    _, po = _shim()
+    from velocycle_amd.svi import Adam, ClippedAdam, FlatClippedAdam, optim_args_of, optimizer_kind_of
+    g = torch.Generator().manual_seed(4)
+    shapes = [(7, 3), (11,)]
+    p0 = [torch.randn(s, dtype=torch.float64, generator=g) for s in shapes]
+    n = sum(x.numel() for x in p0)
+    for wd in (0.0, 0.05):
+        a_args = {"lr": 0.02, "betas": (0.85, 0.98), "eps": 1e-6, "weight_decay": wd}
+        c_args = {"lr": 0.02, "lrd": 0.97, "betas": (0.85, 0.98), "eps": 1e-6, "clip_norm": 2.0, "weight_decay": wd}
+        ref_p = [torch.nn.Parameter(x.clone()) for x in p0]
+        ref = torch.optim.Adam(ref_p, **a_args)
+        shim_p = [x.clone().requires_grad_(True) for x in p0]
+        shim_adam = po.Adam(dict(a_args))
+        clip_p = [x.clone().requires_grad_(True) for x in p0]
+        shim_clip = po.ClippedAdam(dict(c_args))
+        o_adam, o_clip = orc.Adam(dict(a_args)), orc.ClippedAdam(dict(c_args))
+        oa = {str(i): x.clone() for i, x in enumerate(p0)}
+        oc = {str(i): x.clone() for i, x in enumerate(p0)}
+        fa, fc = (torch.cat([x.reshape(-1) for x in p0]).float() for _ in range(2))
+        f_adam = FlatClippedAdam(n, optim_args_of(Adam(dict(a_args))), "cpu")
+        f_clip = FlatClippedAdam(n, optim_args_of(ClippedAdam(dict(c_args))), "cpu")
+        assert f_adam.kind == "adam" and f_clip.kind == "clipped_adam" and f_adam.wd == wd and f_clip.wd == wd
+        for t in range(50):
+            grads = [torch.randn(s, dtype=torch.float64, generator=g) * (1.0 + 0.2 * t) + 0.3 for s in shapes]
+            flatg = torch.cat([gr.reshape(-1) for gr in grads]).float()
+            for ps, opt in ((ref_p, None), (shim_p, shim_adam), (clip_p, shim_clip)):
+                for q, gr in zip(ps, grads):
+                    q.grad = gr.clone()
+                (ref.step() if opt is None else opt(ps))
+            oa = o_adam.step(oa, {str(i): gr for i, gr in enumerate(grads)})
+            oc = o_clip.step(oc, {str(i): gr for i, gr in enumerate(grads)})
+            f_adam.step(fa, flatg)
+            f_clip.step(fc, flatg)
+        want_a = torch.cat([q.data.reshape(-1) for q in ref_p])
+        want_c = torch.cat([q.data.reshape(-1) for q in clip_p])
+        assert torch.allclose(torch.cat([q.data.reshape(-1) for q in shim_p]), want_a, rtol=1e-12, atol=1e-13)
+        assert torch.allclose(torch.cat([oa[str(i)].reshape(-1) for i in range(len(p0))]), want_a, rtol=1e-12, atol=1e-13)
+        assert torch.allclose(torch.cat([oc[str(i)].reshape(-1) for i in range(len(p0))]), want_c, rtol=1e-12, atol=1e-13)
+        assert torch.allclose(fa.double(), want_a, rtol=2e-5, atol=2e-6), (fa.double() - want_a).abs().max()
+        assert torch.allclose(fc.double(), want_c, rtol=2e-5, atol=2e-6), (fc.double() - want_c).abs().max()
+        assert (want_a - want_c).abs().max() > 1e-3          # the two optimisers are not the same thing
+    # the contract: recognised by what PyroOptim wraps / by class name, everything else named and refused
+    class P:
+        def __init__(self, ctor, args):
+            self.pt_optim_constructor, self.pt_optim_args = ctor, args
+    assert optimizer_kind_of(P(torch.optim.Adam, {})) == "adam" and optimizer_kind_of(po.Adam({"lr": 1e-3})) == "adam"
+    assert optimizer_kind_of(po.ClippedAdam({"lr": 1e-3})) == "clipped_adam" and optimizer_kind_of({"lr": 1e-3, "lrd": 0.9}) == "clipped_adam"
+    for bad, exc in ((P(torch.optim.SGD, {"lr": 0.1}), TypeError), (P(torch.optim.AdamW, {}), TypeError), (Adam({"amsgrad": True}), NotImplementedError),
+                     (ClippedAdam({"momentum": 0.1}), TypeError), (Adam({"lrd": 0.9}), TypeError), (object(), TypeError)):
+        with pytest.raises(exc):
+            optim_args_of(bad)
+
+
 def test_lowrank_mvn_rsample_draw_order_and_value():
     """LowRankMultivariateNormal.rsample draws eps_W (rank) first, then eps_D (dims), each with
     torch.empty(shape).normal_() on the default generator, and returns loc + W eps_W + sqrt(D) eps_D -- the order

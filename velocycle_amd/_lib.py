@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("VC_LIB_PATH") or os.path.join(HERE, "libvelocycle_hip
 VC_ABI_VERSION = 1
 VC_OK = 0
 VC_PHASE_A, VC_PHASE_B, VC_PHASE_AB = 1, 2, 3
+VC_OPT_CLIPPED_ADAM, VC_OPT_ADAM = 0, 1
 VC_ERR_ARG, VC_ERR_HIP, VC_ERR_UNSUPPORTED, VC_ERR_STATE, VC_ERR_NONFINITE = -1, -2, -3, -4, -5
 MODEL = {"phase": 0, "velocity": 1}
 GUIDE = {"meanfield": 0, "lrmn": 1}
@@ -116,6 +117,10 @@ EXPORTS = {
     "vc_clipped_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vc_set_optimizer": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "vc_adam_update": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int64, C.c_void_p]),
     "vc_sample_guide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),
     "vc_sample_posterior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),

@@ -168,8 +168,9 @@ struct VcBufs {
   long long* status;                        // [0] number of steps with a non-finite loss, [1] 1 + index of the first one
   // fused single-rank pipeline (vc_svi_step_fused)
   long long* step_ctr;                      // non-null: K_main advances this device step counter (block 0) ...
-  float* step_size;                         // ... and leaves the ClippedAdam step size of the new step here (fp64 math, once)
+  float* step_size;                         // ... and leaves the optimiser's step size [0] and second-moment bias correction [1] of the new step here (fp64 math, once)
   double adam_lr0, adam_lrd_l, adam_b1l, adam_b2l;
+  int adam_kind;                            // VC_OPT_*: which step size / bias correction K_main leaves in step_size[0..1]
   double* LPF;                              // [2][nlpf] prior / guide loss terms of the samples of step s in half s & 1
   double* LPP;                              // [nb_post_gene] r-only likelihood terms of the gene blocks (phase A of the sharded step)
   double* LPR;                              // [2][nb_post_gene] -nmat_r Nc sum_g r log r of the sample of step s in half s & 1 (written when
@@ -401,18 +402,29 @@ __device__ __forceinline__ void vc_lgamma_digamma_diff(float x, float k, float& 
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// pyro.optim.ClippedAdam for one element (the arithmetic of vc_adam_kernel): returns the new parameter value
+// The optimisers fit() accepts (velocity_inference_model.py:76-84,111 hands whatever PyroOptim it is given to SVI):
+//   VC_OPT_CLIPPED_ADAM  pyro.optim.ClippedAdam (pyro-ppl 1.8.6 optim/clipped_adam.py; every package tutorial): lr <- lr * lrd before the
+//                        update, g = clamp(g, +-clip), [g += wd * p], m / v moments, p -= lr_t sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)
+//   VC_OPT_ADAM          pyro.optim.Adam = torch.optim.Adam (tutorials/1D_Pancreas_Analysis.ipynb cell 26): [g += wd * p], no clamp, no
+//                        decay, p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)   (eps INSIDE the bias correction)
+// One element, both of them: p - step_size * m / (sqrt(v) * c2 + eps) with (step_size, c2) of vc_adam_step_size / vc_adam_c2.
+// (VC_OPT_CLIPPED_ADAM / VC_OPT_ADAM: include/velocycle_hip.h)
 __device__ __forceinline__ float vc_adam_elem(float p, float g, float& m, float& v, float step_size, float fb1, float fb2,
-                                              float eps, float clip) {
-  const float gi = fminf(fmaxf(g, -clip), clip);
+                                              float eps, float clip, float c2 = 1.f, float wd = 0.f) {
+  float gi = fminf(fmaxf(g, -clip), clip);
+  if (wd != 0.f) gi = gi + wd * p;            // (guarded: 0 * p is NaN for a parameter at -inf, e.g. log of a cov_factor entry clipped to 0)
   m = fb1 * m + (1.f - fb1) * gi;
   v = fb2 * v + (1.f - fb2) * gi * gi;
-  return p - step_size * (m / (sqrtf(v) + eps));
+  return p - step_size * (m / (sqrtf(v) * c2 + eps));
 }
-// step size of the 1-based optimiser step t: lr0 lrd^t sqrt(1 - b2^t) / (1 - b1^t); lrd_l, b1l, b2l are natural logs
-__device__ __forceinline__ float vc_adam_step_size(long long t, double lr0, double lrd_l, double b1l, double b2l) {
+// step size of the 1-based optimiser step t; lrd_l, b1l, b2l are natural logs
+__device__ __forceinline__ float vc_adam_step_size(long long t, double lr0, double lrd_l, double b1l, double b2l, int kind = VC_OPT_CLIPPED_ADAM) {
   const double td = (double)t;
+  if (kind == VC_OPT_ADAM) return (float)(lr0 / (1.0 - exp(td * b1l)));
   return (float)(lr0 * exp(td * lrd_l) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));
+}
+__device__ __forceinline__ float vc_adam_c2(long long t, double b2l, int kind) {
+  return kind == VC_OPT_ADAM ? (float)(1.0 / sqrt(1.0 - exp((double)t * b2l))) : 1.f;
 }
 
 // d(-ELBO) / d(unconstrained shape_inv) of one gene (the statements of K_post's / K_tail's shape_inv role): r = 1 / shape_inv,
@@ -592,6 +604,8 @@ __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const Vc
 #endif  // __HIPCC__
 
 // launchers implemented in the .hip translation units -----------------------------------------
+// hyper-parameters of the optimiser as the unfused launches take them (kind: VC_OPT_*)
+struct VcAdamHyper { double lr0, lrd, b1, b2; float eps, clip, wd; int kind; };
 static inline int vc_hist_blocks(const VcDims& d, const VcBufs& b, int waves) {
   return d.hist_dense ? d.Ng_pad / 64 : (b.n_tasks + waves - 1) / waves;
 }
@@ -612,8 +626,7 @@ void vc_launch_post_particles(const VcDims& d, const VcBufs& b, const VcBufs* bs
                               hipStream_t st);
 void vc_launch_particle_fin_adam(const VcDims& d, const VcBufs* bs_dev, const VcParticleGrads& pg, float* params, double* loss_dev,
                                  long long loss_slots, long long step, long long* step_dev, double* scratch, float* m, float* v,
-                                 double lr0, double lrd, double b1, double b2, float eps, float clip, int header, long long total,
-                                 hipStream_t st);
+                                 const VcAdamHyper& h, int header, long long total, hipStream_t st);
 void vc_launch_post_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev, hipStream_t st);
 void vc_launch_fin_generic(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev, long long loss_slots,
                            long long step, const long long* step_dev, hipStream_t st);
@@ -640,9 +653,8 @@ void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float
 void vc_launch_fin(const VcDims& d, const VcBufs& b, const float* params, float* grad, double* loss_dev,
                    long long loss_slots, long long step, const long long* step_dev, hipStream_t st);
 void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* grad, double* loss_dev,
-                        long long loss_slots, long long step, long long* step_dev, float* m, float* v, double lr0,
-                        double lrd, double b1, double b2, float eps, float clip, int header, long long total,
-                        hipStream_t st);
+                        long long loss_slots, long long step, long long* step_dev, float* m, float* v, const VcAdamHyper& h,
+                        int header, long long total, hipStream_t st);
 // hyper-parameters of pyro's ClippedAdam as the fused kernels take them (logs precomputed on the host)
 struct VcAdamArgs {
   float* m;            // exp_avg    [total - header]
@@ -650,7 +662,10 @@ struct VcAdamArgs {
   double lr0, lrd_l, b1l, b2l;
   float b1, b2, eps, clip;
   int header;
+  float wd;            // weight decay (0: none)
+  int kind;            // VC_OPT_*
 };
+
 // fused single-rank step (vc_svi_step_fused): K_main(t) -> K_tail(t) -> K_omega(t); boot = 1: sampling only (primes the
 // tables for the step *step_dev)
 // phase: 0 = the whole single-rank launch, 1 = phase A of the sharded step (writes the exchange buffer `xb`)
@@ -672,6 +687,5 @@ void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* gra
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, hipStream_t st);
 void vc_launch_p2p_xchg(const VcP2p& p, long long step, float* out, long long n, long long* status, double timeout_s,
                         unsigned long long* verdict, hipStream_t st);
-void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
-                    double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
-                    const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st);
+void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, const VcAdamHyper& h, long long t_host,
+                    const long long* t_dev, const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st);

@@ -52,6 +52,21 @@ static VcRccl g_rccl;
 struct vc_engine {
   vc_config cfg{};
   vc_tuning tun{};                    // vc_set_tuning: all-zero = defaults (the library reads no environment variable)
+  int opt_kind = VC_OPT_CLIPPED_ADAM; // vc_set_optimizer: which optimiser the step entry points apply
+  double opt_wd = 0.0;                // ... and its weight decay
+  VcAdamHyper hyper(double lr, double lrd, double b1, double b2, double eps, double clip) const {
+    VcAdamHyper h;
+    h.lr0 = lr; h.lrd = opt_kind == VC_OPT_ADAM ? 1.0 : lrd; h.b1 = b1; h.b2 = b2;
+    h.eps = (float)eps; h.clip = opt_kind == VC_OPT_ADAM ? __builtin_inff() : (float)clip; h.wd = (float)opt_wd; h.kind = opt_kind;
+    return h;
+  }
+  void fill(VcAdamArgs& a, float* m, float* v, double lr, double lrd, double b1, double b2, double eps, double clip) const {
+    const VcAdamHyper h = hyper(lr, lrd, b1, b2, eps, clip);
+    a.m = m; a.v = v;
+    a.lr0 = h.lr0; a.lrd_l = log(h.lrd); a.b1l = log(h.b1); a.b2l = log(h.b2);
+    a.b1 = (float)h.b1; a.b2 = (float)h.b2; a.eps = h.eps; a.clip = h.clip;
+    a.header = (int)layout.header; a.wd = h.wd; a.kind = h.kind;
+  }
   VcNcclComm comm = nullptr;          // the engine's own communicator (vc_comm_init_rccl), or null
   double* particle_lsum = nullptr;    // vc_svi_run_particles: scratch slots of the particles' K_fin launches
   // vc_svi_run_particles: particle k >= 1 has its own per-step workspaces, gradient buffer and stream (particle 0: e->b, the
@@ -1086,8 +1101,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   TRY(e->dalloc(&b.EPS, 3 * (size_t)e->layout.eps_total));
   HIPCHK(e, hipMemset(b.EPS, 0, 3 * sizeof(float) * e->layout.eps_total));
   b.step_ctr = nullptr;
-  TRY(e->dalloc(&b.step_size, 1));
-  HIPCHK(e, hipMemset(b.step_size, 0, sizeof(float)));
+  TRY(e->dalloc(&b.step_size, 2));
+  HIPCHK(e, hipMemset(b.step_size, 0, 2 * sizeof(float)));
   TRY(e->dalloc(&b.status, 4));       // [0] steps with a non-finite loss, [1] 1 + the first of them, [2] 1 + step of an exchange time-out
   HIPCHK(e, hipMemset(b.status, 0, 4 * sizeof(long long)));
 
@@ -1303,7 +1318,7 @@ extern "C" int vc_svi_step(vc_engine* e, float* params, const float* eps, uint64
   hipStream_t st = (hipStream_t)hip_stream;
   TRY(launch_front(e, params, eps, seed, step, step_dev, grad, st));
   vc_launch_fin_adam(e->d, e->b, params, grad, loss_dev, (long long)loss_slots, (long long)step, (long long*)step_dev,
-                     exp_avg, exp_avg_sq, lr, lrd, beta1, beta2, (float)adam_eps, (float)clip_norm,
+                     exp_avg, exp_avg_sq, e->hyper(lr, lrd, beta1, beta2, adam_eps, clip_norm),
                      (int)e->layout.header, (long long)e->layout.total, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
@@ -1344,10 +1359,7 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
     return e->fail(VC_ERR_ARG, "vc_svi_run_fused: lr, lrd must be positive and the betas inside (0, 1)");
   hipStream_t st = (hipStream_t)hip_stream;
   VcAdamArgs a;
-  a.m = exp_avg; a.v = exp_avg_sq;
-  a.lr0 = lr; a.lrd_l = log(lrd); a.b1l = log(beta1); a.b2l = log(beta2);
-  a.b1 = (float)beta1; a.b2 = (float)beta2; a.eps = (float)adam_eps; a.clip = (float)clip_norm;
-  a.header = (int)e->layout.header;
+  e->fill(a, exp_avg, exp_avg_sq, lr, lrd, beta1, beta2, adam_eps, clip_norm);
   const long long* sd = (const long long*)step_dev;
   const int with_hist = e->hist_each_step ? 1 : 0;
   if (prime && n_steps > 0) {   // sample the step *step_dev from the parameters as they are: tables, site values, prior terms
@@ -1357,7 +1369,7 @@ extern "C" int vc_svi_run_fused(vc_engine* e, float* params, uint64_t seed, int6
   }
   VcBufs b2 = e->b;
   b2.step_ctr = (long long*)step_dev;
-  b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l;
+  b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l; b2.adam_kind = a.kind;
   // Tutorial flow (U-only kernel with its own nu_omega partials, no histogram terms per step): from the third step after the
   // tables were primed, K_tail's gene blocks and K_omega's blocks go out as ONE launch (vc_launch_tail_merged: why that is
   // safe); the first two steps fill both halves of the loss terms the absent cell blocks would have written.
@@ -1465,8 +1477,8 @@ extern "C" int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, 
     }
     vc_launch_post_particles(e->d, e->b, e->particle_bufs_dev, pg, params, st);
     vc_launch_particle_fin_adam(e->d, e->particle_bufs_dev, pg, params, loss_dev, (long long)loss_slots, (long long)(step0 + i),
-                                (long long*)step_dev, e->particle_lsum, exp_avg, exp_avg_sq, lr, lrd, beta1, beta2, (float)adam_eps,
-                                (float)clip_norm, (int)header, total, st);
+                                (long long*)step_dev, e->particle_lsum, exp_avg, exp_avg_sq, e->hyper(lr, lrd, beta1, beta2, adam_eps, clip_norm),
+                                (int)header, total, st);
   }
   for (int64_t i = 0; i < n_steps && !batched; ++i) {
     // Particle k runs the unfused sequence K_pre -> K_main -> K_post -> K_fin on the Philox stream (seed, t K + k), t read from
@@ -1502,8 +1514,8 @@ extern "C" int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, 
     // average of the K gradients and losses in particle order (what a host loop's g_0 + g_1 + ... and its division by K give),
     // left in the first particle's buffer; advances the step counter
     vc_launch_particle_avg(pg, total, loss_dev, (long long)loss_slots, (long long)(step0 + i), (long long*)step_dev, st);
-    vc_launch_adam(params + header, grad + header, exp_avg, exp_avg_sq, total - header, lr, lrd, beta1, beta2, (float)adam_eps,
-                   (float)clip_norm, 0, (const long long*)step_dev, nullptr, nullptr, 0, st);
+    vc_launch_adam(params + header, grad + header, exp_avg, exp_avg_sq, total - header, e->hyper(lr, lrd, beta1, beta2, adam_eps, clip_norm),
+                   0, (const long long*)step_dev, nullptr, nullptr, 0, st);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
@@ -1651,10 +1663,7 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
     return e->fail(VC_ERR_ARG, "vc_svi_run_sharded: lr, lrd must be positive and the betas inside (0, 1)");
   hipStream_t st = (hipStream_t)hip_stream;
   VcAdamArgs a;
-  a.m = exp_avg; a.v = exp_avg_sq;
-  a.lr0 = lr; a.lrd_l = log(lrd); a.b1l = log(beta1); a.b2l = log(beta2);
-  a.b1 = (float)beta1; a.b2 = (float)beta2; a.eps = (float)adam_eps; a.clip = (float)clip_norm;
-  a.header = (int)e->layout.header;
+  e->fill(a, exp_avg, exp_avg_sq, lr, lrd, beta1, beta2, adam_eps, clip_norm);
   const long long* sd = (const long long*)step_dev;
   const int with_hist = e->hist_each_step ? 1 : 0;
   VcXb xb;
@@ -1665,7 +1674,7 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
   }
   VcBufs b2 = e->b;
   b2.step_ctr = (long long*)step_dev;
-  b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l;
+  b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l; b2.adam_kind = a.kind;
   for (int64_t i = 0; i < n_steps; ++i) {
     if (phase != VC_PHASE_B) {
       if (e->timing) {
@@ -1887,8 +1896,32 @@ extern "C" int vc_clipped_adam(float* params, const float* grad, float* exp_avg,
                                int64_t loss_slots, void* hip_stream) {
   if (!params || !grad || !exp_avg || !exp_avg_sq || n < 0) return VC_ERR_ARG;
   if (n == 0) return VC_OK;
-  vc_launch_adam(params, grad, exp_avg, exp_avg_sq, (long long)n, lr, lrd, beta1, beta2, (float)eps,
-                 (float)clip_norm, (long long)t, (const long long*)t_dev, loss_hdr, loss_ring, (long long)loss_slots,
-                 (hipStream_t)hip_stream);
+  VcAdamHyper h;
+  h.lr0 = lr; h.lrd = lrd; h.b1 = beta1; h.b2 = beta2; h.eps = (float)eps; h.clip = (float)clip_norm; h.wd = 0.f; h.kind = VC_OPT_CLIPPED_ADAM;
+  vc_launch_adam(params, grad, exp_avg, exp_avg_sq, (long long)n, h, (long long)t, (const long long*)t_dev, loss_hdr, loss_ring,
+                 (long long)loss_slots, (hipStream_t)hip_stream);
   return hipGetLastError() == hipSuccess ? VC_OK : VC_ERR_HIP;
+}
+
+extern "C" int vc_adam_update(int kind, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                              double lrd, double beta1, double beta2, double eps, double clip_norm, double weight_decay, int64_t t,
+                              const int64_t* t_dev, const float* loss_hdr, double* loss_ring, int64_t loss_slots, void* hip_stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || n < 0) return VC_ERR_ARG;
+  if (kind != VC_OPT_CLIPPED_ADAM && kind != VC_OPT_ADAM) return VC_ERR_ARG;
+  if (n == 0) return VC_OK;
+  VcAdamHyper h;
+  h.lr0 = lr; h.lrd = kind == VC_OPT_ADAM ? 1.0 : lrd; h.b1 = beta1; h.b2 = beta2; h.eps = (float)eps;
+  h.clip = kind == VC_OPT_ADAM ? __builtin_inff() : (float)clip_norm; h.wd = (float)weight_decay; h.kind = kind;
+  vc_launch_adam(params, grad, exp_avg, exp_avg_sq, (long long)n, h, (long long)t, (const long long*)t_dev, loss_hdr, loss_ring,
+                 (long long)loss_slots, (hipStream_t)hip_stream);
+  return hipGetLastError() == hipSuccess ? VC_OK : VC_ERR_HIP;
+}
+
+extern "C" int vc_set_optimizer(vc_engine* e, int kind, double weight_decay) {
+  if (!e) return VC_ERR_ARG;
+  if (kind != VC_OPT_CLIPPED_ADAM && kind != VC_OPT_ADAM) return e->fail(VC_ERR_ARG, "vc_set_optimizer: kind must be VC_OPT_CLIPPED_ADAM or VC_OPT_ADAM");
+  if (!(weight_decay >= 0.0)) return e->fail(VC_ERR_ARG, "vc_set_optimizer: negative weight_decay");
+  e->opt_kind = kind;
+  e->opt_wd = weight_decay;
+  return VC_OK;
 }

@@ -625,7 +625,8 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     const long long s = *b.step_ctr + 1;
     *b.step_ctr = s;
     // lr0 lrd^s sqrt(1 - b2^s) / (1 - b1^s) in fp64, once per step instead of once per thread of the next launch
-    b.step_size[0] = vc_adam_step_size(s, b.adam_lr0, b.adam_lrd_l, b.adam_b1l, b.adam_b2l);
+    b.step_size[0] = vc_adam_step_size(s, b.adam_lr0, b.adam_lrd_l, b.adam_b1l, b.adam_b2l, b.adam_kind);
+    b.step_size[1] = vc_adam_c2(s, b.adam_b2l, b.adam_kind);
   }
   VC_STAMP(3);
 #ifdef VC_DBG_TIMES

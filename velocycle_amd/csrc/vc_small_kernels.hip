@@ -936,30 +936,30 @@ __global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBuf
 __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       long long n, double lr0, double lrd /* log */, double b1, double b2,
-                                                      double b1l, double b2l, float eps, float clip, long long t_host,
+                                                      double b1l, double b2l, float eps, float clip, float wd, int kind, long long t_host,
                                                       const long long* __restrict__ t_dev,
                                                       const float* __restrict__ loss_hdr,
                                                       double* __restrict__ loss_ring, long long loss_slots) {
-  __shared__ float s_step;
+  __shared__ float s_step, s_c2;
   // multi-rank path: the all-reduced loss (float hi + lo in the gradient header) goes into the loss ring here
   if (loss_ring && blockIdx.x == 0 && threadIdx.x == 0) {
     const long long t1 = t_dev ? *t_dev : t_host;
     loss_ring[loss_slots > 1 ? ((t1 - 1) % loss_slots) : 0] = (double)loss_hdr[0] + (double)loss_hdr[1];
   }
   if (threadIdx.x == 0) {      // lrd^t, b^t as exp(t log .) once per block (the logs come from the host)
-    const double td = (double)(t_dev ? *t_dev : t_host);
-    s_step = (float)(lr0 * exp(td * lrd) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));   // lrd, b1l, b2l: logs
+    const long long t1 = t_dev ? *t_dev : t_host;
+    s_step = vc_adam_step_size(t1, lr0, lrd, b1l, b2l, kind);   // lrd, b1l, b2l: logs
+    s_c2 = vc_adam_c2(t1, b2l, kind);
   }
   __syncthreads();
-  const float step_size = s_step;
+  const float step_size = s_step, c2 = s_c2;
   const float fb1 = (float)b1, fb2 = (float)b2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    float gi = fminf(fmaxf(g[i], -clip), clip);
-    const float mi = fb1 * m[i] + (1.f - fb1) * gi;
-    const float vi = fb2 * v[i] + (1.f - fb2) * gi * gi;
+    float mi = m[i], vi = v[i];
+    const float pn = vc_adam_elem(p[i], g[i], mi, vi, step_size, fb1, fb2, eps, clip, c2, wd);
     m[i] = mi;
     v[i] = vi;
-    p[i] = p[i] - step_size * (mi / (sqrtf(vi) + eps));
+    p[i] = pn;
   }
 }
 
@@ -970,12 +970,12 @@ __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const 
                                                           const long long* step_dev, float* __restrict__ m,
                                                           float* __restrict__ v, double lr0, double lrd /* log */,
                                                           double b1, double b2, double b1l, double b2l, float eps, float clip,
-                                                          int header, long long total) {
-  __shared__ float s_step;
+                                                          float wd, int kind, int header, long long total) {
+  __shared__ float s_step, s_c2;
   const long long t1 = step_dev ? *step_dev : step_host + 1;        // 1-based optimiser step
   if (threadIdx.x == 0) {
-    const double td = (double)t1;
-    s_step = (float)(lr0 * exp(td * lrd) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));   // lrd, b1l, b2l: logs
+    s_step = vc_adam_step_size(t1, lr0, lrd, b1l, b2l, kind);   // lrd, b1l, b2l: logs
+    s_c2 = vc_adam_c2(t1, b2l, kind);
   }
   // parameters whose gradient K_fin produces: nu_omega (mean-field) or the LRMN tail rows
   long long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -993,16 +993,15 @@ __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const 
   if (blockIdx.x == 0) vc_fin_block(d, b, P, G, loss_dev, loss_slots, t1 - 1);
   __syncthreads();
   VC_KSTAMP(2, 1);
-  const float step_size = s_step;
+  const float step_size = s_step, c2 = s_c2;
   const float fb1 = (float)b1, fb2 = (float)b2;
   auto upd = [&](long long idx) {
     const long long j = idx - header;
-    const float gi = fminf(fmaxf(G[idx], -clip), clip);
-    const float mi = fb1 * m[j] + (1.f - fb1) * gi;
-    const float vi = fb2 * v[j] + (1.f - fb2) * gi * gi;
+    float mi = m[j], vi = v[j];
+    const float pn = vc_adam_elem(P[idx], G[idx], mi, vi, step_size, fb1, fb2, eps, clip, c2, wd);
     m[j] = mi;
     v[j] = vi;
-    P[idx] = P[idx] - step_size * (mi / (sqrtf(vi) + eps));
+    P[idx] = pn;
   };
   for (long long idx = header + (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const bool tail = (idx >= lo[0] && idx < hi[0]) || (idx >= lo[1] && idx < hi[1]) || (idx >= lo[2] && idx < hi[2]);
@@ -1023,14 +1022,14 @@ __global__ __launch_bounds__(256) void vc_particle_fin_adam_kernel(const VcDims 
                                                                    float* P, double* loss_dev, long long loss_slots, long long step_host,
                                                                    long long* step_dev, double* __restrict__ scratch, float* __restrict__ m,
                                                                    float* __restrict__ v, double lr0, double lrd /* log */, double b1,
-                                                                   double b2, double b1l, double b2l, float eps, float clip, int header,
-                                                                   long long total) {
-  __shared__ float s_step;
+                                                                   double b2, double b1l, double b2l, float eps, float clip, float wd, int kind,
+                                                                   int header, long long total) {
+  __shared__ float s_step, s_c2;
   const int K = pg.K;
   const long long t1 = step_host + 1;        // 1-based optimiser step (the host's mirror of the device counter: nothing here reads it)
   if (threadIdx.x == 0) {
-    const double td = (double)t1;
-    s_step = (float)(lr0 * exp(td * lrd) * sqrt(1.0 - exp(td * b2l)) / (1.0 - exp(td * b1l)));   // lrd, b1l, b2l: logs
+    s_step = vc_adam_step_size(t1, lr0, lrd, b1l, b2l, kind);   // lrd, b1l, b2l: logs
+    s_c2 = vc_adam_c2(t1, b2l, kind);
   }
   long long lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};      // parameters whose gradient K_fin produces (vc_fin_adam_kernel)
   if (d.model == VC_MODEL_VELOCITY) {
@@ -1060,7 +1059,7 @@ __global__ __launch_bounds__(256) void vc_particle_fin_adam_kernel(const VcDims 
     }
   }
   __syncthreads();
-  const float step_size = s_step;
+  const float step_size = s_step, c2 = s_c2;
   const float fb1 = (float)b1, fb2 = (float)b2, inv = 1.0f / (float)K;
   auto upd = [&](long long idx) {
     const long long j = idx - header;
@@ -1068,12 +1067,11 @@ __global__ __launch_bounds__(256) void vc_particle_fin_adam_kernel(const VcDims 
     for (int k = 1; k < K; ++k) a += pg.g[k][idx];
     const float ga = a * inv;
     pg.g[0][idx] = ga;
-    const float gi = fminf(fmaxf(ga, -clip), clip);
-    const float mi = fb1 * m[j] + (1.f - fb1) * gi;
-    const float vi = fb2 * v[j] + (1.f - fb2) * gi * gi;
+    float mi = m[j], vi = v[j];
+    const float pn = vc_adam_elem(P[idx], ga, mi, vi, step_size, fb1, fb2, eps, clip, c2, wd);
     m[j] = mi;
     v[j] = vi;
-    P[idx] = P[idx] - step_size * (mi / (sqrtf(vi) + eps));
+    P[idx] = pn;
   };
   for (long long idx = header + (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const bool tail = (idx >= lo[0] && idx < hi[0]) || (idx >= lo[1] && idx < hi[1]) || (idx >= lo[2] && idx < hi[2]);
@@ -1085,34 +1083,31 @@ __global__ __launch_bounds__(256) void vc_particle_fin_adam_kernel(const VcDims 
 }
 void vc_launch_particle_fin_adam(const VcDims& d, const VcBufs* bs_dev, const VcParticleGrads& pg, float* params, double* loss_dev,
                                  long long loss_slots, long long step, long long* step_dev, double* scratch, float* m, float* v,
-                                 double lr0, double lrd, double b1, double b2, float eps, float clip, int header, long long total,
-                                 hipStream_t st) {
+                                 const VcAdamHyper& h, int header, long long total, hipStream_t st) {
   long long nb = (total - header + 255) / 256;
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(vc_particle_fin_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, d, bs_dev, pg, params, loss_dev, loss_slots, step,
-                     step_dev, scratch, m, v, lr0, log(lrd), b1, b2, log(b1), log(b2), eps, clip, header, total);
+                     step_dev, scratch, m, v, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1), log(h.b2), h.eps, h.clip, h.wd, h.kind, header, total);
 }
 
 void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* grad, double* loss_dev,
-                        long long loss_slots, long long step, long long* step_dev, float* m, float* v, double lr0,
-                        double lrd, double b1, double b2, float eps, float clip, int header, long long total,
-                        hipStream_t st) {
+                        long long loss_slots, long long step, long long* step_dev, float* m, float* v, const VcAdamHyper& h,
+                        int header, long long total, hipStream_t st) {
   long long nb = (total - header + 255) / 256;
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(vc_fin_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots,
-                     step, step_dev, m, v, lr0, log(lrd), b1, b2, log(b1), log(b2), eps, clip, header, total);
+                     step, step_dev, m, v, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1), log(h.b2), h.eps, h.clip, h.wd, h.kind, header, total);
 }
 
-void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr0, double lrd,
-                    double b1, double b2, float eps, float clip, long long t_host, const long long* t_dev,
-                    const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st) {
+void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, const VcAdamHyper& h, long long t_host,
+                    const long long* t_dev, const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st) {
   long long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(vc_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, lr0, log(lrd), b1, b2, log(b1),
-                     log(b2), eps, clip, t_host, t_dev, loss_hdr, loss_ring, loss_slots);
+  hipLaunchKernelGGL(vc_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1),
+                     log(h.b2), h.eps, h.clip, h.wd, h.kind, t_host, t_dev, loss_hdr, loss_ring, loss_slots);
 }
 
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,

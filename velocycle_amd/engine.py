@@ -439,6 +439,33 @@ class HipEngine:
         if rc != _lib.VC_OK:
             raise HipEngineError("vc_clipped_adam failed")
 
+    def set_optimizer(self, kind: str = "clipped_adam", weight_decay: float = 0.0):
+        """Which optimiser the step entry points of this engine apply (vc_set_optimizer): "clipped_adam" (pyro.optim.ClippedAdam, the
+        default) or "adam" (pyro.optim.Adam = torch.optim.Adam)."""
+        k = {"clipped_adam": _lib.VC_OPT_CLIPPED_ADAM, "adam": _lib.VC_OPT_ADAM}[kind]
+        if not hasattr(self.lib, "vc_set_optimizer"):
+            if k == _lib.VC_OPT_CLIPPED_ADAM and weight_decay == 0.0:
+                return                   # (an older build of the ABI: ClippedAdam without weight decay is all it has)
+            raise HipEngineError("this build of the library has no vc_set_optimizer")
+        self._check(self.lib.vc_set_optimizer(self._h, int(k), float(weight_decay)))
+
+    def adam_update(self, kind, p, g, m, v, lr, lrd, b1, b2, eps, clip, wd, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
+        """The optimiser as one launch on flat float32 buffers (vc_adam_update): kind "clipped_adam" | "adam"."""
+        k = {"clipped_adam": _lib.VC_OPT_CLIPPED_ADAM, "adam": _lib.VC_OPT_ADAM}[kind]
+        if not hasattr(self.lib, "vc_adam_update"):
+            if k != _lib.VC_OPT_CLIPPED_ADAM or wd != 0.0:
+                raise HipEngineError("this build of the library has no vc_adam_update")
+            return self.clipped_adam(p, g, m, v, lr, lrd, b1, b2, eps, clip, t=t, t_dev=t_dev, loss_hdr=loss_hdr, loss_ring=loss_ring)
+        rc = self.lib.vc_adam_update(int(k), C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                     C.c_void_p(v.data_ptr()), p.numel(), lr, lrd, b1, b2, eps,
+                                     clip if math.isfinite(clip) else 3.0e38, wd, int(t),
+                                     C.c_void_p(t_dev.data_ptr()) if t_dev is not None else None,
+                                     C.c_void_p(loss_hdr.data_ptr()) if loss_hdr is not None else None,
+                                     C.c_void_p(loss_ring.data_ptr()) if loss_ring is not None else None,
+                                     loss_ring.numel() if loss_ring is not None else 0, self._stream())
+        if rc != _lib.VC_OK:
+            raise HipEngineError("vc_adam_update failed")
+
     def sample_guide(self, eps: Optional[torch.Tensor] = None, seed: int = 0, step: int = 0):
         """One guide draw + deterministic sites (no likelihood); read the values with read_site()."""
         self._check(self.lib.vc_sample_guide(

@@ -1,2 +1,2 @@
-"""`velocycle_amd.optim.ClippedAdam` -- constructed like `pyro.optim.ClippedAdam({...})`."""
-from .svi import ClippedAdam  # noqa: F401
+"""`velocycle_amd.optim.ClippedAdam` / `Adam` -- constructed like `pyro.optim.ClippedAdam({...})` / `pyro.optim.Adam({...})`."""
+from .svi import Adam, ClippedAdam  # noqa: F401

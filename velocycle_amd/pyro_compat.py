@@ -96,6 +96,11 @@ def _clipped_adam(*a, **k):
     return ClippedAdam(*a, **k)
 
 
+def _adam(*a, **k):
+    from .svi import Adam
+    return Adam(*a, **k)
+
+
 # `import velocycle_amd.pyro_compat as pyro` then reads like the tutorials: pyro.infer.Trace_ELBO(...), pyro.optim.ClippedAdam({...})
 infer = _Namespace(Trace_ELBO=Trace_ELBO)
-optim = _Namespace(ClippedAdam=_clipped_adam)
+optim = _Namespace(ClippedAdam=_clipped_adam, Adam=_adam)
