@@ -437,6 +437,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     from velocycle_amd.engine import HipEngine
+    from velocycle_amd.tuning import Tuning
     from velocycle_amd.svi import SVIRunner
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
 
