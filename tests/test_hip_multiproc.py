@@ -136,5 +136,7 @@ def test_p2p_exchange_survives_a_peer_that_stops():
     assert len(lines) == 1, r.stdout[-2000:]
     got = json.loads(lines[0][len("DEAD_PEER "):])
     assert got["nan"] == [True, True], got                 # both lonely steps poisoned
-    assert 1.5 <= got["waited_s"] < 7.0, got               # two bounded waits of 1 s, not the peer's 8 s
+    # ONE bounded wait of 1 s (the verdict is sticky: a rank that has poisoned a step publishes that and does not wait again --
+    # ADVICE r4), not the peer's 8 s
+    assert 0.8 <= got["waited_s"] < 7.0, got
     assert "peer-to-peer exchange" in got["status"] and "did not publish" in got["status"], got
