@@ -39,6 +39,9 @@
 #ifndef VC_PF_SINGLE
 #define VC_PF_SINGLE 1    // the same for the one-matrix kernels (phase, U-only): they stream half the bytes per cell and lose
 #endif                    // 2 us to waits; 2 or 3 cells ahead measured equal or slower (profiles/r03_kmain.md)
+#ifndef VC_LATENTS_FIRST
+#define VC_LATENTS_FIRST 1 // the per-gene latents are requested ahead of the tile table's scalar load (they do not depend on it)
+#endif
 #ifndef VC_ISSUE_PIN
 #define VC_ISSUE_PIN 1    // sched_barrier behind the issue of the next cell's loads (asm path): keeps them at the top of the cell
 #endif
@@ -116,8 +119,27 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   const int gl = lane * GPL;            // gene offset inside the block
   const int g0 = gb * GBW + gl;
 
-  // ---- this wave's cells; the loads of its first PF cells are issued before anything else, so that their latency
-  // runs in parallel with the loads of the per-gene latents below -------------------------------------------------
+  constexpr int NP = GPL / 2;           // packed pairs per lane
+  constexpr int NV4 = GPL / 4;          // float4 groups of the lane's genes (gene table loads, epilogue stores)
+  // ---- per-gene latents: REQUESTED first (VC_LATENTS_FIRST).  They depend on the workgroup index alone, while the count loads
+  // below wait for the tile table's (cold) scalar load: issued behind it, the two first-touch round trips of a wave ran one
+  // after the other (latents in registers 3.4 us after entry); now they run side by side.  The values are
+  // unpacked where they used to be loaded.
+  const int KT = d.K;     // rows of the gene table in front of log beta: K, or Nh + Nb when the batch offsets are folded (d.onehot)
+  float4 raw_nu[K][NV4], raw_lb[NV4], raw_gm[NV4], raw_rr[NV4];
+  if (VC_LATENTS_FIRST) {
+    const float* gt = b.GT + g0;
+    const size_t gt_stride = (size_t)d.Ng_pad;
+#pragma unroll
+    for (int q4 = 0; q4 < NV4; ++q4) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) raw_nu[k][q4] = *reinterpret_cast<const float4*>(gt + (size_t)k * gt_stride + 4 * q4);
+      raw_lb[q4] = *reinterpret_cast<const float4*>(gt + (size_t)KT * gt_stride + 4 * q4);
+      raw_gm[q4] = *reinterpret_cast<const float4*>(gt + (size_t)(KT + 1) * gt_stride + 4 * q4);
+      raw_rr[q4] = *reinterpret_cast<const float4*>(gt + (size_t)(KT + 2) * gt_stride + 4 * q4);
+    }
+  }
+  // ---- this wave's cells; the loads of its first PF cells are issued before anything else that depends on the tile table ----
   // The workgroups of one dispatch pass (pass_wgs = one per CU) are co-resident with those of the other passes on every
   // CU, and the SIMD arbiter serves the oldest wave first; the passes may therefore take unequal shares of the cells
   // (pass_cw[p] cells per wave in pass p), so that the waves of a SIMD end together (vc_host_logic.h: vc_tile_cells).
@@ -137,8 +159,6 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   if (cend > wg_end) cend = wg_end;
   const int ncell = (int)(cend - cbeg);
   constexpr int ESZ = C16 ? 2 : 4;       // bytes per count element
-  constexpr int NP = GPL / 2;           // packed pairs per lane
-  constexpr int NV4 = GPL / 4;          // float4 groups of the lane's genes (gene table loads, epilogue stores)
   constexpr int NDW = GPL * ESZ / 4;    // dwords per lane per matrix per cell: 8 / 4 (float32), 4 / 2 (uint16)
   // cells in flight ahead of the one being processed.  The S+U kernel at 8 genes per lane has room for a third count buffer
   // (8 more VGPRs) only up to K = 3 coefficients per gene (H = 1, no batch offsets: 248 VGPRs); beyond that the third buffer
@@ -217,9 +237,6 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
 
   // ---- per-gene latents into registers (pairs p = 0,1 hold genes 2p, 2p+1 of the lane) -----------
   v2f nu[K][NP], lb2[NP], ib[NP], gam[NP], rr[NP];
-  // rows of the gene table in front of log beta: K, or Nh + Nb when the batch offsets are folded per workgroup (d.onehot: this
-  // NB = 0 instantiation serves any number of batches)
-  const int KT = d.K;
   {
     const float* gt = b.GT + g0;
     const size_t gt_stride = (size_t)d.Ng_pad;
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     for (int q4 = 0; q4 < NV4; ++q4) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)k * gt_stride + 4 * q4);
+        const float4 v = VC_LATENTS_FIRST ? raw_nu[k][q4] : *reinterpret_cast<const float4*>(gt + (size_t)k * gt_stride + 4 * q4);
         nu[k][2 * q4] = v2f{v.x, v.y}; nu[k][2 * q4 + 1] = v2f{v.z, v.w};
       }
       if (NB == 0 && d.onehot) {
@@ -237,9 +254,9 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)(NH + my_batch) * gt_stride + 4 * q4);
         nu[0][2 * q4] += v2f{v.x, v.y}; nu[0][2 * q4 + 1] += v2f{v.z, v.w};
       }
-      const float4 v0 = *reinterpret_cast<const float4*>(gt + (size_t)KT * gt_stride + 4 * q4);
-      const float4 v1 = *reinterpret_cast<const float4*>(gt + (size_t)(KT + 1) * gt_stride + 4 * q4);
-      const float4 v2r = *reinterpret_cast<const float4*>(gt + (size_t)(KT + 2) * gt_stride + 4 * q4);
+      const float4 v0 = VC_LATENTS_FIRST ? raw_lb[q4] : *reinterpret_cast<const float4*>(gt + (size_t)KT * gt_stride + 4 * q4);
+      const float4 v1 = VC_LATENTS_FIRST ? raw_gm[q4] : *reinterpret_cast<const float4*>(gt + (size_t)(KT + 1) * gt_stride + 4 * q4);
+      const float4 v2r = VC_LATENTS_FIRST ? raw_rr[q4] : *reinterpret_cast<const float4*>(gt + (size_t)(KT + 2) * gt_stride + 4 * q4);
       if (!HLB) { lb2[2 * q4] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[2 * q4 + 1] = v2f{v0.z, v0.w} * VC_LOG2E; }
       else lb2[2 * q4] = lb2[2 * q4 + 1] = v2(0.f);      // not used in the loop (epilogue re-reads log beta)
       ib[2 * q4] = v2f{__expf(-v0.x), __expf(-v0.y)}; ib[2 * q4 + 1] = v2f{__expf(-v0.z), __expf(-v0.w)};   // 1/beta
