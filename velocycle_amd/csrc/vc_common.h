@@ -140,7 +140,7 @@ struct VcBufs {
   // dense histograms (d.hist_dense; vc_host_logic.h: vc_build_dense_hist): tail counts C_j of every gene, [gene block of 64][j][gene]
   const float* HC;                          // rows of 64 floats
   const int* hc_off;                        // [2][Ng_pad / 64] first row of a gene block (matrix S, then U)
-  const int* hc_rows;                       // [2][Ng_pad / 64] rows of a gene block = 1 + its largest count
+  const int* hc_rows;                       // [2][Ng_pad / 64] rows of a gene block = its largest count (row j: cells with count > j)
   const int *wg_tile;                       // [n_main_wg][4] {first cell of wave 0, cells per wave, batch, end of the workgroup's cells} of the
                                             // likelihood kernel's workgroups (cells = POSITIONS of the blocked layout: cell_pos)
   const int *bat_chunk;                     // onehot: [nGB][Nb + 1] first chunk of batch q among the chunks of a gene block (chunks of a batch are

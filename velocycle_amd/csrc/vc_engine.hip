@@ -884,7 +884,18 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     auto occupancy = [&](unsigned dyn_bytes, int* out) -> int {
       int bpc = 0;
       dyn_bytes += gen_dyn;
-      if (dyn_bytes > 0) (void)hipFuncSetAttribute(main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes);
+      if (dyn_bytes > 0) {
+        // the per-gene state of the run-time-sized kernels / the staged W rows must fit the LDS a workgroup of THIS device may ask
+        // for (gfx950: 160 KB; a part with 64 KB refuses here with the dimension named instead of failing at launch: ADVICE r4)
+        const size_t lds_cap = std::max<size_t>(prop.sharedMemPerBlockOptin, prop.maxSharedMemoryPerMultiProcessor);
+        hipError_t er = lds_cap > 0 && dyn_bytes > lds_cap ? hipErrorInvalidValue
+                                                            : hipFuncSetAttribute(main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_bytes);
+        if (er != hipSuccess) {
+          (void)hipGetLastError();
+          return e->fail(VC_ERR_UNSUPPORTED, "the likelihood kernel needs %u bytes of LDS per workgroup (2 n_harmonics + 1 + Nb = %d coefficient rows per gene"
+                                             "%s), this device grants %zu", dyn_bytes, d.K, d.generic ? " on the run-time-sized kernel set" : "", lds_cap);
+        }
+      }
       HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, main_kernel, 64 * wg_waves, dyn_bytes));
       if (d.generic && bpc > 8) bpc = 8;      // (one wave each: two per SIMD hide the LDS latency, more only shorten the runs of cells)
       if (e->tun.blocks_per_cu > 0) bpc = e->tun.blocks_per_cu;
@@ -977,7 +988,10 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     hipFuncAttributes fa;
     if (e->main_fn_nl && knl && (hipFuncGetAttributes(&fa, knl) != hipSuccess || fa.localSizeBytes > 0)) e->main_fn_nl = nullptr;
     const unsigned dyn = vc_main_dyn_lds(d);
-    if (e->main_fn_nl && dyn > 0) (void)hipFuncSetAttribute(knl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (e->main_fn_nl && dyn > 0 && hipFuncSetAttribute(knl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+      (void)hipGetLastError();
+      e->main_fn_nl = nullptr;          // (no gradient-only twin then: vc_set_loss_every says so)
+    }
   }
   {
     // the tiling as a table: {first cell of wave 0, cells per wave} of every workgroup of the likelihood kernel, evaluated

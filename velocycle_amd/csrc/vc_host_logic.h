@@ -118,7 +118,7 @@ static inline double vc_build_hist_host(const float* M, long long gs, long long 
 //   sum_k cnt_k [psi(r + k)    - psi(r)]    = sum_{j >= 0} C_j / (r + j)
 // (lgamma(r + k) - lgamma(r) = sum_{j < k} log(r + j) for integer k): a logarithm and a reciprocal per (gene, j) instead of a
 // Stirling-series evaluation per distinct count value, and -- laid out [gene block of 64][j][gene] -- 64 genes per wave
-// instruction.  Appends the rows of one matrix: rows[gb] = 1 + the largest count of the block's genes (0: all zero),
+// instruction.  Appends the rows of one matrix: rows[gb] = the largest count of the block's genes (0: all zero; row j = C_j),
 // off[gb] = index of the block's first row in HC (rows of 64 floats).  Counts are exact in float up to 2^24 cells.
 static inline void vc_build_dense_hist(const unsigned* tab, int Ng, int Ng_pad, std::vector<float>& HC, std::vector<int>& off,
                                        std::vector<int>& rows) {

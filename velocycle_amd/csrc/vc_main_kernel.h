@@ -40,8 +40,10 @@
 #define VC_PF_SINGLE 1    // the same for the one-matrix kernels (phase, U-only): they stream half the bytes per cell and lose
 #endif                    // 2 us to waits; 2 or 3 cells ahead measured equal or slower (profiles/r03_kmain.md)
 #ifndef VC_LATENTS_FIRST
-#define VC_LATENTS_FIRST 1 // the per-gene latents are requested ahead of the tile table's scalar load (they do not depend on it)
-#endif
+#define VC_LATENTS_FIRST 1 // S+U kernel: the per-gene latents are requested ahead of the tile table's scalar load (they do not depend on it).
+#endif                     // Same-box A/B at 50k x 2k (profiles/r05_ab1_summary.txt): S+U 113.4-114.7 -> 112.7-112.9 us; the phase kernel
+                           // 54.7-54.9 -> 56.0 (worse: its first count loads then queue behind twelve gene-table loads), U-only equal --
+                           // so the S+U kernel only (LATF below)
 #ifndef VC_ISSUE_PIN
 #define VC_ISSUE_PIN 1    // sched_barrier behind the issue of the next cell's loads (asm path): keeps them at the top of the cell
 #endif
@@ -126,8 +128,9 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // after the other (latents in registers 3.4 us after entry); now they run side by side.  The values are
   // unpacked where they used to be loaded.
   const int KT = d.K;     // rows of the gene table in front of log beta: K, or Nh + Nb when the batch offsets are folded (d.onehot)
+  constexpr bool LATF = VC_LATENTS_FIRST && KIND == VC_KIND_VFULL;
   float4 raw_nu[K][NV4], raw_lb[NV4], raw_gm[NV4], raw_rr[NV4];
-  if (VC_LATENTS_FIRST) {
+  if (LATF) {
     const float* gt = b.GT + g0;
     const size_t gt_stride = (size_t)d.Ng_pad;
 #pragma unroll
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
     for (int q4 = 0; q4 < NV4; ++q4) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        const float4 v = VC_LATENTS_FIRST ? raw_nu[k][q4] : *reinterpret_cast<const float4*>(gt + (size_t)k * gt_stride + 4 * q4);
+        const float4 v = LATF ? raw_nu[k][q4] : *reinterpret_cast<const float4*>(gt + (size_t)k * gt_stride + 4 * q4);
         nu[k][2 * q4] = v2f{v.x, v.y}; nu[k][2 * q4 + 1] = v2f{v.z, v.w};
       }
       if (NB == 0 && d.onehot) {
@@ -254,9 +257,9 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
         const float4 v = *reinterpret_cast<const float4*>(gt + (size_t)(NH + my_batch) * gt_stride + 4 * q4);
         nu[0][2 * q4] += v2f{v.x, v.y}; nu[0][2 * q4 + 1] += v2f{v.z, v.w};
       }
-      const float4 v0 = VC_LATENTS_FIRST ? raw_lb[q4] : *reinterpret_cast<const float4*>(gt + (size_t)KT * gt_stride + 4 * q4);
-      const float4 v1 = VC_LATENTS_FIRST ? raw_gm[q4] : *reinterpret_cast<const float4*>(gt + (size_t)(KT + 1) * gt_stride + 4 * q4);
-      const float4 v2r = VC_LATENTS_FIRST ? raw_rr[q4] : *reinterpret_cast<const float4*>(gt + (size_t)(KT + 2) * gt_stride + 4 * q4);
+      const float4 v0 = LATF ? raw_lb[q4] : *reinterpret_cast<const float4*>(gt + (size_t)KT * gt_stride + 4 * q4);
+      const float4 v1 = LATF ? raw_gm[q4] : *reinterpret_cast<const float4*>(gt + (size_t)(KT + 1) * gt_stride + 4 * q4);
+      const float4 v2r = LATF ? raw_rr[q4] : *reinterpret_cast<const float4*>(gt + (size_t)(KT + 2) * gt_stride + 4 * q4);
       if (!HLB) { lb2[2 * q4] = v2f{v0.x, v0.y} * VC_LOG2E; lb2[2 * q4 + 1] = v2f{v0.z, v0.w} * VC_LOG2E; }
       else lb2[2 * q4] = lb2[2 * q4 + 1] = v2(0.f);      // not used in the loop (epilogue re-reads log beta)
       ib[2 * q4] = v2f{__expf(-v0.x), __expf(-v0.y)}; ib[2 * q4 + 1] = v2f{__expf(-v0.z), __expf(-v0.w)};   // 1/beta
