@@ -130,7 +130,10 @@ CASES = {
     "vel_lrmn_joint_dnu2_med": dict(kind="velocity", Nc=700, Ng=300, H=2, Hw=1, nb=2, noise="NegativeBinomial",
                                     model_type="lrmn", wdn=True),
 }
-FIT_CASES = {"phase_nb": 25, "vel_mf_joint": 25, "vel_lrmn_cond": 25, "vel_mf_cond": 15}
+FIT_CASES = {"phase_nb": 25, "vel_mf_joint": 25, "vel_lrmn_cond": 25, "vel_mf_cond": 15,
+             # the medium case through the reference's own fit(): two batches with learned offsets over 12 steps (round 5: the path
+             # on which the engine folds the one-hot batch design per workgroup)
+             "vel_lrmn_joint_dnu2_med": 12}
 
 
 def make_case(name, c, seed=11):
@@ -218,10 +221,25 @@ def make_case(name, c, seed=11):
                  num_steps=n, verbose=False)
         ref_par, _ = ref_params_canonical(p32)
         o_losses, o_par = orc.fit(p32, opt_args, n, seed=seed)
-        check(o_losses, fitm.losses, f"{name}: fit losses", 1e-4, 1e-2)
-        for k in ref_par:
-            check(o_par[k], ref_par[k], f"{name}: fitted {k}", 2e-3, 2e-3)
         l64s, par64f = orc.fit(p64, opt_args, n, seed=seed)
+        if c["Nc"] < 200:
+            check(o_losses, fitm.losses, f"{name}: fit losses", 1e-4, 1e-2)
+            for k in ref_par:
+                check(o_par[k], ref_par[k], f"{name}: fitted {k}", 2e-3, 2e-3)
+        else:
+            # medium size: two float32 runs of the flow (the reference on the shim, the oracle) separate step by step where genes sit
+            # on the relu kink of ElogU -- the yardstick is the distance the float32 oracle itself keeps from the float64 one
+            lr_, lo_, l6_ = np.array(fitm.losses), np.array(o_losses), np.array(l64s)
+            rel, spread = np.abs(lo_ / lr_ - 1), np.abs(lo_ / l6_ - 1)
+            print(f"[fit ] {name}: oracle32 vs reference per step {np.array2string(rel, precision=1)}; oracle32 vs oracle64 {np.array2string(spread, precision=1)}")
+            if rel[:2].max() > 1e-5 or (rel > np.maximum(1e-5, 4 * np.maximum.accumulate(np.maximum(spread, np.abs(lr_ / l6_ - 1))))).any():
+                raise SystemExit(f"ORACLE != REFERENCE for {name}: fit losses beyond the float32 spread")
+            for k in ref_par:
+                a, b, c64 = o_par[k].numpy().astype(np.float64), ref_par[k].numpy().astype(np.float64), par64f[k].numpy()
+                fin = np.isfinite(b)
+                tol = max(1e-3 * np.abs(c64[fin]).max(), 4 * max(np.abs(a[fin] - c64[fin]).max(), np.abs(b[fin] - c64[fin]).max()))
+                if not np.array_equal(np.isfinite(a), fin) or np.abs(a[fin] - b[fin]).max() > tol:
+                    raise SystemExit(f"ORACLE != REFERENCE for {name}: fitted {k}: {np.abs(a[fin] - b[fin]).max()} > {tol}")
         fo = problem_arrays(p32)
         fo.update({"reffit_" + k: v.numpy() for k, v in ref_par.items()})
         fo.update({"fit64_" + k: v.numpy() for k, v in par64f.items()})
@@ -235,6 +253,10 @@ def make_case(name, c, seed=11):
                      "log_gammas", "log_betas", "velocity_coef", "velocity_coef_sd"):
             if hasattr(fitm, attr):
                 fo["attr_" + attr] = np.asarray(getattr(fitm, attr))
+        if c["Nc"] >= 200:      # medium case: the trajectory only (the posterior arrays would be megabytes) -> ref_fitmed_<case>.npz
+            np.savez_compressed(os.path.join(OUT, f"ref_fitmed_{name}.npz"), **fo)
+            print(f"[fit ] {name}: {n} steps, ref final loss {fitm.losses[-1]:.4f}, oracle {o_losses[-1]:.4f}")
+            return
         # the reference's own posterior summaries (velocity_inference_model.py:236-262, phase_inference_model.py:248-265)
         # together with the draw-dependent inputs they were computed from, so that the engine's vc_expected_logs can be
         # checked against the reference's numbers without sharing its RNG stream

@@ -38,6 +38,25 @@ def test_fit_trajectory_matches_reference(case):
     eng.close()
 
 
+@pytest.mark.parametrize("dense", [False, True])
+def test_medium_two_batch_fit_matches_the_references_own_fit(dense):
+    """2 x 700 cells x 300 genes, H = 2, two batches with learned offsets, LRMN guide: 12 steps of the reference's own
+    VelocityFitModel.fit (ref_fitmed_*.npz; velocity_inference_model.py:111-187) against the engine in parity mode on the same eps
+    stream -- through the one-hot fold of the batch design (NB = 0 kernel, the default) and through the dense contraction."""
+    from tests.test_oracle_golden import _medium_fit_bars
+    from velocycle_amd.svi import SVIRunner
+    from velocycle_amd.tuning import Tuning
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fitmed_vel_lrmn_joint_dnu2_med.npz")
+    spec = H.spec_from_fixture(z)
+    eng = _mk(spec, tuning=Tuning(dense_batches=dense))
+    assert eng.stats["onehot_batches"] == (0 if dense else 2) and eng.stats["main_kernel"].startswith("vc_main_kernel<2,%d," % (2 if dense else 0))
+    opt = {"lr": float(z["opt_lr"]), "lrd": float(z["opt_lrd"]), "betas": tuple(float(x) for x in z["opt_betas"])}
+    run = SVIRunner(eng, opt, mode="parity", seed=int(z["seed"]))
+    losses = [run.step() for _ in range(int(z["num_steps"]))]
+    _medium_fit_bars(losses, z)
+    eng.close()
+
+
 def _oracle_eval(spec_case_z, eng, eps_flat):
     p = H.problem_from_fixture(spec_case_z)
     eps = {n: eps_flat[o:o + s].double() for n, (o, s) in eng.eps_slices.items()}

@@ -46,6 +46,28 @@ def test_oracle_fit_matches_reference_fixture(case):
         assert np.allclose(v.numpy()[fin], want[fin], rtol=2e-3, atol=2e-3), k
 
 
+def _medium_fit_bars(losses, z):
+    """Losses of a float32 fit of the medium two-batch problem against the REFERENCE's own fit() (ref_fitmed_*.npz): identical over
+    the first steps; from step 5 on the flow is chaotic at this random initialisation (genes on the relu kink of ElogU: the float32
+    oracle itself leaves the float64 one by 1e-3 within 12 steps), so later steps are held to the measured growth of that separation."""
+    ref = z["ref_losses"]
+    rel = np.abs(np.asarray(losses) / ref - 1)
+    # measured when the fixture was made (make_golden.py prints it): float32 oracle vs reference 7e-8, 7e-8, 7e-8, 0, 1.4e-6, 2.8e-5,
+    # 5.8e-5, 3.6e-4, 2.3e-4, 9.8e-4, 2.2e-4, 1.6e-3; float32 oracle vs float64 oracle the same orders -- the envelope below is that
+    # growth with a factor 3-10 of room; the first four steps are the strict part
+    envelope = np.array([1e-6, 1e-6, 1e-6, 1e-6, 1e-5, 2e-4, 4e-4, 2e-3, 2e-3, 5e-3, 5e-3, 8e-3])
+    assert (rel <= envelope[: len(rel)]).all(), (rel, envelope)
+
+
+def test_oracle_medium_two_batch_fit_matches_reference_fixture():
+    z = H.load_fixture(f"{H.GOLDEN}/ref_fitmed_vel_lrmn_joint_dnu2_med.npz")
+    p = H.problem_from_fixture(z, torch.float32)
+    assert p.Nb == 2 and p.with_delta_nu and (p.Ng, p.Nc) == (300, 1400)          # two samples of 700 cells
+    opt = {"lr": float(z["opt_lr"]), "lrd": float(z["opt_lrd"]), "betas": tuple(float(x) for x in z["opt_betas"])}
+    losses, _ = orc.fit(p, opt, int(z["num_steps"]), seed=int(z["seed"]))
+    _medium_fit_bars(losses, z)
+
+
 @pytest.mark.parametrize("case", H.CONTINUE_CASES)
 @pytest.mark.parametrize("scen", ["same", "new"])
 def test_oracle_continued_fit_matches_reference_fixture(case, scen):
