@@ -272,13 +272,17 @@ int vc_clipped_adam(float* params, const float* grad, float* exp_avg, float* exp
  *   VC_OPT_ADAM          [g += weight_decay * p], no clamp, no decay (lrd and clip_norm are ignored),
  *                        p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)       (amsgrad / maximize: not supported)
  * vc_set_optimizer selects what the step entry points of an engine apply (default: ClippedAdam, no weight decay);
- * vc_adam_update is the optimiser as a call of its own (vc_clipped_adam = kind VC_OPT_CLIPPED_ADAM, weight_decay 0). */
+ * vc_adam_update is the optimiser as a call of its own (vc_clipped_adam = kind VC_OPT_CLIPPED_ADAM, weight_decay 0).
+ * `frozen` (DEVICE bytes, one per float of the flat parameter buffer / of the n updated floats; may be NULL; caller-owned, must stay
+ * valid while the engine uses it): 1 marks a parameter TENSOR that has no path to the loss because its sample site is conditioned
+ * (poutine.block: velocity_inference_model.py:65-66) -- PyroOptim never steps such a tensor (its .grad is None), so weight decay
+ * must not move it either; without weight decay a frozen tensor stays where it is by itself (zero gradient, zero moments). */
 #define VC_OPT_CLIPPED_ADAM 0
 #define VC_OPT_ADAM 1
-int vc_set_optimizer(vc_engine* e, int kind, double weight_decay);
+int vc_set_optimizer(vc_engine* e, int kind, double weight_decay, const uint8_t* frozen);
 int vc_adam_update(int kind, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double lrd,
-                   double beta1, double beta2, double eps, double clip_norm, double weight_decay, int64_t t, const int64_t* t_dev,
-                   const float* loss_hdr, double* loss_ring, int64_t loss_slots, void* hip_stream);
+                   double beta1, double beta2, double eps, double clip_norm, double weight_decay, const uint8_t* frozen, int64_t t,
+                   const int64_t* t_dev, const float* loss_hdr, double* loss_ring, int64_t loss_slots, void* hip_stream);
 
 /* One whole SVI step (single rank): vc_elbo_grad with pyro's ClippedAdam merged into its last kernel -- 4
  * launches instead of 5.  exp_avg / exp_avg_sq: device float[total - header], zero-initialised by the caller;

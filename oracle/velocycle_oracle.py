@@ -399,12 +399,17 @@ def elbo_loss(p: Problem, par: Dict[str, torch.Tensor], eps: Dict[str, torch.Ten
     return -(logp - logq), val, det
 
 
+class _NoPath(torch.Tensor):
+    """A zero gradient that records that autograd found NO path from the loss to the parameter tensor (`.grad is None` in Pyro:
+    PyroOptim skips such a tensor altogether -- it takes no weight decay either)."""
+
+
 def loss_and_grads(p: Problem, par: Dict[str, torch.Tensor], eps: Dict[str, torch.Tensor]):
-    """(loss float, {param name: d loss / d unconstrained param}); params untouched by the loss get 0."""
+    """(loss float, {param name: d loss / d unconstrained param}); params untouched by the loss get 0 (marked `_NoPath`)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in par.items()}
     loss, val, det = elbo_loss(p, leaves, eps)
     loss.backward()
-    grads = {k: (torch.zeros_like(v) if v.grad is None else torch.nan_to_num(v.grad, nan=0.0))
+    grads = {k: (torch.zeros_like(v).as_subclass(_NoPath) if v.grad is None else torch.nan_to_num(v.grad, nan=0.0))
              for k, v in leaves.items()}
     return loss.item(), grads, {k: t.detach() for k, t in val.items()}, {k: t.detach() for k, t in det.items()}
 
@@ -433,6 +438,8 @@ class ClippedAdam:
         b1, b2 = self.betas
         step_size = self.lr * math.sqrt(1 - b2 ** self.t) / (1 - b1 ** self.t)
         for k, g in grads.items():
+            if isinstance(g, _NoPath):                       # pyro: `if p.grad is None: continue`
+                continue
             g = g.clamp(-self.clip_norm, self.clip_norm)
             if self.weight_decay != 0:                       # pyro clipped_adam.py: grad.add(p.data, alpha=weight_decay), behind the clamp
                 g = g.add(par[k], alpha=self.weight_decay)
@@ -464,6 +471,8 @@ class Adam:
         b1, b2 = self.betas
         bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
         for k, g in grads.items():
+            if isinstance(g, _NoPath):                       # torch.optim.Adam: `if p.grad is not None`
+                continue
             if self.weight_decay != 0:
                 g = g.add(par[k], alpha=self.weight_decay)
             m = self.m.setdefault(k, torch.zeros_like(g))

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("kind,wd", [("adam", 0.0), ("adam", 0.03), ("clipped_adam", 0.03), ("clipped_adam", 0.0)])
 def test_adam_update_kernel_equals_torch(kind, wd):
-    """vc_adam_update on flat buffers, 40 steps with a device step counter, against torch.optim.Adam itself (kind "adam") and
+    """(frozen tensors: the second half of the buffer is marked frozen when weight decay is on -- it must not move.)
+    vc_adam_update on flat buffers, 40 steps with a device step counter, against torch.optim.Adam itself (kind "adam") and
     against the oracle's restatement of pyro's clipped_adam.py (kind "clipped_adam", weight decay behind the clamp)."""
     from velocycle_amd.engine import HipEngine
     from velocycle_amd.svi import FlatClippedAdam
@@ -76,19 +77,22 @@ def test_every_step_structure_applies_the_chosen_optimiser(case, args):
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_{case}.npz")
     spec = H.spec_from_fixture(z)
     n = 20
-    runs = {impl: _run(spec, args, impl, n) for impl in ("fused3", "hip", "fused", "torch")}
-    ref = runs["torch"]
-    assert ref["kind"] == args["_kind"]
-    for impl, r in runs.items():
-        # the HIP structures against each other: float32 rounding of re-associated sums; against the PyTorch-op optimiser: two
-        # float32 implementations of the same update (x * (1 / c) vs x / c, fused vs separate multiply-adds), 20 steps on
+    runs = {impl: _run(spec, args, impl, n) for impl in ("fused3", "hip", "fused")}
+    assert runs["hip"]["kind"] == args["_kind"]
+    for impl, r in runs.items():          # the HIP structures against each other: float32 rounding of re-associated sums
         assert r["status"] == (True, -1, 0) and len(r["l"]) == n
-        base, lt, pt = (runs["hip"], 1e-6, (2e-4, 2e-5)) if impl != "torch" else (runs["fused3"], 1e-4, (5e-3, 5e-4))
-        assert np.allclose(r["l"][:3], base["l"][:3], rtol=1e-6, atol=0) and np.allclose(r["l"], base["l"], rtol=lt, atol=0), \
-            (impl, np.abs(r["l"] / base["l"] - 1).max())
+        base = runs["hip"]
+        assert np.allclose(r["l"], base["l"], rtol=1e-6, atol=0), (impl, np.abs(r["l"] / base["l"] - 1).max())
         a, b = r["p"].double().numpy(), base["p"].double().numpy()
         fin = np.isfinite(b)
-        assert np.array_equal(np.isfinite(a), fin) and np.allclose(a[fin], b[fin], rtol=pt[0], atol=pt[1]), (impl, np.abs(a[fin] - b[fin]).max())
+        assert np.array_equal(np.isfinite(a), fin) and np.allclose(a[fin], b[fin], rtol=2e-4, atol=2e-5), (impl, np.abs(a[fin] - b[fin]).max())
+    # the PyTorch-op optimiser (x / c where the kernels multiply by 1 / c, lerp_ instead of two products): the same update to
+    # float32 rounding over three steps (Adam's m / sqrt(v) amplifies such rounding over a long run wherever a gradient is near zero)
+    t3, h3 = _run(spec, args, "torch", 3), _run(spec, args, "hip", 3)
+    assert np.allclose(t3["l"], h3["l"], rtol=1e-6, atol=0)
+    a, b = t3["p"].double().numpy(), h3["p"].double().numpy()
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin) and np.allclose(a[fin], b[fin], rtol=1e-4, atol=1e-5), np.abs(a[fin] - b[fin]).max()
     got = runs["fused3"]
     eps = H.philox_eps_list(spec, got["flat0"], 9, n)
     oargs = {k: v for k, v in args.items() if k != "_kind"}

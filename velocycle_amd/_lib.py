@@ -117,9 +117,9 @@ EXPORTS = {
     "vc_clipped_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "vc_set_optimizer": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "vc_set_optimizer": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "vc_adam_update": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double,
-                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int64, C.c_void_p]),
     "vc_sample_guide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),
     "vc_sample_posterior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p,

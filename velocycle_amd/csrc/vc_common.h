@@ -605,7 +605,7 @@ __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const Vc
 
 // launchers implemented in the .hip translation units -----------------------------------------
 // hyper-parameters of the optimiser as the unfused launches take them (kind: VC_OPT_*)
-struct VcAdamHyper { double lr0, lrd, b1, b2; float eps, clip, wd; int kind; };
+struct VcAdamHyper { double lr0, lrd, b1, b2; float eps, clip, wd; int kind; const unsigned char* frozen; long long frozen_off; };
 static inline int vc_hist_blocks(const VcDims& d, const VcBufs& b, int waves) {
   return d.hist_dense ? d.Ng_pad / 64 : (b.n_tasks + waves - 1) / waves;
 }
@@ -664,7 +664,13 @@ struct VcAdamArgs {
   int header;
   float wd;            // weight decay (0: none)
   int kind;            // VC_OPT_*
+  const unsigned char* frozen;   // [total] 1 = a parameter tensor without a path to the loss (its site is conditioned): PyroOptim skips it
+                                 // (grad None), so it takes no weight decay either; nullptr: none
 };
+// weight decay of the parameter at flat offset `off` (0 where the tensor is frozen)
+__device__ __forceinline__ float vc_wd_at(float wd, const unsigned char* __restrict__ frozen, long long off) {
+  return (wd != 0.f && frozen && frozen[off]) ? 0.f : wd;
+}
 
 // fused single-rank step (vc_svi_step_fused): K_main(t) -> K_tail(t) -> K_omega(t); boot = 1: sampling only (primes the
 // tables for the step *step_dev)

@@ -54,10 +54,12 @@ struct vc_engine {
   vc_tuning tun{};                    // vc_set_tuning: all-zero = defaults (the library reads no environment variable)
   int opt_kind = VC_OPT_CLIPPED_ADAM; // vc_set_optimizer: which optimiser the step entry points apply
   double opt_wd = 0.0;                // ... and its weight decay
+  const unsigned char* opt_frozen = nullptr;   // ... and the parameter tensors it must not touch (caller-owned device bytes [total], or null)
   VcAdamHyper hyper(double lr, double lrd, double b1, double b2, double eps, double clip) const {
     VcAdamHyper h;
     h.lr0 = lr; h.lrd = opt_kind == VC_OPT_ADAM ? 1.0 : lrd; h.b1 = b1; h.b2 = b2;
     h.eps = (float)eps; h.clip = opt_kind == VC_OPT_ADAM ? __builtin_inff() : (float)clip; h.wd = (float)opt_wd; h.kind = opt_kind;
+    h.frozen = opt_frozen; h.frozen_off = 0;
     return h;
   }
   void fill(VcAdamArgs& a, float* m, float* v, double lr, double lrd, double b1, double b2, double eps, double clip) const {
@@ -65,7 +67,7 @@ struct vc_engine {
     a.m = m; a.v = v;
     a.lr0 = h.lr0; a.lrd_l = log(h.lrd); a.b1l = log(h.b1); a.b2l = log(h.b2);
     a.b1 = (float)h.b1; a.b2 = (float)h.b2; a.eps = h.eps; a.clip = h.clip;
-    a.header = (int)layout.header; a.wd = h.wd; a.kind = h.kind;
+    a.header = (int)layout.header; a.wd = h.wd; a.kind = h.kind; a.frozen = h.frozen;
   }
   VcNcclComm comm = nullptr;          // the engine's own communicator (vc_comm_init_rccl), or null
   double* particle_lsum = nullptr;    // vc_svi_run_particles: scratch slots of the particles' K_fin launches
@@ -1528,8 +1530,9 @@ extern "C" int vc_svi_run_particles(vc_engine* e, float* params, uint64_t seed, 
     // average of the K gradients and losses in particle order (what a host loop's g_0 + g_1 + ... and its division by K give),
     // left in the first particle's buffer; advances the step counter
     vc_launch_particle_avg(pg, total, loss_dev, (long long)loss_slots, (long long)(step0 + i), (long long*)step_dev, st);
-    vc_launch_adam(params + header, grad + header, exp_avg, exp_avg_sq, total - header, e->hyper(lr, lrd, beta1, beta2, adam_eps, clip_norm),
-                   0, (const long long*)step_dev, nullptr, nullptr, 0, st);
+    VcAdamHyper hy = e->hyper(lr, lrd, beta1, beta2, adam_eps, clip_norm);
+    hy.frozen_off = header;             // (the flat update starts behind the header)
+    vc_launch_adam(params + header, grad + header, exp_avg, exp_avg_sq, total - header, hy, 0, (const long long*)step_dev, nullptr, nullptr, 0, st);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
@@ -1912,30 +1915,34 @@ extern "C" int vc_clipped_adam(float* params, const float* grad, float* exp_avg,
   if (n == 0) return VC_OK;
   VcAdamHyper h;
   h.lr0 = lr; h.lrd = lrd; h.b1 = beta1; h.b2 = beta2; h.eps = (float)eps; h.clip = (float)clip_norm; h.wd = 0.f; h.kind = VC_OPT_CLIPPED_ADAM;
+  h.frozen = nullptr; h.frozen_off = 0;
   vc_launch_adam(params, grad, exp_avg, exp_avg_sq, (long long)n, h, (long long)t, (const long long*)t_dev, loss_hdr, loss_ring,
                  (long long)loss_slots, (hipStream_t)hip_stream);
   return hipGetLastError() == hipSuccess ? VC_OK : VC_ERR_HIP;
 }
 
 extern "C" int vc_adam_update(int kind, float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
-                              double lrd, double beta1, double beta2, double eps, double clip_norm, double weight_decay, int64_t t,
-                              const int64_t* t_dev, const float* loss_hdr, double* loss_ring, int64_t loss_slots, void* hip_stream) {
+                              double lrd, double beta1, double beta2, double eps, double clip_norm, double weight_decay,
+                              const uint8_t* frozen, int64_t t, const int64_t* t_dev, const float* loss_hdr, double* loss_ring,
+                              int64_t loss_slots, void* hip_stream) {
   if (!params || !grad || !exp_avg || !exp_avg_sq || n < 0) return VC_ERR_ARG;
   if (kind != VC_OPT_CLIPPED_ADAM && kind != VC_OPT_ADAM) return VC_ERR_ARG;
   if (n == 0) return VC_OK;
   VcAdamHyper h;
   h.lr0 = lr; h.lrd = kind == VC_OPT_ADAM ? 1.0 : lrd; h.b1 = beta1; h.b2 = beta2; h.eps = (float)eps;
   h.clip = kind == VC_OPT_ADAM ? __builtin_inff() : (float)clip_norm; h.wd = (float)weight_decay; h.kind = kind;
+  h.frozen = frozen; h.frozen_off = 0;
   vc_launch_adam(params, grad, exp_avg, exp_avg_sq, (long long)n, h, (long long)t, (const long long*)t_dev, loss_hdr, loss_ring,
                  (long long)loss_slots, (hipStream_t)hip_stream);
   return hipGetLastError() == hipSuccess ? VC_OK : VC_ERR_HIP;
 }
 
-extern "C" int vc_set_optimizer(vc_engine* e, int kind, double weight_decay) {
+extern "C" int vc_set_optimizer(vc_engine* e, int kind, double weight_decay, const uint8_t* frozen) {
   if (!e) return VC_ERR_ARG;
   if (kind != VC_OPT_CLIPPED_ADAM && kind != VC_OPT_ADAM) return e->fail(VC_ERR_ARG, "vc_set_optimizer: kind must be VC_OPT_CLIPPED_ADAM or VC_OPT_ADAM");
   if (!(weight_decay >= 0.0)) return e->fail(VC_ERR_ARG, "vc_set_optimizer: negative weight_decay");
   e->opt_kind = kind;
   e->opt_wd = weight_decay;
+  e->opt_frozen = frozen;
   return VC_OK;
 }

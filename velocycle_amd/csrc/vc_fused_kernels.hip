@@ -32,7 +32,7 @@
 #define VC_MAXOWN 5      // parameters one (gene, role) thread owns (the LRMN cov_factor row is split over two roles)
 #define VC_COVW 4        // cov_factor entries per role: role 14 holds k = 0..3, role 15 k = 4..7
 
-struct VcOpt { float step_size, b1, b2, eps, clip, c2, wd; };
+struct VcOpt { float step_size, b1, b2, eps, clip, c2, wd; const unsigned char* frozen; };
 
 #define VC_NWE (VC_MAX_NW * (VC_MAX_RANK + 2))      // nu_omega-related parameter elements at most
 #define VC_HIST_ROUNDS 1     // one-launch tail, list form: rounds of 16 histogram tasks per 1024-thread block (2: measured slower)
@@ -383,7 +383,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
         else {
           G[po] = gq;
           float mm = Mm[po - header], vv = Vv[po - header];
-          p = vc_adam_elem(p, gq, mm, vv, o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, o.wd);
+          p = vc_adam_elem(p, gq, mm, vv, o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, vc_wd_at(o.wd, o.frozen, po));
           Mm[po - header] = mm; Vv[po - header] = vv; P[po] = p;
         }
       }
@@ -401,7 +401,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     for (int k = 0; k < VC_MAXOWN; ++k)
       if (k < nown) {
         G[off[k]] = gg[k];
-        const float np = vc_adam_elem(pp[k], gg[k], pm[k], pv[k], o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, o.wd);
+        const float np = vc_adam_elem(pp[k], gg[k], pm[k], pv[k], o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, vc_wd_at(o.wd, o.frozen, off[k]));
         Mm[off[k] - header] = pm[k];
         Vv[off[k] - header] = pv[k];
         P[off[k]] = np;
@@ -654,8 +654,8 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
         const float gx = -(dphi * (-y * inv) - (x - pxy.x));
         const float gy = -(dphi * (x * inv) - (y - pxy.y));
         *reinterpret_cast<float2*>(G + poff) = make_float2(gx, gy);
-        pp.x = vc_adam_elem(pp.x, gx, pm.x, pv.x, o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, o.wd);
-        pp.y = vc_adam_elem(pp.y, gy, pm.y, pv.y, o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, o.wd);
+        pp.x = vc_adam_elem(pp.x, gx, pm.x, pv.x, o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, vc_wd_at(o.wd, o.frozen, poff));
+        pp.y = vc_adam_elem(pp.y, gy, pm.y, pv.y, o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, vc_wd_at(o.wd, o.frozen, poff));
         *reinterpret_cast<float2*>(Mm + (poff - header)) = pm;
         *reinterpret_cast<float2*>(Vv + (poff - header)) = pv;
         *reinterpret_cast<float2*>(P + poff) = pp;
@@ -760,7 +760,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   VC_WSTAMP(0, 5);
   if (OMEGA && vel) {
     // the nu_omega chain (gradient from K_main's partials, optimiser, next sample) and omega_c of this block's cells
-    vc_nuw_chain(d, b, P, G, s, seed, VcAdamArgs{Mm, Vv, 0.0, 0.0, 0.0, 0.0, o.b1, o.b2, o.eps, o.clip, header, o.wd, 0}, boot, cblock == 0, phase,
+    vc_nuw_chain(d, b, P, G, s, seed, VcAdamArgs{Mm, Vv, 0.0, 0.0, 0.0, 0.0, o.b1, o.b2, o.eps, o.clip, header, o.wd, 0, o.frozen}, boot, cblock == 0, phase,
                  xb, in_range ? c : d.Nc, s1_new, c1_new, VC_TC, sh_nuw);
   }
   {
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(1024) void vc_tail_kernel(const VcDims d, const VcB
   const long long s = *step_dev;
   VcOpt o;
   o.step_size = boot ? 0.f : b.step_size[0];       // written by K_main together with the counter
-  o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd;
+  o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd; o.frozen = a.frozen;
   if ((int)blockIdx.x < d.nb_post_gene) vc_tail_gene_block<MQ, phase>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, boot, xb);
   else if ((int)blockIdx.x < d.nb_post_gene + d.nb_tail_cell)
     vc_tail_cell_block<phase>(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, boot, xb);
@@ -946,7 +946,8 @@ __device__ __forceinline__ void vc_hist_rederive_block(const VcDims& d, const Vc
   for (int w = 0; w < VC_PG_WAVES; ++w) U_r += sm_a[w][wv];          // wave order, as the gene block's T()
   if (d.kind == VC_KIND_VU) U_r = 0.f;
   const float gg = vc_si_grad(d, 1.0f / si, si, U_r, HDg, d.root_w);
-  const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], a.wd);
+  const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1],
+                                vc_wd_at(a.wd, a.frozen, d.poff[VC_P_SHAPE_INV_ULOCS] + g));
   VC_WSTAMP(1, 6);
   if (have) vc_hist_wave(d, b, P, 0, task, lane, expf(np), (int)(s & 1));
   VC_WSTAMP(1, 7);
@@ -1003,7 +1004,8 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
   for (int w = 0; w < VC_PG_WAVES; ++w) U_r += sm_a[w][lane];          // wave order, as the gene block's T()
   if (d.kind == VC_KIND_VU) U_r = 0.f;
   const float gg = vc_si_grad(d, 1.0f / si, si, U_r, HDg, d.root_w);
-  const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], a.wd);
+  const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1],
+                                vc_wd_at(a.wd, a.frozen, d.poff[VC_P_SHAPE_INV_ULOCS] + (live ? g : 0)));
   VC_WSTAMP(1, 6);
   vc_hist_dense16_finish(d, b, gb, live ? expf(np) : 1.f, (int)(s & 1), hp, sm_hd);
   VC_WSTAMP(1, 7);
@@ -1046,7 +1048,7 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
         // gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
         const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
         float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
-        si = expf(vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], a.wd));
+        si = expf(vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off)));
       }
       vc_hist_dense_block(d, b, xblk, si, half, nthr >> 6, sm_hd);
       return;
@@ -1068,7 +1070,7 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
         const int g = b.h_task[4 * task];
         const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
         float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
-        const float np = vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], a.wd);
+        const float np = vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off));
         vc_hist_wave(d, b, P, 0, task, lane, expf(np), half);
       } else {
         vc_hist_wave(d, b, P, 0, task, lane, -1.f, half);
@@ -1248,7 +1250,7 @@ __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, f
         }
       }
       float mm = nws[VC_NWE + tt], vv = nws[2 * VC_NWE + tt];
-      p = vc_adam_elem(p, gv, mm, vv, step_size, a.b1, a.b2, a.eps, a.clip, b.step_size[1], a.wd);
+      p = vc_adam_elem(p, gv, mm, vv, step_size, a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off));
       if (first) {
         G[off] = gv; a.m[off - a.header] = mm; a.v[off - a.header] = vv; P[off] = p;
         // ... and the snapshot of the NEXT step (the other copy: nobody reads it in this launch), for a step whose K_tail
@@ -1371,7 +1373,7 @@ __global__ __launch_bounds__(1024) void vc_phase_b_kernel(const VcDims d, const 
   if ((int)blockIdx.x < d.nb_post_gene) {
     VcOpt o;
     o.step_size = b.step_size[0];
-    o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd;
+    o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd; o.frozen = a.frozen;
     vc_tail_gene_block<MQ, VC_PH_B>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, xb);
     return;
   }
@@ -1417,7 +1419,7 @@ __global__ __launch_bounds__(1024) void vc_tail_merged_kernel(const VcDims d, co
   if ((int)blockIdx.x < d.nb_post_gene) {
     VcOpt o;
     o.step_size = b.step_size[0];
-    o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd;
+    o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd; o.frozen = a.frozen;
     vc_tail_gene_block<MQ, VC_PH_ALL>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, VcXb{});
     return;
   }
@@ -1458,7 +1460,7 @@ __global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const Vc
   const long long s = *step_dev;
   VcOpt o;
   o.step_size = b.step_size[0];
-  o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd;
+  o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd; o.frozen = a.frozen;
   if ((int)blockIdx.x < d.nb_post_gene) {
     vc_tail_gene_block<MQ, VC_PH_ALL>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, VcXb{});
     return;

@@ -936,7 +936,8 @@ __global__ __launch_bounds__(256) void vc_fin_kernel(const VcDims d, const VcBuf
 __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       long long n, double lr0, double lrd /* log */, double b1, double b2,
-                                                      double b1l, double b2l, float eps, float clip, float wd, int kind, long long t_host,
+                                                      double b1l, double b2l, float eps, float clip, float wd, int kind,
+                                                      const unsigned char* __restrict__ frozen, long long frozen_off, long long t_host,
                                                       const long long* __restrict__ t_dev,
                                                       const float* __restrict__ loss_hdr,
                                                       double* __restrict__ loss_ring, long long loss_slots) {
@@ -956,7 +957,7 @@ __global__ __launch_bounds__(256) void vc_adam_kernel(float* __restrict__ p, con
   const float fb1 = (float)b1, fb2 = (float)b2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float mi = m[i], vi = v[i];
-    const float pn = vc_adam_elem(p[i], g[i], mi, vi, step_size, fb1, fb2, eps, clip, c2, wd);
+    const float pn = vc_adam_elem(p[i], g[i], mi, vi, step_size, fb1, fb2, eps, clip, c2, vc_wd_at(wd, frozen, frozen_off + i));
     m[i] = mi;
     v[i] = vi;
     p[i] = pn;
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const 
                                                           const long long* step_dev, float* __restrict__ m,
                                                           float* __restrict__ v, double lr0, double lrd /* log */,
                                                           double b1, double b2, double b1l, double b2l, float eps, float clip,
-                                                          float wd, int kind, int header, long long total) {
+                                                          float wd, int kind, const unsigned char* __restrict__ frozen, int header, long long total) {
   __shared__ float s_step, s_c2;
   const long long t1 = step_dev ? *step_dev : step_host + 1;        // 1-based optimiser step
   if (threadIdx.x == 0) {
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const 
   auto upd = [&](long long idx) {
     const long long j = idx - header;
     float mi = m[j], vi = v[j];
-    const float pn = vc_adam_elem(P[idx], G[idx], mi, vi, step_size, fb1, fb2, eps, clip, c2, wd);
+    const float pn = vc_adam_elem(P[idx], G[idx], mi, vi, step_size, fb1, fb2, eps, clip, c2, vc_wd_at(wd, frozen, idx));
     m[j] = mi;
     v[j] = vi;
     P[idx] = pn;
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(256) void vc_particle_fin_adam_kernel(const VcDims 
                                                                    long long* step_dev, double* __restrict__ scratch, float* __restrict__ m,
                                                                    float* __restrict__ v, double lr0, double lrd /* log */, double b1,
                                                                    double b2, double b1l, double b2l, float eps, float clip, float wd, int kind,
-                                                                   int header, long long total) {
+                                                                   const unsigned char* __restrict__ frozen, int header, long long total) {
   __shared__ float s_step, s_c2;
   const int K = pg.K;
   const long long t1 = step_host + 1;        // 1-based optimiser step (the host's mirror of the device counter: nothing here reads it)
@@ -1068,7 +1069,7 @@ __global__ __launch_bounds__(256) void vc_particle_fin_adam_kernel(const VcDims 
     const float ga = a * inv;
     pg.g[0][idx] = ga;
     float mi = m[j], vi = v[j];
-    const float pn = vc_adam_elem(P[idx], ga, mi, vi, step_size, fb1, fb2, eps, clip, c2, wd);
+    const float pn = vc_adam_elem(P[idx], ga, mi, vi, step_size, fb1, fb2, eps, clip, c2, vc_wd_at(wd, frozen, idx));
     m[j] = mi;
     v[j] = vi;
     P[idx] = pn;
@@ -1088,7 +1089,7 @@ void vc_launch_particle_fin_adam(const VcDims& d, const VcBufs* bs_dev, const Vc
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(vc_particle_fin_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, d, bs_dev, pg, params, loss_dev, loss_slots, step,
-                     step_dev, scratch, m, v, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1), log(h.b2), h.eps, h.clip, h.wd, h.kind, header, total);
+                     step_dev, scratch, m, v, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1), log(h.b2), h.eps, h.clip, h.wd, h.kind, h.frozen, header, total);
 }
 
 void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* grad, double* loss_dev,
@@ -1098,7 +1099,7 @@ void vc_launch_fin_adam(const VcDims& d, const VcBufs& b, float* params, float* 
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(vc_fin_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, d, b, params, grad, loss_dev, loss_slots,
-                     step, step_dev, m, v, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1), log(h.b2), h.eps, h.clip, h.wd, h.kind, header, total);
+                     step, step_dev, m, v, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1), log(h.b2), h.eps, h.clip, h.wd, h.kind, h.frozen, header, total);
 }
 
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, const VcAdamHyper& h, long long t_host,
@@ -1107,7 +1108,7 @@ void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, c
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(vc_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1),
-                     log(h.b2), h.eps, h.clip, h.wd, h.kind, t_host, t_dev, loss_hdr, loss_ring, loss_slots);
+                     log(h.b2), h.eps, h.clip, h.wd, h.kind, h.frozen, h.frozen_off, t_host, t_dev, loss_hdr, loss_ring, loss_slots);
 }
 
 void vc_launch_post(const VcDims& d, const VcBufs& b, const float* params, float* grad, long long* step_dev,

@@ -439,17 +439,35 @@ class HipEngine:
         if rc != _lib.VC_OK:
             raise HipEngineError("vc_clipped_adam failed")
 
-    def set_optimizer(self, kind: str = "clipped_adam", weight_decay: float = 0.0):
+    def frozen_mask(self):
+        """uint8 device tensor over the flat parameter buffer: 1 = a parameter tensor PyroOptim never steps because its site is
+        conditioned (svi.frozen_param_names) -- what weight decay must leave alone; None when nothing is conditioned."""
+        if getattr(self, "_frozen_mask", None) is None:
+            from .svi import frozen_param_names
+            names = frozen_param_names(self.spec) & set(self.param_slices)
+            if not names:
+                self._frozen_mask = False
+            else:
+                fm = torch.zeros(self.total, dtype=torch.uint8)
+                for n in names:
+                    off, size = self.param_slices[n]
+                    fm[off:off + size] = 1
+                self._frozen_mask = fm.to(self.device)
+        return None if self._frozen_mask is False else self._frozen_mask
+
+    def set_optimizer(self, kind: str = "clipped_adam", weight_decay: float = 0.0, frozen=None):
         """Which optimiser the step entry points of this engine apply (vc_set_optimizer): "clipped_adam" (pyro.optim.ClippedAdam, the
-        default) or "adam" (pyro.optim.Adam = torch.optim.Adam)."""
+        default) or "adam" (pyro.optim.Adam = torch.optim.Adam); `frozen` = frozen_mask() when weight decay is on."""
         k = {"clipped_adam": _lib.VC_OPT_CLIPPED_ADAM, "adam": _lib.VC_OPT_ADAM}[kind]
         if not hasattr(self.lib, "vc_set_optimizer"):
             if k == _lib.VC_OPT_CLIPPED_ADAM and weight_decay == 0.0:
                 return                   # (an older build of the ABI: ClippedAdam without weight decay is all it has)
             raise HipEngineError("this build of the library has no vc_set_optimizer")
-        self._check(self.lib.vc_set_optimizer(self._h, int(k), float(weight_decay)))
+        self._opt_frozen = frozen        # (the engine keeps the pointer)
+        self._check(self.lib.vc_set_optimizer(self._h, int(k), float(weight_decay),
+                                              C.c_void_p(frozen.data_ptr()) if frozen is not None else None))
 
-    def adam_update(self, kind, p, g, m, v, lr, lrd, b1, b2, eps, clip, wd, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
+    def adam_update(self, kind, p, g, m, v, lr, lrd, b1, b2, eps, clip, wd, frozen=None, t=0, t_dev=None, loss_hdr=None, loss_ring=None):
         """The optimiser as one launch on flat float32 buffers (vc_adam_update): kind "clipped_adam" | "adam"."""
         k = {"clipped_adam": _lib.VC_OPT_CLIPPED_ADAM, "adam": _lib.VC_OPT_ADAM}[kind]
         if not hasattr(self.lib, "vc_adam_update"):
@@ -458,7 +476,8 @@ class HipEngine:
             return self.clipped_adam(p, g, m, v, lr, lrd, b1, b2, eps, clip, t=t, t_dev=t_dev, loss_hdr=loss_hdr, loss_ring=loss_ring)
         rc = self.lib.vc_adam_update(int(k), C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                      C.c_void_p(v.data_ptr()), p.numel(), lr, lrd, b1, b2, eps,
-                                     clip if math.isfinite(clip) else 3.0e38, wd, int(t),
+                                     clip if math.isfinite(clip) else 3.0e38, wd,
+                                     C.c_void_p(frozen.data_ptr()) if frozen is not None else None, int(t),
                                      C.c_void_p(t_dev.data_ptr()) if t_dev is not None else None,
                                      C.c_void_p(loss_hdr.data_ptr()) if loss_hdr is not None else None,
                                      C.c_void_p(loss_ring.data_ptr()) if loss_ring is not None else None,

@@ -84,6 +84,39 @@ def optim_args_of(optimizer) -> dict:
     return a
 
 
+def frozen_param_names(spec) -> set:
+    """Names of the guide's parameter TENSORS that have no path to the loss because every sample site they feed is conditioned
+    (`poutine.condition` on the model + `poutine.block(guide, hide=...)`: velocity_inference_model.py:65-66).  Their `.grad` stays
+    None in Pyro, PyroOptim skips them, so weight decay must not move them either (without weight decay they stay put by
+    themselves: zero gradient, zero moments).  Tensor granularity, as autograd sees it: tests/test_pyro_boundary_cpu.py holds this
+    table against the oracle's autograd connectivity on every fixture."""
+    c = set(spec.condition_on)
+    out = set()
+    if "ν" in c:
+        out |= {"ν_locs", "ν_scales"}
+    if "Δν" in c:
+        out.add("Δν_locs")
+    if "ϕxy" in c:
+        out.add("ϕxy_locs")
+    if "shape_inv" in c:
+        out.add("shape_inv_locs")
+    if spec.kind == "velocity":
+        if "logβg" in c:
+            out |= {"logβg_locs", "logβg_scales"}
+        if spec.guide == "lrmn":
+            # X = loc + W eps_W + sqrt(D) eps_D feeds log gamma (X[:Ng]), nu_omega (X[Ng:]) and the conditional mean of log beta
+            if {"logγg", "νω", "logβg"} <= c:
+                out |= {"loc", "cov_factor", "cov_diag"}
+            if {"logβg", "rho_real"} <= c:
+                out.add("rho_real_loc")
+        else:
+            if "logγg" in c:
+                out |= {"logγg_locs", "logγg_scales"}
+            if "νω" in c:
+                out |= {"νω_locs", "νω_scales"}
+    return out
+
+
 class FlatClippedAdam:
     """The optimiser on ONE flat tensor: pyro's ClippedAdam (kind "clipped_adam", the default) or torch's Adam (kind "adam",
     what pyro.optim.Adam wraps), both with optional weight decay (pyro: `grad.add(p, alpha=wd)` behind the clamp; torch: in
@@ -101,6 +134,13 @@ class FlatClippedAdam:
         self.clip = float(a.get("clip_norm", 10.0)) if self.kind == "clipped_adam" else math.inf
         self.lrd = float(a.get("lrd", 1.0)) if self.kind == "clipped_adam" else 1.0
         self.wd = float(a.get("weight_decay", 0.0))
+        # weight decay skips the parameter tensors PyroOptim never steps (frozen_param_names): a float mask over the n updated
+        # floats for the PyTorch-op path, a byte mask over the whole flat buffer for the kernels (engine.frozen_mask)
+        self.decay_mask = None
+        if self.wd != 0.0 and engine is not None and hasattr(engine, "frozen_mask"):
+            fm = engine.frozen_mask()
+            if fm is not None:
+                self.decay_mask = (1 - fm[engine.header:].to(torch.float32)).to(device)
         self.m = torch.zeros(n, dtype=torch.float32, device=device)
         self.v = torch.zeros(n, dtype=torch.float32, device=device)
         self.t = 0
@@ -118,13 +158,15 @@ class FlatClippedAdam:
                                f"(impl={self.impl!r}, capturable={self.capturable})")
         if self.impl == "hip":
             self.t += 1
+            fm = self.engine.frozen_mask() if self.wd != 0.0 else None
             self.engine.adam_update(self.kind, p, g, self.m, self.v, self.lr0, self.lrd, self.b1, self.b2, self.eps,
-                                    self.clip, self.wd, t=self.t, t_dev=t_dev, loss_hdr=loss_hdr, loss_ring=loss_ring)
+                                    self.clip, self.wd, frozen=None if fm is None else fm[self.engine.header:],
+                                    t=self.t, t_dev=t_dev, loss_hdr=loss_hdr, loss_ring=loss_ring)
             return
         if self.kind == "clipped_adam":
             g = g.clamp(-self.clip, self.clip)
         if self.wd != 0.0:
-            g = g.add(p, alpha=self.wd)
+            g = g.add(p if self.decay_mask is None else torch.nan_to_num(p, neginf=0.0) * self.decay_mask, alpha=self.wd)
         self.m.lerp_(g, 1.0 - self.b1)
         self.v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
         if self.kind == "adam":
@@ -300,7 +342,7 @@ class SVIRunner:
                                    capturable=self.use_graph,
                                    impl=("hip" if self.adam_impl in ("fused", "fused3", "sharded") else self.adam_impl), engine=engine)
         if hasattr(engine, "set_optimizer"):             # what the engine's own step entry points apply (the engine outlives its runners)
-            engine.set_optimizer(self.opt.kind, self.opt.wd)
+            engine.set_optimizer(self.opt.kind, self.opt.wd, engine.frozen_mask() if self.opt.wd != 0.0 else None)
         if self.opt.kind == "adam" and self.use_graph and self.opt.impl == "torch":
             raise ValueError("pyro.optim.Adam with hipGraph replay of the PyTorch-op optimiser is not supported (use the default launches)")
         self._primed = False          # fused3: the tables of the current step have been sampled from the current params
