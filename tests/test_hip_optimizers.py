@@ -14,15 +14,15 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("kind,wd", [("adam", 0.0), ("adam", 0.03), ("clipped_adam", 0.03), ("clipped_adam", 0.0)])
 def test_adam_update_kernel_equals_torch(kind, wd):
-    """(frozen tensors: the second half of the buffer is marked frozen when weight decay is on -- it must not move.)
-    vc_adam_update on flat buffers, 40 steps with a device step counter, against torch.optim.Adam itself (kind "adam") and
-    against the oracle's restatement of pyro's clipped_adam.py (kind "clipped_adam", weight decay behind the clamp)."""
+    """vc_adam_update on flat buffers, 40 steps with a device step counter, against torch.optim.Adam itself (kind "adam") and
+    against the oracle's restatement of pyro's clipped_adam.py (kind "clipped_adam", weight decay behind the clamp).  The second
+    half of the buffer is a FROZEN tensor (a parameter without a path to the loss: its gradient is zero, PyroOptim never steps
+    it): with weight decay on it must not move either."""
     from velocycle_amd.engine import HipEngine
-    from velocycle_amd.svi import FlatClippedAdam
     z = H.load_fixture(f"{H.GOLDEN}/ref_step_phase_nb.npz")
     eng = HipEngine(H.spec_from_fixture(z))
     g = torch.Generator().manual_seed(2)
-    n = 1000
+    n, half = 1000, 500
     p0 = torch.randn(n, generator=g, dtype=torch.float64)
     args = {"lr": 0.02, "betas": (0.85, 0.98), "eps": 1e-7, "weight_decay": wd}
     if kind == "clipped_adam":
@@ -30,25 +30,31 @@ def test_adam_update_kernel_equals_torch(kind, wd):
         ref = orc.ClippedAdam(dict(args))
     else:
         ref = orc.Adam(dict(args))
-        tp = torch.nn.Parameter(p0.clone())
+        tp = torch.nn.Parameter(p0[:half].clone())
         topt = torch.optim.Adam([tp], **args)
-    par = {"p": p0.clone()}
+    par = {"live": p0[:half].clone(), "frozen": p0[half:].clone()}
     dev = eng.device
     p = p0.float().to(dev)
-    opt = FlatClippedAdam(n, dict(args, _kind=kind), dev, impl="hip", engine=eng)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    frozen = torch.zeros(n, dtype=torch.uint8, device=dev)
+    frozen[half:] = 1
     t_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     for t in range(40):
-        gr = torch.randn(n, generator=g, dtype=torch.float64) * (1 + 0.1 * t) + 0.2
-        par = ref.step(par, {"p": gr})
+        gr = torch.randn(half, generator=g, dtype=torch.float64) * (1 + 0.1 * t) + 0.2
+        par = ref.step(par, {"live": gr, "frozen": torch.zeros(n - half, dtype=torch.float64).as_subclass(orc._NoPath)})
         if kind == "adam":
             tp.grad = gr.clone()
             topt.step()
         t_dev += 1
-        opt.step(p, gr.float().to(dev), t_dev=t_dev)
+        gfull = torch.cat([gr, torch.zeros(n - half, dtype=torch.float64)]).float().to(dev)
+        eng.adam_update(kind, p, gfull, m, v, args["lr"], args.get("lrd", 1.0), 0.85, 0.98, 1e-7, args.get("clip_norm", float("inf")), wd,
+                        frozen=frozen, t=t + 1, t_dev=t_dev)
     torch.cuda.synchronize()
-    assert torch.allclose(p.double().cpu(), par["p"], rtol=3e-5, atol=3e-6), (p.double().cpu() - par["p"]).abs().max()
+    want = torch.cat([par["live"], par["frozen"]])
+    assert torch.allclose(p.double().cpu(), want, rtol=3e-5, atol=3e-6), (p.double().cpu() - want).abs().max()
+    assert torch.equal(p[half:].cpu(), p0[half:].float())                    # the frozen half has not moved at all
     if kind == "adam":
-        assert torch.allclose(par["p"], tp.data, rtol=1e-12, atol=1e-13)
+        assert torch.allclose(par["live"], tp.data, rtol=1e-12, atol=1e-13)
     eng.close()
 
 
