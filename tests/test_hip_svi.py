@@ -42,8 +42,12 @@ def test_fit_trajectory_matches_reference(case):
 def test_medium_two_batch_fit_matches_the_references_own_fit(dense):
     """2 x 700 cells x 300 genes, H = 2, two batches with learned offsets, LRMN guide: 12 steps of the reference's own
     VelocityFitModel.fit (ref_fitmed_*.npz; velocity_inference_model.py:111-187) against the engine in parity mode on the same eps
-    stream -- through the one-hot fold of the batch design (NB = 0 kernel, the default) and through the dense contraction."""
-    from tests.test_oracle_golden import _medium_fit_bars
+    stream -- through the one-hot fold of the batch design (NB = 0 kernel, the default) and through the dense contraction.
+    The flow is chaotic at this random initialisation (lr 0.03 on genes that sit on the relu kink of ElogU: the losses go
+    1.854e6, 1.872e6, 1.804e6, 1.980e6, ...; the float32 oracle leaves the reference's float32 run by 1e-3 within 12 steps), so what
+    is pinned is (i) the first two steps against the REFERENCE's losses -- two whole SVI steps with batches through its fit() --,
+    (ii) EVERY step's loss against the float64 oracle evaluated at the run's own parameters and draws (teacher forcing: 1e-5), and
+    (iii) the free-running losses within the measured growth of the separation of two float32 runs."""
     from velocycle_amd.svi import SVIRunner
     from velocycle_amd.tuning import Tuning
     z = H.load_fixture(f"{H.GOLDEN}/ref_fitmed_vel_lrmn_joint_dnu2_med.npz")
@@ -51,9 +55,25 @@ def test_medium_two_batch_fit_matches_the_references_own_fit(dense):
     eng = _mk(spec, tuning=Tuning(dense_batches=dense))
     assert eng.stats["onehot_batches"] == (0 if dense else 2) and eng.stats["main_kernel"].startswith("vc_main_kernel<2,%d," % (2 if dense else 0))
     opt = {"lr": float(z["opt_lr"]), "lrd": float(z["opt_lrd"]), "betas": tuple(float(x) for x in z["opt_betas"])}
-    run = SVIRunner(eng, opt, mode="parity", seed=int(z["seed"]))
-    losses = [run.step() for _ in range(int(z["num_steps"]))]
-    _medium_fit_bars(losses, z)
+    n, seed = int(z["num_steps"]), int(z["seed"])
+    run = SVIRunner(eng, opt, mode="parity", seed=seed)
+    losses, snaps = [], {}
+    for t in range(n):
+        snaps[t] = {k: v.detach().cpu().clone() for k, v in eng.named().items()}
+        losses.append(run.step())
+    rel = np.abs(np.array(losses) / z["ref_losses"] - 1)
+    assert rel[:2].max() <= 1e-6, rel[:3]
+    envelope = np.array([1e-6, 1e-6, 5e-5, 5e-4, 5e-3, 5e-3, 5e-3, 1e-2, 1e-2, 2e-2, 2e-2, 3e-2])
+    assert (rel <= envelope).all(), (rel, envelope)
+    # teacher forcing: the loss of step t at the run's own parameters, same host eps stream, float64 oracle
+    from velocycle_amd.rng import draw_eps
+    p64 = H.problem_from_spec(spec, torch.float64)
+    g = torch.Generator().manual_seed(seed)
+    draw_eps(spec, g)                                   # the fresh ELBO object's extra guide pass
+    for t in range(n):
+        e = draw_eps(spec, g)
+        l_tf, _, _, _ = orc.loss_and_grads(p64, {k: v.double() for k, v in snaps[t].items()}, {k: v.double() for k, v in e.items() if not k.startswith("_")})
+        assert abs(losses[t] - l_tf) <= 1e-5 * abs(l_tf), (t, losses[t], l_tf)
     eng.close()
 
 
