@@ -85,6 +85,13 @@ def test_every_step_structure_applies_the_chosen_optimiser(case, args):
     n = 20
     runs = {impl: _run(spec, args, impl, n) for impl in ("fused3", "hip", "fused")}
     assert runs["hip"]["kind"] == args["_kind"]
+    if spec.guide == "lrmn" and args.get("weight_decay"):
+        # Pyro's own answer: `cov_factor` is initialised to clip(N(0, 0.02), min=0) (velocity_inference_guide.py:91-92), its zeros are
+        # -inf in the unconstrained space PyroOptim steps in, and `grad.add(p, alpha=weight_decay)` makes them NaN -- the reference
+        # cannot run weight decay on the LRMN guide, and neither does the engine pretend to: every structure latches the NaN
+        for impl, r in runs.items():
+            assert not r["status"][0] and r["status"][1] >= 0, (impl, r["status"])
+        return
     for impl, r in runs.items():          # the HIP structures against each other: float32 rounding of re-associated sums
         assert r["status"] == (True, -1, 0) and len(r["l"]) == n
         base = runs["hip"]
@@ -110,7 +117,7 @@ def test_every_step_structure_applies_the_chosen_optimiser(case, args):
                          params={k: v.float().clone() for k, v in got["par0"].items()}, opt=mk(dict(oargs)))
     l64, l32 = np.array(l64), np.array(l32)
     rel, rel32 = np.abs(got["l"] - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
-    assert rel[:5].max() <= 1e-5 and (rel <= np.maximum(1e-5, 4 * np.maximum.accumulate(rel32))).all(), (rel.max(), rel32.max())
+    assert rel[:5].max() <= 1e-5 and (rel <= np.maximum(1e-5, 4 * np.maximum.accumulate(rel32))).all(), (rel, rel32)
     H.assert_params_track_oracle(got["named"], {k: v.numpy() for k, v in par64.items()}, {k: v.double().numpy() for k, v in par32.items()})
     # ... and it is NOT what the other optimiser would have done (the contract used to run Adam objects as ClippedAdam)
     other = dict(args, _kind="clipped_adam" if args["_kind"] == "adam" else "adam")
