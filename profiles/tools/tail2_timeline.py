@@ -77,3 +77,15 @@ for k, tag in ((6, "histogram waves: update re-derived"), (7, "histogram waves: 
         print(f"   {tag:34s} stamp{k}: min {v.min():6.2f} med {np.median(v):6.2f} max {v.max():6.2f}  (n={len(v)})")
         end = max(end, v.max())
 print(f"   last stamp of the launch at {end:.2f} us")
+# the slowest histogram blocks, one line each: block index, when its update was re-derived / when it was done (max over its waves)
+sel = s1[:, :, 7] > 0
+if sel.any():
+    done = np.where(sel, (s1[:, :, 7] - z) / 100.0, -1e9).max(1)
+    red = np.where(s1[:, :, 6] > 0, (s1[:, :, 6] - z) / 100.0, -1e9).max(1)
+    first = np.where(s1[:, :, 6] > 0, (s1[:, :, 6] - z) / 100.0, 1e9).min(1)
+    order = np.argsort(-done)[:6]
+    print("   slowest histogram blocks (block: first wave re-derived / last wave re-derived / done): " +
+          "; ".join(f"{int(i)}: {first[i]:.2f} / {red[i]:.2f} / {done[i]:.2f}" for i in order))
+    blk = np.where(sel.any(1))[0]
+    print(f"   histogram blocks {blk.min()}..{blk.max()}: done by block index (every 8th): " +
+          " ".join(f"{done[i]:.1f}" for i in blk[::8]))

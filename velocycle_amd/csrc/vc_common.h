@@ -533,20 +533,27 @@ __device__ __forceinline__ void vc_hist_dense_block(const VcDims& d, const VcBuf
 // requests its first 16 count levels of every matrix (nothing is consumed), `finish` -- once shape_inv of the lane's gene
 // is known -- adds them up (+ further levels of a block whose largest count exceeds 256), one barrier, and waves 0 / 1 add
 // the slices of matrix S / U in slice order.  Same sums as vc_hist_dense_block, bit for bit.
+// msel >= 0: this block evaluates matrix msel only (the one-launch tail gives every (gene block, matrix) a block of its own: the
+// evaluation is 16 waves of log / rcp / double arithmetic on ONE CU -- 5 us for two matrices -- beside idle CUs)
 struct VcHistPre { float c[2][16]; int rows[2], off[2]; };
-__device__ __forceinline__ void vc_hist_dense16_rows(const VcDims& d, const VcBufs& b, int gb, VcHistPre& h) {
+__device__ __forceinline__ void vc_hist_dense16_rows(const VcDims& d, const VcBufs& b, int gb, VcHistPre& h, int msel = -1) {
   const int nblk = d.Ng_pad / 64, nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
-    const bool used = m < nm && ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U));
+    const bool used = m < nm && (msel < 0 || m == msel) && ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U));
     h.rows[m] = used ? b.hc_rows[m * nblk + gb] : 0;
     h.off[m] = used ? b.hc_off[m * nblk + gb] : 0;
   }
 }
-__device__ __forceinline__ void vc_hist_dense16_issue(const VcDims& d, const VcBufs& b, VcHistPre& h) {
+__device__ __forceinline__ void vc_hist_dense16_issue(const VcDims& d, const VcBufs& b, VcHistPre& h, int msel = -1) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
+    if (msel >= 0 && m != msel) {           // (uniform per block)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) h.c[m][u] = 0.f;
+      continue;
+    }
     const float* __restrict__ tabp = b.HC + (size_t)h.off[m] * 64 + lane;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {        // (no branch around a load: a clamped row, the value dropped afterwards)
@@ -557,7 +564,7 @@ __device__ __forceinline__ void vc_hist_dense16_issue(const VcDims& d, const VcB
   }
 }
 __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const VcBufs& b, int gb, float si, int half, const VcHistPre& h,
-                                                       double* sm /* 4096 doubles */) {
+                                                       double* sm /* 4096 doubles */, int msel = -1) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
   const int g = gb * 64 + lane;
@@ -565,7 +572,7 @@ __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const Vc
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     double al = 0.0, ad = 0.0;
-    if (m < nm) {
+    if (m < nm && (msel < 0 || m == msel)) {
       const float* __restrict__ tabp = b.HC + (size_t)h.off[m] * 64 + lane;
       constexpr int UB = 8;            // (the association of vc_hist_dense_block: levels in increasing order, one by one)
 #pragma unroll
@@ -590,7 +597,7 @@ __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const Vc
     sm[((m * 16 + wv) * 2 + 1) * 64 + lane] = ad;
   }
   __syncthreads();
-  if (wv < nm && g < d.Ng) {
+  if (wv < nm && (msel < 0 || wv == msel) && g < d.Ng) {
     const int m = wv;
     double hl = 0.0, hd = 0.0;
 #pragma unroll

@@ -126,22 +126,22 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   const bool samp = phase != VC_PH_A;                 // ... the next sample
 
   VC_WSTAMP(0, 0);
-  // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k fetches, readlane
-  // broadcasts while every lane is active
-  float ew_old[VC_MAX_RANK], ew_new[VC_MAX_RANK];
-  {
-    float mine_old = 0.f, mine_new = 0.f;
-    if (r_cov && lane < d.R) {
-      if (chain) mine_old = eps_old[d.eoff[VC_E_LRMN_W] + lane];
-      if (samp) mine_new = draw_new(d.eoff[VC_E_LRMN_W] + lane);
-    }
+  // ---- second-stage reduction, REQUEST: the first U chunk groups of K_main's gene-level partial rows depend on nothing else in
+  // this block, so they are asked for before anything is consumed -- the LRMN roles' eps_W fetch and the shape_inv role's histogram
+  // sums below are dependent round trips of their own, and those waves used to START the reduction when the others had finished
+  // it (round 5, profiles/r05_tail2_timeline_*.txt: waves 12..15 reached the barrier 2.5 us after wave 0).  Added up further
+  // down in the same chunk order: the same bits.
+  constexpr int U = MQ <= 2 ? 16 : (MQ <= 4 ? 12 : (MQ <= 6 ? 8 : 2));     // chunk groups in flight per wave (register budget: 128)
+  float v0[U][MQ];
+  if (chain) {
 #pragma unroll
-    for (int k = 0; k < VC_MAX_RANK; ++k) {
-      ew_old[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_old), k));
-      ew_new[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_new), k));
+    for (int u = 0; u < U; ++u) {
+      const int ch = wave + u * VC_PG_WAVES;
+      const float* go = b.GO + ((size_t)(ch < d.n_chunks ? ch : 0) * d.nq) * NP + g;
+#pragma unroll
+      for (int q = 0; q < MQ; ++q) v0[u][q] = (q < d.nq) ? go[(size_t)q * NP] : 0.f;
     }
   }
-
   // ---- owned parameters of this (gene, role) and everything else that does not depend on K_main's partials --------
   int off[VC_MAXOWN];
   float pp[VC_MAXOWN], pm[VC_MAXOWN], pv[VC_MAXOWN], gg[VC_MAXOWN];
@@ -153,6 +153,10 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 #pragma unroll
   for (int i = 0; i < NIN; ++i) in[i] = 0.f;
   double HLg = 0.0, HDg = 0.0;
+  double hl4[4] = {0.0, 0.0, 0.0, 0.0}, hd4[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* __restrict__ HLs = b.HL;
+  const double* __restrict__ HDs = b.HD;
+  int ht0 = 0, ht1 = 0;
   float e0 = 0.f, e1 = 0.f;        // the Philox draws of step s this role needs
   long long jj = 0;                // flat index of the role's site element
   if (live) {
@@ -172,24 +176,16 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       if (chain) {
         in[0] = b.GT[(size_t)(KT + 2) * NP + g];
         if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
-        {
-          // the gene's histogram terms (usually 2..4 tasks): four requested per trip instead of one (a dependent round trip
-          // each on this role's way to the barrier), the sums formed in task order as before.  They belong to the sample of
-          // the step being finished: half (s - 1) & 1 when shape_inv is learned (the histogram blocks of THIS launch write
-          // the other half)
-          const double* __restrict__ HLs = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
-          const double* __restrict__ HDs = b.HD + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
-          // (dense tables: one task per matrix and gene, no table of first tasks to wait for)
-          const int nmat = vel ? 2 : 1;
-          const int t0 = d.hist_dense ? nmat * g : b.h_tptr[g], t1 = d.hist_dense ? nmat * (g + 1) : b.h_tptr[g + 1];
-          for (int tb = t0; tb < t1; tb += 4) {
-            double hl[4], hd[4];
+        // the gene's histogram terms (usually 2..4 tasks; dense tables: one per matrix, no table of first tasks to wait for).  They
+        // belong to the sample of the step being finished: half (s - 1) & 1 when shape_inv is learned (the histogram blocks of THIS
+        // launch write the other half).  The first four are only REQUESTED here and added behind the last request of the block
+        HLs = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
+        HDs = b.HD + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
+        const int nmat = vel ? 2 : 1;
+        ht0 = d.hist_dense ? nmat * g : b.h_tptr[g]; ht1 = d.hist_dense ? nmat * (g + 1) : b.h_tptr[g + 1];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int t = tb + k < t1 ? tb + k : tb; hl[k] = HLs[t]; hd[k] = HDs[t]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (tb + k < t1) { HLg += hl[k]; HDg += hd[k]; }
-          }
-        }
+        for (int k = 0; k < 4; ++k)
+          if (ht0 < ht1) { const int t = ht0 + k < ht1 ? ht0 + k : ht0; hl4[k] = HLs[t]; hd4[k] = HDs[t]; }
       }
     } else if (r_mf || r_core || r_cov) {
       in[2] = b.sd_g[g]; in[3] = b.mu_g[g]; in[5] = b.sd_b[g]; in[6] = b.mu_b[g];
@@ -242,15 +238,50 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     }
   }
 
+  // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k fetches, readlane
+  // broadcasts while every lane is active.  (Behind the requests above, not in front of them: the broadcast consumes the fetch,
+  // and loads return in order -- in front, it cost the cov roles a round trip of their own before they had asked for anything else)
+  float ew_old[VC_MAX_RANK], ew_new[VC_MAX_RANK];
+  {
+    float mine_old = 0.f, mine_new = 0.f;
+    if (r_cov && lane < d.R) {
+      if (chain) mine_old = eps_old[d.eoff[VC_E_LRMN_W] + lane];
+      if (samp) mine_new = draw_new(d.eoff[VC_E_LRMN_W] + lane);
+    }
+#pragma unroll
+    for (int k = 0; k < VC_MAX_RANK; ++k) {
+      ew_old[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_old), k));
+      ew_new[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_new), k));
+    }
+  }
+
+  // ---- the shape_inv role's histogram sums, in task order (four requested per trip: a plain load-and-add loop is a dependent
+  // round trip per task)
+  if (live && r_si && chain) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (ht0 + k < ht1) { HLg += hl4[k]; HDg += hd4[k]; }
+    for (int tb = ht0 + 4; tb < ht1; tb += 4) {
+      double hl[4], hd[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int t = tb + k < ht1 ? tb + k : tb; hl[k] = HLs[t]; hd[k] = HDs[t]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (tb + k < ht1) { HLg += hl[k]; HDg += hd[k]; }
+    }
+  }
   VC_WSTAMP(0, 1);
   double loss_post = 0.0;
   if (chain) {
     // ---- second-stage reduction of K_main's gene-level partials (as K_post) ------------------------------------
-    constexpr int U = MQ <= 2 ? 16 : (MQ <= 6 ? 8 : 2);     // chunk groups in flight per wave (register budget: 128)
     float acc[MQ];
 #pragma unroll
     for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
-    for (int ch0 = wave; ch0 < d.n_chunks; ch0 += U * VC_PG_WAVES) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)                      // the rows requested at the top of the block
+      if (wave + u * VC_PG_WAVES < d.n_chunks) {
+#pragma unroll
+        for (int q = 0; q < MQ; ++q) acc[q] += v0[u][q];
+      }
+    for (int ch0 = wave + U * VC_PG_WAVES; ch0 < d.n_chunks; ch0 += U * VC_PG_WAVES) {
       float v[U][MQ];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -564,6 +595,9 @@ __device__ __forceinline__ void vc_nuw_sums_finish(const VcDims& d, const VcBufs
 __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
                                              long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
                                              const VcXb& xb, int c, float s1, float c1, int nthr, VcNuwShared& sh);
+__device__ __forceinline__ void vc_nuw_wave(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                            long long s, uint64_t seed, const VcAdamArgs& a, bool first, VcNuwShared& sh);
+__device__ __forceinline__ void vc_nuw_cells(const VcDims& d, const VcBufs& b, int c, float s1, float c1, const VcNuwShared& sh);
 // OMEGA: the nu_omega chain of K_omega runs INSIDE this block (every cell block redundantly, block 0 stores), on K_main's own
 // partials (pw_inline) -- the cell record of step s leaves this block complete, omega_c included (vc_tail2_kernel)
 template <int phase, bool OMEGA = false>
@@ -574,16 +608,27 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   __shared__ float sm_w[VC_TC_MAX / 64][VC_MAX_NW];
   __shared__ double sm_lc[VC_TC_MAX / 64];
   const int VC_TC = d.tail_tc;
-  if ((int)threadIdx.x >= VC_TC) return;   // 256-cell blocks: waves 4..15 of the block have nothing to do
+  const bool vel = d.model == VC_MODEL_VELOCITY;
+  // OMEGA, blocks with a wave to spare (<= 960 cells): the nu_omega chain -- sums of K_main's partials, gradient, optimiser, next
+  // sample -- depends on nothing the cell waves do, so ONE extra wave (the "chain wave", right behind the cell waves) runs it
+  // BESIDE them; the cell waves meet it at one barrier and only add omega_c to their records (round 5: the chain used to start
+  // when the cell part was done, 4 us of barriers and dependent exp / sqrt / divide at the end of the launch's longest block)
+  const bool cwm = OMEGA && vel && !boot && d.pw_inline && VC_TC <= VC_TC_MAX - 64;
+  if ((int)threadIdx.x >= VC_TC + (cwm ? 64 : 0)) return;   // 256-cell blocks: the other waves of the block have nothing to do
   VC_WSTAMP(0, 0);
   __shared__ VcNuwShared sh_nuw;
-  // OMEGA: the sums of K_main's partials of d loglik / d nu_omega depend on nothing in this block -- requested first, so that their
-  // round trip runs beside the cell part's
+  if (cwm && (int)threadIdx.x >= VC_TC) {
+    vc_nuw_wave(d, b, P, G, s, seed, VcAdamArgs{Mm, Vv, 0.0, 0.0, 0.0, 0.0, o.b1, o.b2, o.eps, o.clip, header, o.wd, 0, o.frozen}, cblock == 0, sh_nuw);
+    __syncthreads();          // sh_nuw.nuw is complete: the cell waves take it from here
+    __syncthreads();          // (the block's last barrier, below)
+    return;
+  }
+  // OMEGA without a chain wave: the sums of K_main's partials of d loglik / d nu_omega depend on nothing in this block -- requested
+  // first, so that their round trip runs beside the cell part's
   VcNuwRaw nuw_raw;
-  if (OMEGA && d.model == VC_MODEL_VELOCITY) vc_nuw_sums_issue(d, b, boot, phase, xb, VC_TC, nuw_raw);
+  if (OMEGA && vel && !cwm) vc_nuw_sums_issue(d, b, boot, phase, xb, VC_TC, nuw_raw);
   const int c = cblock * VC_TC + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool vel = d.model == VC_MODEL_VELOCITY;
   const bool in_range = c < d.Nc;
   const bool cxy = CND(VC_SITE_PHIXY);
   float A[3] = {0.f, 0.f, 0.f};
@@ -666,7 +711,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
     }
   }
   VC_WSTAMP(0, 3);
-  if (OMEGA && vel) vc_nuw_sums_finish(d, b, boot, phase, xb, VC_TC, nuw_raw, sh_nuw);      // (their rows arrived with the cell's own loads)
+  if (OMEGA && vel && !cwm) vc_nuw_sums_finish(d, b, boot, phase, xb, VC_TC, nuw_raw, sh_nuw);      // (their rows arrived with the cell's own loads)
   // (single rank with K_main's own partials: nobody reads the cell blocks' -- K_omega / the chain below take PWM)
   if (vel && !boot && !(phase == VC_PH_ALL && d.pw_inline)) {
     // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c) at the phases of step s - 1
@@ -760,8 +805,12 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   VC_WSTAMP(0, 5);
   if (OMEGA && vel) {
     // the nu_omega chain (gradient from K_main's partials, optimiser, next sample) and omega_c of this block's cells
-    vc_nuw_chain(d, b, P, G, s, seed, VcAdamArgs{Mm, Vv, 0.0, 0.0, 0.0, 0.0, o.b1, o.b2, o.eps, o.clip, header, o.wd, 0, o.frozen}, boot, cblock == 0, phase,
-                 xb, in_range ? c : d.Nc, s1_new, c1_new, VC_TC, sh_nuw);
+    if (cwm) {
+      __syncthreads();        // the chain wave has left nu_omega of step s in sh_nuw
+      vc_nuw_cells(d, b, in_range ? c : d.Nc, s1_new, c1_new, sh_nuw);
+    } else
+      vc_nuw_chain(d, b, P, G, s, seed, VcAdamArgs{Mm, Vv, 0.0, 0.0, 0.0, 0.0, o.b1, o.b2, o.eps, o.clip, header, o.wd, 0, o.frozen}, boot, cblock == 0, phase,
+                   xb, in_range ? c : d.Nc, s1_new, c1_new, VC_TC, sh_nuw);
   }
   {
     const double ws = vc_wave_sum_d63(loss);
@@ -831,6 +880,7 @@ void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad
     else hipLaunchKernelGGL((vc_tail_kernel<MQ_, VC_PH_ALL>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot, xb); \
   } while (0)
   if (d.nq <= 2) VC_TAIL_LAUNCH(2);
+  else if (d.nq <= 4) VC_TAIL_LAUNCH(4);
   else if (d.nq <= 6) VC_TAIL_LAUNCH(6);
   else VC_TAIL_LAUNCH(VC_MAXQ);
 #undef VC_TAIL_LAUNCH
@@ -957,7 +1007,7 @@ __device__ __forceinline__ void vc_hist_rederive_block(const VcDims& d, const Vc
 // K_main's shape_inv row exactly as wave v of the gene block does (coalesced rows), the 16 wave sums meet in the LDS, every wave
 // then holds shape_inv(s) of the block's 64 genes and takes its slices of the count axis (vc_hist_dense_block).
 __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const VcBufs& b, long long s, const VcAdamArgs& a, int gb,
-                                                       double* sm_hd) {
+                                                       double* sm_hd, int msel) {
   __shared__ float sm_a[VC_PG_WAVES][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t NP = d.Ng_pad;
@@ -965,7 +1015,7 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
   const int g = gb * 64 + lane;
   const bool live = g < d.Ng;
   VcHistPre hp;
-  vc_hist_dense16_rows(d, b, gb, hp);          // (arrives with the loads below)
+  vc_hist_dense16_rows(d, b, gb, hp, msel);    // (arrives with the loads below)
   float acc = 0.f;
   if (d.kind != VC_KIND_VU) {
     constexpr int UB = 8;
@@ -981,7 +1031,7 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
         if (ch0 + u * VC_PG_WAVES < d.n_chunks) acc += v[u];
     }
   }
-  vc_hist_dense16_issue(d, b, hp);             // the table rows travel while the update is re-derived
+  vc_hist_dense16_issue(d, b, hp, msel);       // the table rows travel while the update is re-derived
   const float* sis = b.SIS + (size_t)((s - 1) & 1) * 4 * NP + g;
   const float p0 = sis[0], si = live ? sis[3 * NP] : 1.f;
   float mm = sis[NP], vv = sis[2 * NP];
@@ -1007,7 +1057,7 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
   const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1],
                                 vc_wd_at(a.wd, a.frozen, d.poff[VC_P_SHAPE_INV_ULOCS] + (live ? g : 0)));
   VC_WSTAMP(1, 6);
-  vc_hist_dense16_finish(d, b, gb, live ? expf(np) : 1.f, (int)(s & 1), hp, sm_hd);
+  vc_hist_dense16_finish(d, b, gb, live ? expf(np) : 1.f, (int)(s & 1), hp, sm_hd, msel);
   VC_WSTAMP(1, 7);
 }
 
@@ -1034,11 +1084,14 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
     if (d.hist_dense) {                            // dense tables: one block per gene block (barriers inside)
       double* sm_hd = vc_hist_lds();
       if (TAIL2) {                                 // (compiled into the one-launch tail only: 16-wave blocks, update re-derived)
-        if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense(d, b, s, a, xblk, sm_hd); return; }
+        // one block per (matrix, gene block): vc_launch_tail2 asks for nm x Ng_pad / 64 of them
+        const int nblk = d.Ng_pad / 64, nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
+        const int msel = nm > 1 ? xblk / nblk : -1, gb = nm > 1 ? xblk % nblk : xblk;
+        if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense(d, b, s, a, gb, sm_hd, msel); return; }
         VcHistPre hp;
-        vc_hist_dense16_rows(d, b, xblk, hp);
-        vc_hist_dense16_issue(d, b, hp);
-        vc_hist_dense16_finish(d, b, xblk, vc_hist_si(d, b, P, 0, xblk * 64 + lane), half, hp, sm_hd);
+        vc_hist_dense16_rows(d, b, gb, hp, msel);
+        vc_hist_dense16_issue(d, b, hp, msel);
+        vc_hist_dense16_finish(d, b, gb, vc_hist_si(d, b, P, 0, gb * 64 + lane), half, hp, sm_hd, msel);
         return;
       }
       const int g = xblk * 64 + lane;
@@ -1198,11 +1251,22 @@ __device__ __forceinline__ void vc_nuw_sums_direct(const VcDims& d, const VcBufs
   }
 }
 
-// part 2 (sh.up filled by every wave that took part in part 1; the barrier below orders it)
-__device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
-                                             long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
-                                             const VcXb& xb, int c, float s1, float c1, int nthr, VcNuwShared& sh) {
-  const int t = threadIdx.x;
+// part 2 (sh.up filled by every wave that took part in part 1; the barrier below orders it): gradient, optimiser and next sample
+// of the nu_omega-related parameters.  WAVE: ONE wave runs it (the chain wave of vc_tail_cell_block: its 64 lanes stride the
+// elements, the block barriers become wavefront-scope fences) -- the same statements per element, the same bits
+template <bool WAVE>
+__device__ __forceinline__ void vc_nuw_params(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                              long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
+                                              int nthr_, VcNuwShared& sh) {
+  const int t = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int nthr = WAVE ? 64 : nthr_;
+  auto sync = [&]() {
+    if (WAVE) {           // LDS operations of one wave complete in order; the fence keeps the compiler from moving them
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else __syncthreads();
+  };
   const bool lrmn = d.guide == VC_GUIDE_LRMN;
   const float rw = phase == VC_PH_B ? 1.f : d.root_w;
   const int nw = d.NW;
@@ -1219,7 +1283,7 @@ __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, f
   const float* __restrict__ eps_old = b.EPS + (size_t)((s + 2) % 3) * d.eps_total;
   const float* __restrict__ nws = b.NWS + (size_t)(s & 1) * 4 * VC_NWE;        // the nu_omega snapshot of this step ...
   float* __restrict__ nws_next = b.NWS + (size_t)((s + 1) & 1) * 4 * VC_NWE;   // ... and the copy block 0 fills for the next
-  __syncthreads();
+  sync();
   VC_WSTAMP(1, 2);
   // ---- gradient + ClippedAdam of the nu_omega-related parameters: one thread per element, every block alike ----------
   const float step_size = boot ? 0.f : b.step_size[0];
@@ -1262,7 +1326,7 @@ __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, f
     }
     sh.np[tt] = p;
   }
-  __syncthreads();
+  sync();
   VC_WSTAMP(1, 3);
   // ---- the nu_omega sample of step s ------------------------------------------------------------------------------
   if (t < VC_MAX_NW) sh.lq[t] = 0.0;
@@ -1293,14 +1357,18 @@ __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, f
     }
     sh.nuw[j] = x;
   }
-  __syncthreads();
+  sync();
   VC_WSTAMP(1, 4);
   if (first && t == 0) {
     double tot = 0.0;
     for (int j = 0; j < nw; ++j) tot += sh.lq[j];
     b.LPF[(size_t)(s & 1) * d.nlpf + d.nlpf - 1] = tot;
   }
-  // ---- omega_c and d omega / d phi of step s into the cell records ---------------------------------------------------
+}
+
+// part 3 (sh.nuw complete and visible to the caller's threads): omega_c and d omega / d phi of step s into the record of cell c
+// (sin, cos of its phase of step s: s1, c1)
+__device__ __forceinline__ void vc_nuw_cells(const VcDims& d, const VcBufs& b, int c, float s1, float c1, const VcNuwShared& sh) {
   if (c < d.Nc) {
     // harmonics by the angle-addition recurrence; fully unrolled (compile-time indices keep sk / ck in registers)
     float sk[VC_MAXH], ck[VC_MAXH];
@@ -1329,6 +1397,49 @@ __device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, f
     b.lat_domega[c] = domega;
   }
   VC_WSTAMP(1, 5);
+}
+
+__device__ __forceinline__ void vc_nuw_chain(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                             long long s, uint64_t seed, const VcAdamArgs& a, int boot, bool first, int phase,
+                                             const VcXb& xb, int c, float s1, float c1, int nthr, VcNuwShared& sh) {
+  vc_nuw_params<false>(d, b, P, G, s, seed, a, boot, first, phase, nthr, sh);
+  vc_nuw_cells(d, b, c, s1, c1, sh);
+}
+
+// The chain wave of the one-launch tail's cell blocks (vc_tail_cell_block, OMEGA): parts 1 and 2 by ONE wave, beside the block's
+// cell waves instead of behind them.  Part 1 in the order of vc_nuw_sums_finish (lane i adds rows i, i + 64, ... in double, then the
+// 64 lanes); K_main's rows are 4 or 8 floats long (pw_inline): one or two 16-byte loads fetch every coefficient of a row.
+__device__ __forceinline__ void vc_nuw_wave(const VcDims& d, const VcBufs& b, float* __restrict__ P, float* __restrict__ G,
+                                            long long s, uint64_t seed, const VcAdamArgs& a, bool first, VcNuwShared& sh) {
+  const int lane = threadIdx.x & 63;
+  const float* __restrict__ PWs = b.PWM;
+  const int n_pw = d.n_main_wg, pw_ld = d.pw_inline, nw = d.NW;
+  VC_WSTAMP(1, 1);
+  for (int j0 = 0; j0 < nw; j0 += 4) {
+    double u[4] = {0.0, 0.0, 0.0, 0.0};
+    if (n_pw <= 64 * VC_NUW_RAW) {
+      float4 raw[VC_NUW_RAW];
+#pragma unroll
+      for (int k = 0; k < VC_NUW_RAW; ++k) {            // no branch around a load: a clamped row, the value dropped afterwards
+        const int i = lane + 64 * k, ic = i < n_pw ? i : 0;
+        raw[k] = *reinterpret_cast<const float4*>(PWs + (size_t)ic * pw_ld + j0);
+      }
+#pragma unroll
+      for (int k = 0; k < VC_NUW_RAW; ++k)
+        if (lane + 64 * k < n_pw) { u[0] += (double)raw[k].x; u[1] += (double)raw[k].y; u[2] += (double)raw[k].z; u[3] += (double)raw[k].w; }
+    } else {
+      for (int i = lane; i < n_pw; i += 64) {
+        const float4 r = *reinterpret_cast<const float4*>(PWs + (size_t)i * pw_ld + j0);
+        u[0] += (double)r.x; u[1] += (double)r.y; u[2] += (double)r.z; u[3] += (double)r.w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double r = vc_wave_sum_d63(u[q]);
+      if (lane == 63 && j0 + q < nw) sh.up[j0 + q] = (float)r;
+    }
+  }
+  vc_nuw_params<true>(d, b, P, G, s, seed, a, 0, first, VC_PH_ALL, 64, sh);
 }
 
 // One block of K_omega's grid (256 threads; `oblk` = its index in that grid).  Also called from the 1024-thread launch of
@@ -1433,6 +1544,7 @@ void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, floa
   const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
   const dim3 grid(d.nb_post_gene + nb_ocell + 1 + nb_eps), block(1024);
   if (d.nq <= 2) hipLaunchKernelGGL((vc_tail_merged_kernel<2>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
+  else if (d.nq <= 4) hipLaunchKernelGGL((vc_tail_merged_kernel<4>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
   else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail_merged_kernel<6>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
   else hipLaunchKernelGGL((vc_tail_merged_kernel<VC_MAXQ>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
 }
@@ -1475,11 +1587,13 @@ __global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const Vc
 
 void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, hipStream_t st) {
-  const int nb_hist = !with_hist ? 0 : (d.hist_dense ? d.Ng_pad / 64 : (b.n_tasks + 16 * VC_HIST_ROUNDS - 1) / (16 * VC_HIST_ROUNDS));
+  const int nb_hist = !with_hist ? 0 : (d.hist_dense ? (d.model == VC_MODEL_VELOCITY ? 2 : 1) * (d.Ng_pad / 64)      // a block per (matrix, gene block)
+                                                       : (b.n_tasks + 16 * VC_HIST_ROUNDS - 1) / (16 * VC_HIST_ROUNDS));
   const int nb_eps = (int)((d.eps_total / 2 + 1024 * VC_EPS_PER_THREAD - 1) / (1024 * VC_EPS_PER_THREAD));
   const dim3 grid(d.nb_post_gene + d.nb_tail_cell + 1 + nb_hist + nb_eps), block(1024);
   const unsigned dyn = vc_hist_dyn_lds(d, with_hist, 1024);
   if (d.nq <= 2) hipLaunchKernelGGL((vc_tail2_kernel<2>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
+  else if (d.nq <= 4) hipLaunchKernelGGL((vc_tail2_kernel<4>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
   else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail2_kernel<6>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
   else hipLaunchKernelGGL((vc_tail2_kernel<VC_MAXQ>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
 }
