@@ -27,6 +27,7 @@ from velocycle_amd.workloads import make_velocity_spec  # noqa: E402
 
 mode = next((a for a in sys.argv[1:] if not a.startswith("--")), "vjoint")
 with_nccl = "--nccl" in sys.argv
+quick = "--quick" in sys.argv          # A/B runs: the eager fused step, K_main and the sharded step only, at 6 250 / 12 500 / 50 000 cells
 dev = torch.device("cuda:0")
 OPT = {"lr": 0.03, "lrd": 0.9999, "betas": (0.8, 0.99)}
 if with_nccl:
@@ -62,6 +63,11 @@ for n_ranks, nc in ((8, 6250), (4, 12500), (2, 25000), (1, 50000)):
                      ("sharded_fused_eager", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="torch")),
                      ("sharded_fused_engine_rccl", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="engine")),
                      ("sharded_fused_no_exchange", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="none"))]
+    if quick:
+        if nc == 25000:
+            continue
+        keep = ("fused_3_launches", "fused_3_launches_eager", "sharded_fused_engine_rccl", "sharded_fused_no_exchange")
+        variants = [v for v in variants if v[0] in keep]
     for name, kw in variants:
         eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
         run = SVIRunner(eng, OPT, mode="perf", seed=0, **kw)
@@ -79,6 +85,8 @@ for n_ranks, nc in ((8, 6250), (4, 12500), (2, 25000), (1, 50000)):
     print(json.dumps(row), flush=True)
 b = {r["ranks"]: r for r in rows}
 for name in ("unfused_4_launches", "fused_3_launches"):
+    if quick:
+        break
     print(f"{name}: strong-scaling bound of one step at 8 ranks (before any all-reduce latency): "
           f"{b[1][name] / b[8][name]:.2f}x")
 if with_nccl:

@@ -126,22 +126,22 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   const bool samp = phase != VC_PH_A;                 // ... the next sample
 
   VC_WSTAMP(0, 0);
-  // ---- second-stage reduction, REQUEST: the first U chunk groups of K_main's gene-level partial rows depend on nothing else in
-  // this block, so they are asked for before anything is consumed -- the LRMN roles' eps_W fetch and the shape_inv role's histogram
-  // sums below are dependent round trips of their own, and those waves used to START the reduction when the others had finished
-  // it (round 5, profiles/r05_tail2_timeline_*.txt: waves 12..15 reached the barrier 2.5 us after wave 0).  Added up further
-  // down in the same chunk order: the same bits.
-  constexpr int U = MQ <= 2 ? 16 : (MQ <= 4 ? 12 : (MQ <= 6 ? 8 : 2));     // chunk groups in flight per wave (register budget: 128)
-  float v0[U][MQ];
-  if (chain) {
+  // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k fetches, readlane
+  // broadcasts while every lane is active
+  float ew_old[VC_MAX_RANK], ew_new[VC_MAX_RANK];
+  {
+    float mine_old = 0.f, mine_new = 0.f;
+    if (r_cov && lane < d.R) {
+      if (chain) mine_old = eps_old[d.eoff[VC_E_LRMN_W] + lane];
+      if (samp) mine_new = draw_new(d.eoff[VC_E_LRMN_W] + lane);
+    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ch = wave + u * VC_PG_WAVES;
-      const float* go = b.GO + ((size_t)(ch < d.n_chunks ? ch : 0) * d.nq) * NP + g;
-#pragma unroll
-      for (int q = 0; q < MQ; ++q) v0[u][q] = (q < d.nq) ? go[(size_t)q * NP] : 0.f;
+    for (int k = 0; k < VC_MAX_RANK; ++k) {
+      ew_old[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_old), k));
+      ew_new[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_new), k));
     }
   }
+
   // ---- owned parameters of this (gene, role) and everything else that does not depend on K_main's partials --------
   int off[VC_MAXOWN];
   float pp[VC_MAXOWN], pm[VC_MAXOWN], pv[VC_MAXOWN], gg[VC_MAXOWN];
@@ -153,10 +153,6 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 #pragma unroll
   for (int i = 0; i < NIN; ++i) in[i] = 0.f;
   double HLg = 0.0, HDg = 0.0;
-  double hl4[4] = {0.0, 0.0, 0.0, 0.0}, hd4[4] = {0.0, 0.0, 0.0, 0.0};
-  const double* __restrict__ HLs = b.HL;
-  const double* __restrict__ HDs = b.HD;
-  int ht0 = 0, ht1 = 0;
   float e0 = 0.f, e1 = 0.f;        // the Philox draws of step s this role needs
   long long jj = 0;                // flat index of the role's site element
   if (live) {
@@ -176,16 +172,24 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       if (chain) {
         in[0] = b.GT[(size_t)(KT + 2) * NP + g];
         if (!CND(VC_SITE_SHAPE_INV)) in[1] = b.lat[VC_SITE_SHAPE_INV][g];
-        // the gene's histogram terms (usually 2..4 tasks; dense tables: one per matrix, no table of first tasks to wait for).  They
-        // belong to the sample of the step being finished: half (s - 1) & 1 when shape_inv is learned (the histogram blocks of THIS
-        // launch write the other half).  The first four are only REQUESTED here and added behind the last request of the block
-        HLs = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
-        HDs = b.HD + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
-        const int nmat = vel ? 2 : 1;
-        ht0 = d.hist_dense ? nmat * g : b.h_tptr[g]; ht1 = d.hist_dense ? nmat * (g + 1) : b.h_tptr[g + 1];
+        {
+          // the gene's histogram terms (usually 2..4 tasks): four requested per trip instead of one (a dependent round trip
+          // each on this role's way to the barrier), the sums formed in task order as before.  They belong to the sample of
+          // the step being finished: half (s - 1) & 1 when shape_inv is learned (the histogram blocks of THIS launch write
+          // the other half)
+          const double* __restrict__ HLs = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
+          const double* __restrict__ HDs = b.HD + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
+          // (dense tables: one task per matrix and gene, no table of first tasks to wait for)
+          const int nmat = vel ? 2 : 1;
+          const int t0 = d.hist_dense ? nmat * g : b.h_tptr[g], t1 = d.hist_dense ? nmat * (g + 1) : b.h_tptr[g + 1];
+          for (int tb = t0; tb < t1; tb += 4) {
+            double hl[4], hd[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (ht0 < ht1) { const int t = ht0 + k < ht1 ? ht0 + k : ht0; hl4[k] = HLs[t]; hd4[k] = HDs[t]; }
+            for (int k = 0; k < 4; ++k) { const int t = tb + k < t1 ? tb + k : tb; hl[k] = HLs[t]; hd[k] = HDs[t]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (tb + k < t1) { HLg += hl[k]; HDg += hd[k]; }
+          }
+        }
       }
     } else if (r_mf || r_core || r_cov) {
       in[2] = b.sd_g[g]; in[3] = b.mu_g[g]; in[5] = b.sd_b[g]; in[6] = b.mu_b[g];
@@ -238,50 +242,15 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     }
   }
 
-  // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k fetches, readlane
-  // broadcasts while every lane is active.  (Behind the requests above, not in front of them: the broadcast consumes the fetch,
-  // and loads return in order -- in front, it cost the cov roles a round trip of their own before they had asked for anything else)
-  float ew_old[VC_MAX_RANK], ew_new[VC_MAX_RANK];
-  {
-    float mine_old = 0.f, mine_new = 0.f;
-    if (r_cov && lane < d.R) {
-      if (chain) mine_old = eps_old[d.eoff[VC_E_LRMN_W] + lane];
-      if (samp) mine_new = draw_new(d.eoff[VC_E_LRMN_W] + lane);
-    }
-#pragma unroll
-    for (int k = 0; k < VC_MAX_RANK; ++k) {
-      ew_old[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_old), k));
-      ew_new[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine_new), k));
-    }
-  }
-
-  // ---- the shape_inv role's histogram sums, in task order (four requested per trip: a plain load-and-add loop is a dependent
-  // round trip per task)
-  if (live && r_si && chain) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (ht0 + k < ht1) { HLg += hl4[k]; HDg += hd4[k]; }
-    for (int tb = ht0 + 4; tb < ht1; tb += 4) {
-      double hl[4], hd[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { const int t = tb + k < ht1 ? tb + k : tb; hl[k] = HLs[t]; hd[k] = HDs[t]; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) if (tb + k < ht1) { HLg += hl[k]; HDg += hd[k]; }
-    }
-  }
   VC_WSTAMP(0, 1);
   double loss_post = 0.0;
   if (chain) {
     // ---- second-stage reduction of K_main's gene-level partials (as K_post) ------------------------------------
+    constexpr int U = MQ <= 2 ? 16 : (MQ <= 4 ? 12 : (MQ <= 6 ? 8 : 2));     // chunk groups in flight per wave (register budget: 128)
     float acc[MQ];
 #pragma unroll
     for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
-#pragma unroll
-    for (int u = 0; u < U; ++u)                      // the rows requested at the top of the block
-      if (wave + u * VC_PG_WAVES < d.n_chunks) {
-#pragma unroll
-        for (int q = 0; q < MQ; ++q) acc[q] += v0[u][q];
-      }
-    for (int ch0 = wave + U * VC_PG_WAVES; ch0 < d.n_chunks; ch0 += U * VC_PG_WAVES) {
+    for (int ch0 = wave; ch0 < d.n_chunks; ch0 += U * VC_PG_WAVES) {
       float v[U][MQ];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1573,6 +1542,11 @@ __global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const Vc
   VcOpt o;
   o.step_size = b.step_size[0];
   o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd; o.frozen = a.frozen;
+#ifdef VC_DBG_SKIP      // measurement aid (scratch/skip_ab.sh): which kind of block bounds the launch -- bit 0 gene, 1 cell, 2 loss / histogram / eps
+  if ((VC_DBG_SKIP & 1) && (int)blockIdx.x < d.nb_post_gene) return;
+  if ((VC_DBG_SKIP & 2) && (int)blockIdx.x >= d.nb_post_gene && (int)blockIdx.x < d.nb_post_gene + d.nb_tail_cell) return;
+  if ((VC_DBG_SKIP & 4) && (int)blockIdx.x >= d.nb_post_gene + d.nb_tail_cell) return;
+#endif
   if ((int)blockIdx.x < d.nb_post_gene) {
     vc_tail_gene_block<MQ, VC_PH_ALL>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, VcXb{});
     return;
