@@ -523,6 +523,7 @@ def main():
                                + (f", {args.conditions} samples (Nx = Nb = {args.conditions}, per-batch offsets)" if args.conditions > 1 and args.mode != "phase" else ""),
                    "cells": args.cells, "genes": args.genes, "mode": args.mode, "conditions": args.conditions,
                    "launches_per_step": eng.stats.get("launches_per_step"),
+                   "small_kernels": eng.stats.get("tail_spec_name"),
                    "nu_omega_partials_from_main_kernel": bool(eng.stats.get("pw_inline")),
                    "parallelism": f"cells sharded over {world} GPU(s), one all-reduce of gene-level gradients per step",
                    "step": ("Philox eps -> ELBO+grad (HIP kernels) -> " + (("gloo (test hook) " if one_device else "RCCL ") + "all-reduce"
@@ -598,7 +599,7 @@ def main():
             ts2 = time_steps(r2, args.steps, args.warmup, False, device, args.repeats)
             rf = kernel_roofline(e2, r2, args.roofline_launches, median(ts2) / args.steps)
             extra[m] = {"steps_per_s": round(args.steps / median(ts2), 2), "ms_per_step": round(1e3 * median(ts2) / args.steps, 4),
-                        "launches_per_step": e2.stats.get("launches_per_step"),
+                        "launches_per_step": e2.stats.get("launches_per_step"), "small_kernels": e2.stats.get("tail_spec_name"),
                         "kernel": rf["kernel"],
                         "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"],
                         "hbm_frac": rf["frac"], "step_frac": rf["step_frac"], "step_overhead_us": rf["step_overhead_us"], "hbm_pipe_frac": rf["hbm_pipe_frac"], "valu_frac": (rf["valu"] or {}).get("frac"),
@@ -615,7 +616,7 @@ def main():
             rf = kernel_roofline(e2, r2, args.roofline_launches, median(ts2) / args.steps)
             extra[m + "_2sample"] = {"steps_per_s": round(args.steps / median(ts2), 2), "ms_per_step": round(1e3 * median(ts2) / args.steps, 4),
                                      "launches_per_step": e2.stats.get("launches_per_step"), "kernel": rf["kernel"],
-                                     "onehot_batches": e2.stats.get("onehot_batches"),
+                                     "onehot_batches": e2.stats.get("onehot_batches"), "small_kernels": e2.stats.get("tail_spec_name"),
                                      "kernel_avg_us": rf["kernel_avg_us"], "hbm_achieved_GBs": rf["achieved"], "hbm_frac": rf["frac"],
                                      "step_frac": rf["step_frac"], "step_overhead_us": rf["step_overhead_us"],
                                      "hbm_pipe_frac": rf["hbm_pipe_frac"], "valu_frac": (rf["valu"] or {}).get("frac")}

@@ -165,7 +165,8 @@ typedef struct vc_tuning {
   int32_t particles_layout;  /* vc_svi_run_particles: 0 batched (K + 3 launches) | 1 serial | 2 streams */
   int32_t dense_batches;     /* 1: batch offsets as the dense Db contraction even when Db is one-hot (A/B, tests) */
   float p2p_timeout_s;       /* bound of the peer-to-peer exchange's wait; 0 = 2 s */
-  int32_t reserved[7];
+  int32_t no_tail_spec;      /* 1: the run-time-flag small kernels even where an instantiation compiled for this configuration exists (A/B, tests) */
+  int32_t reserved[6];
 } vc_tuning;
 
 typedef struct vc_layout {
@@ -197,6 +198,10 @@ typedef struct vc_stats {
                                      fast set (H > 3, > 4 batches, LRMN rank > 8, > 64 angular-speed coefficients) */
   int32_t onehot_batches;         /* n > 0: the batch design matrix Db is one-hot, its n batch offsets are folded into the constant
                                      harmonic per workgroup of the likelihood kernel (the kernel's NB is 0: nothing per cell) */
+  int32_t tail_spec;              /* > 0: the small kernels of the fused steps run in the instantiation compiled for this
+                                     configuration (row of csrc/vc_tail_spec_rows.inc, name in tail_spec_name); 0: run-time flags */
+  int32_t reserved2;
+  char tail_spec_name[32];
 } vc_stats;
 
 /* lifecycle ------------------------------------------------------------------------------- */
@@ -214,6 +219,9 @@ int vc_get_tuning(const vc_engine* e, vc_tuning* out);
 /* Builds of the library with -DVC_DBG_TIMES only (profiles/tools): writes the per-wave / per-block time stamps of the last
  * launches to `path`; VC_ERR_UNSUPPORTED in the product build. */
 int vc_dbg_dump_times(vc_engine* e, const char* path);
+/* the size-independent signature of the finalized configuration (csrc/vc_common.h: VcSig), n >= 27 ints: what
+ * profiles/tools/print_signature.py turns into a row of csrc/vc_tail_spec_rows.inc */
+int vc_dbg_signature(const vc_engine* e, int32_t* out, int n);
 
 /* inputs (call before vc_finalize) ---------------------------------------------------------- */
 /* Count matrices, element (g, c) at ptr[g*gene_stride + c*cell_stride] (so both the reference's

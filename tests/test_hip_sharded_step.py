@@ -27,9 +27,9 @@ def _cov_draw(spec, seed):
 
 
 class _Rank:
-    def __init__(self, spec, rank, world, seed):
+    def __init__(self, spec, rank, world, seed, tuning=None):
         from velocycle_amd.engine import HipEngine
-        self.e = HipEngine(spec, rank=rank, world_size=world)
+        self.e = HipEngine(spec, rank=rank, world_size=world, tuning=tuning)
         self.e.init_params(_cov_draw(spec, seed))
         n = self.e.total - self.e.header
         dev = self.e.device
@@ -43,9 +43,9 @@ class _Rank:
                                seed=seed, step_dev=self.sd, loss_buf=self.ring, prime=prime, phase=phase, n_steps=1)
 
 
-def _run_sharded(spec, world, n, seed):
+def _run_sharded(spec, world, n, seed, tuning=None):
     from velocycle_amd import _lib
-    ranks = [_Rank(spec, r, world, seed) for r in range(world)]
+    ranks = [_Rank(spec, r, world, seed, tuning) for r in range(world)]
     for t in range(n):
         for r in ranks:
             r.call(seed, _lib.VC_PHASE_A, prime=(t == 0))

@@ -1,0 +1,80 @@
+"""GPU: the small kernels compiled for a configuration's SIGNATURE (csrc/vc_tail_spec.h, round 5) against the run-time-flag kernels
+they specialise.  The specialised instantiation is the same source with the signature's fields as compile-time facts -- dead
+branches removed, loops unrolled, every remaining statement in the same order -- so parameters, optimiser moments, gradients and
+losses must be EQUAL BIT FOR BIT, on every row of csrc/vc_tail_spec_rows.inc, under each launch structure the row is compiled for
+(one-launch tail, merged tail of the tutorial flow, phases A / B of a sharded rank).  Also: the rows are keyed on the whole
+signature -- a configuration that differs in one field runs the run-time-flag kernels."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_hip_fused import _bits_equal, _run
+from tests.test_hip_sharded_step import _run_sharded
+
+pytestmark = pytest.mark.gpu
+
+ROWS = {            # name of the row a workload must select: (builder, mode, samples)
+    "vjoint": ("vel", "vjoint", 1), "vcond": ("vel", "vcond", 1), "phase": ("phase", None, 1),
+    # the "multi" rows leave the number of batches / conditions open: two and three samples run the same instantiation
+    "vjoint_multi": ("vel", "vjoint", 2), "vcond_multi": ("vel", "vcond", 2), "phase_multi": ("phase", None, 3),
+}
+RANK_ROWS = {"vjoint_rank": ("vel", "vjoint", 1), "vcond_rank": ("vel", "vcond", 1), "phase": ("phase", None, 1),
+             "vjoint_multi_rank": ("vel", "vjoint", 2), "vcond_multi_rank": ("vel", "vcond", 2), "phase_multi": ("phase", None, 2)}
+
+
+def _spec(kind, mode, ncond, nc=2100, ng=260):
+    from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
+    if kind == "phase":
+        return make_phase_spec(nc // ncond, ng, seed=3, n_batches=ncond)
+    return make_velocity_spec(nc // ncond, ng, mode, n_conditions=ncond, Hw=1, seed=3)
+
+
+@pytest.mark.parametrize("row", sorted(ROWS))
+def test_single_rank_specialisation_is_bit_identical(row):
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.tuning import Tuning
+    spec = _spec(*ROWS[row])
+    e = HipEngine(spec)
+    assert e.stats["tail_spec_name"] == row and e.stats["tail_spec"] > 0 and e.stats["launches_per_step"] == 2, e.stats
+    e.close()
+    e = HipEngine(spec, tuning=Tuning(no_tail_spec=True))
+    assert e.stats["tail_spec_name"] == "generic" and e.stats["tail_spec"] == 0
+    e.close()
+    for use_graph in (False, True):
+        a = _run(spec, "fused3", 12, use_graph)
+        b = _run(spec, "fused3", 12, use_graph, tuning=Tuning(no_tail_spec=True))
+        _bits_equal(a, b, row)
+
+
+@pytest.mark.parametrize("row", sorted(RANK_ROWS))
+def test_sharded_rank_specialisation_is_bit_identical(row):
+    from velocycle_amd.tuning import Tuning
+    spec = _spec(*RANK_ROWS[row])
+    n, seed, world = 6, 5, 3
+    a = _run_sharded(spec, world, n, seed)
+    b = _run_sharded(spec, world, n, seed, tuning=Tuning(no_tail_spec=True))
+    nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+    for ra, rb in zip(a, b):
+        assert ra.e.stats["tail_spec_name"] == row and rb.e.stats["tail_spec_name"] == "generic", (ra.e.stats, rb.e.stats)
+        assert torch.equal(nz(ra.e.params), nz(rb.e.params)) and torch.equal(ra.m, rb.m) and torch.equal(ra.v, rb.v)
+        assert torch.equal(ra.ring[:n], rb.ring[:n]) and int(ra.sd.item()) == int(rb.sd.item()) == n
+        assert ra.e.status() == rb.e.status() == (True, -1, 0)
+    for r in a + b:
+        r.e.close()
+
+
+@pytest.mark.parametrize("case", ["vel_mf_poisson", "vel_lrmn_joint", "phase_poisson"])
+def test_a_signature_without_a_row_runs_the_generic_kernels(case):
+    """A Poisson noise model, the LRMN guide with nothing conditioned: configurations the library has no compiled row for keep the
+    run-time-flag kernels (and say so); the signature is 27 ints."""
+    import os
+    from tests import helpers as H
+    from velocycle_amd.engine import HipEngine
+    path = f"{H.GOLDEN}/ref_step_{case}.npz"
+    if not os.path.exists(path):
+        pytest.skip(f"no fixture {case}")
+    spec = H.spec_from_fixture(H.load_fixture(path))
+    e = HipEngine(spec)
+    assert e.stats["tail_spec_name"] == "generic" and e.stats["tail_spec"] == 0, e.stats
+    assert len(e.signature()) == 27
+    e.close()

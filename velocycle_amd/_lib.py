@@ -55,7 +55,8 @@ class vc_tuning(C.Structure):
                 ("tail_cells", C.c_int32), ("count_storage", C.c_int32), ("host_hist", C.c_int32),
                 ("hist_dense", C.c_int32), ("pw_inline", C.c_int32), ("no_tail2", C.c_int32),
                 ("no_tail_merged", C.c_int32), ("force_generic", C.c_int32), ("particles_layout", C.c_int32),
-                ("dense_batches", C.c_int32), ("p2p_timeout_s", C.c_float), ("reserved", C.c_int32 * 7)]
+                ("dense_batches", C.c_int32), ("p2p_timeout_s", C.c_float), ("no_tail_spec", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class vc_layout(C.Structure):
@@ -71,7 +72,8 @@ class vc_stats(C.Structure):
                 ("hist_on_device", C.c_int32), ("main_kernel_name", C.c_char * 96),
                 ("setup_transient_bytes", C.c_int64), ("count_storage_bytes", C.c_int64),
                 ("pass_cells", C.c_int32 * 4), ("launches_per_step", C.c_int32), ("pw_inline", C.c_int32),
-                ("generic", C.c_int32), ("onehot_batches", C.c_int32)]
+                ("generic", C.c_int32), ("onehot_batches", C.c_int32), ("tail_spec", C.c_int32), ("reserved2", C.c_int32),
+                ("tail_spec_name", C.c_char * 32)]
 
 
 EXPORTS = {
@@ -82,6 +84,7 @@ EXPORTS = {
     "vc_set_tuning": (C.c_int, [C.c_void_p, C.POINTER(vc_tuning)]),
     "vc_get_tuning": (C.c_int, [C.c_void_p, C.POINTER(vc_tuning)]),
     "vc_dbg_dump_times": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "vc_dbg_signature": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "vc_set_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
     "vc_set_counts_csr": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "vc_get_histogram": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p]),

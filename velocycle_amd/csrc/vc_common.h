@@ -95,7 +95,35 @@ struct VcDims {
   int tail_tc;            // cells per cell block of K_tail: 256 (one wave per SIMD, shortest chain) or 1024 (large shards)
   int nlpf;               // fused pipeline: loss slots per half of LPF = nb_post_gene + nb_tail_cell + 1
   float lgamma_alpha;     // lgamma(gamma_alpha) of the shape_inv prior, evaluated once on the host
+  int spec;               // > 0: the small kernels of the fused steps run in the instantiation compiled for this configuration's
+                          // SIGNATURE (vc_tail_spec.h: VC_SIGS[spec - 1]); 0: the run-time-flag kernels
 };
+
+// The SIGNATURE of a configuration: every field of VcDims the small kernels branch or loop on that does NOT depend on the size of
+// the problem (cells, genes, ranks, tiling).  The kernels of the fused steps carry the code of every model, guide, noise model and
+// conditioning pattern behind run-time flags -- 99 KB of instructions and 219 spilled SGPRs in the one-launch tail, most of which
+// a given configuration never runs (round 5: profiles/r05_tail_spec.md).  For the signatures listed in vc_tail_spec.h the same
+// source is compiled again with the signature's values as compile-time facts (__builtin_assume on exactly these fields, checked on
+// the host by comparing the whole signature): dead branches go, loops unroll, the statements that remain are the same ones in the
+// same order -- the same bits (tests/test_hip_fused.py holds the two against each other).
+#define VC_SIG_FIELDS(X)                                                                                                             \
+  X(model) X(guide) X(noise) X(with_dnu) X(kind) X(H) X(Nh) X(Hw) X(Nhw) X(Nb) X(Nx) X(R) X(NW) X(K) X(Kq) X(nbk) X(onehot)         \
+  X(pw_inline) X(nq) X(nco) X(hist_has_S) X(hist_has_U) X(hist_dense) X(hist_par) X(nmat_r) X(generic)
+struct VcSig {
+#define VC_SIG_DECL(f) int f;
+  VC_SIG_FIELDS(VC_SIG_DECL)
+#undef VC_SIG_DECL
+  unsigned cond;
+};
+#define VC_SIG_INTS 27        // ints of a signature as vc_dbg_signature lists them (the fields above in order, then cond)
+static inline VcSig vc_sig_of(const VcDims& d) {
+  VcSig s;
+#define VC_SIG_GET(f) s.f = d.f;
+  VC_SIG_FIELDS(VC_SIG_GET)
+#undef VC_SIG_GET
+  s.cond = d.cond;
+  return s;
+}
 
 // dynamic shared memory of a K_main launch (bytes)
 __host__ __device__ inline unsigned vc_main_dyn_lds(const VcDims& d) {

@@ -16,6 +16,7 @@
 
 #include "vc_common.h"
 #include "vc_host_logic.h"
+#include "vc_tail_spec.h"
 
 namespace {
 
@@ -418,7 +419,7 @@ extern "C" int vc_set_tuning(vc_engine* e, const vc_tuning* t) {
   if (!in(z.tail_cells, {0, 256, 512, 1024})) return e->fail(VC_ERR_ARG, "vc_set_tuning: tail_cells must be 0, 256, 512 or 1024");
   if (!in(z.count_storage, {0, 1}) || !in(z.host_hist, {0, 1}) || !in(z.hist_dense, {0, 1, 2}) || !in(z.pw_inline, {0, 1, 2}) ||
       !in(z.no_tail2, {0, 1}) || !in(z.no_tail_merged, {0, 1}) || !in(z.force_generic, {0, 1}) || !in(z.particles_layout, {0, 1, 2}) ||
-      !in(z.dense_batches, {0, 1}))
+      !in(z.dense_batches, {0, 1}) || !in(z.no_tail_spec, {0, 1}))
     return e->fail(VC_ERR_ARG, "vc_set_tuning: a switch is outside its documented values");
   if (z.p2p_timeout_s < 0.f) return e->fail(VC_ERR_ARG, "vc_set_tuning: negative p2p_timeout_s");
   e->tun = z;
@@ -448,6 +449,18 @@ extern "C" int vc_dbg_dump_times(vc_engine* e, const char* path) {
 #else
   return e->fail(VC_ERR_UNSUPPORTED, "vc_dbg_dump_times: this build of the library carries no time stamps (-DVC_DBG_TIMES)");
 #endif
+}
+
+extern "C" int vc_dbg_signature(const vc_engine* e, int32_t* out, int n) {
+  if (!e || !out || n < VC_SIG_INTS) return VC_ERR_ARG;
+  if (!e->finalized) return VC_ERR_STATE;
+  const VcSig s = vc_sig_of(e->d);
+  int i = 0;
+#define VC_SIG_PUT(f) out[i++] = s.f;
+  VC_SIG_FIELDS(VC_SIG_PUT)
+#undef VC_SIG_PUT
+  out[i++] = (int32_t)s.cond;
+  return VC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1088,6 +1101,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   d.nb_tail_cell = (d.Nc + d.tail_tc - 1) / d.tail_tc;
   d.nlpf = d.nb_post_gene + d.nb_tail_cell + 1;
   d.lgamma_alpha = lgammaf(d.gamma_alpha);
+  d.spec = VC_SPEC_NONE;      // (chosen at the end: the histogram form below is part of the signature)
   {
     // exchange buffer of the sharded fused step (include/velocycle_hip.h): gradient region, PW rows, loss pairs
     const long long world = e->cfg.world_size, ncg = e->cfg.Nc_global > 0 ? e->cfg.Nc_global : d.Nc;
@@ -1278,6 +1292,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   b.const_loss = cl;
   HIPCHK(e, hipStreamSynchronize(st));
   HIPCHK(e, hipGetLastError());
+  // the instantiation of the small kernels compiled for this configuration, if there is one (vc_tail_spec.h)
+  d.spec = e->tun.no_tail_spec ? VC_SPEC_NONE : vc_spec_match(d);
   e->finalized = true;
   return VC_OK;
 }
@@ -1833,6 +1849,10 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.nbk, e->main_name, d.gpl,
            d.c16 ? ",u16" : "");
   out->onehot_batches = d.onehot ? d.Nb : 0;
+  out->tail_spec = d.spec;
+  out->reserved2 = 0;
+  memset(out->tail_spec_name, 0, sizeof(out->tail_spec_name));
+  strncpy(out->tail_spec_name, VC_SPECS[d.spec].name, sizeof(out->tail_spec_name) - 1);
   return VC_OK;
 }
 

@@ -26,6 +26,7 @@
 // of a * b + c depends on the surroundings of the statement.  Where a fused operation is wanted it is written as fmaf().
 #pragma clang fp contract(off)
 #include "vc_common.h"
+#include "vc_tail_spec.h"
 
 #define VC_PG_WAVES 16
 #define VC_MAXQ (2 * VC_MAXH + 1 + VC_MAXNB + 3)
@@ -821,10 +822,12 @@ __device__ __forceinline__ void vc_tail_loss_base_block(const VcDims& d, const V
   }
 }
 
-template <int MQ, int phase>
+template <int MQ, int phase, int SPEC = 0>
 __global__ __launch_bounds__(1024) void vc_tail_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
                                                        float* __restrict__ G, const long long* __restrict__ step_dev,
                                                        uint64_t seed, const VcAdamArgs a, int boot, const VcXb xb) {
+  vc_spec_assume<SPEC>(d);
+  if (SPEC > 0) __builtin_assume(boot == 0);      // (vc_launch_tail: the compiled signatures serve the steady-state launches only)
   // s: index of the step whose sample this launch draws (boot: the step about to run; else K_main has advanced the
   // counter, s = t + 1 is also the 1-based optimiser step of the update applied here)
   const long long s = *step_dev;
@@ -842,6 +845,11 @@ void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad
   // phase A: + the loss-base block (phase B has its own launch: vc_launch_phase_b)
   const int nblk = d.nb_post_gene + d.nb_tail_cell + (phase == VC_PH_A ? 1 : 0);
   const dim3 grid(nblk), block(1024);
+  // phase A of a configuration with a compiled signature (vc_tail_spec.h)
+  if (phase == VC_PH_A && !boot && vc_spec_launch<VC_SPECK_SHARDED, 0>(d.spec, [&](auto mq, auto sp) {
+        hipLaunchKernelGGL((vc_tail_kernel<decltype(mq)::value, VC_PH_A, decltype(sp)::value>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, boot, xb);
+      }))
+    return;
   // the phase is a template parameter: the single-rank kernel carries none of the sharded step's code (or registers)
 #define VC_TAIL_LAUNCH(MQ_)                                                                                                       \
   do {                                                                                                                            \
@@ -1444,11 +1452,12 @@ __global__ __launch_bounds__(256) void vc_omega_kernel(const VcDims d, const VcB
 
 // Phase B of the sharded step in ONE launch: gene blocks (optimiser on the summed gradient + next sample) and K_omega's
 // blocks (which depend on phase A and on the exchange, not on the gene blocks) side by side
-template <int MQ>
+template <int MQ, int SPEC = 0>
 __global__ __launch_bounds__(1024) void vc_phase_b_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
                                                           float* __restrict__ G, const long long* __restrict__ step_dev,
                                                           uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
                                                           long long loss_slots, int nb_cell, int nb_hist, const VcXb xb) {
+  vc_spec_assume<SPEC>(d);
   const long long s = *step_dev;
   if ((int)blockIdx.x < d.nb_post_gene) {
     VcOpt o;
@@ -1475,6 +1484,11 @@ void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* g
   const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
   const dim3 grid(d.nb_post_gene + nb_cell + 1 + nb_hist + nb_eps), block(1024);
   // (the gene blocks of phase B neither reduce nor stage rows: the smallest row bound keeps their registers free)
+  if (vc_spec_launch<VC_SPECK_SHARDED, 0>(d.spec, [&](auto mq, auto sp) {
+        hipLaunchKernelGGL((vc_phase_b_kernel<2, decltype(sp)::value>), grid, block, vc_hist_dyn_lds(d, with_hist, 1024), st, d, b, params, grad,
+                           step_dev, seed, a, loss_dev, loss_slots, nb_cell, nb_hist, xb);
+      }))
+    return;
   hipLaunchKernelGGL(vc_phase_b_kernel<2>, grid, block, vc_hist_dyn_lds(d, with_hist, 1024), st, d, b, params, grad, step_dev, seed, a,
                      loss_dev, loss_slots, nb_cell, nb_hist, xb);
 }
@@ -1490,11 +1504,12 @@ void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* g
 //   * no histogram blocks (shape_inv conditioned), the eps blocks depend on nothing.
 // vc_svi_run_fused runs the first two steps of every call the ordinary way and the rest through this launch.
 // ---------------------------------------------------------------------------------------------
-template <int MQ>
+template <int MQ, int SPEC = 0>
 __global__ __launch_bounds__(1024) void vc_tail_merged_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
                                                               float* __restrict__ G, const long long* __restrict__ step_dev,
                                                               uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
                                                               long long loss_slots, int nb_ocell) {
+  vc_spec_assume<SPEC>(d);
   const long long s = *step_dev;
   if ((int)blockIdx.x < d.nb_post_gene) {
     VcOpt o;
@@ -1512,6 +1527,11 @@ void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, floa
   const int nb_ocell = (d.Nc + 255) / 256;
   const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
   const dim3 grid(d.nb_post_gene + nb_ocell + 1 + nb_eps), block(1024);
+  if (vc_spec_launch<VC_SPECK_MERGED, 0>(d.spec, [&](auto mq, auto sp) {
+        hipLaunchKernelGGL((vc_tail_merged_kernel<decltype(mq)::value, decltype(sp)::value>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a,
+                           loss_dev, loss_slots, nb_ocell);
+      }))
+    return;
   if (d.nq <= 2) hipLaunchKernelGGL((vc_tail_merged_kernel<2>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
   else if (d.nq <= 4) hipLaunchKernelGGL((vc_tail_merged_kernel<4>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
   else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail_merged_kernel<6>), grid, block, 0, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_ocell);
@@ -1533,11 +1553,12 @@ void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, floa
 //   * the eps blocks depend on nothing.
 // Launch structures give the same bits: tests/test_hip_fused.py.
 // ---------------------------------------------------------------------------------------------
-template <int MQ>
+template <int MQ, int SPEC = 0>
 __global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
                                                         float* __restrict__ G, const long long* __restrict__ step_dev,
                                                         uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
                                                         long long loss_slots, int nb_hist) {
+  vc_spec_assume<SPEC>(d);
   const long long s = *step_dev;
   VcOpt o;
   o.step_size = b.step_size[0];
@@ -1566,6 +1587,11 @@ void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* gra
   const int nb_eps = (int)((d.eps_total / 2 + 1024 * VC_EPS_PER_THREAD - 1) / (1024 * VC_EPS_PER_THREAD));
   const dim3 grid(d.nb_post_gene + d.nb_tail_cell + 1 + nb_hist + nb_eps), block(1024);
   const unsigned dyn = vc_hist_dyn_lds(d, with_hist, 1024);
+  if (vc_spec_launch<VC_SPECK_TAIL2, 0>(d.spec, [&](auto mq, auto sp) {
+        hipLaunchKernelGGL((vc_tail2_kernel<decltype(mq)::value, decltype(sp)::value>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a,
+                           loss_dev, loss_slots, nb_hist);
+      }))
+    return;
   if (d.nq <= 2) hipLaunchKernelGGL((vc_tail2_kernel<2>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
   else if (d.nq <= 4) hipLaunchKernelGGL((vc_tail2_kernel<4>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);
   else if (d.nq <= 6) hipLaunchKernelGGL((vc_tail2_kernel<6>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_hist);

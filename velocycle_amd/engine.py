@@ -179,7 +179,8 @@ class HipEngine:
                           setup_transient_bytes=st.setup_transient_bytes,
                           count_storage="u16" if st.count_storage_bytes == 2 else "f32",
                           pass_cells=[int(x) for x in st.pass_cells], launches_per_step=int(st.launches_per_step),
-                          pw_inline=int(st.pw_inline), generic=bool(st.generic), onehot_batches=int(st.onehot_batches))
+                          pw_inline=int(st.pw_inline), generic=bool(st.generic), onehot_batches=int(st.onehot_batches),
+                          tail_spec=int(getattr(st, "tail_spec", 0)), tail_spec_name=bytes(getattr(st, "tail_spec_name", b"")).decode() or "generic")
 
     # ------------------------------------------------------------------------------------------
     def param_shape(self, name):
@@ -579,6 +580,13 @@ class HipEngine:
     def dump_dbg_times(self, path: str):
         """profiles/tools: the time stamps of a -DVC_DBG_TIMES build of the library (vc_dbg_dump_times)."""
         self._check(self.lib.vc_dbg_dump_times(self._h, path.encode()))
+
+    def signature(self):
+        """The size-independent signature of this configuration (vc_dbg_signature; csrc/vc_common.h VcSig) -- the key of the
+        compiled specialisations of the small kernels (csrc/vc_tail_spec_rows.inc; profiles/tools/print_signature.py)."""
+        out = (C.c_int32 * 27)()
+        self._check(self.lib.vc_dbg_signature(self._h, out, 27))
+        return [int(x) for x in out]
 
     def set_timing(self, enable: bool):
         self._check(self.lib.vc_set_timing(self._h, int(enable)))

@@ -38,6 +38,7 @@ class Tuning:
     particles_layout: Optional[str] = None      # None / "batched" | "serial" | "streams"
     dense_batches: bool = False                 # True: batch offsets as the dense Db contraction even for a one-hot Db
     p2p_timeout_s: float = 0.0                  # 0 = 2 s
+    no_tail_spec: bool = False                  # True: the run-time-flag small kernels even where a compiled signature matches
     # ---- the host side (SVIRunner / fit) ---------------------------------------------------------------------------
     adam_impl: Optional[str] = None             # single-rank perf step: None = "fused3"
     adam_impl_dist: Optional[str] = None        # sharded perf step: None = "sharded"
@@ -67,6 +68,7 @@ class Tuning:
         t.particles_layout = _LAYOUT[self.particles_layout]
         t.dense_batches = int(bool(self.dense_batches))
         t.p2p_timeout_s = float(self.p2p_timeout_s)
+        t.no_tail_spec = int(bool(self.no_tail_spec))
         return t
 
     def digest(self) -> int:
@@ -107,6 +109,7 @@ class Tuning:
         if e.get("VC_PARTICLES_LAYOUT"):
             kw["particles_layout"] = e["VC_PARTICLES_LAYOUT"]
         kw["dense_batches"] = e.get("VC_DENSE_BATCHES", "0") not in ("", "0")
+        kw["no_tail_spec"] = e.get("VC_NO_TAIL_SPEC", "0") not in ("", "0")
         if e.get("VC_P2P_TIMEOUT_S"):
             kw["p2p_timeout_s"] = float(e["VC_P2P_TIMEOUT_S"])
         kw["adam_impl"] = e.get("VC_ADAM_IMPL") or None

@@ -19,7 +19,7 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
     on ϕxy, ν, shape_inv [, Δν] like the tutorials), "vcond_mf" (same conditioning, mean-field).
     `sim`: a stored output of `simulate_counts` (the sampling kernels of torch are not bit-reproducible across hosts, so
     fixtures that must describe the SAME data on every machine carry the simulated counts: tests/golden/oracle_fit_data_*)."""
-    omegas = (0.4, 0.3)[:n_conditions]
+    omegas = (0.4, 0.3, 0.35, 0.25, 0.45, 0.2, 0.38, 0.28)[:n_conditions]
     if sim is None:
         sim = simulate_counts(Nc, Ng, omegas=omegas, seed=seed, device=device)
     S_cm, U_cm = sim["S"], sim["U"]                  # (Nc_total, Ng) cell-major, like AnnData layers
@@ -59,9 +59,10 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
     return spec
 
 
-def make_phase_spec(Nc=3000, Ng=200, seed=0, device="cpu", noisemodel="NegativeBinomial", sim=None) -> ModelSpec:
-    v = make_velocity_spec(Nc, Ng, "vjoint", 1, 0, seed, device, noisemodel, sim=sim)
-    spec = ModelSpec(kind="phase", guide="meanfield", noisemodel=noisemodel, with_delta_nu=False, H=1,
+def make_phase_spec(Nc=3000, Ng=200, seed=0, device="cpu", noisemodel="NegativeBinomial", sim=None, n_batches=1) -> ModelSpec:
+    """n_batches > 1: that many samples of Nc cells each with a one-hot batch design and per-batch offsets (with_delta_nu)."""
+    v = make_velocity_spec(Nc, Ng, "vjoint", n_batches, 0, seed, device, noisemodel, sim=sim)
+    spec = ModelSpec(kind="phase", guide="meanfield", noisemodel=noisemodel, with_delta_nu=n_batches > 1, H=1,
                      S=v.S, count_factor=v.count_factor, Db=v.Db, mu_nu=v.mu_nu, sd_nu=v.sd_nu,
                      phixy_prior=v.phixy_prior, sigma_ln_s=0.5)
     spec.truth = v.truth
