@@ -256,14 +256,14 @@ __device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c
 }
 // onehot: d loglik / d dnu[q, g] = the sum of the constant harmonic's partial row (GO row 0) over the workgroups of batch q of the
 // likelihood kernel's gene block that holds gene g -- chunks [c0, c1) of that gene block, added in chunk order (one fixed
-// association for every caller: K_post, K_tail, phase A), 16 chunks requested per trip
+// association for every caller: K_post, K_tail, phase A), 32 chunks requested per trip
 __device__ __forceinline__ float vc_dnu_range_sum(const VcDims& d, const VcBufs& b, int g, int q) {
   const int gbm = g / d.gbw;
   const int c0 = b.bat_chunk[gbm * (d.Nb + 1) + q], c1 = b.bat_chunk[gbm * (d.Nb + 1) + q + 1];
   const float* __restrict__ go = b.GO + g;
   const size_t stride = (size_t)d.nq * d.Ng_pad;
   float acc = 0.f;
-  constexpr int UB = 16;
+  constexpr int UB = 32;
   for (int ch0 = c0; ch0 < c1; ch0 += UB) {
     float v[UB];
 #pragma unroll

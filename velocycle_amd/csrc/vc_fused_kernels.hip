@@ -245,6 +245,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 
   VC_WSTAMP(0, 1);
   double loss_post = 0.0;
+  float dnu_first = 0.f;
   if (chain) {
     // ---- second-stage reduction of K_main's gene-level partials (as K_post) ------------------------------------
     constexpr int U = MQ <= 2 ? 16 : (MQ <= 4 ? 12 : (MQ <= 6 ? 8 : 2));     // chunk groups in flight per wave (register budget: 128)
@@ -269,6 +270,17 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     }
 #pragma unroll
     for (int q = 0; q < MQ; ++q) sm[wave][q][lane] = acc[q];
+    // one-hot batches: the first batch of this wave's loop further down is summed HERE, in front of the barrier -- it needs K_main's
+    // rows only, and its round trips (the batch's chunk range, then the rows) otherwise start when every other role is done
+    if (r_dnu1 && live && role - Nh < d.Nb && !CND(VC_SITE_DNU)) dnu_first = vc_dnu_range_sum(d, b, g, role - Nh);
+    // Everything requested at the top of the block must have ARRIVED before this barrier: several roles read values another role of
+    // the same gene rewrites behind it (the LRMN cov roles read log-scale and rho of the core role's parameters, every velocity role
+    // reads gamma and the samples of log gamma / log beta) -- correct only if the read happens in front of the barrier.  `P` and the
+    // tables are __restrict__ / plain pointers the compiler may read as late as the first use, i.e. BEHIND the barrier, next to the
+    // other wave's store (round 5: vel_lrmn_joint lost its 2e-10 agreement with the unfused sequence in one build of this file and
+    // kept it in the next).  An empty asm that takes the values as operands pins the loads here.
+    // (only the roles that read what another role owns: 13..15; their own parameters and moments need no pin)
+    if (role >= 13) asm volatile("" ::"v"(in[0]), "v"(in[1]), "v"(in[4]), "v"(in[7]), "v"(in[8]), "v"(in[9]), "v"(in[10]));
     VC_WSTAMP(0, 2);
     __syncthreads();
     VC_WSTAMP(0, 3);
@@ -379,7 +391,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       if (!boot) {
         float gq = 0.f;
         if (phase == VC_PH_B) gq = xb.x[po];                           // the gradient summed over ranks
-        else if (!CND(VC_SITE_DNU)) gq = -(vc_dnu_range_sum(d, b, g, q) - rw * b.lat[VC_SITE_DNU][jq] / (sd * sd));
+        else if (!CND(VC_SITE_DNU)) gq = -((q == role - Nh ? dnu_first : vc_dnu_range_sum(d, b, g, q)) - rw * b.lat[VC_SITE_DNU][jq] / (sd * sd));
         if (phase == VC_PH_A) xb.x[po] = gq;
         else {
           G[po] = gq;
@@ -583,7 +595,11 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   // sample -- depends on nothing the cell waves do, so ONE extra wave (the "chain wave", right behind the cell waves) runs it
   // BESIDE them; the cell waves meet it at one barrier and only add omega_c to their records (round 5: the chain used to start
   // when the cell part was done, 4 us of barriers and dependent exp / sqrt / divide at the end of the launch's longest block)
+#ifdef VC_NO_CHAIN_WAVE
+  const bool cwm = false;
+#else
   const bool cwm = OMEGA && vel && !boot && d.pw_inline && VC_TC <= VC_TC_MAX - 64;
+#endif
   if ((int)threadIdx.x >= VC_TC + (cwm ? 64 : 0)) return;   // 256-cell blocks: the other waves of the block have nothing to do
   VC_WSTAMP(0, 0);
   __shared__ VcNuwShared sh_nuw;
