@@ -4,7 +4,7 @@ library compiles specialised small kernels for, read back from a finalized engin
 
   python profiles/tools/print_signature.py > velocycle_amd/csrc/vc_tail_spec_rows.inc        (on a GPU box; then rebuild)
 
-A row: {name, kinds of launch (bits: 1 one-launch tail | 2 merged tail of the tutorial flow | 4 phases A / B of a sharded rank), MQ of the
+A row: {name, kinds of launch (bits: 1 one-launch tail | 2 merged tail of the tutorial flow | 4 phases A / B of a sharded rank | 8 the K-particle step), MQ of the
 gene blocks (2 | 4 | 6 | 14 >= the likelihood kernel's gene-level rows), {signature ints in VC_SIG_FIELDS order, cond}}."""
 import os
 import sys
@@ -42,6 +42,8 @@ def add(name, spec, world=1, multi=False):
         kind = 1
     else:
         kind = 0
+    if world == 1 and kind:
+        kind |= 8            # the K-particle step of a single rank runs the same configuration
     eng.close()
     if kind == 0:
         print(f"// {name}: three launches per step on this configuration -- no row", file=sys.stderr)

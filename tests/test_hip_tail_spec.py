@@ -63,6 +63,28 @@ def test_sharded_rank_specialisation_is_bit_identical(row):
         r.e.close()
 
 
+@pytest.mark.parametrize("row", ["vjoint", "vcond", "phase", "vjoint_multi"])
+def test_particle_step_specialisation_is_bit_identical(row):
+    """vc_svi_run_particles (K_pre / K_post of all particles, K_fin + average + optimiser: K + 3 launches) in the instantiations compiled
+    for the row against the run-time-flag kernels: K = 3, eight steps, parameters / moments / losses bit for bit."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.svi import SVIRunner
+    from velocycle_amd.tuning import Tuning
+    spec = _spec(*ROWS[row])
+    out = []
+    for tun in (None, Tuning(no_tail_spec=True)):
+        e = HipEngine(spec, tuning=tun)
+        assert e.stats["tail_spec_name"] == (row if tun is None else "generic")
+        r = SVIRunner(e, {"lr": 0.03, "lrd": 0.995, "betas": (0.8, 0.99)}, mode="perf", seed=9, num_particles=3)
+        r.run_perf(8)
+        out.append((e.params.clone().cpu(), r.opt.m.clone().cpu(), r.opt.v.clone().cpu(), np.array(r.perf_losses()), e.status()))
+        e.close()
+    nz = lambda t: torch.nan_to_num(t, neginf=-1e30)
+    a, b = out
+    assert torch.equal(nz(a[0]), nz(b[0])) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert a[4] == b[4] == (True, -1, 0) and len(a[3]) == 8
+
+
 @pytest.mark.parametrize("case", ["vel_mf_poisson", "vel_lrmn_joint", "phase_poisson"])
 def test_a_signature_without_a_row_runs_the_generic_kernels(case):
     """A Poisson noise model, the LRMN guide with nothing conditioned: configurations the library has no compiled row for keep the

@@ -13,6 +13,7 @@
 // of a * b + c depends on the surroundings of the statement.  Where a fused operation is wanted it is written as fmaf().
 #pragma clang fp contract(off)
 #include "vc_common.h"
+#include "vc_tail_spec.h"
 #include "vc_host_logic.h"     // VC_HIST_CAP
 
 
@@ -157,13 +158,15 @@ void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int c
 // ---------------------------------------------------------------------------------------------
 // MULTI (vc_svi_run_particles): ONE launch draws the samples of all K particles of a step -- blockIdx.y = particle, whose
 // workspaces are entry blockIdx.y of `bs` (device array; the parameters are the same for all of them)
-template <bool MULTI>
+template <bool MULTI, int SPEC = 0>
 __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBufs b0, const VcBufs* __restrict__ bs,
                                                      const float* __restrict__ P,
                                                      const float* __restrict__ eps_in, uint64_t seed,
                                                      long long step_host,
                                                      const long long* __restrict__ step_dev,
                                                      int cond_only, int particles, int particle_in) {
+  vc_spec_assume<SPEC>(d);      // (vc_tail_spec.h: the K-particle step of a configuration with a compiled signature)
+  if (SPEC > 0) { __builtin_assume(cond_only == 0); __builtin_assume(eps_in == nullptr); }
   __shared__ double sm_red[16];
   __shared__ float s_nuw[VC_MAX_NW];
   VcBufs bm;
@@ -443,7 +446,13 @@ void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const 
 void vc_launch_pre_particles(const VcDims& d, const VcBufs& b, const VcBufs* bs_dev, const float* params, uint64_t seed,
                              const long long* step_dev, int with_hist, int K, hipStream_t st) {
   const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
-  hipLaunchKernelGGL(vc_pre_kernel<true>, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist, K), dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st,
+  const dim3 grid(d.nb_pre_gene + d.nb_pre_cell + nb_hist, K);
+  if (vc_spec_launch<VC_SPECK_PARTICLES, 0>(d.spec, [&](auto mq, auto sp) {
+        hipLaunchKernelGGL((vc_pre_kernel<true, decltype(sp)::value>), grid, dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st, d, b, bs_dev, params,
+                           (const float*)nullptr, seed, 0LL, step_dev, 0, K, 0);
+      }))
+    return;
+  hipLaunchKernelGGL(vc_pre_kernel<true>, grid, dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st,
                      d, b, bs_dev, params, (const float*)nullptr, seed, 0LL, step_dev, 0, K, 0);
 }
 
@@ -783,10 +792,11 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
 }
 
 // one launch for both second-stage reductions: blocks [0, nb_post_gene) gene level, the rest cell level
-template <int MQ, bool MULTI = false>
+template <int MQ, bool MULTI = false, int SPEC = 0>
 __global__ __launch_bounds__(1024) void vc_post_kernel(const VcDims d, const VcBufs b0, const float* __restrict__ P,
                                                        float* __restrict__ G0, long long* __restrict__ step_dev,
                                                        const VcBufs* __restrict__ bs, const VcParticleGrads pg) {
+  vc_spec_assume<SPEC>(d);
   // every reader of this step's counter (K_pre) has finished and nothing in this launch reads it:
   // advance it here, so that K_fin / the optimiser (which only read it) see step + 1 = the 1-based Adam step
   // (MULTI: blockIdx.y = particle, its workspaces bs[blockIdx.y], its gradient buffer pg.g[blockIdx.y]; step_dev is null)
@@ -1019,12 +1029,14 @@ __global__ __launch_bounds__(256) void vc_fin_adam_kernel(const VcDims d, const 
 // workspaces and gradient buffer, one after the other), all blocks then average the K gradients in particle order --
 // (g_0 + g_1 + ...) * (1 / K), what a host loop's sum and PyTorch's division by a scalar give; left in particle 0's buffer --
 // and apply ClippedAdam to the average; block 0 files the averaged loss and sets the step counter to t + 1.
+template <int SPEC = 0>
 __global__ __launch_bounds__(256) void vc_particle_fin_adam_kernel(const VcDims d, const VcBufs* __restrict__ bs, const VcParticleGrads pg,
                                                                    float* P, double* loss_dev, long long loss_slots, long long step_host,
                                                                    long long* step_dev, double* __restrict__ scratch, float* __restrict__ m,
                                                                    float* __restrict__ v, double lr0, double lrd /* log */, double b1,
                                                                    double b2, double b1l, double b2l, float eps, float clip, float wd, int kind,
                                                                    const unsigned char* __restrict__ frozen, int header, long long total) {
+  vc_spec_assume<SPEC>(d);
   __shared__ float s_step, s_c2;
   const int K = pg.K;
   const long long t1 = step_host + 1;        // 1-based optimiser step (the host's mirror of the device counter: nothing here reads it)
@@ -1088,7 +1100,13 @@ void vc_launch_particle_fin_adam(const VcDims& d, const VcBufs* bs_dev, const Vc
   long long nb = (total - header + 255) / 256;
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(vc_particle_fin_adam_kernel, dim3((unsigned)nb), dim3(256), 0, st, d, bs_dev, pg, params, loss_dev, loss_slots, step,
+  if (vc_spec_launch<VC_SPECK_PARTICLES, 0>(d.spec, [&](auto mq, auto sp) {
+        hipLaunchKernelGGL((vc_particle_fin_adam_kernel<decltype(sp)::value>), dim3((unsigned)nb), dim3(256), 0, st, d, bs_dev, pg, params, loss_dev,
+                           loss_slots, step, step_dev, scratch, m, v, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1), log(h.b2), h.eps, h.clip, h.wd,
+                           h.kind, h.frozen, header, total);
+      }))
+    return;
+  hipLaunchKernelGGL((vc_particle_fin_adam_kernel<0>), dim3((unsigned)nb), dim3(256), 0, st, d, bs_dev, pg, params, loss_dev, loss_slots, step,
                      step_dev, scratch, m, v, h.lr0, log(h.lrd), h.b1, h.b2, log(h.b1), log(h.b2), h.eps, h.clip, h.wd, h.kind, h.frozen, header, total);
 }
 
@@ -1124,6 +1142,11 @@ void vc_launch_post_particles(const VcDims& d, const VcBufs& b, const VcBufs* bs
   const dim3 grid(d.nb_post_gene + d.nb_post_cell, pg.K), block(1024);
   long long* no_ctr = nullptr;
   float* no_g = nullptr;
+  if (vc_spec_launch<VC_SPECK_PARTICLES, 0>(d.spec, [&](auto mq, auto sp) {
+        constexpr int MQP = decltype(mq)::value <= 2 ? 2 : (decltype(mq)::value <= 6 ? 6 : VC_MAXQ);      // (K_post's row bounds: 2 | 6 | all)
+        hipLaunchKernelGGL((vc_post_kernel<MQP, true, decltype(sp)::value>), grid, block, 0, st, d, b, params, no_g, no_ctr, bs_dev, pg);
+      }))
+    return;
   if (d.nq <= 2) hipLaunchKernelGGL((vc_post_kernel<2, true>), grid, block, 0, st, d, b, params, no_g, no_ctr, bs_dev, pg);
   else if (d.nq <= 6) hipLaunchKernelGGL((vc_post_kernel<6, true>), grid, block, 0, st, d, b, params, no_g, no_ctr, bs_dev, pg);
   else hipLaunchKernelGGL((vc_post_kernel<VC_MAXQ, true>), grid, block, 0, st, d, b, params, no_g, no_ctr, bs_dev, pg);

@@ -15,6 +15,7 @@
 #define VC_SPECK_TAIL2 1      // single rank, one launch behind K_main (vc_tail2_kernel)
 #define VC_SPECK_MERGED 2     // single rank, tutorial flow (vc_tail_merged_kernel)
 #define VC_SPECK_SHARDED 4    // rank of a sharded run (vc_tail_kernel phase A, vc_phase_b_kernel)
+#define VC_SPECK_PARTICLES 8  // single rank, Trace_ELBO(num_particles = K) from one call (vc_svi_run_particles: K_pre / K_post of all particles, K_fin + average + optimiser)
 
 struct VcSpecRow { const char* name; int kind; int mq; VcSig sig; };
 // clang-format off
