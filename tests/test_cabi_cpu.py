@@ -34,7 +34,7 @@ def test_struct_sizes_match_header_layout():
     mod, _ = _lib()
     assert C.sizeof(mod.vc_config) == 12 * 4 + 4 * 8 + 8 * 4
     assert C.sizeof(mod.vc_layout) == 8 * (4 + 2 * mod.VC_P_COUNT + 2 + 2 * mod.VC_E_COUNT)
-    assert C.sizeof(mod.vc_stats) == 4 * 8 + 2 * 4 + 96 + 2 * 8 + 4 * 4 + 4 * 4
+    assert C.sizeof(mod.vc_stats) == 4 * 8 + 2 * 4 + 96 + 2 * 8 + 4 * 4 + 4 * 4 + 2 * 4 + 32      # (+ tail_spec, reserved2, tail_spec_name: round 5)
 
 
 def test_create_validates_and_reports_errors():
@@ -128,3 +128,34 @@ def test_tuning_is_data_not_environment(monkeypatch):
     # an ambient variable changes nothing by itself
     monkeypatch.setenv("VC_GPL", "4")
     assert Tuning() == Tuning.from_env({})
+
+
+def test_compiled_signature_rows_are_well_formed():
+    """csrc/vc_tail_spec_rows.inc (the configurations the small kernels are compiled for, printed by profiles/tools/print_signature.py):
+    27 ints per signature in the order of VC_SIG_FIELDS, launch kinds a bit set of {1, 2, 4, 8}, MQ one of the gene blocks' row bounds
+    and >= the row count nq, names unique, -1 (left open) only on the fields a "multi" row opens -- and a row that leaves pw_inline
+    open stands BEHIND every rank row (pw_inline = 0) it would otherwise shadow (vc_spec_match takes the first row that fits)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = open(os.path.join(root, "velocycle_amd", "csrc", "vc_common.h")).read()
+    block = common[common.index("#define VC_SIG_FIELDS(X)"):common.index("struct VcSig {")]
+    fields = re.findall(r"X\((\w+)\)", block) + ["cond"]
+    assert len(fields) == 27 and "#define VC_SIG_INTS 27" in common
+    rows = []
+    for line in open(os.path.join(root, "velocycle_amd", "csrc", "vc_tail_spec_rows.inc")):
+        m = re.match(r'\s*\{"(\w+)", (\d+), (\d+), \{(.*)\}\},', line)
+        if m:
+            vals = [int(x.rstrip("u")) for x in m.group(4).split(",")]
+            rows.append((m.group(1), int(m.group(2)), int(m.group(3)), dict(zip(fields, vals)), len(vals)))
+    assert len(rows) >= 6 and len({r[0] for r in rows}) == len(rows)
+    for name, kinds, mq, sig, n in rows:
+        assert n == 27 and 1 <= kinds <= 15 and mq in (2, 4, 6, 14) and mq >= sig["nq"] > 0, name
+        opened = {f for f, v in sig.items() if v == -1}
+        assert opened <= {"Nb", "Nx", "NW", "K", "pw_inline"}, (name, opened)
+        if opened:
+            assert sig["onehot"] == 1 and sig["with_dnu"] == 1, name
+        assert not (kinds & 4 and kinds & 3 and sig["pw_inline"] != 0), name        # a rank's kernels never take K_main's own partials
+    for i, (name, kinds, mq, sig, n) in enumerate(rows):
+        if sig["pw_inline"] == -1:
+            twin = dict(sig, pw_inline=0)
+            later = [r[0] for r in rows[i + 1:] if r[3] == twin]
+            assert not later, (name, "shadows", later)
