@@ -38,6 +38,11 @@ print(f"K_main (last launch of the run): first entry -> last exit {(mt3 - mt0) /
 NGB = ((NG + 63) // 64 * 64 + 255) // 256 * 256 // 64 if False else None
 s0 = w[0]
 live = s0[:, :, 0] > 0
+# (blocks that lead the grid as histogram blocks may hold kid-0 stamps of an EARLIER launch structure of the same run: the boot launches)
+_hist_lead = 0
+while _hist_lead < w.shape[1] and (w[1][_hist_lead, :, 7] > 0).any():
+    _hist_lead += 1
+live[:_hist_lead] = False
 z = s0[:, :, 0][live].min()
 print(f"K_main last exit -> first wave of the next launch: {(z - mt3) / 100:.2f} us")
 nblk = np.where(live.any(1))[0]
@@ -54,12 +59,17 @@ def show(tag, arr, sel, ks=range(8)):
 
 
 u[s0 <= 0] = -1e9
-gene = np.zeros_like(live); gene[:ngb] = True
+# (round 5: the histogram blocks lead the grid of the one-launch tail -- the gene blocks start behind them)
+lead = 0
+hist_blk = (w[1][:, :, 7] > 0).any(1)
+while lead < len(hist_blk) and hist_blk[lead]:
+    lead += 1
+gene = np.zeros_like(live); gene[lead:lead + ngb] = True
 show("gene blocks (all waves)", u, live & gene)
 for wv, role in ((0, "nu[0]"), (12, "shape_inv"), (13, "role 14"), (15, "role 13")):
-    r = np.zeros_like(live); r[:ngb, wv] = True
+    r = np.zeros_like(live); r[lead:lead + ngb, wv] = True
     show(f"gene wave {wv} ({role})", u, live & r)
-cell = np.zeros_like(live); cell[ngb:] = True
+cell = np.zeros_like(live); cell[lead + ngb:] = True
 show("cell blocks", u, live & cell)
 s1 = w[1]
 live1 = s1[:, :, 1] > 0

@@ -535,6 +535,7 @@ __device__ __forceinline__ void vc_hist_dense_block(const VcDims& d, const VcBuf
         for (int u = 0; u < UB; ++u) { const int j = j0 + 16 * u; c[u] = j < rows ? tabp[(size_t)j * 64] : 0.f; }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
+          if (j0 + 16 * u >= 256 && __builtin_amdgcn_ballot_w64(c[u] != 0.f) == 0ull) continue;      // (an empty level: see vc_hist_dense16_finish)
           const float t = r + (float)(j0 + 16 * u);
           al += (double)c[u] * (double)__builtin_amdgcn_logf(t);
           ad += (double)c[u] * (double)__builtin_amdgcn_rcpf(t);
@@ -556,81 +557,81 @@ __device__ __forceinline__ void vc_hist_dense_block(const VcDims& d, const VcBuf
   }
 }
 
-// The same for a block of exactly 16 waves (the 1024-thread launches: one-launch tail, phase B), in two halves so that the caller
-// can put its own work between the request and the use of the table rows: wave v owns slice v of the count axis; `issue`
-// requests its first 16 count levels of every matrix (nothing is consumed), `finish` -- once shape_inv of the lane's gene
-// is known -- adds them up (+ further levels of a block whose largest count exceeds 256), one barrier, and waves 0 / 1 add
-// the slices of matrix S / U in slice order.  Same sums as vc_hist_dense_block, bit for bit.
-// msel >= 0: this block evaluates matrix msel only (the one-launch tail gives every (gene block, matrix) a block of its own: the
-// evaluation is 16 waves of log / rcp / double arithmetic on ONE CU -- 5 us for two matrices -- beside idle CUs)
-struct VcHistPre { float c[2][16]; int rows[2], off[2]; };
-__device__ __forceinline__ void vc_hist_dense16_rows(const VcDims& d, const VcBufs& b, int gb, VcHistPre& h, int msel = -1) {
+// The same for a block of exactly 16 waves and ONE matrix (the one-launch tail: a block per (matrix, gene block) -- the evaluation is
+// 16 waves of log / rcp / double arithmetic on one CU, 5 us for two matrices, beside idle CUs), in two halves so that the caller can
+// put its own work between the request and the use of the table rows: wave v owns slice v of the count axis; `issue` requests its
+// first VC_HIST_PRE count levels (nothing is consumed: 640 levels of the table -- a second, dependent round trip for the levels
+// beyond 256 cost the blocks that have them 4.5 us at the end of the launch, round 5), `finish` -- once shape_inv of the lane's gene
+// is known -- adds them up in increasing order (+ further levels of a block whose largest count exceeds 639), one barrier, and
+// wave 0 adds the slices in slice order.  A level beyond 256 at which none of the block's 64 genes has a cell is skipped by the whole
+// wave (its terms are 0 x finite).  Same sums as vc_hist_dense_block, bit for bit.
+#define VC_HIST_PRE 40
+struct VcHistPre { float c[VC_HIST_PRE]; int rows, off, m; };
+__device__ __forceinline__ void vc_hist_dense16_rows(const VcDims& d, const VcBufs& b, int gb, VcHistPre& h, int m) {
   const int nblk = d.Ng_pad / 64, nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const bool used = m < nm && (msel < 0 || m == msel) && ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U));
-    h.rows[m] = used ? b.hc_rows[m * nblk + gb] : 0;
-    h.off[m] = used ? b.hc_off[m * nblk + gb] : 0;
-  }
+  const bool used = m < nm && ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U));
+  h.m = m;
+  h.rows = used ? b.hc_rows[m * nblk + gb] : 0;
+  h.off = used ? b.hc_off[m * nblk + gb] : 0;
 }
-__device__ __forceinline__ void vc_hist_dense16_issue(const VcDims& d, const VcBufs& b, VcHistPre& h, int msel = -1) {
+__device__ __forceinline__ void vc_hist_dense16_issue(const VcDims& d, const VcBufs& b, VcHistPre& h) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* __restrict__ tabp = b.HC + (size_t)h.off * 64 + lane;
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    if (msel >= 0 && m != msel) {           // (uniform per block)
+  for (int u = 0; u < 16; ++u) {                 // (no branch around a load: a clamped row, the value dropped afterwards)
+    const int j = wv + 16 * u, jc = j < h.rows ? j : (h.rows > 0 ? h.rows - 1 : 0);
+    const float x = tabp[(size_t)jc * 64];
+    h.c[u] = j < h.rows ? x : 0.f;
+  }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) h.c[m][u] = 0.f;
-      continue;
-    }
-    const float* __restrict__ tabp = b.HC + (size_t)h.off[m] * 64 + lane;
+  for (int u = 16; u < VC_HIST_PRE; ++u) h.c[u] = 0.f;
+  if (h.rows > 256) {                            // (uniform per block: only a block with counts beyond 255 asks for more)
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {        // (no branch around a load: a clamped row, the value dropped afterwards)
-      const int j = wv + 16 * u, jc = j < h.rows[m] ? j : (h.rows[m] > 0 ? h.rows[m] - 1 : 0);
+    for (int u = 16; u < VC_HIST_PRE; ++u) {
+      const int j = wv + 16 * u, jc = j < h.rows ? j : h.rows - 1;
       const float x = tabp[(size_t)jc * 64];
-      h.c[m][u] = j < h.rows[m] ? x : 0.f;
+      h.c[u] = j < h.rows ? x : 0.f;
     }
   }
 }
 __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const VcBufs& b, int gb, float si, int half, const VcHistPre& h,
-                                                       double* sm /* 4096 doubles */, int msel = -1) {
+                                                       double* sm /* 2048 doubles */) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
   const int g = gb * 64 + lane;
   const float r = 1.0f / si;
+  double al = 0.0, ad = 0.0;
+  {
+    const float* __restrict__ tabp = b.HC + (size_t)h.off * 64 + lane;
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    double al = 0.0, ad = 0.0;
-    if (m < nm && (msel < 0 || m == msel)) {
-      const float* __restrict__ tabp = b.HC + (size_t)h.off[m] * 64 + lane;
-      constexpr int UB = 8;            // (the association of vc_hist_dense_block: levels in increasing order, one by one)
+    for (int u = 0; u < VC_HIST_PRE; ++u) {      // (the association of vc_hist_dense_block: levels in increasing order, one by one)
+      if (u >= 16 && (h.rows <= 256 || __builtin_amdgcn_ballot_w64(h.c[u] != 0.f) == 0ull)) continue;
+      const float t = r + (float)(wv + 16 * u);
+      al += (double)h.c[u] * (double)__builtin_amdgcn_logf(t);
+      ad += (double)h.c[u] * (double)__builtin_amdgcn_rcpf(t);
+    }
+    constexpr int UT = 32;
+    for (int j0 = wv + 16 * VC_HIST_PRE; j0 < h.rows; j0 += 16 * UT) {
+      float c[UT];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const float t = r + (float)(wv + 16 * u);
-        al += (double)h.c[m][u] * (double)__builtin_amdgcn_logf(t);
-        ad += (double)h.c[m][u] * (double)__builtin_amdgcn_rcpf(t);
-      }
-      for (int j0 = wv + 256; j0 < h.rows[m]; j0 += 16 * UB) {
-        float c[UB];
+      for (int u = 0; u < UT; ++u) { const int j = j0 + 16 * u; c[u] = j < h.rows ? tabp[(size_t)j * 64] : 0.f; }
 #pragma unroll
-        for (int u = 0; u < UB; ++u) { const int j = j0 + 16 * u; c[u] = j < h.rows[m] ? tabp[(size_t)j * 64] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const float t = r + (float)(j0 + 16 * u);
-          al += (double)c[u] * (double)__builtin_amdgcn_logf(t);
-          ad += (double)c[u] * (double)__builtin_amdgcn_rcpf(t);
-        }
+      for (int u = 0; u < UT; ++u) {
+        if (__builtin_amdgcn_ballot_w64(c[u] != 0.f) == 0ull) continue;
+        const float t = r + (float)(j0 + 16 * u);
+        al += (double)c[u] * (double)__builtin_amdgcn_logf(t);
+        ad += (double)c[u] * (double)__builtin_amdgcn_rcpf(t);
       }
     }
-    sm[((m * 16 + wv) * 2 + 0) * 64 + lane] = al;
-    sm[((m * 16 + wv) * 2 + 1) * 64 + lane] = ad;
   }
+  sm[(wv * 2 + 0) * 64 + lane] = al;
+  sm[(wv * 2 + 1) * 64 + lane] = ad;
   __syncthreads();
-  if (wv < nm && (msel < 0 || wv == msel) && g < d.Ng) {
-    const int m = wv;
+  if (wv == 0 && h.m < nm && g < d.Ng) {
     double hl = 0.0, hd = 0.0;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { hl += sm[((m * 16 + v) * 2 + 0) * 64 + lane]; hd += sm[((m * 16 + v) * 2 + 1) * 64 + lane]; }
-    const size_t t = (size_t)half * b.n_tasks + (size_t)nm * g + m;
+    for (int v = 0; v < 16; ++v) { hl += sm[(v * 2 + 0) * 64 + lane]; hd += sm[(v * 2 + 1) * 64 + lane]; }
+    const size_t t = (size_t)half * b.n_tasks + (size_t)nm * g + h.m;
     b.HL[t] = hl * 0.6931471805599453094;
     b.HD[t] = hd;
   }

@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
         if (ch0 + u * VC_PG_WAVES < d.n_chunks) acc += v[u];
     }
   }
-  vc_hist_dense16_issue(d, b, hp, msel);       // the table rows travel while the update is re-derived
+  vc_hist_dense16_issue(d, b, hp);             // the table rows travel while the update is re-derived
   const float* sis = b.SIS + (size_t)((s - 1) & 1) * 4 * NP + g;
   const float p0 = sis[0], si = live ? sis[3 * NP] : 1.f;
   float mm = sis[NP], vv = sis[2 * NP];
@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
   const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1],
                                 vc_wd_at(a.wd, a.frozen, d.poff[VC_P_SHAPE_INV_ULOCS] + (live ? g : 0)));
   VC_WSTAMP(1, 6);
-  vc_hist_dense16_finish(d, b, gb, live ? expf(np) : 1.f, (int)(s & 1), hp, sm_hd, msel);
+  vc_hist_dense16_finish(d, b, gb, live ? expf(np) : 1.f, (int)(s & 1), hp, sm_hd);
   VC_WSTAMP(1, 7);
 }
 
@@ -1079,12 +1079,12 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
       if (TAIL2) {                                 // (compiled into the one-launch tail only: 16-wave blocks, update re-derived)
         // one block per (matrix, gene block): vc_launch_tail2 asks for nm x Ng_pad / 64 of them
         const int nblk = d.Ng_pad / 64, nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
-        const int msel = nm > 1 ? xblk / nblk : -1, gb = nm > 1 ? xblk % nblk : xblk;
+        const int msel = nm > 1 ? xblk / nblk : 0, gb = nm > 1 ? xblk % nblk : xblk;
         if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense(d, b, s, a, gb, sm_hd, msel); return; }
         VcHistPre hp;
         vc_hist_dense16_rows(d, b, gb, hp, msel);
-        vc_hist_dense16_issue(d, b, hp, msel);
-        vc_hist_dense16_finish(d, b, gb, vc_hist_si(d, b, P, 0, gb * 64 + lane), half, hp, sm_hd, msel);
+        vc_hist_dense16_issue(d, b, hp);
+        vc_hist_dense16_finish(d, b, gb, vc_hist_si(d, b, P, 0, gb * 64 + lane), half, hp, sm_hd);
         return;
       }
       const int g = xblk * 64 + lane;
@@ -1579,21 +1579,28 @@ __global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const Vc
   VcOpt o;
   o.step_size = b.step_size[0];
   o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd; o.frozen = a.frozen;
-#ifdef VC_DBG_SKIP      // measurement aid (scratch/skip_ab.sh): which kind of block bounds the launch -- bit 0 gene, 1 cell, 2 loss / histogram / eps
-  if ((VC_DBG_SKIP & 1) && (int)blockIdx.x < d.nb_post_gene) return;
-  if ((VC_DBG_SKIP & 2) && (int)blockIdx.x >= d.nb_post_gene && (int)blockIdx.x < d.nb_post_gene + d.nb_tail_cell) return;
-  if ((VC_DBG_SKIP & 4) && (int)blockIdx.x >= d.nb_post_gene + d.nb_tail_cell) return;
+  // Block order = dispatch order: the histogram blocks first (with the signatures compiled in they carry the longest chain of the
+  // launch: a block whose counts go beyond 255 ends ~3 us behind the gene blocks), then gene blocks, cell blocks, the loss block, eps
+  int bid = blockIdx.x, kind;      // kind: 0 gene, 1 cell, 2 loss / histogram / eps
+  int xblk = 0;                    // index among the extras as vc_omega_extra_block counts them: 0 loss, 1 .. nb_hist histogram, then eps
+#ifdef VC_HIST_LAST       // (A/B: the order of rounds 4 / early 5 -- histogram blocks behind the loss block)
+  const int lead = 0;
+#else
+  const int lead = nb_hist;
 #endif
-  if ((int)blockIdx.x < d.nb_post_gene) {
-    vc_tail_gene_block<MQ, VC_PH_ALL>(d, b, P, G, a.m, a.v, a.header, blockIdx.x, s, seed, o, 0, VcXb{});
-    return;
+  if (bid < lead) { kind = 2; xblk = 1 + bid; }
+  else {
+    bid -= lead;
+    if (bid < d.nb_post_gene) kind = 0;
+    else if (bid < d.nb_post_gene + d.nb_tail_cell) { kind = 1; bid -= d.nb_post_gene; }
+    else { kind = 2; xblk = bid - d.nb_post_gene - d.nb_tail_cell; if (xblk > 0) xblk += lead; }
   }
-  if ((int)blockIdx.x < d.nb_post_gene + d.nb_tail_cell) {
-    vc_tail_cell_block<VC_PH_ALL, true>(d, b, P, G, a.m, a.v, a.header, blockIdx.x - d.nb_post_gene, s, seed, o, 0, VcXb{});
-    return;
-  }
-  vc_omega_extra_block<true>(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, blockIdx.x - d.nb_post_gene - d.nb_tail_cell,
-                             VC_PH_ALL, VcXb{}, true, 1024);
+#ifdef VC_DBG_SKIP      // measurement aid (profiles/r05_tail2_skip_variants.txt): which kind of block bounds the launch -- bit 0 gene, 1 cell, 2 the rest
+  if ((VC_DBG_SKIP >> kind) & 1) return;
+#endif
+  if (kind == 0) vc_tail_gene_block<MQ, VC_PH_ALL>(d, b, P, G, a.m, a.v, a.header, bid, s, seed, o, 0, VcXb{});
+  else if (kind == 1) vc_tail_cell_block<VC_PH_ALL, true>(d, b, P, G, a.m, a.v, a.header, bid, s, seed, o, 0, VcXb{});
+  else vc_omega_extra_block<true>(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, xblk, VC_PH_ALL, VcXb{}, true, 1024);
 }
 
 void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
