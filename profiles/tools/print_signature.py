@@ -65,11 +65,12 @@ NC, NG = 50000, 2000
 # ranks of a sharded run first: a single-rank "multi" row leaves pw_inline open and would otherwise shadow its rank row
 for world in (8, 1):
     tag = "_rank" if world > 1 else ""
-    add("vjoint" + tag, make_velocity_spec(NC, NG, "vjoint", 1, 1, seed=0, device=dev), world)
-    add("vcond" + tag, make_velocity_spec(NC, NG, "vcond", 1, 1, seed=0, device=dev), world)
+    # velocity: mean-field / LRMN (the reference's default model_type) guide x nothing conditioned / the tutorials' conditioning
+    for name, mode in (("vjoint", "vjoint"), ("vcond", "vcond"), ("vjoint_lrmn", "vjoint_lrmn"), ("vcond_mf", "vcond_mf")):
+        add(name + tag, make_velocity_spec(NC, NG, mode, 1, 1, seed=0, device=dev), world)
     add("phase" + tag, make_phase_spec(NC, NG, seed=0, device=dev), world)
-    add("vjoint_multi" + tag, make_velocity_spec(NC // 2, NG, "vjoint", 2, 1, seed=0, device=dev), world, multi=True)
-    add("vcond_multi" + tag, make_velocity_spec(NC // 2, NG, "vcond", 2, 1, seed=0, device=dev), world, multi=True)
+    for name, mode in (("vjoint", "vjoint"), ("vcond", "vcond"), ("vjoint_lrmn", "vjoint_lrmn"), ("vcond_mf", "vcond_mf")):
+        add(name + "_multi" + tag, make_velocity_spec(NC // 2, NG, mode, 2, 1, seed=0, device=dev), world, multi=True)
     add("phase_multi" + tag, make_phase_spec(NC // 2, NG, seed=0, device=dev, n_batches=2), world, multi=True)
 print("// rows of VC_SPECS (vc_tail_spec.h): {name, kinds of launch, MQ of the gene blocks, signature} -- printed by profiles/tools/print_signature.py")
 print("// signature = " + " ".join(FIELDS) + "; -1 = left open")

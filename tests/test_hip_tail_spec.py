@@ -15,11 +15,15 @@ pytestmark = pytest.mark.gpu
 
 ROWS = {            # name of the row a workload must select: (builder, mode, samples)
     "vjoint": ("vel", "vjoint", 1), "vcond": ("vel", "vcond", 1), "phase": ("phase", None, 1),
+    "vjoint_lrmn": ("vel", "vjoint_lrmn", 1), "vcond_mf": ("vel", "vcond_mf", 1),
     # the "multi" rows leave the number of batches / conditions open: two and three samples run the same instantiation
     "vjoint_multi": ("vel", "vjoint", 2), "vcond_multi": ("vel", "vcond", 2), "phase_multi": ("phase", None, 3),
+    "vjoint_lrmn_multi": ("vel", "vjoint_lrmn", 2), "vcond_mf_multi": ("vel", "vcond_mf", 2),
 }
 RANK_ROWS = {"vjoint_rank": ("vel", "vjoint", 1), "vcond_rank": ("vel", "vcond", 1), "phase": ("phase", None, 1),
-             "vjoint_multi_rank": ("vel", "vjoint", 2), "vcond_multi_rank": ("vel", "vcond", 2), "phase_multi": ("phase", None, 2)}
+             "vjoint_lrmn_rank": ("vel", "vjoint_lrmn", 1), "vcond_mf_rank": ("vel", "vcond_mf", 1),
+             "vjoint_multi_rank": ("vel", "vjoint", 2), "vcond_multi_rank": ("vel", "vcond", 2), "phase_multi": ("phase", None, 2),
+             "vjoint_lrmn_multi_rank": ("vel", "vjoint_lrmn", 2), "vcond_mf_multi_rank": ("vel", "vcond_mf", 2)}
 
 
 def _spec(kind, mode, ncond, nc=2100, ng=260):
@@ -63,7 +67,7 @@ def test_sharded_rank_specialisation_is_bit_identical(row):
         r.e.close()
 
 
-@pytest.mark.parametrize("row", ["vjoint", "vcond", "phase", "vjoint_multi"])
+@pytest.mark.parametrize("row", ["vjoint", "vcond", "phase", "vjoint_multi", "vjoint_lrmn"])
 def test_particle_step_specialisation_is_bit_identical(row):
     """vc_svi_run_particles (K_pre / K_post of all particles, K_fin + average + optimiser: K + 3 launches) in the instantiations compiled
     for the row against the run-time-flag kernels: K = 3, eight steps, parameters / moments / losses bit for bit."""
@@ -85,10 +89,10 @@ def test_particle_step_specialisation_is_bit_identical(row):
     assert a[4] == b[4] == (True, -1, 0) and len(a[3]) == 8
 
 
-@pytest.mark.parametrize("case", ["vel_mf_poisson", "vel_lrmn_joint", "phase_poisson"])
+@pytest.mark.parametrize("case", ["vel_mf_poisson", "vel_mf_lognormal", "phase_poisson"])
 def test_a_signature_without_a_row_runs_the_generic_kernels(case):
-    """A Poisson noise model, the LRMN guide with nothing conditioned: configurations the library has no compiled row for keep the
-    run-time-flag kernels (and say so); the signature is 27 ints."""
+    """A Poisson or Lognormal noise model: configurations the library has no compiled row for keep the run-time-flag kernels (and say
+    so); the signature is 27 ints."""
     import os
     from tests import helpers as H
     from velocycle_amd.engine import HipEngine

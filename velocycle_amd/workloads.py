@@ -16,7 +16,8 @@ from .spec import ModelSpec
 def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, seed=0, device="cpu",
                        noisemodel="NegativeBinomial", concentration=5.0, sim=None) -> ModelSpec:
     """mode: "vjoint" (mean-field guide, nothing conditioned), "vcond" (default LRMN guide conditioned
-    on ϕxy, ν, shape_inv [, Δν] like the tutorials), "vcond_mf" (same conditioning, mean-field).
+    on ϕxy, ν, shape_inv [, Δν] like the tutorials), "vcond_mf" (same conditioning, mean-field), "vjoint_lrmn" (LRMN guide,
+    nothing conditioned: the reference's default `model_type` without `condition_on`).
     `sim`: a stored output of `simulate_counts` (the sampling kernels of torch are not bit-reproducible across hosts, so
     fixtures that must describe the SAME data on every machine carry the simulated counts: tests/golden/oracle_fit_data_*)."""
     omegas = (0.4, 0.3, 0.35, 0.25, 0.45, 0.2, 0.38, 0.28)[:n_conditions]
