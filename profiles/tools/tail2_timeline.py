@@ -2,7 +2,7 @@
 """Per-wave wall-clock timeline of the step's second launch (vc_tail2_kernel, or K_tail + K_omega with VC_TAIL2=0), from the
 VC_DBG_TIMES build:
   make -C velocycle_amd/csrc BUILD=build_dbg OUT=../../scratch/libs/dbg.so EXTRA=-DVC_DBG_TIMES
-  VC_LIB_PATH=$PWD/scratch/libs/dbg.so python profiles/tools/tail2_timeline.py [vjoint|phase|vcond] [cells] [genes]
+  VC_LIB_PATH=$PWD/scratch/libs/dbg.so python profiles/tools/tail2_timeline.py [vjoint|phase|vcond] [cells] [genes] [samples]
 Stamps are s_memrealtime (100 MHz): 1 tick = 10 ns.  Printed: K_main's span, the gap to the first wave of the next launch, when
 each stage of the gene / cell blocks is reached (relative to that launch's first wave entry; median / max over waves), the
 stages of the nu_omega chain inside the cell blocks, the last stamp of the launch, and the gap back to K_main."""
@@ -19,7 +19,9 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "vjoint"
 NC = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 NG = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 dev = torch.device("cuda:0")
-spec = make_phase_spec(NC, NG, seed=0, device=dev) if mode == "phase" else make_velocity_spec(NC, NG, mode, 1, 1, seed=0, device=dev)
+NCOND = int(sys.argv[4]) if len(sys.argv) > 4 else 1       # samples (conditions = batches): NC cells in total
+spec = (make_phase_spec(NC // NCOND, NG, seed=0, device=dev, n_batches=NCOND) if mode == "phase"
+        else make_velocity_spec(NC // NCOND, NG, mode, NCOND, 1, seed=0, device=dev))
 eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
 nwg = eng.stats["main_grid"]
 print(mode, NC, NG, eng.stats["main_kernel"], "launches per step", eng.stats["launches_per_step"], "pw_inline", eng.stats["pw_inline"])

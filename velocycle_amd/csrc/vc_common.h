@@ -257,6 +257,33 @@ __device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c
 // onehot: d loglik / d dnu[q, g] = the sum of the constant harmonic's partial row (GO row 0) over the workgroups of batch q of the
 // likelihood kernel's gene block that holds gene g -- chunks [c0, c1) of that gene block, added in chunk order (one fixed
 // association for every caller: K_post, K_tail, phase A), 32 chunks requested per trip
+// The same sum in two halves (the one-launch tail's gene blocks): `issue` only REQUESTS the first 32 chunk rows of the range (the
+// range itself was fetched at the top of the block), `finish` adds them in chunk order and takes further trips for a longer range --
+// the same association as vc_dnu_range_sum.
+#define VC_DNU_PRE 32
+struct VcDnuPre { float v[VC_DNU_PRE]; int c0, c1; };
+__device__ __forceinline__ void vc_dnu_range_issue(const VcDims& d, const VcBufs& b, int g, VcDnuPre& h) {
+  const float* __restrict__ go = b.GO + g;
+  const size_t stride = (size_t)d.nq * d.Ng_pad;
+#pragma unroll
+  for (int u = 0; u < VC_DNU_PRE; ++u)        // (an EMPTY range -- a batch without cells on this rank -- may start at n_chunks: row 0 instead)
+    h.v[u] = go[(size_t)(h.c0 + u < h.c1 ? h.c0 + u : (h.c0 < h.c1 ? h.c0 : 0)) * stride];
+}
+__device__ __forceinline__ float vc_dnu_range_finish(const VcDims& d, const VcBufs& b, int g, const VcDnuPre& h) {
+  const float* __restrict__ go = b.GO + g;
+  const size_t stride = (size_t)d.nq * d.Ng_pad;
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < VC_DNU_PRE; ++u) if (h.c0 + u < h.c1) acc += h.v[u];
+  for (int ch0 = h.c0 + VC_DNU_PRE; ch0 < h.c1; ch0 += VC_DNU_PRE) {
+    float v[VC_DNU_PRE];
+#pragma unroll
+    for (int u = 0; u < VC_DNU_PRE; ++u) v[u] = go[(size_t)(ch0 + u < h.c1 ? ch0 + u : ch0) * stride];
+#pragma unroll
+    for (int u = 0; u < VC_DNU_PRE; ++u) if (ch0 + u < h.c1) acc += v[u];
+  }
+  return acc;
+}
 __device__ __forceinline__ float vc_dnu_range_sum(const VcDims& d, const VcBufs& b, int g, int q) {
   const int gbm = g / d.gbw;
   const int c0 = b.bat_chunk[gbm * (d.Nb + 1) + q], c1 = b.bat_chunk[gbm * (d.Nb + 1) + q + 1];

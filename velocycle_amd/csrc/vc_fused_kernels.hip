@@ -243,9 +243,26 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     }
   }
 
+  // one-hot batches: the chunk range of this wave's first batch (a dependent fetch in front of its rows: asked for with the rest)
+  VcDnuPre dnu_pre;
+  const bool dnu_pre_on = chain && r_dnu1 && live && role - Nh < d.Nb && !CND(VC_SITE_DNU);
+  dnu_pre.c0 = 0; dnu_pre.c1 = 0;
+  float dq_p = 0.f, dq_m = 0.f, dq_v = 0.f, dq_lat = 0.f;      // ... and that batch's parameter, moments and sample (as the roles above)
+  const bool dq_on = r_dnu1 && live && role - Nh < d.Nb;
+  if (dq_on) {
+    const long long jq0 = (long long)(role - Nh) * d.Ng + g;
+    const int po0 = (int)(d.poff[VC_P_DNU_LOCS] + jq0);
+    dq_p = P[po0];
+    if (upd) { dq_m = Mm[po0 - header]; dq_v = Vv[po0 - header]; }
+    if (chain && !CND(VC_SITE_DNU)) dq_lat = b.lat[VC_SITE_DNU][jq0];
+  }
+  if (dnu_pre_on) {
+    const int gbm = g / d.gbw;
+    dnu_pre.c0 = b.bat_chunk[gbm * (d.Nb + 1) + role - Nh];
+    dnu_pre.c1 = b.bat_chunk[gbm * (d.Nb + 1) + role - Nh + 1];
+  }
   VC_WSTAMP(0, 1);
   double loss_post = 0.0;
-  float dnu_first = 0.f;
   if (chain) {
     // ---- second-stage reduction of K_main's gene-level partials (as K_post) ------------------------------------
     constexpr int U = MQ <= 2 ? 16 : (MQ <= 4 ? 12 : (MQ <= 6 ? 8 : 2));     // chunk groups in flight per wave (register budget: 128)
@@ -270,9 +287,10 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     }
 #pragma unroll
     for (int q = 0; q < MQ; ++q) sm[wave][q][lane] = acc[q];
-    // one-hot batches: the first batch of this wave's loop further down is summed HERE, in front of the barrier -- it needs K_main's
-    // rows only, and its round trips (the batch's chunk range, then the rows) otherwise start when every other role is done
-    if (r_dnu1 && live && role - Nh < d.Nb && !CND(VC_SITE_DNU)) dnu_first = vc_dnu_range_sum(d, b, g, role - Nh);
+    // one-hot batches: the rows of the first batch of this wave's loop further down are REQUESTED here (the batch's chunk range was
+    // fetched at the top), nothing is consumed: the barrier is not held up, and the rows are there when the loop wants them
+    // (summing them in front of the barrier held every role of the block back by 3 us: profiles/r05_tail_spec.md)
+    if (dnu_pre_on) vc_dnu_range_issue(d, b, g, dnu_pre);
     // Everything requested at the top of the block must have ARRIVED before this barrier: several roles read values another role of
     // the same gene rewrites behind it (the LRMN cov roles read log-scale and rho of the core role's parameters, every velocity role
     // reads gamma and the samples of log gamma / log beta) -- correct only if the read happens in front of the barrier.  `P` and the
@@ -387,15 +405,18 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       const long long jq = (long long)q * d.Ng + g;
       const int po = (int)(d.poff[VC_P_DNU_LOCS] + jq);
       const float sd = vel ? 0.01f : b.sd_dnu[jq];
-      float p = P[po];
+      const bool first = q == role - Nh;          // (its inputs were requested at the top of the block)
+      float p = first ? dq_p : P[po];
       if (!boot) {
         float gq = 0.f;
         if (phase == VC_PH_B) gq = xb.x[po];                           // the gradient summed over ranks
-        else if (!CND(VC_SITE_DNU)) gq = -((q == role - Nh ? dnu_first : vc_dnu_range_sum(d, b, g, q)) - rw * b.lat[VC_SITE_DNU][jq] / (sd * sd));
+        else if (!CND(VC_SITE_DNU))
+          gq = -(((dnu_pre_on && first) ? vc_dnu_range_finish(d, b, g, dnu_pre) : vc_dnu_range_sum(d, b, g, q)) -
+                 rw * (first ? dq_lat : b.lat[VC_SITE_DNU][jq]) / (sd * sd));
         if (phase == VC_PH_A) xb.x[po] = gq;
         else {
           G[po] = gq;
-          float mm = Mm[po - header], vv = Vv[po - header];
+          float mm = first ? dq_m : Mm[po - header], vv = first ? dq_v : Vv[po - header];
           p = vc_adam_elem(p, gq, mm, vv, o.step_size, o.b1, o.b2, o.eps, o.clip, o.c2, vc_wd_at(o.wd, o.frozen, po));
           Mm[po - header] = mm; Vv[po - header] = vv; P[po] = p;
         }
@@ -1408,6 +1429,32 @@ __device__ __forceinline__ void vc_nuw_wave(const VcDims& d, const VcBufs& b, fl
   const float* __restrict__ PWs = b.PWM;
   const int n_pw = d.n_main_wg, pw_ld = d.pw_inline, nw = d.NW;
   VC_WSTAMP(1, 1);
+  if (n_pw <= 64 * 8) {
+    // up to 512 rows (the 8-genes-per-lane kernels' grid): both halves of an 8-float row are requested before anything is added -- two
+    // samples (6 coefficients) otherwise paid a second, dependent round trip; every coefficient still adds its rows in the same order
+    constexpr int R = 8;
+    float4 raw[2][R];
+    const bool two = nw > 4;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {                       // no branch around a load: a clamped row, the value dropped afterwards
+      const int i = lane + 64 * k, ic = i < n_pw ? i : 0;
+      raw[0][k] = *reinterpret_cast<const float4*>(PWs + (size_t)ic * pw_ld);
+      raw[1][k] = *reinterpret_cast<const float4*>(PWs + (size_t)ic * pw_ld + (two ? 4 : 0));
+    }
+    double u[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      if (lane + 64 * k < n_pw) {
+        u[0] += (double)raw[0][k].x; u[1] += (double)raw[0][k].y; u[2] += (double)raw[0][k].z; u[3] += (double)raw[0][k].w;
+        u[4] += (double)raw[1][k].x; u[5] += (double)raw[1][k].y; u[6] += (double)raw[1][k].z; u[7] += (double)raw[1][k].w;
+      }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q >= 4 && !two) break;
+      const double r = vc_wave_sum_d63(u[q]);
+      if (lane == 63 && q < nw) sh.up[q] = (float)r;
+    }
+  } else
   for (int j0 = 0; j0 < nw; j0 += 4) {
     double u[4] = {0.0, 0.0, 0.0, 0.0};
     if (n_pw <= 64 * VC_NUW_RAW) {
