@@ -94,7 +94,9 @@ class _FitBase:
         process_group of this engine.  loss_every = k > 1 is an opt-in that is NOT in the reference: only every k-th step forms
         the loss (`losses` holds NaN in between), the others run a gradient-only likelihood kernel -- NB noise, perf mode, one
         rank; + 23 % steps/s for the velocity stage of the tutorial flow (phases, nu, delta nu, shape_inv conditioned), + 4-7 % for
-        the models that learn shape_inv."""
+        the models that learn shape_inv.  tuning: a `velocycle_amd.tuning.Tuning` (engine knobs as DATA: the library reads no
+        environment variable); None = the measured defaults.  The engine is built by the first fit() and kept: a later call with
+        another Tuning raises."""
         self._warn_sizes()
         import time
         t_start = time.perf_counter()
