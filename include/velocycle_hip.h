@@ -42,7 +42,10 @@
 extern "C" {
 #endif
 
-#define VC_ABI_VERSION 1
+/* 2 (round 6): vc_stats ends with onehot_batches, tail_spec, tail_spec_matched, tail_spec_name[32] (a consumer built against
+ * version 1 would have its smaller vc_stats overrun by vc_get_stats: vc_create refuses it); vc_tuning, vc_set_tuning / vc_get_tuning,
+ * vc_dbg_signature, vc_set_optimizer / vc_adam_update exist. */
+#define VC_ABI_VERSION 2
 
 /* return codes */
 #define VC_OK 0
@@ -198,9 +201,11 @@ typedef struct vc_stats {
                                      fast set (H > 3, > 4 batches, LRMN rank > 8, > 64 angular-speed coefficients) */
   int32_t onehot_batches;         /* n > 0: the batch design matrix Db is one-hot, its n batch offsets are folded into the constant
                                      harmonic per workgroup of the likelihood kernel (the kernel's NB is 0: nothing per cell) */
-  int32_t tail_spec;              /* > 0: the small kernels of the fused steps run in the instantiation compiled for this
-                                     configuration (row of csrc/vc_tail_spec_rows.inc, name in tail_spec_name); 0: run-time flags */
-  int32_t reserved2;
+  int32_t tail_spec;              /* > 0: the small kernels of this engine's fused steps (vc_svi_run_fused on one rank, vc_svi_run_sharded
+                                     on a shard) RUN in the instantiation compiled for this configuration (row of
+                                     csrc/vc_tail_spec_rows.inc, name in tail_spec_name); 0: run-time flags */
+  int32_t tail_spec_matched;      /* the row the configuration's signature matched, whether or not that row is compiled for the launch
+                                     structure in use (e.g. a "*_rank" row matched by a single-rank engine kept at three launches) */
   char tail_spec_name[32];
 } vc_stats;
 

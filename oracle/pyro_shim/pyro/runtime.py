@@ -42,6 +42,11 @@ class ParamStore:
     def unconstrained(self, name):
         return self._uncon[name]
 
+    def named_parameters(self):
+        """pyro-ppl 1.8.6 params/param_store.py ParamStoreDict.named_parameters: (name, UNCONSTRAINED leaf) pairs -- the one
+        accessor the fixture generators use, so that they read the real library's store the same way (oracle/ref_loader.py)."""
+        return self._uncon.items()
+
     def __getitem__(self, name):
         return self.get(name)
 

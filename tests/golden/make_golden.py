@@ -13,7 +13,14 @@ eps stream, and the reference's outputs (losses, gradients, fitted parameters, p
 While generating, every case is also evaluated with the oracle restatement (oracle/velocycle_oracle.py)
 and the script ABORTS if the two disagree -- this is what pins the oracle.
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [--real-pyro | --shim] [--check] [--continue | --particles | <case> ...]
+
+  --real-pyro   run the reference on the installed pyro-ppl 1.8.x instead of oracle/pyro_shim (error if it is not importable);
+                without a flag the real library is used whenever it is there (oracle/ref_loader.py)
+  --check       write NOTHING: regenerate every fixture in memory and diff it against the committed .npz (the tolerances of
+                check()); exit status 1 on any disagreement.  `--check --real-pyro` is the one command that pins the Pyro
+                boundary (Trace_ELBO, ClippedAdam, plate, poutine.condition / block) for whoever has the library; on the shim
+                it proves that the committed fixtures are what this script produces.
 """
 import os
 import sys
@@ -25,9 +32,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 OUT = os.path.dirname(os.path.abspath(__file__))
 
-from oracle.ref_loader import load_reference          # noqa: E402
-vc = load_reference()
-import pyro                                           # noqa: E402  (the shim)
+from oracle import ref_loader                          # noqa: E402
+ARGS = [a for a in sys.argv[1:] if a not in ("--real-pyro", "--shim", "--check")] if __name__ == "__main__" else []
+CHECK = __name__ == "__main__" and "--check" in sys.argv[1:]
+_backend = "auto"
+if __name__ == "__main__" and "--real-pyro" in sys.argv[1:]:
+    _backend = "real"
+if __name__ == "__main__" and "--shim" in sys.argv[1:]:
+    _backend = "shim"
+vc = ref_loader.load_reference(_backend)
+import pyro                                           # noqa: E402  (the real library or the shim: ref_loader.BACKEND)
 from oracle import velocycle_oracle as orc            # noqa: E402
 from velocycle_amd.simulate import simulate_counts    # noqa: E402
 from velocycle_amd.anndata_lite import AnnDataLite    # noqa: E402
@@ -66,11 +80,48 @@ def build_inputs(Nc, Ng, H, n_batches, seed):
     return d, ad, cyc, ph, Db
 
 
+MISMATCH = []          # --check: what differed from the committed fixtures
+
+
+def save(fname, out):
+    """Writes the fixture -- or, with --check, holds the freshly generated arrays against the committed file: float arrays within
+    the tolerances check() uses for oracle == reference (2e-4 relative / absolute, the absolute part scaled by the block's
+    largest element), everything else exactly."""
+    path = os.path.join(OUT, fname)
+    if not CHECK:
+        np.savez_compressed(path, **out)
+        return
+    if not os.path.exists(path):
+        MISMATCH.append(f"{fname}: no committed fixture")
+        return
+    z = np.load(path, allow_pickle=False)
+    new = {k: np.asarray(v) for k, v in out.items()}
+    for k in sorted(set(z.files) | set(new)):
+        if k not in z.files or k not in new:
+            MISMATCH.append(f"{fname}: key {k} only in the {'regenerated' if k in new else 'committed'} fixture")
+            continue
+        a, b = new[k], z[k]
+        if a.shape != b.shape:
+            MISMATCH.append(f"{fname}: {k} shape {a.shape} != committed {b.shape}")
+        elif a.dtype.kind in "fc" and b.dtype.kind in "fc":
+            a64, b64 = a.astype(np.float64), b.astype(np.float64)
+            fin = np.isfinite(a64) & np.isfinite(b64)
+            scale = np.abs(b64[fin]).max() if fin.any() else 0.0
+            if not np.array_equal(np.isfinite(a64), np.isfinite(b64)) or \
+                    not np.allclose(a64[fin], b64[fin], rtol=2e-4, atol=2e-4 * max(1.0, scale)):
+                err = np.abs(a64[fin] - b64[fin]).max() if fin.any() else float("nan")
+                MISMATCH.append(f"{fname}: {k} max abs difference {err:.3e} (block max {scale:.3e})")
+        elif not np.array_equal(a, b):
+            MISMATCH.append(f"{fname}: {k} differs (exact comparison)")
+    print(f"[check] {fname}: {len(new)} arrays compared")
+
+
 def ref_params_canonical(p):
     store = pyro.get_param_store()
+    uncon = ref_loader.unconstrained_params(store)
     vals, grads = {}, {}
     for name in store.keys():
-        u = store.unconstrained(name)
+        u = uncon[name]
         shp = CANON[name](p)
         vals[name] = u.detach().reshape(shp).clone()
         grads[name] = (torch.zeros_like(u) if u.grad is None else u.grad).detach().reshape(shp).clone()
@@ -207,7 +258,7 @@ def make_case(name, c, seed=11):
     out["ref_loss"] = np.array(ref_loss)
     out["loss64"] = np.array(l64)
     out["seed"] = np.array(seed)
-    np.savez_compressed(os.path.join(OUT, f"ref_step_{name}.npz"), **out)
+    save(f"ref_step_{name}.npz", out)
     print(f"[step] {name}: ref loss {ref_loss:.4f}  oracle32 {o_loss:.4f}  oracle64 {l64:.4f}")
 
     # ---- N steps of the reference's own fit() ---------------------------------------------------
@@ -254,7 +305,7 @@ def make_case(name, c, seed=11):
             if hasattr(fitm, attr):
                 fo["attr_" + attr] = np.asarray(getattr(fitm, attr))
         if c["Nc"] >= 200:      # medium case: the trajectory only (the posterior arrays would be megabytes) -> ref_fitmed_<case>.npz
-            np.savez_compressed(os.path.join(OUT, f"ref_fitmed_{name}.npz"), **fo)
+            save(f"ref_fitmed_{name}.npz", fo)
             print(f"[fit ] {name}: {n} steps, ref final loss {fitm.losses[-1]:.4f}, oracle {o_losses[-1]:.4f}")
             return
         # the reference's own posterior summaries (velocity_inference_model.py:236-262, phase_inference_model.py:248-265)
@@ -273,7 +324,7 @@ def make_case(name, c, seed=11):
             fo["post_omega_draws"] = post["ω"].reshape(post["ω"].shape[0], -1).numpy()
             fo["post_nuw_draws"] = post["νω"].reshape(post["νω"].shape[0], p32.Nx, p32.Nhw).numpy()
             fo["post_phi_draws"] = post["ϕ"].reshape(post["ϕ"].shape[0], -1).numpy()
-        np.savez_compressed(os.path.join(OUT, f"ref_fit_{name}.npz"), **fo)
+        save(f"ref_fit_{name}.npz", fo)
         print(f"[fit ] {name}: {n} steps, ref final loss {fitm.losses[-1]:.4f}, oracle {o_losses[-1]:.4f}")
 
 
@@ -293,7 +344,7 @@ def make_basis():
     out["xy"] = xy.numpy()
     out["pack_direction"] = ref.numpy()
     out["unpack_direction"] = U.unpack_direction(ref, 1.0).numpy()
-    np.savez_compressed(os.path.join(OUT, "basis.npz"), **out)
+    save("basis.npz", out)
     print("[basis] ok")
 
 
@@ -325,7 +376,7 @@ def make_preprocess():
         out["nonint_phase_" + k] = getattr(mp2, k).numpy()
     for k in ("S", "U", "logU"):
         out["nonint_vel_" + k] = getattr(mv2, k).numpy()
-    np.savez_compressed(os.path.join(OUT, "ref_preprocess.npz"), **out)
+    save("ref_preprocess.npz", out)
     print("[preprocess] ok")
 
 
@@ -345,7 +396,7 @@ def make_phase_prior():
         out["corr_" + tag] = np.array(corr)
         p.rotate(angle=-shift)
         out["rot_" + tag] = p.phi_xy.values
-    np.savez_compressed(os.path.join(OUT, "ref_phase_prior.npz"), **out)
+    save("ref_phase_prior.npz", out)
     print("[phase prior] ok")
 
 
@@ -384,7 +435,7 @@ def make_tutorial_flow():
         out["vel_" + a] = np.asarray(getattr(vf, a))
     out["vel_loc"] = pyro.param("loc").detach().numpy()
     out["vel_logβg_scales"] = pyro.param("logβg_scales").detach().numpy()
-    np.savez_compressed(os.path.join(OUT, "ref_tutorial_flow.npz"), **out)
+    save("ref_tutorial_flow.npz", out)
     print(f"[tutorial flow] phase {pf.losses[-1]:.3f} velocity {vf.losses[-1]:.3f}")
 
 
@@ -438,7 +489,7 @@ def make_particles(seed=11, K=3, n=12):
                   num_particles=np.array(K))
         for k, v in opt_args.items():
             fo["opt_" + k] = np.array(v)
-        np.savez_compressed(os.path.join(OUT, f"ref_fitK{K}_{name}.npz"), **fo)
+        save(f"ref_fitK{K}_{name}.npz", fo)
         print(f"[fit K={K}] {name}: {n} steps, ref final loss {fitm.losses[-1]:.4f}, oracle {o_losses[-1]:.4f}")
 
 
@@ -524,17 +575,34 @@ def make_continue(seed=11, n=10):
         fo.update(num_steps=np.array(n), seed=np.array(seed))
         for k, v in opt_args.items():
             fo["opt_" + k] = np.array(v)
-        np.savez_compressed(os.path.join(OUT, f"ref_fit_continue_{name}.npz"), **fo)
+        save(f"ref_fit_continue_{name}.npz", fo)
+
+
+def _finish(what):
+    kind, ver = ref_loader.BACKEND
+    on = f"pyro-ppl {ver}" if kind == "real" else "oracle/pyro_shim (pyro-ppl is not installed: the Pyro boundary stays restated)"
+    if CHECK:
+        for m in MISMATCH:
+            print("MISMATCH", m)
+        print(f"--check on {on}: {what}: " + ("every regenerated array agrees with the committed fixtures" if not MISMATCH
+                                              else f"{len(MISMATCH)} disagreement(s)"))
+        sys.exit(1 if MISMATCH else 0)
+    print(f"{what} written on {on}; oracle == reference on every case")
+    sys.exit(0)
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["--continue"]:
+    if ARGS == ["--continue"]:
         make_continue()
-        sys.exit(0)
-    if sys.argv[1:] == ["--particles"]:
+        _finish("continue fixtures")
+    if ARGS == ["--particles"]:
         make_particles()
-        sys.exit(0)
-    only = sys.argv[1:]
+        _finish("particle fixtures")
+    if ARGS == ["--all"]:
+        make_continue()
+        make_particles()
+        ARGS = []
+    only = ARGS
     if not only:
         make_basis()
         make_tutorial_flow()
@@ -544,4 +612,4 @@ if __name__ == "__main__":
         if only and nm not in only:
             continue
         make_case(nm, c)
-    print("all golden fixtures written; oracle == reference on every case")
+    _finish("golden fixtures")

@@ -133,9 +133,10 @@ def main_reference():
     phase_inference_model.py:162-201; unmodified files from build/lib on oracle/pyro_shim), float32 as the reference computes,
     `torch.manual_seed(seed)` = the eps stream of the oracle fits -> ref_fitlong_<case>.npz (losses + fitted unconstrained
     parameters in canonical shapes).  Aborts unless the reference's container and the workload spec describe the same problem."""
-    from oracle.ref_loader import load_reference
-    vc = load_reference()
+    from oracle import ref_loader
+    vc = ref_loader.load_reference("real" if "--real-pyro" in sys.argv[1:] else "auto")      # real pyro-ppl 1.8.x when installed, else the shim
     import pyro
+    print("reference on", ref_loader.BACKEND, flush=True)
     from tests.golden.make_golden import CANON
     for name, (key, kw, seed) in CASES.items():
         mp, cond, FitCls, kind = reference_metaparams(name, vc)
@@ -164,8 +165,9 @@ def main_reference():
         fitm.fit(pyro.optim.ClippedAdam(dict(OPT)), loss=pyro.infer.Trace_ELBO(num_particles=1), num_steps=N_STEPS, verbose=False)
         store = pyro.get_param_store()
         out = {"digest": digest(spec), "seed": seed, "n_steps": N_STEPS, "ref_losses": np.array(fitm.losses, dtype=np.float64)}
+        uncon = ref_loader.unconstrained_params(store)
         for pn in store.keys():
-            out["reffit_" + pn] = store.unconstrained(pn).detach().reshape(CANON[pn](pr)).double().numpy()
+            out["reffit_" + pn] = uncon[pn].detach().reshape(CANON[pn](pr)).double().numpy()
         np.savez_compressed(os.path.join(HERE, f"ref_fitlong_{name}.npz"), **out)
         z = np.load(os.path.join(HERE, f"oracle_fit_{name}.npz"))
         l32, l64, lr = z["loss32"], z["loss64"], out["ref_losses"]
@@ -174,7 +176,7 @@ def main_reference():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["--reference"]:
+    if "--reference" in sys.argv[1:]:
         main_reference()
     else:
         main()

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # without touching the in-tree product library; it must still be a HIP build of this ABI -- there is no fallback.
 LIB_PATH = os.environ.get("VC_LIB_PATH") or os.path.join(HERE, "libvelocycle_hip.so")
 
-VC_ABI_VERSION = 1
+VC_ABI_VERSION = 2
 VC_OK = 0
 VC_PHASE_A, VC_PHASE_B, VC_PHASE_AB = 1, 2, 3
 VC_OPT_CLIPPED_ADAM, VC_OPT_ADAM = 0, 1
@@ -72,7 +72,7 @@ class vc_stats(C.Structure):
                 ("hist_on_device", C.c_int32), ("main_kernel_name", C.c_char * 96),
                 ("setup_transient_bytes", C.c_int64), ("count_storage_bytes", C.c_int64),
                 ("pass_cells", C.c_int32 * 4), ("launches_per_step", C.c_int32), ("pw_inline", C.c_int32),
-                ("generic", C.c_int32), ("onehot_batches", C.c_int32), ("tail_spec", C.c_int32), ("reserved2", C.c_int32),
+                ("generic", C.c_int32), ("onehot_batches", C.c_int32), ("tail_spec", C.c_int32), ("tail_spec_matched", C.c_int32),
                 ("tail_spec_name", C.c_char * 32)]
 
 
@@ -156,6 +156,15 @@ def load():
             "velocycle_amd has no CPU fallback")
     import torch  # noqa: F401  (its bundled libamdhip64 must be the one already mapped)
     lib = C.CDLL(LIB_PATH)
+    # The structs of this file are the ones of ABI version VC_ABI_VERSION: a library of ANY other version is refused before a
+    # single struct crosses (vc_get_stats writes the whole struct of ITS version).  VC_LIB_OLDER=1 only tolerates missing entry
+    # points of an older build of the SAME version.
+    lib.vc_abi_version.restype = C.c_int
+    lib.vc_abi_version.argtypes = []
+    got = lib.vc_abi_version()
+    if got != VC_ABI_VERSION:
+        raise HipLibraryError(f"{LIB_PATH}: ABI version {got}, this host side was written against {VC_ABI_VERSION} "
+                              "(rebuild with `make -C velocycle_amd/csrc`)")
     older = bool(os.environ.get("VC_LIB_PATH")) and os.environ.get("VC_LIB_OLDER") == "1"
     for name, (res, args) in EXPORTS.items():
         if older and not hasattr(lib, name):
@@ -163,7 +172,5 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a symbol of the header is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.vc_abi_version() != VC_ABI_VERSION:
-        raise HipLibraryError("libvelocycle_hip.so ABI version mismatch")
     _lib = lib
     return lib

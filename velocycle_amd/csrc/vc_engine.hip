@@ -97,6 +97,8 @@ struct vc_engine {
   std::string err;
   std::vector<void*> allocs;
   bool finalized = false;
+  bool finalize_started = false;      // vc_finalize got past its call-order checks
+  bool finalize_failed = false;       // vc_finalize returned an error after it had started to consume its inputs
   bool generic_needed = false;        // the configuration lies outside the compiled fast set for a reason other than its batches (vc_create)
   bool generic_nb = false;            // ... because it has more than VC_MAXNB batches: generic only if their design matrix is not one-hot
   std::vector<float> hDb;             // host copy of the batch design matrix (vc_finalize: is it one-hot?)
@@ -642,9 +644,18 @@ static int upload(vc_engine* e, const std::vector<T>& h, const T** dev) {
 static int finalize_impl(vc_engine* e, void* hip_stream);
 extern "C" int vc_finalize(vc_engine* e, void* hip_stream) {
   if (!e) return VC_ERR_ARG;
-  VC_GUARD_BEGIN
-  return finalize_impl(e, hip_stream);
-  VC_GUARD_END(e)
+  // A finalize that failed half way has consumed part of its inputs (host copies of the counts are released as they are
+  // ingested) and left workspaces behind: it is not restartable on the same engine -- say so instead of running on freed inputs.
+  if (e->finalize_failed)
+    return e->fail(VC_ERR_STATE, "vc_finalize failed earlier on this engine: vc_destroy it and create a new one");
+  auto guarded = [&]() -> int {
+    VC_GUARD_BEGIN
+    return finalize_impl(e, hip_stream);
+    VC_GUARD_END(e)
+  };
+  const int rc = guarded();
+  if (rc != VC_OK && e->finalize_started) e->finalize_failed = true;   // before that mark nothing was touched (inputs missing)
+  return rc;
 }
 
 static int finalize_impl(vc_engine* e, void* hip_stream) {
@@ -665,6 +676,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       if (!e->prior_set[w]) return e->fail(VC_ERR_STATE, "vc_finalize: prior %d not set", w);
   if (!vel && d.with_dnu && !e->prior_set[VC_PRIOR_SD_DNU])
     return e->fail(VC_ERR_STATE, "vc_finalize: sd_dnu prior not set");
+  e->finalize_started = true;
 
   // Batch offsets.  The reference's design matrix is one-hot by construction (make_design_matrix, preprocessing.py:65-93): then the
   // offset of a cell's batch is folded into the constant harmonic per workgroup of the likelihood kernel (cells ordered by batch,
@@ -679,7 +691,6 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     d.onehot = 1;
     bat_sorted = vc_order_by_batch(bat_id, d.Nb, bat_pos, bat_ord, bat_len);
   }
-  std::vector<float>().swap(e->hDb);
   d.generic = (e->tun.force_generic || e->generic_needed || (e->generic_nb && !d.onehot)) ? 1 : 0;
   d.Kq = d.onehot ? d.Nh : d.K;
   d.nbk = d.onehot ? 0 : d.Nb;
@@ -1295,6 +1306,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // the instantiation of the small kernels compiled for this configuration, if there is one (vc_tail_spec.h)
   d.spec = e->tun.no_tail_spec ? VC_SPEC_NONE : vc_spec_match(d);
   e->finalized = true;
+  std::vector<float>().swap(e->hDb);   // kept until here: every failure above leaves the batch design matrix in place
   return VC_OK;
 }
 
@@ -1849,10 +1861,17 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.nbk, e->main_name, d.gpl,
            d.c16 ? ",u16" : "");
   out->onehot_batches = d.onehot ? d.Nb : 0;
-  out->tail_spec = d.spec;
-  out->reserved2 = 0;
+  // The row the signature matched, and the row the steps of vc_svi_run_fused / vc_svi_run_sharded actually LAUNCH: a matched row
+  // serves only the launch structures its kind bits name (a single-rank engine kept at three launches by tuning.no_tail2 /
+  // pw_inline matches a "*_rank" row and still runs the run-time-flag kernels) -- report what runs, and the match beside it.
+  int speck = 0;
+  if (e->cfg.world_size > 1) speck = VC_SPECK_SHARDED;
+  else { const int tk = fused_tail_kind(e); speck = tk == 1 ? VC_SPECK_MERGED : (tk == 2 ? VC_SPECK_TAIL2 : 0); }
+  const int used = (d.spec > 0 && (VC_SPECS[d.spec].kind & speck)) ? d.spec : VC_SPEC_NONE;
+  out->tail_spec = used;
+  out->tail_spec_matched = d.spec;
   memset(out->tail_spec_name, 0, sizeof(out->tail_spec_name));
-  strncpy(out->tail_spec_name, VC_SPECS[d.spec].name, sizeof(out->tail_spec_name) - 1);
+  strncpy(out->tail_spec_name, VC_SPECS[used].name, sizeof(out->tail_spec_name) - 1);
   return VC_OK;
 }
 

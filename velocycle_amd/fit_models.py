@@ -280,7 +280,7 @@ class _FitBase:
             tv = torch.zeros(eng.total - h, dtype=torch.float64, device=eng.device)
             for name, (off, n) in eng.param_slices.items():
                 tv[off - h:off - h + n] = float(plan["steps"][name])
-            run.opt.t_vec = tv
+            run.opt.set_step_counts(tv)
             return 0
         t0 = int(plan["t0"])
         run.opt.t = t0

@@ -140,10 +140,13 @@ class FlatClippedAdam:
         if self.wd != 0.0 and engine is not None and hasattr(engine, "frozen_mask"):
             fm = engine.frozen_mask()
             if fm is not None:
-                self.decay_mask = (1 - fm[engine.header:].to(torch.float32)).to(device)
+                self.decay_mask = (fm[engine.header:] == 0).to(device)      # True: the entry takes weight decay
+        if self.kind == "adam" and capturable and impl == "torch":
+            raise ValueError("pyro.optim.Adam with hipGraph replay of the PyTorch-op optimiser is not supported (use the default launches)")
         self.m = torch.zeros(n, dtype=torch.float32, device=device)
         self.v = torch.zeros(n, dtype=torch.float32, device=device)
         self.t = 0
+        self.t_vec = None
         self.capturable = capturable
         self.impl, self.engine = impl, engine
         if capturable and impl == "torch":     # step counter and schedule live on the device so the update can be replayed
@@ -151,11 +154,20 @@ class FlatClippedAdam:
             self._c = {k: torch.tensor(v, dtype=torch.float64, device=device)
                        for k, v in dict(lr0=self.lr0, lrd=self.lrd, b1=self.b1, b2=self.b2).items()}
 
+    def set_step_counts(self, t_vec: torch.Tensor):
+        """Per-element step counts (a 'mixed' continued fit: pyro_compat).  Refused here, before any step has touched the
+        moments, where no implementation applies them: only the PyTorch-op ClippedAdam does."""
+        if self.kind != "clipped_adam" or self.impl != "torch" or self.capturable:
+            raise RuntimeError("per-parameter step counts (a 'mixed' continued fit) run on the PyTorch-op ClippedAdam only "
+                               f"(kind={self.kind!r}, impl={self.impl!r}, capturable={self.capturable})")
+        self.t_vec = t_vec
+
     def step(self, p: torch.Tensor, g: torch.Tensor, t_dev: Optional[torch.Tensor] = None, loss_hdr=None,
              loss_ring=None):
-        if getattr(self, "t_vec", None) is not None and (self.impl != "torch" or self.capturable):
+        if self.t_vec is not None and (self.kind != "clipped_adam" or self.impl != "torch" or self.capturable):
+            # (a state dict loaded into another kind of optimiser: still refused before m / v move)
             raise RuntimeError("per-parameter step counts (a 'mixed' continued fit) run on the PyTorch-op ClippedAdam only "
-                               f"(impl={self.impl!r}, capturable={self.capturable})")
+                               f"(kind={self.kind!r}, impl={self.impl!r}, capturable={self.capturable})")
         if self.impl == "hip":
             self.t += 1
             fm = self.engine.frozen_mask() if self.wd != 0.0 else None
@@ -166,20 +178,21 @@ class FlatClippedAdam:
         if self.kind == "clipped_adam":
             g = g.clamp(-self.clip, self.clip)
         if self.wd != 0.0:
-            g = g.add(p if self.decay_mask is None else torch.nan_to_num(p, neginf=0.0) * self.decay_mask, alpha=self.wd)
+            # only the FROZEN entries are masked: a live parameter sitting at -inf (LRMN cov_factor zeros, stored as logs) decays
+            # to NaN here exactly as in vc_adam_elem and in Pyro itself (and trips the non-finite latch) -- ADVICE r5
+            g = g.add(p if self.decay_mask is None else torch.where(self.decay_mask, p, torch.zeros((), dtype=p.dtype, device=p.device)),
+                      alpha=self.wd)
         self.m.lerp_(g, 1.0 - self.b1)
         self.v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
         if self.kind == "adam":
             # torch.optim.Adam: step lr / (1 - b1^t), denominator sqrt(v) / sqrt(1 - b2^t) + eps
-            if getattr(self, "t_vec", None) is not None or self.capturable:
-                raise RuntimeError("pyro.optim.Adam: per-parameter step counts / capturable replay run on ClippedAdam only")
             self.t += 1
             bc1, bc2 = 1.0 - self.b1 ** self.t, 1.0 - self.b2 ** self.t
             denom = (self.v.sqrt() / math.sqrt(bc2)).add_(self.eps)
             p.addcdiv_(self.m, denom, value=-self.lr0 / bc1)
             return
         denom = self.v.sqrt().add_(self.eps)
-        if getattr(self, "t_vec", None) is not None:
+        if self.t_vec is not None:
             # per-element step counts (a fit that continues SOME parameters of an earlier one with the same optimizer object,
             # pyro_compat: PyroOptim keeps one step count per parameter tensor): the schedule of each element is its own
             self.t += 1
@@ -213,7 +226,7 @@ class FlatClippedAdam:
 
     def state_dict(self, step_dev: Optional[torch.Tensor] = None):
         sd = dict(m=self.m.detach().cpu().clone(), v=self.v.detach().cpu().clone(), t=self.steps_done(step_dev))
-        if getattr(self, "t_vec", None) is not None:      # per-element step counts of a 'mixed' continued fit
+        if self.t_vec is not None:      # per-element step counts of a 'mixed' continued fit
             sd["t_vec"] = self.t_vec.detach().cpu().clone()
         return sd
 
@@ -280,6 +293,10 @@ class SVIRunner:
             from .tuning import Tuning
             tun = Tuning()
         self.tuning = tun
+        if self.world > 1:
+            # FIRST collective of the runner, in front of every check that may raise on a subset of the ranks (unknown exchange,
+            # RCCL / p2p initialisation): a rank that raised later would leave the others waiting in this all-reduce
+            self._assert_same_tuning_on_every_rank()
         if adam_impl is None and self.K > 1 and mode == "perf":
             adam_impl = "hip"
         if adam_impl is None and mode == "perf" and (getattr(engine, "stats", None) or {}).get("generic"):
@@ -335,16 +352,12 @@ class SVIRunner:
                 raise ValueError(f"unknown exchange {want!r}")
             self.exchange = want
             self.xbuf = torch.zeros(engine.exchange_size(), dtype=torch.float32, device=engine.device)
-        if self.world > 1:
-            self._assert_same_tuning_on_every_rank()
         optim_args = optim_args_of(optim_args)          # (validated; a plain dict means ClippedAdam's arguments)
         self.opt = FlatClippedAdam(engine.total - engine.header, optim_args, engine.device,
                                    capturable=self.use_graph,
                                    impl=("hip" if self.adam_impl in ("fused", "fused3", "sharded") else self.adam_impl), engine=engine)
         if hasattr(engine, "set_optimizer"):             # what the engine's own step entry points apply (the engine outlives its runners)
             engine.set_optimizer(self.opt.kind, self.opt.wd, engine.frozen_mask() if self.opt.wd != 0.0 else None)
-        if self.opt.kind == "adam" and self.use_graph and self.opt.impl == "torch":
-            raise ValueError("pyro.optim.Adam with hipGraph replay of the PyTorch-op optimiser is not supported (use the default launches)")
         self._primed = False          # fused3: the tables of the current step have been sampled from the current params
         self.step_idx = 0
         self.losses: List[float] = []
@@ -382,8 +395,12 @@ class SVIRunner:
         import torch.distributed as dist
         e = self.e
         stats = getattr(e, "stats", None) or {}
-        desc = repr((self.tuning.digest(), e.header, e.n_global, stats.get("main_kernel", "").split("gpl")[-1],
-                     e.exchange_size() if self.adam_impl == "sharded" else 0))
+        try:
+            xsize = e.exchange_size()
+        except Exception:
+            xsize = -1
+        # the whole kernel name (one-hot batch detection changes its NB argument, not only genes per lane) and the batch count
+        desc = repr((self.tuning.digest(), e.header, e.n_global, stats.get("main_kernel", ""), stats.get("onehot_batches", 0), xsize))
         h = int.from_bytes(hashlib.sha256(desc.encode()).digest()[:8], "little") >> 2
         dev = e.device if dist.get_backend(self.pg) == "nccl" else "cpu"
         lo = torch.tensor([h], dtype=torch.int64, device=dev)
