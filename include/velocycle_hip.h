@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-/* 2 (round 6): vc_stats ends with onehot_batches, tail_spec, tail_spec_matched, tail_spec_name[32] (a consumer built against
+/* 2 (round 6): vc_stats ends with onehot_batches, tail_spec, tail_spec_matched, tail_spec_name[32], pw_lane, reserved3 (a consumer built against
  * version 1 would have its smaller vc_stats overrun by vc_get_stats: vc_create refuses it); vc_tuning, vc_set_tuning / vc_get_tuning,
  * vc_dbg_signature, vc_set_optimizer / vc_adam_update exist. */
 #define VC_ABI_VERSION 2
@@ -169,7 +169,9 @@ typedef struct vc_tuning {
   int32_t dense_batches;     /* 1: batch offsets as the dense Db contraction even when Db is one-hot (A/B, tests) */
   float p2p_timeout_s;       /* bound of the peer-to-peer exchange's wait; 0 = 2 s */
   int32_t no_tail_spec;      /* 1: the run-time-flag small kernels even where an instantiation compiled for this configuration exists (A/B, tests) */
-  int32_t reserved[6];
+  int32_t no_pw_lane;        /* 1: the U-only kernel reduces its per-cell sums over the wave even where the per-lane accumulation of the
+                                nu_omega partials applies (one condition, D == 1; A/B, tests) */
+  int32_t reserved[5];
 } vc_tuning;
 
 typedef struct vc_layout {
@@ -207,6 +209,9 @@ typedef struct vc_stats {
   int32_t tail_spec_matched;      /* the row the configuration's signature matched, whether or not that row is compiled for the launch
                                      structure in use (e.g. a "*_rank" row matched by a single-rank engine kept at three launches) */
   char tail_spec_name[32];
+  int32_t pw_lane;                /* 1: the U-only likelihood kernel accumulates its d loglik / d nu_omega partials per lane from the cell
+                                     record (one condition, D == 1: W_c = (1, sin k phi_c, cos k phi_c)) and stores no per-cell rows */
+  int32_t reserved3;
 } vc_stats;
 
 /* lifecycle ------------------------------------------------------------------------------- */

@@ -14,7 +14,7 @@ def main():
     for f in sorted(glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)):
         lines.append(f"## kernel stats ({os.path.basename(f)}): name, calls, avg_us, total_ms, pct")
         rows = list(csv.DictReader(open(f)))
-        for r in rows[:14]:
+        for r in rows[:40]:
             name = r["Name"]
             name = name if len(name) < 90 else name[:87] + "..."
             lines.append(f"{name} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['TotalDurationNs'])/1e6:.3f} | {r['Percentage']}")

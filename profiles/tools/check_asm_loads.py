@@ -29,7 +29,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "velocycle_amd", "csrc")
 DEFAULT_TUS = ["vc_main_vfull_nb_u16.hip", "vc_main_vu_nb_u16.hip", "vc_main_phase_nb_u16.hip", "vc_main_vu_nb_u16_noloss.hip",
-               "vc_main_vfull_nb_u16_noloss.hip", "vc_main_phase_nb_u16_noloss.hip"]
+               "vc_main_vfull_nb_u16_noloss.hip", "vc_main_phase_nb_u16_noloss.hip", "vc_main_vu_nb_u16_pwl.hip", "vc_main_vu_nb_u16_pwl_noloss.hip"]
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LOAD = re.compile(r"^\s*global_load_dwordx(\d)\s+(v\[\d+:\d+\]|v\d+)\s*,")
 WAIT = re.compile(r"^\s*s_waitcnt\s+vmcnt\((\d+)\)")

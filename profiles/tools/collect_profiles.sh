@@ -14,10 +14,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc_fetch -- $CMD --no-graph > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc_write -- $CMD --no-graph > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_pmc_sq -- $CMD --no-graph > /dev/null 2>&1
+# (round 6, VERDICT r5 item 4: the wave-cycle side of the VALU floor -- own pass: a counter the part does not have fails this pass only)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/${tag}_pmc_sq2 -- $CMD --no-graph > $out/pmc_sq2.err 2>&1
 python3 profiles/summarize.py gpurun_out/${tag}_stats $out/kernel_stats_graph.txt "$tag: $CMD (hipGraph replay)" > /dev/null
 python3 profiles/summarize.py gpurun_out/${tag}_stats_eager $out/kernel_stats_eager.txt "$tag: $CMD --no-graph" > /dev/null
-for p in fetch write sq; do python3 profiles/summarize.py gpurun_out/${tag}_pmc_$p $out/pmc_$p.txt "$tag: --pmc pass ($p) of $CMD --no-graph" > /dev/null; done
-cat $out/pmc_fetch.txt $out/pmc_write.txt $out/pmc_sq.txt > $out/pmc.txt
+for p in fetch write sq sq2; do python3 profiles/summarize.py gpurun_out/${tag}_pmc_$p $out/pmc_$p.txt "$tag: --pmc pass ($p) of $CMD --no-graph" > /dev/null; done
+cat $out/pmc_fetch.txt $out/pmc_write.txt $out/pmc_sq.txt $out/pmc_sq2.txt > $out/pmc.txt
+# the roofline of bench_under_rocprof_eager.json reproduced from the kernel trace of THAT process (one collection: stats + JSON of one run on one board)
+python3 profiles/tools/roofline_from_trace.py gpurun_out/${tag}_stats_eager $out/bench_under_rocprof_eager.json $out/roofline_check.txt > /dev/null
+python3 profiles/tools/roofline_from_trace.py gpurun_out/${tag}_stats $out/bench_under_rocprof.json $out/roofline_check_graph.txt > /dev/null
 python3 profiles/tools/pmc_to_traffic.py $out/pmc.txt $out/latest_traffic.json $tag
 # the plain run last, with the traffic file of THIS library in place (bench.py takes `roofline.traffic` from
 # profiles/latest_traffic.json only if its csrc hash matches the library it runs)

@@ -19,8 +19,9 @@ for line in open(src):
     if m:
         h, nb, kind, noise, gpl = (int(x) for x in m.groups()[:5])
         c16 = int(m.group(6) or 0)
-        # (last template argument: bit 0 = uint16 count storage, bit 1 = the gradient-only instantiation of vc_set_loss_every)
-        name = f"vc_main_kernel<{h},{nb},{KIND[kind]}_{NOISE[noise]}{'_gradonly' if c16 & 2 else ''},gpl{gpl}{',u16' if c16 & 1 else ''}>"
+        # (last template argument: bit 0 = uint16 count storage, bit 1 = the gradient-only instantiation of vc_set_loss_every,
+        # bit 2 = the U-only kernel with the nu_omega partials per lane)
+        name = f"vc_main_kernel<{h},{nb},{KIND[kind]}_{NOISE[noise]}{'_gradonly' if c16 & 2 else ''},gpl{gpl}{',u16' if c16 & 1 else ''}{',pwl' if c16 & 4 else ''}>"
         vals.setdefault(name, {})[m.group(7) + "_KiB"] = float(m.group(9))
 for v in vals.values():
     if "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:

@@ -63,14 +63,22 @@ def add(name, spec, world=1, multi=False):
 
 NC, NG = 50000, 2000
 # ranks of a sharded run first: a single-rank "multi" row leaves pw_inline open and would otherwise shadow its rank row
+# (first match wins: the CLOSED rows of a configuration -- one sample, exactly two samples -- stand in front of its open "multi" row)
 for world in (8, 1):
     tag = "_rank" if world > 1 else ""
     # velocity: mean-field / LRMN (the reference's default model_type) guide x nothing conditioned / the tutorials' conditioning
     for name, mode in (("vjoint", "vjoint"), ("vcond", "vcond"), ("vjoint_lrmn", "vjoint_lrmn"), ("vcond_mf", "vcond_mf")):
         add(name + tag, make_velocity_spec(NC, NG, mode, 1, 1, seed=0, device=dev), world)
+    # round 6: the tutorials' FIRST velocity stage -- constant angular speed, AngularSpeed.trivial_prior(harmonics=0) /
+    # omega_n_harmonics=0 (Tutorial_Capolupo_HumanFibroblasts_OneSample.ipynb:690,721; angularspeed.py:311-354)
+    add("vcond_hw0" + tag, make_velocity_spec(NC, NG, "vcond", 1, 0, seed=0, device=dev), world)
     add("phase" + tag, make_phase_spec(NC, NG, seed=0, device=dev), world)
+    # round 6: exactly two samples (BASELINE configs[4], Tutorial_Aissa_PC9_TwoSample: Nx = Nb = 2) with every count closed
+    for name, mode, hw in (("vjoint_2s", "vjoint", 1), ("vcond_2s", "vcond", 1), ("vcond_hw0_2s", "vcond", 0)):
+        add(name + tag, make_velocity_spec(NC // 2, NG, mode, 2, hw, seed=0, device=dev), world)
     for name, mode in (("vjoint", "vjoint"), ("vcond", "vcond"), ("vjoint_lrmn", "vjoint_lrmn"), ("vcond_mf", "vcond_mf")):
         add(name + "_multi" + tag, make_velocity_spec(NC // 2, NG, mode, 2, 1, seed=0, device=dev), world, multi=True)
+    add("vcond_hw0_multi" + tag, make_velocity_spec(NC // 2, NG, "vcond", 2, 0, seed=0, device=dev), world, multi=True)
     add("phase_multi" + tag, make_phase_spec(NC // 2, NG, seed=0, device=dev, n_batches=2), world, multi=True)
 print("// rows of VC_SPECS (vc_tail_spec.h): {name, kinds of launch, MQ of the gene blocks, signature} -- printed by profiles/tools/print_signature.py")
 print("// signature = " + " ".join(FIELDS) + "; -1 = left open")

@@ -27,7 +27,9 @@ TRANS_SLOW = re.compile(r"^v_(exp|log|sin|cos)_")
 KERNELS = [("vc_main_vfull_nb_u16.hip", 1, 0, 1, 0, 8, 1), ("vc_main_vu_nb_u16.hip", 1, 0, 2, 0, 8, 1),
            ("vc_main_phase_nb_u16.hip", 1, 0, 0, 0, 8, 1),
            ("vc_main_vfull_nb.hip", 1, 0, 1, 0, 8, 0), ("vc_main_vu_nb.hip", 1, 0, 2, 0, 8, 0), ("vc_main_phase_nb.hip", 1, 0, 0, 0, 8, 0),
-           ("vc_main_vfull_nb_u16.hip", 1, 2, 1, 0, 8, 1), ("vc_main_vu_nb_u16.hip", 1, 2, 2, 0, 8, 1)]
+           ("vc_main_vfull_nb_u16.hip", 1, 2, 1, 0, 8, 1), ("vc_main_vu_nb_u16.hip", 1, 2, 2, 0, 8, 1),
+           # round 6: the U-only kernel with the nu_omega partials per lane (one condition, D == 1: every one-sample tutorial flow)
+           ("vc_main_vu_nb_u16_pwl.hip", 1, 0, 2, 0, 8, 5), ("vc_main_vu_nb_pwl.hip", 1, 0, 2, 0, 8, 4)]
 KIND_NAME = {0: "phase", 1: "vfull", 2: "vu"}
 NOISE_NAME = {0: "nb", 1: "poisson", 2: "lognormal"}
 MIX_OF_KIND = {0: "mix phase (S only)", 1: "mix vfull (S+U)", 2: "mix vu (U only)"}
@@ -129,7 +131,7 @@ def count(tu, H, NB, KIND, NOISE, GPL, C16):
     mix = MIXES[MIX_OF_KIND[KIND]]
     res["mix"] = MIX_OF_KIND[KIND]
     res["floor_ns_per_cell_iter"] = {w: round(ns * res["valu_per_cell_iter"] / mix["instr"], 1) for w, ns in mix["ns"].items()}
-    return f"vc_main_kernel<{H},{NB},{KIND_NAME[KIND]}_{NOISE_NAME[NOISE]},gpl{GPL}{',u16' if C16 else ''}>", res
+    return f"vc_main_kernel<{H},{NB},{KIND_NAME[KIND]}_{NOISE_NAME[NOISE]},gpl{GPL}{',u16' if C16 & 1 else ''}{',pwl' if C16 & 4 else ''}>", res
 
 
 def main():

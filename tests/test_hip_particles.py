@@ -134,5 +134,16 @@ def test_fit_reads_num_particles_from_the_loss_object():
 
     class Vec:
         num_particles, vectorize_particles = 3, True
+    # vectorize_particles=True: the same estimator (K draws averaged).  Parity mode (the reference's host RNG order) refuses it by
+    # name; perf mode runs it as the batched K-particle step -- the same numbers as Trace_ELBO(num_particles=3) on the same seed
     with pytest.raises(NotImplementedError, match="vectorize_particles"):
-        PhaseFitModel(mp, num_samples=2, n_per_bin=2).fit(pyro.optim.ClippedAdam(_opt(z)), loss=Vec(), num_steps=1, verbose=False)
+        PhaseFitModel(mp, num_samples=2, n_per_bin=2).fit(pyro.optim.ClippedAdam(_opt(z)), loss=Vec(), num_steps=1, verbose=False,
+                                                          mode="parity", seed=1)
+    out = []
+    for elbo_k in (Vec(), pyro.infer.Trace_ELBO(num_particles=3), pyro.infer.Trace_ELBO(num_particles=3, vectorize_particles=True)):
+        pyro.clear_param_store()
+        f = PhaseFitModel(mp, num_samples=2, n_per_bin=2)
+        f.fit(pyro.optim.ClippedAdam(_opt(z)), loss=elbo_k, num_steps=6, verbose=False, mode="perf", seed=5)
+        assert f._runner.K == 3 and len(f.losses) == 6 and np.isfinite(f.losses).all()
+        out.append(np.array(f.losses))
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[1], out[2])

@@ -13,24 +13,32 @@ from tests.test_hip_sharded_step import _run_sharded
 
 pytestmark = pytest.mark.gpu
 
-ROWS = {            # name of the row a workload must select: (builder, mode, samples)
+ROWS = {            # name of the row a workload must select: (builder, mode, samples[, omega harmonics Hw = 1])
     "vjoint": ("vel", "vjoint", 1), "vcond": ("vel", "vcond", 1), "phase": ("phase", None, 1),
     "vjoint_lrmn": ("vel", "vjoint_lrmn", 1), "vcond_mf": ("vel", "vcond_mf", 1),
-    # the "multi" rows leave the number of batches / conditions open: two and three samples run the same instantiation
-    "vjoint_multi": ("vel", "vjoint", 2), "vcond_multi": ("vel", "vcond", 2), "phase_multi": ("phase", None, 3),
+    # round 6: the tutorials' constant-omega first velocity stage (omega_n_harmonics = 0), one sample / two / any number
+    "vcond_hw0": ("vel", "vcond", 1, 0), "vcond_hw0_2s": ("vel", "vcond", 2, 0), "vcond_hw0_multi": ("vel", "vcond", 3, 0),
+    # round 6: exactly two samples (BASELINE configs[4]) with every count closed ...
+    "vjoint_2s": ("vel", "vjoint", 2), "vcond_2s": ("vel", "vcond", 2),
+    # ... in front of the "multi" rows that leave the number of batches / conditions open (three samples here; two where no closed row exists)
+    # (three conditions x three omega coefficients are more than K_main's own nu_omega partials carry -- three launches, no single-rank
+    # row: the open rows are reached with three BATCHES under two conditions)
+    "vjoint_multi": ("vel", "vjoint", 2, 1, 3), "vcond_multi": ("vel", "vcond", 2, 1, 3), "phase_multi": ("phase", None, 3),
     "vjoint_lrmn_multi": ("vel", "vjoint_lrmn", 2), "vcond_mf_multi": ("vel", "vcond_mf", 2),
 }
 RANK_ROWS = {"vjoint_rank": ("vel", "vjoint", 1), "vcond_rank": ("vel", "vcond", 1), "phase": ("phase", None, 1),
              "vjoint_lrmn_rank": ("vel", "vjoint_lrmn", 1), "vcond_mf_rank": ("vel", "vcond_mf", 1),
-             "vjoint_multi_rank": ("vel", "vjoint", 2), "vcond_multi_rank": ("vel", "vcond", 2), "phase_multi": ("phase", None, 2),
+             "vcond_hw0_rank": ("vel", "vcond", 1, 0), "vcond_hw0_2s_rank": ("vel", "vcond", 2, 0), "vcond_hw0_multi_rank": ("vel", "vcond", 3, 0),
+             "vjoint_2s_rank": ("vel", "vjoint", 2), "vcond_2s_rank": ("vel", "vcond", 2),
+             "vjoint_multi_rank": ("vel", "vjoint", 3), "vcond_multi_rank": ("vel", "vcond", 3), "phase_multi": ("phase", None, 2),
              "vjoint_lrmn_multi_rank": ("vel", "vjoint_lrmn", 2), "vcond_mf_multi_rank": ("vel", "vcond_mf", 2)}
 
 
-def _spec(kind, mode, ncond, nc=2100, ng=260):
+def _spec(kind, mode, ncond, hw=1, nbatch=None, nc=2100, ng=260):
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
     if kind == "phase":
         return make_phase_spec(nc // ncond, ng, seed=3, n_batches=ncond)
-    return make_velocity_spec(nc // ncond, ng, mode, n_conditions=ncond, Hw=1, seed=3)
+    return make_velocity_spec(nc // (nbatch or ncond), ng, mode, n_conditions=ncond, Hw=hw, seed=3, n_batches=nbatch)
 
 
 @pytest.mark.parametrize("row", sorted(ROWS))
@@ -67,7 +75,7 @@ def test_sharded_rank_specialisation_is_bit_identical(row):
         r.e.close()
 
 
-@pytest.mark.parametrize("row", ["vjoint", "vcond", "phase", "vjoint_multi", "vjoint_lrmn"])
+@pytest.mark.parametrize("row", ["vjoint", "vcond", "phase", "vjoint_multi", "vjoint_lrmn", "vcond_hw0", "vjoint_2s"])
 def test_particle_step_specialisation_is_bit_identical(row):
     """vc_svi_run_particles (K_pre / K_post of all particles, K_fin + average + optimiser: K + 3 launches) in the instantiations compiled
     for the row against the run-time-flag kernels: K = 3, eight steps, parameters / moments / losses bit for bit."""

@@ -33,7 +33,7 @@ def test_measurement_aid_builds(flag, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("tu", ["vc_main_vfull_nb_u16.hip", "vc_main_vu_nb_u16.hip", "vc_main_phase_nb.hip"])
+@pytest.mark.parametrize("tu", ["vc_main_vfull_nb_u16.hip", "vc_main_vu_nb_u16.hip", "vc_main_phase_nb.hip", "vc_main_vu_nb_u16_pwl.hip"])
 def test_asm_count_loads_are_never_touched_in_flight(tu):
     """The likelihood kernel issues its count loads from inline asm with hand-placed waits (VC_ASM_LOADS).  hipcc does not
     model such loads, so the emitted code object is audited (profiles/tools/check_asm_loads.py): in every instantiation the

@@ -56,7 +56,7 @@ class vc_tuning(C.Structure):
                 ("hist_dense", C.c_int32), ("pw_inline", C.c_int32), ("no_tail2", C.c_int32),
                 ("no_tail_merged", C.c_int32), ("force_generic", C.c_int32), ("particles_layout", C.c_int32),
                 ("dense_batches", C.c_int32), ("p2p_timeout_s", C.c_float), ("no_tail_spec", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("no_pw_lane", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class vc_layout(C.Structure):
@@ -73,7 +73,7 @@ class vc_stats(C.Structure):
                 ("setup_transient_bytes", C.c_int64), ("count_storage_bytes", C.c_int64),
                 ("pass_cells", C.c_int32 * 4), ("launches_per_step", C.c_int32), ("pw_inline", C.c_int32),
                 ("generic", C.c_int32), ("onehot_batches", C.c_int32), ("tail_spec", C.c_int32), ("tail_spec_matched", C.c_int32),
-                ("tail_spec_name", C.c_char * 32)]
+                ("tail_spec_name", C.c_char * 32), ("pw_lane", C.c_int32), ("reserved3", C.c_int32)]
 
 
 EXPORTS = {

@@ -65,6 +65,8 @@ struct VcDims {
   int pw_inline;          // 4 | 8: K_main (U-only and S+U kernels) writes PWM rows of that many floats, K_omega / K_fin read them
                           // instead of the cell blocks' PW; 0: off
   int pw_slots;           // float4 slots per wave of K_main's staged W rows (>= cells per wave x float4 per row)
+  int pw_lane;            // 1 (U-only kernel, one condition with D == 1, Hw <= H): W_c = (1, sin k phi_c, cos k phi_c) is the cell record itself --
+                          // the partials are accumulated per lane, no W rows in the LDS, no per-cell rows stored
   int ctw;                // floats per cell record: {x,x} pairs of [sin k, cos k]*H, Db[Nb], omega, cf, S+U kernel: [k omega cos k,
                           // k omega sin k]*H (padded); omega and cf carry the scale factors of vc_rec_*_scale
   int model, guide, noise, with_dnu;
@@ -240,6 +242,21 @@ __device__ __forceinline__ void vc_rec_put_omega(float2* ct, const VcDims& d, fl
   }
 }
 // position of cell c in the likelihood kernel's layout (blocked counts, cell table, per-cell partial rows, W table)
+// sin phi, cos phi of the packed direction phi = atan2(y, x) (utils.py:488-506) WITHOUT the round trip through the angle: the
+// reference rounds phi to float32 (up to 2.4e-7 absolute near +-pi) and then takes cos / sin of that; y / r and x / r are within
+// ~1.5 ulp of the exact values.  It matters where ElogU's relu kink amplifies: d loglik / d z carries 1 / (z + 1e-5) with
+// z = nu . zeta'(phi) omega + gamma, so an error of 1e-7 in zeta' is a per-cent error of that element's term (round 6:
+// profiles/r06_kink_error.md).  Division and square root are correctly rounded (hipcc's default).  atan2(0, 0) = 0.
+__device__ __forceinline__ void vc_dir_sincos(float x, float y, float* s1, float* c1) {
+#ifdef VC_DIR_VIA_ANGLE       // (A/B build of profiles/tools/kink_error.py: rounds 1-5, the reference's own order of operations)
+  sincosf(atan2f(y, x), s1, c1);
+  return;
+#endif
+  const float r = sqrtf(fmaf(x, x, y * y));
+  if (r == 0.f) { *s1 = 0.f; *c1 = 1.f; return; }
+  *s1 = y / r;
+  *c1 = x / r;
+}
 __device__ __forceinline__ int vc_pos(const VcBufs& b, int c) { return b.cell_pos ? b.cell_pos[c] : c; }
 // Row of cell c (at position cp) of the W table of the U-only / S+U kernels (pw_inline): sk / ck = sin, cos of k phi_c up to Hw
 __device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c, int cp, const float* sk, const float* ck) {

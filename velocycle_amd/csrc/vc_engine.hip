@@ -97,6 +97,8 @@ struct vc_engine {
   std::string err;
   std::vector<void*> allocs;
   bool finalized = false;
+  vc_main_launch_fn main_fn_rows = nullptr;   // pw_lane engines: the U-only kernel WITH per-cell rows (main_fn stores none)
+  bool D_all_ones = false;            // velocity: one condition and D == 1 for every cell (vc_set_cell_data): W_c = zeta_omega(phi_c)
   bool finalize_started = false;      // vc_finalize got past its call-order checks
   bool finalize_failed = false;       // vc_finalize returned an error after it had started to consume its inputs
   bool generic_needed = false;        // the configuration lies outside the compiled fast set for a reason other than its batches (vc_create)
@@ -421,7 +423,7 @@ extern "C" int vc_set_tuning(vc_engine* e, const vc_tuning* t) {
   if (!in(z.tail_cells, {0, 256, 512, 1024})) return e->fail(VC_ERR_ARG, "vc_set_tuning: tail_cells must be 0, 256, 512 or 1024");
   if (!in(z.count_storage, {0, 1}) || !in(z.host_hist, {0, 1}) || !in(z.hist_dense, {0, 1, 2}) || !in(z.pw_inline, {0, 1, 2}) ||
       !in(z.no_tail2, {0, 1}) || !in(z.no_tail_merged, {0, 1}) || !in(z.force_generic, {0, 1}) || !in(z.particles_layout, {0, 1, 2}) ||
-      !in(z.dense_batches, {0, 1}) || !in(z.no_tail_spec, {0, 1}))
+      !in(z.dense_batches, {0, 1}) || !in(z.no_tail_spec, {0, 1}) || !in(z.no_pw_lane, {0, 1}))
     return e->fail(VC_ERR_ARG, "vc_set_tuning: a switch is outside its documented values");
   if (z.p2p_timeout_s < 0.f) return e->fail(VC_ERR_ARG, "vc_set_tuning: negative p2p_timeout_s");
   e->tun = z;
@@ -576,6 +578,8 @@ extern "C" int vc_set_cell_data(vc_engine* e, const float* count_factor, const f
   if (d.Nx > 0) {
     TRY(e->dalloc(&dm, (size_t)d.Nx * d.Nc));
     HIPCHK(e, hipMemcpy(dm, D, sizeof(float) * d.Nx * d.Nc, hipMemcpyHostToDevice));
+    e->D_all_ones = d.Nx == 1;
+    for (long long i = 0; i < (long long)d.Nc && e->D_all_ones; ++i) e->D_all_ones = D[i] == 1.f;
   }
   if (d.Nb > 0) {
     TRY(e->dalloc(&dbm, (size_t)d.Nb * d.Nc));
@@ -984,6 +988,32 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     d.pw_slots = 0;
     const bool pw_kind = VC_PW_INLINE && (d.kind == VC_KIND_VU || d.kind == VC_KIND_VFULL) && d.NW >= 1 && d.NW <= VC_PWQ &&
                          e->cfg.world_size == 1 && !d.generic;
+    d.pw_lane = 0;
+    if (pw_kind && e->tun.pw_inline != 1 && d.kind == VC_KIND_VU && e->D_all_ones && d.Hw <= d.H && !e->tun.no_pw_lane) {
+      // Round 6: ONE condition with D == 1 (every one-sample fit): the W row of a cell is (1, sin k phi_c, cos k phi_c) -- what its
+      // record already holds as wave-uniform SGPR pairs.  The U-only kernel's PWL instantiation (count storage | 4) accumulates
+      // A3 x W per LANE (1 + 2 Hw plain VALU per cell) instead of reducing A3 over the wave first (a 64-lane DPP tree + staging
+      // per cell): no W rows in the LDS, no per-cell rows stored (nothing reads them once K_main delivers the partials itself).
+      const void* kl = nullptr;
+      const char* nm = nullptr;
+      hipFuncAttributes fa;
+      vc_main_launch_fn fl = vc_find_main_kernel(d.H, knb, d.kind, d.noise, d.gpl, d.c16 | 4, &nm, &kl);
+      if (fl && kl && hipFuncGetAttributes(&fa, kl) == hipSuccess && fa.localSizeBytes == 0) {
+        e->main_fn_rows = e->main_fn;       // the instantiation that stores per-cell rows: what the sharded phases launch (vc_svi_run_sharded)
+        e->main_fn = fl;
+        main_kernel = kl;
+        d.pw_inline = 4;
+        d.pw_slots = 0;
+        d.pw_lane = 1;
+        // (without the staging registers of the wave-level reduction this instantiation needs 120 VGPRs instead of 160: four
+        // workgroups per CU instead of three -- the tiling follows the occupancy of the kernel that will run)
+        int bl = 0;
+        TRY(occupancy(0, &bl));
+        if (bl != bpc0) tile(bl);
+      }
+    }
+    if (d.pw_lane) {
+    } else
     if (pw_kind && e->tun.pw_inline != 1) {
       const int row = d.NW <= 4 ? 4 : 8;
       int bpc = bpc0;
@@ -1010,7 +1040,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   if (!d.generic && d.noise == VC_NOISE_NB) {
     // the gradient-only twin of the selected kernel (same tiling, same dynamic LDS); used only after vc_set_loss_every(k > 1)
     const void* knl = nullptr;
-    e->main_fn_nl = vc_find_main_kernel(d.H, knb, d.kind, d.noise, d.gpl, d.c16 | 2, &e->main_name_nl, &knl);
+    e->main_fn_nl = vc_find_main_kernel(d.H, knb, d.kind, d.noise, d.gpl, d.c16 | 2 | (d.pw_lane ? 4 : 0), &e->main_name_nl, &knl);
     hipFuncAttributes fa;
     if (e->main_fn_nl && knl && (hipFuncGetAttributes(&fa, knl) != hipSuccess || fa.localSizeBytes > 0)) e->main_fn_nl = nullptr;
     const unsigned dyn = vc_main_dyn_lds(d);
@@ -1087,6 +1117,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   const int nq_max = std::max(d.nq, d.kind == VC_KIND_VU ? nq_of(VC_KIND_PHASE) : 0);
   TRY(e->dalloc(&b.GO, (size_t)d.n_chunks * nq_max * d.Ng_pad));
   TRY(e->dalloc(&b.CO, (size_t)d.nGB * 3 * d.Nc));
+  HIPCHK(e, hipMemset(b.CO, 0, sizeof(float) * (size_t)d.nGB * 3 * d.Nc));   // (pw_lane: K_main stores no per-cell rows; their unfused readers see zeros)
   TRY(e->dalloc(&b.LO, (size_t)d.n_main_wg));
 #ifdef VC_DBG_TIMES
   TRY(e->dalloc(&b.dbg, VC_DBG_WORDS(d.n_main_wg)));   // + per-block stamps of K_pre / K_post / K_fin, per-wave of K_tail / K_omega
@@ -1711,11 +1742,17 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
   e->fill(a, exp_avg, exp_avg_sq, lr, lrd, beta1, beta2, adam_eps, clip_norm);
   const long long* sd = (const long long*)step_dev;
   const int with_hist = e->hist_each_step ? 1 : 0;
+  // A single-rank engine whose U-only kernel keeps the nu_omega partials per lane (pw_lane) stores no per-cell rows -- but phase A
+  // builds the exchange buffer's per-cell-block rows from exactly those.  The sharded phases therefore run such an engine as a rank
+  // of an N > 1 run would run it: K_main without its own partials (the tiling is the same: pw_lane holds nothing in the LDS).
+  VcDims ds = e->d;
+  vc_main_launch_fn main_fn = e->main_fn;
+  if (ds.pw_lane) { ds.pw_lane = 0; ds.pw_inline = 0; ds.pw_slots = 0; main_fn = e->main_fn_rows; }
   VcXb xb;
   xb.x = xbuf; xb.pw_off = e->xb_pw_off; xb.pw_cap = e->xb_pw_cap; xb.loss_off = e->xb_loss_off; xb.sis = e->sis;
   if (prime && n_steps > 0 && phase != VC_PHASE_B) {      // sampling is rank-local: the single-rank priming launches
-    vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 1, 0, VcXb{}, st);
-    vc_launch_omega(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 1, with_hist, st);
+    vc_launch_tail(ds, e->b, params, grad, sd, seed, a, 1, 0, VcXb{}, st);
+    vc_launch_omega(ds, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, 1, with_hist, st);
   }
   VcBufs b2 = e->b;
   b2.step_ctr = (long long*)step_dev;
@@ -1726,15 +1763,15 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
         if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
         auto& pr = e->ev_pool[e->ev_used++];
         HIPCHK(e, hipEventRecord(pr.first, st));
-        e->main_fn(e->d, b2, st);
+        main_fn(ds, b2, st);
         HIPCHK(e, hipEventRecord(pr.second, st));
       } else {
-        e->main_fn(e->d, b2, st);
+        main_fn(ds, b2, st);
       }
       VcXb xa = xb;
       if (use_p2p)        // phase A writes this rank's slot of the step's parity; K_xchg sums every rank's slot into xbuf
         xa.x = reinterpret_cast<float*>(e->p2p_own) + e->p2p.flag_words + (size_t)(e->p2p_step & 1) * (size_t)e->p2p.slot_floats;
-      vc_launch_tail(e->d, e->b, params, grad, sd, seed, a, 0, 1, xa, st);
+      vc_launch_tail(ds, e->b, params, grad, sd, seed, a, 0, 1, xa, st);
     }
     if (use_p2p) {
       vc_launch_p2p_xchg(e->p2p, e->p2p_step, xbuf, (long long)e->xb_total, e->b.status, e->p2p_timeout_s, e->p2p_verdict, st);
@@ -1744,7 +1781,7 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
       if (rc != 0) return e->fail(VC_ERR_STATE, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed");
     }
     if (phase != VC_PHASE_A)
-      vc_launch_phase_b(e->d, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, with_hist, xb, st);
+      vc_launch_phase_b(ds, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, with_hist, xb, st);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
@@ -1858,8 +1895,8 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   out->launches_per_step = fused_launches_per_step(e);
   out->pw_inline = d.pw_inline;
   out->generic = d.generic;
-  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s>", d.H, d.nbk, e->main_name, d.gpl,
-           d.c16 ? ",u16" : "");
+  snprintf(out->main_kernel_name, sizeof out->main_kernel_name, "vc_main_kernel<%d,%d,%s,gpl%d%s%s>", d.H, d.nbk, e->main_name, d.gpl,
+           d.c16 ? ",u16" : "", d.pw_lane ? ",pwl" : "");
   out->onehot_batches = d.onehot ? d.Nb : 0;
   // The row the signature matched, and the row the steps of vc_svi_run_fused / vc_svi_run_sharded actually LAUNCH: a matched row
   // serves only the launch structures its kind bits name (a single-rank engine kept at three launches by tuning.no_tail2 /
@@ -1868,6 +1905,8 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   if (e->cfg.world_size > 1) speck = VC_SPECK_SHARDED;
   else { const int tk = fused_tail_kind(e); speck = tk == 1 ? VC_SPECK_MERGED : (tk == 2 ? VC_SPECK_TAIL2 : 0); }
   const int used = (d.spec > 0 && (VC_SPECS[d.spec].kind & speck)) ? d.spec : VC_SPEC_NONE;
+  out->pw_lane = d.pw_lane;
+  out->reserved3 = 0;
   out->tail_spec = used;
   out->tail_spec_matched = d.spec;
   memset(out->tail_spec_name, 0, sizeof(out->tail_spec_name));

@@ -248,7 +248,11 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   const bool dnu_pre_on = chain && r_dnu1 && live && role - Nh < d.Nb && !CND(VC_SITE_DNU);
   dnu_pre.c0 = 0; dnu_pre.c1 = 0;
   float dq_p = 0.f, dq_m = 0.f, dq_v = 0.f, dq_lat = 0.f;      // ... and that batch's parameter, moments and sample (as the roles above)
-  const bool dq_on = r_dnu1 && live && role - Nh < d.Nb;
+  // conditioned batch offsets (the tutorials' velocity stage hands over the phase fit's delta nu: Tutorial_Aissa_PC9_TwoSample cell 42)
+  // never change: parameter, moments, site value and gene-table row hold what the priming launch wrote -- only their (constant)
+  // prior term is re-formed per step; no load / optimiser / store round trip on these waves (round 6: the two-sample tail gap)
+  const bool dnu_fixed = CND(VC_SITE_DNU) && !boot && phase != VC_PH_A;
+  const bool dq_on = r_dnu1 && live && role - Nh < d.Nb && !dnu_fixed;
   if (dq_on) {
     const long long jq0 = (long long)(role - Nh) * d.Ng + g;
     const int po0 = (int)(d.poff[VC_P_DNU_LOCS] + jq0);
@@ -406,6 +410,10 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       const int po = (int)(d.poff[VC_P_DNU_LOCS] + jq);
       const float sd = vel ? 0.01f : b.sd_dnu[jq];
       const bool first = q == role - Nh;          // (its inputs were requested at the top of the block)
+      if (dnu_fixed) {
+        if (samp) logp_dnu += vc_normal_lp(b.cnd[VC_SITE_DNU][jq], 0.f, sd);
+        continue;
+      }
       float p = first ? dq_p : P[po];
       if (!boot) {
         float gq = 0.f;
@@ -782,9 +790,9 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
     }
     if (!cxy || boot) {          // conditioned phases never change: their record is written once
       *reinterpret_cast<float2*>(b.lat[VC_SITE_PHIXY] + 2 * (size_t)c) = make_float2(x, y);
-      const float ph = atan2f(y, x);
+      const float ph = atan2f(y, x);          // (the deterministic site only)
       float s1, c1;
-      sincosf(ph, &s1, &c1);
+      vc_dir_sincos(x, y, &s1, &c1);
       float sk[VC_MAXH], ck[VC_MAXH];
       sk[0] = s1; ck[0] = c1;
       const int hm = d.H > d.Hw ? d.H : d.Hw;          // the W table (vc_put_w) goes up to Hw

@@ -405,9 +405,9 @@ __global__ __launch_bounds__(256) void vc_pre_generic_kernel(const VcDims d, con
         b.lat[VC_SITE_PHIXY][2 * c] = x;
         b.lat[VC_SITE_PHIXY][2 * c + 1] = y;
       }
-      const float phi = atan2f(y, x);                      // utils.py:505-506
+      const float phi = atan2f(y, x);                      // utils.py:505-506 (the deterministic site)
       float s1, c1;
-      sincosf(phi, &s1, &c1);
+      vc_dir_sincos(x, y, &s1, &c1);
       float2* ct = reinterpret_cast<float2*>(b.CT + (size_t)c * d.ctw);
       const int nbk = d.with_dnu ? d.Nb : 0;
       const int hm = d.H > d.Hw ? d.H : d.Hw;
@@ -575,9 +575,9 @@ __global__ __launch_bounds__(256) void vc_post_generic_kernel(const VcDims d, co
   const int c = cblock * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float A[3] = {0.f, 0.f, 0.f};
-  float phi = 0.f;
+  float s1 = 0.f, c1 = 1.f;
   if (c < d.Nc) {
-    phi = b.lat_phi[c];
+    { const float* ct = b.CT + (size_t)c * d.ctw; s1 = ct[0]; c1 = ct[2]; }     // the cell record's own sin / cos
     for (int gb = 0; gb < d.nGB; ++gb)
       for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + c];
     if (d.poff[VC_P_PHIXY_LOCS] >= 0) {
@@ -597,8 +597,6 @@ __global__ __launch_bounds__(256) void vc_post_generic_kernel(const VcDims d, co
   if (vel) {
     // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c), one coefficient after the other
     const float a3 = (c < d.Nc) ? (d.kind == VC_KIND_VFULL ? A[2] : A[0]) : 0.f;
-    float s1, c1;
-    sincosf(phi, &s1, &c1);
     for (int xq = 0; xq < d.Nx; ++xq) {
       const float dx = (c < d.Nc) ? b.Dm[(size_t)xq * d.Nc + c] : 0.f;
       float sk = s1, ck = c1;

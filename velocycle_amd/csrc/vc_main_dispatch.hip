@@ -21,6 +21,10 @@ extern const VcMainEntry vc_tab_vfull_nb_nl[30];
 extern const VcMainEntry vc_tab_vfull_nb_u16_nl[30];
 extern const VcMainEntry vc_tab_phase_nb_nl[30];
 extern const VcMainEntry vc_tab_phase_nb_u16_nl[30];
+extern const VcMainEntry vc_tab_vu_nb_pwl[30];         // nu_omega partials per lane (c16 | 4), + gradient-only (| 2)
+extern const VcMainEntry vc_tab_vu_nb_u16_pwl[30];
+extern const VcMainEntry vc_tab_vu_nb_pwl_nl[30];
+extern const VcMainEntry vc_tab_vu_nb_u16_pwl_nl[30];
 
 vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, int c16, const char** name,
                                       const void** kernel) {
@@ -29,11 +33,13 @@ vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gp
                                       vc_tab_vu_lognormal, vc_tab_phase_nb_u16, vc_tab_phase_poisson_u16,
                                       vc_tab_vfull_nb_u16, vc_tab_vfull_poisson_u16, vc_tab_vu_nb_u16, vc_tab_vu_poisson_u16,
                                       vc_tab_vu_nb_nl, vc_tab_vu_nb_u16_nl, vc_tab_vfull_nb_nl, vc_tab_vfull_nb_u16_nl,
-                                      vc_tab_phase_nb_nl, vc_tab_phase_nb_u16_nl};
+                                      vc_tab_phase_nb_nl, vc_tab_phase_nb_u16_nl, vc_tab_vu_nb_pwl, vc_tab_vu_nb_u16_pwl,
+                                      vc_tab_vu_nb_pwl_nl, vc_tab_vu_nb_u16_pwl_nl};
   static const char* tab_names[] = {"phase_nb", "phase_poisson", "phase_lognormal", "vfull_nb", "vfull_poisson",
                                     "vfull_lognormal", "vu_nb", "vu_poisson", "vu_lognormal", "phase_nb", "phase_poisson",
                                     "vfull_nb", "vfull_poisson", "vu_nb", "vu_poisson", "vu_nb_gradonly", "vu_nb_gradonly",
-                                    "vfull_nb_gradonly", "vfull_nb_gradonly", "phase_nb_gradonly", "phase_nb_gradonly"};
+                                    "vfull_nb_gradonly", "vfull_nb_gradonly", "phase_nb_gradonly", "phase_nb_gradonly",
+                                    "vu_nb", "vu_nb", "vu_nb_gradonly", "vu_nb_gradonly"};
   for (unsigned t = 0; t < sizeof(tabs) / sizeof(tabs[0]); ++t)
     for (int i = 0; i < 30; ++i) {
       const VcMainEntry& e = tabs[t][i];

@@ -72,7 +72,7 @@
 // C16 (bit 0 of CS): the counts are stored as uint16 (every count of the matrix is an integer <= 65535: decided by vc_finalize from the
 // histograms) -- half the HBM bytes of the reference's float32 storage, one v_cvt_f32_u32 with a WORD_n source select per
 // element; C16 = 0 reads the float32 layout (Lognormal noise stores log(k+1); non-integer or huge counts).
-// CS = C16 | 2 NOLOSS.  NOLOSS (negative-binomial noise; opt-in through vc_set_loss_every): the gradient alone.  U-only kernel: with
+// CS = C16 | 2 NOLOSS | 4 PWL.  PWL (U-only kernel, round 6): see `pw_on` below.  NOLOSS (negative-binomial noise; opt-in through vc_set_loss_every): the gradient alone.  U-only kernel: with
 // shape_inv conditioned both v_log_f32 per element serve only the loss VALUE, and mu = 2^eta_S * zp needs no log of zp either:
 // 4 of 8 transcendentals and 4 of 21 packed operations per gene pair less (68 -> 52 us at 50k x 2k, profiles/r04_vcond.md).
 // S+U / S-only kernels (shape_inv learned: log2(r + mu) feeds d / d shape_inv and stays): log2(zp) and the two loss
@@ -82,6 +82,8 @@ template <int H, int NB, int KIND, int NOISE, int GPL, int CS>
 __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB_SINGLE) : 1)) void vc_main_kernel(const VcDims d, const VcBufs b) {
   constexpr int C16 = CS & 1;
   constexpr bool NOLOSS = (CS & 2) != 0;
+  constexpr bool PWL = (CS & 4) != 0;          // the nu_omega partials per lane from the cell record (U-only kernel, d.pw_lane)
+  static_assert(!PWL || (KIND == VC_KIND_VU && VC_PW_INLINE), "per-lane nu_omega partials: the U-only kernel");
   static_assert(!NOLOSS || (NOISE == VC_NOISE_NB && VC_RCP_MERGE), "gradient-only: negative-binomial noise");
   constexpr int GBW = 64 * GPL;
   constexpr int NH = 2 * H + 1;
@@ -102,6 +104,13 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // With these partials the nu_omega chain needs nothing from the next launch's cell blocks (vc_fused_kernels.hip: vc_tail2_kernel).
   constexpr bool PWI = VC_PW_INLINE && (KIND == VC_KIND_VU || KIND == VC_KIND_VFULL);
   const bool pw_on = PWI && d.pw_inline != 0;
+  // round 6, U-only kernel, one condition with D == 1 (PWL): W_c = (1, sin k phi_c, cos k phi_c) = the cell's record -- A3 x W is accumulated
+  // per LANE (lane = the wave's genes; 1 + 2 Hw plain VALU per cell) instead of reducing A3 over the wave first (a 64-lane DPP
+  // tree, a select and the staging per cell); the lanes are added up once, in the epilogue.  No per-cell row is stored.
+  // PWL (bit 2 of CS; U-only kernel; selected by vc_finalize where d.pw_lane holds): compiled as an instantiation of its own -- a
+  // run-time choice between the two per-cell tails made hipcc either merge their accumulators with register copies inside the
+  // loop or, with the loop duplicated, copy count tuples whose asm-issued loads were in flight (check_asm_loads.py caught it).
+  const int pw_hw = d.Hw;
   float pwacc[VC_PWQ];
 #pragma unroll
   for (int j = 0; j < VC_PWQ; ++j) pwacc[j] = 0.f;
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   const int PW_SLOTS = d.pw_slots;
   const int pw_rq = pw_on ? d.pw_inline / 4 : 1;      // float4 per W row: 1 or 2
   float4* pw_acc = lds_w + (size_t)VC_WAVES * PW_SLOTS + wave * 32;      // [16 cells of a tile][2]
-  if (PWI && pw_on) {
+  if (PWI && pw_on && !PWL) {
     float4* mine = lds_w + wave * PW_SLOTS;
     const float4* src = reinterpret_cast<const float4*>(b.WT) + (size_t)cbeg * pw_rq;
     for (int i = lane; i < ncell * pw_rq; i += 64) mine[i] = src[i];
@@ -530,6 +539,16 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
           if (LDSR) {
             tile_put(p0, p1, p2, i & (TILE_C - 1));
             if ((i & (TILE_C - 1)) == TILE_C - 1 || i + 1 == ncell) tile_flush(cbeg + (i & ~(TILE_C - 1)), (i & (TILE_C - 1)) + 1);
+          } else if (PWL) {
+            // the W row of this cell is its record: A3 x (1, sin k phi, cos k phi) per lane, no reduction over the wave
+            const VcCellRec<H, NB>& rc = rec_bf[j];
+            pwacc[0] += p0;
+#pragma unroll
+            for (int k = 0; k < H; ++k)
+              if (k < pw_hw) {          // (wave-uniform)
+                pwacc[2 * k + 1] = __builtin_fmaf(p0, rc.sn[k].x, pwacc[2 * k + 1]);
+                pwacc[2 * k + 2] = __builtin_fmaf(p0, rc.cs[k].x, pwacc[2 * k + 2]);
+              }
           } else {
             stage1(p0, p1, p2, i & 63);
             if ((i & 63) == 63 || i + 1 == ncell) flush(cbeg + (i & ~63), (i & 63) + 1);

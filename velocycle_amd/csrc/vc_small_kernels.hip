@@ -387,9 +387,9 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
         b.lat[VC_SITE_PHIXY][2 * c] = x;
         b.lat[VC_SITE_PHIXY][2 * c + 1] = y;
       }
-      const float phi = atan2f(y, x);                      // utils.py:505-506
+      const float phi = atan2f(y, x);                      // utils.py:505-506 (the deterministic site; the basis does not go through it)
       float s1, c1;
-      sincosf(phi, &s1, &c1);
+      vc_dir_sincos(x, y, &s1, &c1);
       float sk[VC_MAXH], ck[VC_MAXH];
       sk[0] = s1; ck[0] = c1;
       const int hm = d.H > d.Hw ? d.H : d.Hw;
@@ -727,14 +727,13 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool vel = d.model == VC_MODEL_VELOCITY;
   float A[3] = {0.f, 0.f, 0.f};
-  float phi = 0.f;
+  float2 sc1 = make_float2(0.f, 1.f);    // sin phi, cos phi of the cell (from its record)
   float dx01[2] = {0.f, 0.f};             // design-matrix entries of the first two conditions
   if (c < d.Nc) {
     // everything this cell needs is requested in one go (the partial sums and the site values are independent loads)
     const bool need_xy = d.poff[VC_P_PHIXY_LOCS] >= 0 && !CND(VC_SITE_PHIXY);
     float2 xy = make_float2(1.f, 0.f), pxy = make_float2(0.f, 0.f);
     float om = 0.f, dom = 0.f;
-    phi = b.lat_phi[c];
     if (vel) {
       dx01[0] = b.Dm[c];
       if (d.Nx > 1) dx01[1] = b.Dm[(size_t)d.Nc + c];
@@ -745,6 +744,7 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
       if (d.kind == VC_KIND_VFULL) { om = b.lat_omega[c]; dom = b.lat_domega[c]; }
     }
     const int cp = vc_pos(b, c);
+    { const float* ct = b.CT + (size_t)cp * d.ctw; sc1 = make_float2(ct[0], ct[2]); }     // {sin, sin}, {cos, cos} of the first harmonic
     for (int gb = 0; gb < d.nGB; ++gb)
       for (int j = 0; j < d.nco; ++j) A[j] += b.CO[((size_t)gb * d.nco + j) * d.Nc + cp];
     VC_KSTAMP(1, 1);
@@ -765,8 +765,7 @@ __device__ __forceinline__ void vc_post_cell_block(const VcDims& d, const VcBufs
   if (vel) {
     // partial sums of d loglik / d nu_omega[x,h] = sum_c A3_c D[x,c] zeta_omega_h(phi_c)
     const float a3 = (c < d.Nc) ? (d.kind == VC_KIND_VFULL ? A[2] : A[0]) : 0.f;
-    float s1, c1;
-    sincosf(phi, &s1, &c1);
+    float s1 = sc1.x, c1 = sc1.y;                 // (the cell record's own sin / cos: the bits K_pre built the basis from)
     float sk[VC_MAXH], ck[VC_MAXH];
     sk[0] = s1; ck[0] = c1;
     for (int k = 1; k < d.Hw && k < VC_MAXH; ++k) {

@@ -119,8 +119,12 @@ class _FitBase:
         particles = int(getattr(loss, "num_particles", 1)) if loss is not None else 1
         if particles < 1:
             raise ValueError("loss.num_particles must be >= 1")
-        if loss is not None and getattr(loss, "vectorize_particles", False):
-            raise NotImplementedError("Trace_ELBO(vectorize_particles=True) is not supported by the HIP engine")
+        if loss is not None and getattr(loss, "vectorize_particles", False) and mode == "parity" and particles > 1:
+            # the same estimator (K draws averaged): perf mode runs it as the batched particle step.  Parity mode promises the
+            # reference's host RNG order, and a vectorised trace consumes the generator site-major -- an order no fixture pins
+            # (pyro_compat.Trace_ELBO's docstring)
+            raise NotImplementedError("Trace_ELBO(vectorize_particles=True) with mode='parity': the host RNG order of a vectorised "
+                                      "trace is not pinned; use mode='perf' (same estimator: K draws per step, averaged)")
         exact = mode == "parity" or self.early_exit or store_output
         if int(loss_every) > 1 and (exact or particles > 1 or self._world > 1):
             raise ValueError("loss_every > 1 needs mode='perf' on one rank without early_exit / store_output / particles "

@@ -74,15 +74,25 @@ class Trace_ELBO:
     (velocity_inference_model.py:79,111; phase_inference_model.py:128,162): a holder of `num_particles` -- K guide draws per
     step, loss and gradients averaged over them before the optimiser step -- and of the one piece of state Pyro's object
     carries between fits: a fresh object makes one extra guide pass before its first step (`fresh`, cleared on first use).
-    Any object with a `num_particles` attribute (a real pyro ELBO included) is read the same way by fit()."""
+    Any object with a `num_particles` attribute (a real pyro ELBO included) is read the same way by fit().
 
-    def __init__(self, num_particles: int = 1, **kwargs):
+    `vectorize_particles=True` (pyro-ppl 1.8.6 infer/elbo.py: the K particles as one trace under an extra plate) is the same
+    estimator -- K draws per step, loss and gradients averaged -- and is what the engine's batched particle step computes anyway
+    (vc_svi_run_particles: K_pre / K_post of all particles in one launch each): fit(mode="perf") accepts it.  What differs in
+    Pyro is only the ORDER in which the host RNG is consumed (site-major instead of particle-major), which matters to
+    mode="parity" alone -- refused there by name, since no fixture pins that order (the reference's own einsum
+    "...gch,...ch->gc" sums over a leading particle dimension, so its model cannot run vectorised as it is)."""
+
+    def __init__(self, num_particles: int = 1, max_plate_nesting=float("inf"), vectorize_particles: bool = False, **kwargs):
         if int(num_particles) < 1:
             raise ValueError("num_particles must be >= 1")
-        unsupported = {k: v for k, v in kwargs.items() if k in ("vectorize_particles",) and v}
+        unsupported = {k: v for k, v in kwargs.items() if k not in ("max_iarange_nesting", "strict_enumeration_warning", "ignore_jit_warnings",
+                                                                    "jit_options", "retain_graph", "tail_adaptive_beta")}
         if unsupported:
-            raise NotImplementedError(f"Trace_ELBO options not supported by the HIP engine: {sorted(unsupported)}")
+            raise TypeError(f"Trace_ELBO: unexpected arguments {sorted(unsupported)}")
         self.num_particles = int(num_particles)
+        self.max_plate_nesting = max_plate_nesting
+        self.vectorize_particles = bool(vectorize_particles)
         self.fresh = True
 
 

@@ -14,13 +14,18 @@ from .spec import ModelSpec
 
 
 def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, seed=0, device="cpu",
-                       noisemodel="NegativeBinomial", concentration=5.0, sim=None) -> ModelSpec:
+                       noisemodel="NegativeBinomial", concentration=5.0, sim=None, n_batches=None) -> ModelSpec:
     """mode: "vjoint" (mean-field guide, nothing conditioned), "vcond" (default LRMN guide conditioned
     on ϕxy, ν, shape_inv [, Δν] like the tutorials), "vcond_mf" (same conditioning, mean-field), "vjoint_lrmn" (LRMN guide,
     nothing conditioned: the reference's default `model_type` without `condition_on`).
     `sim`: a stored output of `simulate_counts` (the sampling kernels of torch are not bit-reproducible across hosts, so
     fixtures that must describe the SAME data on every machine carry the simulated counts: tests/golden/oracle_fit_data_*)."""
-    omegas = (0.4, 0.3, 0.35, 0.25, 0.45, 0.2, 0.38, 0.28)[:n_conditions]
+    # n_batches (default: = n_conditions, the tutorials' layout): samples of Nc cells each; with more batches than conditions the last
+    # condition takes the remaining samples (batch design Db and condition design D are separate arguments of
+    # preprocess_for_velocity_estimation, preprocessing.py:207-240)
+    n_samples = n_conditions if n_batches is None else int(n_batches)
+    assert n_samples >= n_conditions
+    omegas = (0.4, 0.3, 0.35, 0.25, 0.45, 0.2, 0.38, 0.28)[:n_samples]
     if sim is None:
         sim = simulate_counts(Nc, Ng, omegas=omegas, seed=seed, device=device)
     S_cm, U_cm = sim["S"], sim["U"]                  # (Nc_total, Ng) cell-major, like AnnData layers
@@ -36,8 +41,9 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
     phi0 = sim["phis"].cpu() + 0.3 * torch.randn(nct, generator=g)
     pxy = concentration * torch.stack([torch.cos(phi0), torch.sin(phi0)], 1)
     batch = sim["batch"]
-    D = torch.stack([(batch == b).float() for b in range(n_conditions)])       # (Nx, Nc)
-    with_dnu = n_conditions > 1
+    Db = torch.stack([(batch == b).float() for b in range(n_samples)])         # (Nb, Nc)
+    D = torch.stack([((batch == b) if b < n_conditions - 1 else (batch >= b)).float() for b in range(n_conditions)])       # (Nx, Nc)
+    with_dnu = n_samples > 1
     Nhw = 2 * Hw + 1
     mu_w = torch.zeros(n_conditions, Nhw)
     sd_w = torch.full((n_conditions, Nhw), 0.05)
@@ -45,7 +51,7 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
     spec = ModelSpec(
         kind="velocity", guide="meanfield" if mode in ("vjoint", "vcond_mf") else "lrmn",
         noisemodel=noisemodel, with_delta_nu=with_dnu, H=1, Hw=Hw,
-        S=S_cm.t(), U=U_cm.t(), count_factor=cf, Db=D.clone(), D=D,
+        S=S_cm.t(), U=U_cm.t(), count_factor=cf, Db=Db, D=D,
         mu_nu=mu_nu, sd_nu=sd_nu, phixy_prior=pxy,
         mu_gamma=torch.zeros(Ng), sd_gamma=torch.full((Ng,), 0.5),
         mu_beta=torch.full((Ng,), 2.0), sd_beta=torch.full((Ng,), 3.0),
@@ -55,7 +61,7 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
         spec.condition_on = {"ϕxy": torch.stack([torch.cos(sim["phis"].cpu()), torch.sin(sim["phis"].cpu())], 1),
                              "ν": true_nu, "shape_inv": sim["shape_inv"].cpu()}
         if with_dnu:
-            spec.condition_on["Δν"] = torch.zeros(n_conditions, Ng)
+            spec.condition_on["Δν"] = torch.zeros(n_samples, Ng)
     spec.truth = sim
     return spec
 
