@@ -73,6 +73,11 @@ for world in (8, 1):
     # omega_n_harmonics=0 (Tutorial_Capolupo_HumanFibroblasts_OneSample.ipynb:690,721; angularspeed.py:311-354)
     add("vcond_hw0" + tag, make_velocity_spec(NC, NG, "vcond", 1, 0, seed=0, device=dev), world)
     add("phase" + tag, make_phase_spec(NC, NG, seed=0, device=dev), world)
+    # round 6: the default of preprocess_for_phase_estimation / preprocess_for_velocity_estimation -- n_harmonics = 2
+    # (preprocessing.py:108,217; the package tutorials pass 1)
+    for name, mode in (("vjoint_h2", "vjoint"), ("vcond_h2", "vcond")):
+        add(name + tag, make_velocity_spec(NC, NG, mode, 1, 1, seed=0, device=dev, H=2), world)
+    add("phase_h2" + tag, make_phase_spec(NC, NG, seed=0, device=dev, H=2), world)
     # round 6: exactly two samples (BASELINE configs[4], Tutorial_Aissa_PC9_TwoSample: Nx = Nb = 2) with every count closed
     for name, mode, hw in (("vjoint_2s", "vjoint", 1), ("vcond_2s", "vcond", 1), ("vcond_hw0_2s", "vcond", 0)):
         add(name + tag, make_velocity_spec(NC // 2, NG, mode, 2, hw, seed=0, device=dev), world)

@@ -25,20 +25,24 @@ ROWS = {            # name of the row a workload must select: (builder, mode, sa
     # row: the open rows are reached with three BATCHES under two conditions)
     "vjoint_multi": ("vel", "vjoint", 2, 1, 3), "vcond_multi": ("vel", "vcond", 2, 1, 3), "phase_multi": ("phase", None, 3),
     "vjoint_lrmn_multi": ("vel", "vjoint_lrmn", 2), "vcond_mf_multi": ("vel", "vcond_mf", 2),
+    # round 6: two harmonics of the expression map -- the default n_harmonics of preprocess_for_* (preprocessing.py:108,217); V-joint with
+    # five coefficients per gene runs three launches on one rank (no single-rank row), its rank row exists
+    "vcond_h2": ("vel", "vcond", 1, 1, None, 2), "phase_h2": ("phase", None, 1, 1, None, 2),
 }
 RANK_ROWS = {"vjoint_rank": ("vel", "vjoint", 1), "vcond_rank": ("vel", "vcond", 1), "phase": ("phase", None, 1),
              "vjoint_lrmn_rank": ("vel", "vjoint_lrmn", 1), "vcond_mf_rank": ("vel", "vcond_mf", 1),
              "vcond_hw0_rank": ("vel", "vcond", 1, 0), "vcond_hw0_2s_rank": ("vel", "vcond", 2, 0), "vcond_hw0_multi_rank": ("vel", "vcond", 3, 0),
              "vjoint_2s_rank": ("vel", "vjoint", 2), "vcond_2s_rank": ("vel", "vcond", 2),
              "vjoint_multi_rank": ("vel", "vjoint", 3), "vcond_multi_rank": ("vel", "vcond", 3), "phase_multi": ("phase", None, 2),
-             "vjoint_lrmn_multi_rank": ("vel", "vjoint_lrmn", 2), "vcond_mf_multi_rank": ("vel", "vcond_mf", 2)}
+             "vjoint_lrmn_multi_rank": ("vel", "vjoint_lrmn", 2), "vcond_mf_multi_rank": ("vel", "vcond_mf", 2),
+             "vjoint_h2_rank": ("vel", "vjoint", 1, 1, None, 2), "vcond_h2_rank": ("vel", "vcond", 1, 1, None, 2), "phase_h2": ("phase", None, 1, 1, None, 2)}
 
 
-def _spec(kind, mode, ncond, hw=1, nbatch=None, nc=2100, ng=260):
+def _spec(kind, mode, ncond, hw=1, nbatch=None, H=1, nc=2100, ng=260):
     from velocycle_amd.workloads import make_phase_spec, make_velocity_spec
     if kind == "phase":
-        return make_phase_spec(nc // ncond, ng, seed=3, n_batches=ncond)
-    return make_velocity_spec(nc // (nbatch or ncond), ng, mode, n_conditions=ncond, Hw=hw, seed=3, n_batches=nbatch)
+        return make_phase_spec(nc // ncond, ng, seed=3, n_batches=ncond, H=H)
+    return make_velocity_spec(nc // (nbatch or ncond), ng, mode, n_conditions=ncond, Hw=hw, seed=3, n_batches=nbatch, H=H)
 
 
 @pytest.mark.parametrize("row", sorted(ROWS))

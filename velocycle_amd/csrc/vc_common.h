@@ -271,6 +271,60 @@ __device__ __forceinline__ void vc_put_w(const VcDims& d, const VcBufs& b, int c
       }
   }
 }
+// The second-stage reduction of K_main's gene-level partial rows by the 16 waves of a gene block (K_post, the tails' gene blocks, phase A):
+// wave w adds the rows of chunks first, first + stride, ... < end in that order; the block's sum is then sm[0] + ... + sm[15].
+// Plain: first = w, stride = 16 over all chunks.  One-hot batches, 2 <= Nb <= VC_WALK_MAXNB (round 6): the waves are dealt out to
+// the BATCHES (16 / Nb each, the last batch takes the rest) and walk only their batch's chunk range -- the sum of the constant
+// harmonic's row over batch q, i.e. d loglik / d dnu[q, g], is then the sum of that batch's waves' partials in the LDS: no second pass
+// over the rows (round 5 summed the range again behind the barrier: two dependent round trips of 32 rows on one wave per batch).
+// ONE association for every caller, like vc_dnu_range_sum.
+#define VC_WALK_WAVES 16
+#define VC_WALK_MAXNB 8
+struct VcChunkWalk { int first, stride, end; };
+__device__ __forceinline__ bool vc_walk_by_batch(const VcDims& d) { return d.onehot && d.Nb >= 2 && d.Nb <= VC_WALK_MAXNB; }
+__device__ __forceinline__ void vc_walk_waves_of(const VcDims& d, int q, int* w0, int* nw) {      // the waves of batch q
+  const int wb = VC_WALK_WAVES / d.Nb;
+  *w0 = q * wb;
+  *nw = (q == d.Nb - 1) ? VC_WALK_WAVES - q * wb : wb;
+}
+// the same walk where the lanes of a wave hold genes of DIFFERENT gene blocks of the likelihood kernel (the histogram blocks that
+// re-derive the shape_inv update lane by lane): ordinary loads of the batch's range
+__device__ __forceinline__ VcChunkWalk vc_chunk_walk_lane(const VcDims& d, const VcBufs& b, int g, int wave) {
+  VcChunkWalk k;
+  if (vc_walk_by_batch(d)) {
+    const int wb = VC_WALK_WAVES / d.Nb;
+    int q = wave / wb;
+    if (q > d.Nb - 1) q = d.Nb - 1;
+    int w0, nw;
+    vc_walk_waves_of(d, q, &w0, &nw);
+    const int* bc = b.bat_chunk + (size_t)(g / d.gbw) * (d.Nb + 1) + q;
+    k.first = bc[0] + (wave - w0);
+    k.stride = nw;
+    k.end = bc[1];
+  } else {
+    k.first = wave; k.stride = VC_WALK_WAVES; k.end = d.n_chunks;
+  }
+  return k;
+}
+__device__ __forceinline__ VcChunkWalk vc_chunk_walk(const VcDims& d, const VcBufs& b, int g, int wave) {
+  VcChunkWalk k;
+  if (vc_walk_by_batch(d)) {
+    const int wb = VC_WALK_WAVES / d.Nb;
+    int q = wave / wb;
+    if (q > d.Nb - 1) q = d.Nb - 1;
+    int w0, nw;
+    vc_walk_waves_of(d, q, &w0, &nw);
+    // (wave-uniform: the 64 genes of the block lie in one gene block of the likelihood kernel; a scalar load like the tile table's)
+    typedef const __attribute__((address_space(4))) int* ciptr;
+    ciptr bc = (ciptr)(const void*)(b.bat_chunk + (size_t)__builtin_amdgcn_readfirstlane(g / d.gbw) * (d.Nb + 1) + q);
+    k.first = bc[0] + (wave - w0);
+    k.stride = nw;
+    k.end = bc[1];
+  } else {
+    k.first = wave; k.stride = VC_WALK_WAVES; k.end = d.n_chunks;
+  }
+  return k;
+}
 // onehot: d loglik / d dnu[q, g] = the sum of the constant harmonic's partial row (GO row 0) over the workgroups of batch q of the
 // likelihood kernel's gene block that holds gene g -- chunks [c0, c1) of that gene block, added in chunk order (one fixed
 // association for every caller: K_post, K_tail, phase A), 32 chunks requested per trip

@@ -104,6 +104,8 @@ struct vc_engine {
   bool generic_needed = false;        // the configuration lies outside the compiled fast set for a reason other than its batches (vc_create)
   bool generic_nb = false;            // ... because it has more than VC_MAXNB batches: generic only if their design matrix is not one-hot
   std::vector<float> hDb;             // host copy of the batch design matrix (vc_finalize: is it one-hot?)
+  std::vector<float> hD;              // host copy of the condition design matrix (vc_finalize: one condition per workgroup of the U-only kernel?)
+  std::vector<int> bat_cond;          // pw_lane with several conditions: the condition every cell of batch q belongs to
   bool have_counts = false, have_cells = false;
   bool prior_set[VC_PRIOR_COUNT] = {};
   // host copies needed at finalize
@@ -580,6 +582,7 @@ extern "C" int vc_set_cell_data(vc_engine* e, const float* count_factor, const f
     HIPCHK(e, hipMemcpy(dm, D, sizeof(float) * d.Nx * d.Nc, hipMemcpyHostToDevice));
     e->D_all_ones = d.Nx == 1;
     for (long long i = 0; i < (long long)d.Nc && e->D_all_ones; ++i) e->D_all_ones = D[i] == 1.f;
+    try { e->hD.assign(D, D + (size_t)d.Nx * d.Nc); } catch (...) { return e->fail(VC_ERR_ARG, "out of host memory"); }
   }
   if (d.Nb > 0) {
     TRY(e->dalloc(&dbm, (size_t)d.Nb * d.Nc));
@@ -694,6 +697,24 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
       vc_onehot_batches(e->hDb.data(), d.Nb, d.Nc, bat_id)) {
     d.onehot = 1;
     bat_sorted = vc_order_by_batch(bat_id, d.Nb, bat_pos, bat_ord, bat_len);
+    // the condition design D (Nx, Nc) is one-hot and CONSTANT within every batch (the tutorials pass the same matrix for both:
+    // Tutorial_Aissa_PC9_TwoSample cell 40)?  Then every workgroup of the likelihood kernel lies inside one condition too.
+    e->bat_cond.assign((size_t)d.Nb, -1);
+    bool okc = vel && d.Nx >= 1 && e->hD.size() == (size_t)d.Nx * d.Nc;
+    for (long long c = 0; c < (long long)d.Nc && okc; ++c) {
+      int xc = -1;
+      for (int x = 0; x < d.Nx; ++x) {
+        const float v = e->hD[(size_t)x * d.Nc + c];
+        if (v == 1.f && xc < 0) xc = x;
+        else if (v != 0.f) okc = false;
+      }
+      if (xc < 0) okc = false;
+      int& bc = e->bat_cond[(size_t)bat_id[(size_t)c]];
+      if (bc < 0) bc = xc;
+      else if (bc != xc) okc = false;
+    }
+    for (int& v : e->bat_cond) if (v < 0) v = 0;       // (a batch without cells on this rank)
+    if (!okc) e->bat_cond.clear();
   }
   d.generic = (e->tun.force_generic || e->generic_needed || (e->generic_nb && !d.onehot)) ? 1 : 0;
   d.Kq = d.onehot ? d.Nh : d.K;
@@ -989,7 +1010,8 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     const bool pw_kind = VC_PW_INLINE && (d.kind == VC_KIND_VU || d.kind == VC_KIND_VFULL) && d.NW >= 1 && d.NW <= VC_PWQ &&
                          e->cfg.world_size == 1 && !d.generic;
     d.pw_lane = 0;
-    if (pw_kind && e->tun.pw_inline != 1 && d.kind == VC_KIND_VU && e->D_all_ones && d.Hw <= d.H && !e->tun.no_pw_lane) {
+    const bool lane_conds = e->D_all_ones || (d.onehot && !e->bat_cond.empty());     // one condition per workgroup of K_main
+    if (pw_kind && e->tun.pw_inline != 1 && d.kind == VC_KIND_VU && lane_conds && d.Hw <= d.H && !e->tun.no_pw_lane) {
       // Round 6: ONE condition with D == 1 (every one-sample fit): the W row of a cell is (1, sin k phi_c, cos k phi_c) -- what its
       // record already holds as wave-uniform SGPR pairs.  The U-only kernel's PWL instantiation (count storage | 4) accumulates
       // A3 x W per LANE (1 + 2 Hw plain VALU per cell) instead of reducing A3 over the wave first (a 64-lane DPP tree + staging
@@ -1002,7 +1024,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         e->main_fn_rows = e->main_fn;       // the instantiation that stores per-cell rows: what the sharded phases launch (vc_svi_run_sharded)
         e->main_fn = fl;
         main_kernel = kl;
-        d.pw_inline = 4;
+        d.pw_inline = d.NW <= 4 ? 4 : 8;
         d.pw_slots = 0;
         d.pw_lane = 1;
         // (without the staging registers of the wave-level reduction this instantiation needs 120 VGPRs instead of 160: four
@@ -1067,6 +1089,11 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
     } else {
       if (tile_host.size() != 4 * (size_t)d.n_main_wg) return e->fail(VC_ERR_STATE, "internal: batch-aligned tile table of the wrong size");
       TRY(upload(e, bat_chunk_host, &b.bat_chunk));
+      if (d.pw_lane && !e->bat_cond.empty())       // {.., batch | condition << 16, ..}: the PWL kernel places its partials in its condition's columns
+        for (int w = 0; w < d.n_main_wg; ++w) {
+          const int q = tile_host[4 * (size_t)w + 2];
+          tile_host[4 * (size_t)w + 2] = q | (e->bat_cond[(size_t)q] << 16);
+        }
     }
     TRY(upload(e, tile_host, &b.wg_tile));
   }
@@ -1337,6 +1364,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // the instantiation of the small kernels compiled for this configuration, if there is one (vc_tail_spec.h)
   d.spec = e->tun.no_tail_spec ? VC_SPEC_NONE : vc_spec_match(d);
   e->finalized = true;
+  std::vector<float>().swap(e->hD);
   std::vector<float>().swap(e->hDb);   // kept until here: every failure above leaves the batch design matrix in place
   return VC_OK;
 }

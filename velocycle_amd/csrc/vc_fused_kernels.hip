@@ -245,7 +245,8 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
 
   // one-hot batches: the chunk range of this wave's first batch (a dependent fetch in front of its rows: asked for with the rest)
   VcDnuPre dnu_pre;
-  const bool dnu_pre_on = chain && r_dnu1 && live && role - Nh < d.Nb && !CND(VC_SITE_DNU);
+  const bool dnu_lds = vc_walk_by_batch(d);      // the batches' sums come out of the second-stage reduction itself (vc_chunk_walk)
+  const bool dnu_pre_on = chain && r_dnu1 && live && role - Nh < d.Nb && !CND(VC_SITE_DNU) && !dnu_lds;
   dnu_pre.c0 = 0; dnu_pre.c1 = 0;
   float dq_p = 0.f, dq_m = 0.f, dq_v = 0.f, dq_lat = 0.f;      // ... and that batch's parameter, moments and sample (as the roles above)
   // conditioned batch offsets (the tutorials' velocity stage hands over the phase fit's delta nu: Tutorial_Aissa_PC9_TwoSample cell 42)
@@ -273,18 +274,19 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     float acc[MQ];
 #pragma unroll
     for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
-    for (int ch0 = wave; ch0 < d.n_chunks; ch0 += U * VC_PG_WAVES) {
+    const VcChunkWalk wk = vc_chunk_walk(d, b, g, wave);
+    for (int ch0 = wk.first; ch0 < wk.end; ch0 += U * wk.stride) {
       float v[U][MQ];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int ch = ch0 + u * VC_PG_WAVES;
-        const float* go = b.GO + ((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq) * NP + g;
+        const int ch = ch0 + u * wk.stride;
+        const float* go = b.GO + ((size_t)(ch < wk.end ? ch : ch0) * d.nq) * NP + g;
 #pragma unroll
         for (int q = 0; q < MQ; ++q) v[u][q] = (q < d.nq) ? go[(size_t)q * NP] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (ch0 + u * VC_PG_WAVES < d.n_chunks) {
+        if (ch0 + u * wk.stride < wk.end) {
 #pragma unroll
           for (int q = 0; q < MQ; ++q) acc[q] += v[u][q];
         }
@@ -418,9 +420,18 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       if (!boot) {
         float gq = 0.f;
         if (phase == VC_PH_B) gq = xb.x[po];                           // the gradient summed over ranks
-        else if (!CND(VC_SITE_DNU))
-          gq = -(((dnu_pre_on && first) ? vc_dnu_range_finish(d, b, g, dnu_pre) : vc_dnu_range_sum(d, b, g, q)) -
-                 rw * (first ? dq_lat : b.lat[VC_SITE_DNU][jq]) / (sd * sd));
+        else if (!CND(VC_SITE_DNU)) {
+          float lik;
+          if (dnu_lds) {          // the partials of this batch's waves, in wave order (row 0 = the constant harmonic)
+            int w0, nw;
+            vc_walk_waves_of(d, q, &w0, &nw);
+            lik = 0.f;
+            for (int w = w0; w < w0 + nw; ++w) lik += sm[w][0][lane];
+          } else {
+            lik = (dnu_pre_on && first) ? vc_dnu_range_finish(d, b, g, dnu_pre) : vc_dnu_range_sum(d, b, g, q);
+          }
+          gq = -(lik - rw * (first ? dq_lat : b.lat[VC_SITE_DNU][jq]) / (sd * sd));
+        }
         if (phase == VC_PH_A) xb.x[po] = gq;
         else {
           G[po] = gq;
@@ -984,16 +995,17 @@ __device__ __forceinline__ void vc_hist_rederive_block(const VcDims& d, const Vc
   if (lane < VC_PG_WAVES && d.kind != VC_KIND_VU) {
     // eight chunks requested per trip, added in chunk order (a plain `acc += load` loop is eight dependent round trips)
     constexpr int UB = 8;
-    for (int ch0 = wv; ch0 < d.n_chunks; ch0 += UB * VC_PG_WAVES) {
+    const VcChunkWalk wk = vc_chunk_walk_lane(d, b, gi, wv);       // (lane i: the gene of task i -- its own gene block's batch ranges)
+    for (int ch0 = wk.first; ch0 < wk.end; ch0 += UB * wk.stride) {
       float v[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int ch = ch0 + u * VC_PG_WAVES;
-        v[u] = b.GO[((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq + q) * NP + gi];
+        const int ch = ch0 + u * wk.stride;
+        v[u] = b.GO[((size_t)(ch < wk.end ? ch : ch0) * d.nq + q) * NP + gi];
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if (ch0 + u * VC_PG_WAVES < d.n_chunks) acc += v[u];
+        if (ch0 + u * wk.stride < wk.end) acc += v[u];
     }
   }
   const float* sis = b.SIS + (size_t)((s - 1) & 1) * 4 * NP + g;
@@ -1041,16 +1053,17 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
   float acc = 0.f;
   if (d.kind != VC_KIND_VU) {
     constexpr int UB = 8;
-    for (int ch0 = wv; ch0 < d.n_chunks; ch0 += UB * VC_PG_WAVES) {
+    const VcChunkWalk wk = vc_chunk_walk(d, b, gb * 64, wv);       // as wave wv of the gene block that owns these 64 genes
+    for (int ch0 = wk.first; ch0 < wk.end; ch0 += UB * wk.stride) {
       float v[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int ch = ch0 + u * VC_PG_WAVES;
-        v[u] = b.GO[((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq + q) * NP + g];
+        const int ch = ch0 + u * wk.stride;
+        v[u] = b.GO[((size_t)(ch < wk.end ? ch : ch0) * d.nq + q) * NP + g];
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if (ch0 + u * VC_PG_WAVES < d.n_chunks) acc += v[u];
+        if (ch0 + u * wk.stride < wk.end) acc += v[u];
     }
   }
   vc_hist_dense16_issue(d, b, hp);             // the table rows travel while the update is re-derived

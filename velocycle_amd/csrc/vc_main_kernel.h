@@ -155,14 +155,15 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
   // The workgroups of one dispatch pass (pass_wgs = one per CU) are co-resident with those of the other passes on every
   // CU, and the SIMD arbiter serves the oldest wave first; the passes may therefore take unequal shares of the cells
   // (pass_cw[p] cells per wave in pass p), so that the waves of a SIMD end together (vc_host_logic.h: vc_tile_cells).
-  int my_cw, my_batch;
+  int my_cw, my_batch, my_cond;
   long long cbeg, wg_end;
   {   // from the table vc_finalize wrote (vc_host_logic.h: vc_wave_first_cell / vc_tile_batches): one scalar load (constant
       // address space) of {first cell, cells per wave, batch, end of the workgroup's cells}
     typedef const __attribute__((address_space(4))) int* ciptr;
     ciptr tl = (ciptr)(const void*)(b.wg_tile + 4 * (size_t)blockIdx.x);
     my_cw = tl[1];
-    my_batch = tl[2];
+    my_batch = tl[2] & 0xffff;
+    my_cond = tl[2] >> 16;            // (PWL with several conditions: the condition of this workgroup's batch; else 0)
     wg_end = tl[3];
     cbeg = (long long)tl[0] + (long long)wave * my_cw;
   }
@@ -654,9 +655,14 @@ __global__ __launch_bounds__(256, (GPL == 8 ? (KIND == VC_KIND_VFULL ? 2 : VC_LB
       if (lane == 0) sm_pw[wave][q] = t;
     }
     __syncthreads();
-    if ((int)threadIdx.x < d.pw_inline)
-      b.PWM[(size_t)blockIdx.x * d.pw_inline + threadIdx.x] =
-          ((sm_pw[0][threadIdx.x] + sm_pw[1][threadIdx.x]) + (sm_pw[2][threadIdx.x] + sm_pw[3][threadIdx.x])) * CO_SCALE;
+    if ((int)threadIdx.x < d.pw_inline) {
+      // PWL: the lanes hold the partials of THIS workgroup's condition (coefficients 0 .. Nhw - 1): placed in its columns of the row
+      const int jq = PWL ? (int)threadIdx.x - my_cond * d.Nhw : (int)threadIdx.x;
+      const bool mine = !PWL || (jq >= 0 && jq < d.Nhw);
+      const int js = mine ? jq : 0;
+      const float t = ((sm_pw[0][js] + sm_pw[1][js]) + (sm_pw[2][js] + sm_pw[3][js])) * CO_SCALE;
+      b.PWM[(size_t)blockIdx.x * d.pw_inline + threadIdx.x] = mine ? t : 0.f;
+    }
   }
   // fused pipeline (vc_svi_step_fused): nothing in this launch reads the device step counter, so it is advanced here;
   // the two launches that follow read s = t + 1 (= the 1-based optimiser step, = the index of the next sample)

@@ -576,18 +576,19 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
   float acc[MQ];
 #pragma unroll
   for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
-  for (int ch0 = wave; ch0 < d.n_chunks; ch0 += U * VC_PG_WAVES) {
+  const VcChunkWalk wk = vc_chunk_walk(d, b, g, wave);      // (one-hot batches: the waves walk their batch's chunks -- vc_common.h)
+  for (int ch0 = wk.first; ch0 < wk.end; ch0 += U * wk.stride) {
     float v[U][MQ];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int ch = ch0 + u * VC_PG_WAVES;
-      const float* go = b.GO + ((size_t)(ch < d.n_chunks ? ch : ch0) * d.nq) * d.Ng_pad + g;
+      const int ch = ch0 + u * wk.stride;
+      const float* go = b.GO + ((size_t)(ch < wk.end ? ch : ch0) * d.nq) * d.Ng_pad + g;
 #pragma unroll
       for (int q = 0; q < MQ; ++q) v[u][q] = (q < d.nq) ? go[(size_t)q * d.Ng_pad] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (ch0 + u * VC_PG_WAVES < d.n_chunks) {
+      if (ch0 + u * wk.stride < wk.end) {
 #pragma unroll
         for (int q = 0; q < MQ; ++q) acc[q] += v[u][q];
       }
@@ -635,7 +636,16 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
         float gl = 0.f;
         if (!CND(VC_SITE_DNU)) {
           const float x = b.lat[VC_SITE_DNU][j], sd = vel ? 0.01f : b.sd_dnu[j];
-          gl = -(vc_dnu_range_sum(d, b, g, q) - rw * x / (sd * sd));
+          float lik;
+          if (vc_walk_by_batch(d)) {      // the partials of this batch's waves, in wave order (as the tails' gene blocks)
+            int w0, nw;
+            vc_walk_waves_of(d, q, &w0, &nw);
+            lik = 0.f;
+            for (int w = w0; w < w0 + nw; ++w) lik += sm[w][0][lane];
+          } else {
+            lik = vc_dnu_range_sum(d, b, g, q);
+          }
+          gl = -(lik - rw * x / (sd * sd));
         }
         G[d.poff[VC_P_DNU_LOCS] + j] = gl;
       }

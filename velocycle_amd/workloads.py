@@ -14,7 +14,7 @@ from .spec import ModelSpec
 
 
 def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, seed=0, device="cpu",
-                       noisemodel="NegativeBinomial", concentration=5.0, sim=None, n_batches=None) -> ModelSpec:
+                       noisemodel="NegativeBinomial", concentration=5.0, sim=None, n_batches=None, H=1) -> ModelSpec:
     """mode: "vjoint" (mean-field guide, nothing conditioned), "vcond" (default LRMN guide conditioned
     on ϕxy, ν, shape_inv [, Δν] like the tutorials), "vcond_mf" (same conditioning, mean-field), "vjoint_lrmn" (LRMN guide,
     nothing conditioned: the reference's default `model_type` without `condition_on`).
@@ -35,8 +35,10 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
     meanS = S_cm.mean(0).clamp_min(1e-3)
     nu0 = torch.log(meanS).cpu()
     nu0std = (torch.log(S_cm + 1).std(0) / 2).clamp_min(0.05).cpu()
-    mu_nu = torch.stack([nu0, torch.zeros_like(nu0), torch.zeros_like(nu0)], 1)
-    sd_nu = torch.stack([nu0std, 0.5 * nu0std, 0.5 * nu0std], 1)
+    # H harmonics of the expression map (preprocess_for_* default n_harmonics=2, preprocessing.py:108,217; the tutorials pass 1): the
+    # simulated data has one, the higher ones get the same zero-mean prior
+    mu_nu = torch.stack([nu0] + [torch.zeros_like(nu0)] * (2 * H), 1)
+    sd_nu = torch.stack([nu0std] + [0.5 * nu0std] * (2 * H), 1)
     g = torch.Generator().manual_seed(seed + 7)
     phi0 = sim["phis"].cpu() + 0.3 * torch.randn(nct, generator=g)
     pxy = concentration * torch.stack([torch.cos(phi0), torch.sin(phi0)], 1)
@@ -50,7 +52,7 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
     sd_w[:, 0] = 3.0
     spec = ModelSpec(
         kind="velocity", guide="meanfield" if mode in ("vjoint", "vcond_mf") else "lrmn",
-        noisemodel=noisemodel, with_delta_nu=with_dnu, H=1, Hw=Hw,
+        noisemodel=noisemodel, with_delta_nu=with_dnu, H=H, Hw=Hw,
         S=S_cm.t(), U=U_cm.t(), count_factor=cf, Db=Db, D=D,
         mu_nu=mu_nu, sd_nu=sd_nu, phixy_prior=pxy,
         mu_gamma=torch.zeros(Ng), sd_gamma=torch.full((Ng,), 0.5),
@@ -58,6 +60,8 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
         mu_nuw=mu_w, sd_nuw=sd_w, sd_dnu=0.01, sigma_ln_s=0.1, sigma_ln_u=0.1)
     if mode.startswith("vcond"):
         true_nu = sim["nu"].cpu()
+        if H > 1:
+            true_nu = torch.cat([true_nu, torch.zeros(true_nu.shape[0], 2 * (H - 1))], 1)
         spec.condition_on = {"ϕxy": torch.stack([torch.cos(sim["phis"].cpu()), torch.sin(sim["phis"].cpu())], 1),
                              "ν": true_nu, "shape_inv": sim["shape_inv"].cpu()}
         if with_dnu:
@@ -66,10 +70,10 @@ def make_velocity_spec(Nc=10000, Ng=500, mode="vjoint", n_conditions=1, Hw=1, se
     return spec
 
 
-def make_phase_spec(Nc=3000, Ng=200, seed=0, device="cpu", noisemodel="NegativeBinomial", sim=None, n_batches=1) -> ModelSpec:
+def make_phase_spec(Nc=3000, Ng=200, seed=0, device="cpu", noisemodel="NegativeBinomial", sim=None, n_batches=1, H=1) -> ModelSpec:
     """n_batches > 1: that many samples of Nc cells each with a one-hot batch design and per-batch offsets (with_delta_nu)."""
-    v = make_velocity_spec(Nc, Ng, "vjoint", n_batches, 0, seed, device, noisemodel, sim=sim)
-    spec = ModelSpec(kind="phase", guide="meanfield", noisemodel=noisemodel, with_delta_nu=n_batches > 1, H=1,
+    v = make_velocity_spec(Nc, Ng, "vjoint", n_batches, 0, seed, device, noisemodel, sim=sim, H=H)
+    spec = ModelSpec(kind="phase", guide="meanfield", noisemodel=noisemodel, with_delta_nu=n_batches > 1, H=H,
                      S=v.S, count_factor=v.count_factor, Db=v.Db, mu_nu=v.mu_nu, sd_nu=v.sd_nu,
                      phixy_prior=v.phixy_prior, sigma_ln_s=0.5)
     spec.truth = v.truth
