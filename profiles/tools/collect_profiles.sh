@@ -24,6 +24,10 @@ cat $out/pmc_fetch.txt $out/pmc_write.txt $out/pmc_sq.txt $out/pmc_sq2.txt > $ou
 python3 profiles/tools/roofline_from_trace.py gpurun_out/${tag}_stats_eager $out/bench_under_rocprof_eager.json $out/roofline_check.txt > /dev/null
 python3 profiles/tools/roofline_from_trace.py gpurun_out/${tag}_stats $out/bench_under_rocprof.json $out/roofline_check_graph.txt > /dev/null
 python3 profiles/tools/pmc_to_traffic.py $out/pmc.txt $out/latest_traffic.json $tag
+# gpurun copies at most 64 MiB back: the raw traces (7 passes x 10-15 MB) go, their summaries stay; the small per-kernel stats csv of the
+# two trace passes is kept beside them
+for p in stats stats_eager; do f=$(ls gpurun_out/${tag}_$p/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_$p.csv; done
+rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_stats_eager gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write gpurun_out/${tag}_pmc_sq gpurun_out/${tag}_pmc_sq2
 # the plain run last, with the traffic file of THIS library in place (bench.py takes `roofline.traffic` from
 # profiles/latest_traffic.json only if its csrc hash matches the library it runs)
 cp $out/latest_traffic.json profiles/latest_traffic.json
