@@ -171,7 +171,9 @@ typedef struct vc_tuning {
   int32_t no_tail_spec;      /* 1: the run-time-flag small kernels even where an instantiation compiled for this configuration exists (A/B, tests) */
   int32_t no_pw_lane;        /* 1: the U-only kernel reduces its per-cell sums over the wave even where the per-lane accumulation of the
                                 nu_omega partials applies (one condition, D == 1; A/B, tests) */
-  int32_t reserved[5];
+  int32_t p2p_separate;      /* 1: the peer-to-peer exchange as a launch of its own between phases A and B (rounds 3-5); 0: folded into
+                                phase B (its blocks pass the exchange's gate and add the ranks' slots where they read them) */
+  int32_t reserved[4];
 } vc_tuning;
 
 typedef struct vc_layout {
@@ -410,7 +412,8 @@ int vc_comm_allreduce(vc_engine* e, float* buf, int64_t n, void* hip_stream);
  * bits on every rank, no float atomics).  vc_p2p_alloc creates this rank's region and returns its 64-byte hipIpcMemHandle_t;
  * the host side gathers the handles of all ranks in rank order (any transport) and hands the world_size x 64 bytes to
  * vc_p2p_connect (collective in effect: every rank must do it before the first step).  When connected, VC_PHASE_AB uses
- * this exchange instead of RCCL.  A peer that never publishes is detected by a bounded wait (vc_tuning.p2p_timeout_s, default 2 s):
+ * this exchange instead of RCCL -- since round 6 without a launch of its own: phase B's blocks run the publish / wait protocol
+ * and add the ranks' buffers in rank order where they read them (vc_tuning.p2p_separate = 1: the separate exchange kernel).  A peer that never publishes is detected by a bounded wait (vc_tuning.p2p_timeout_s, default 2 s):
  * vc_get_status then returns VC_ERR_STATE.  Opt-in: it has run across processes on one device only. */
 int vc_p2p_alloc(vc_engine* e, void* ipc_handle_out_64_bytes);
 int vc_p2p_connect(vc_engine* e, const void* all_handles_world_x_64_bytes);

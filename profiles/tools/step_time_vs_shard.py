@@ -62,14 +62,20 @@ for n_ranks, nc in ((8, 6250), (4, 12500), (2, 25000), (1, 50000)):
                      ("sharded_fused_graph", dict(adam_impl="sharded", use_graph=True, force_reduce=True, exchange="torch")),
                      ("sharded_fused_eager", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="torch")),
                      ("sharded_fused_engine_rccl", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="engine")),
-                     ("sharded_fused_no_exchange", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="none"))]
+                     ("sharded_fused_no_exchange", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="none")),
+                     # round 6: the one-shot peer-to-peer exchange on this one rank (own region: publish, wait, sum of one slot) --
+                     # folded into phase B (default) and as the launch of its own of rounds 3-5
+                     ("sharded_fused_p2p_folded", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="p2p", _tun=dict(p2p_fold=True))),
+                     ("sharded_fused_p2p_separate", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="p2p", _tun=dict(p2p_fold=False)))]
     if quick:
         if nc == 25000:
             continue
-        keep = ("fused_3_launches", "fused_3_launches_eager", "sharded_fused_engine_rccl", "sharded_fused_no_exchange")
+        keep = ("fused_3_launches", "fused_3_launches_eager", "sharded_fused_engine_rccl", "sharded_fused_no_exchange",
+                "sharded_fused_p2p_folded", "sharded_fused_p2p_separate")
         variants = [v for v in variants if v[0] in keep]
     for name, kw in variants:
-        eng = HipEngine(spec, device=dev, tuning=Tuning.from_env())
+        kw = dict(kw)
+        eng = HipEngine(spec, device=dev, tuning=Tuning.from_env().replace(**kw.pop("_tun", {})))
         run = SVIRunner(eng, OPT, mode="perf", seed=0, **kw)
         row[name] = round(timed(run), 2)
         if name == "fused_3_launches":

@@ -100,13 +100,15 @@ def _two_ranks(env_extra, extra_args=(), n=2):
     return _json_line(r.stdout)
 
 
-def test_two_process_p2p_exchange_equals_the_collective():
-    """VC_EXCHANGE=p2p: the one-shot exchange over peer-mapped device memory (vc_p2p_exchange.hip) between two PROCESSES (both
+@pytest.mark.parametrize("fold", ["1", "0"])
+def test_two_process_p2p_exchange_equals_the_collective(fold):
+    """(fold = 1, the default since round 6: phase B runs the exchange's publish / wait protocol itself and adds the ranks' slots where it
+    reads them -- K_main, phase A, phase B and nothing else; fold = 0: the exchange as a launch of its own.)  VC_EXCHANGE=p2p: the one-shot exchange over peer-mapped device memory (vc_p2p_exchange.hip) between two PROCESSES (both
     on cuda:0 -- hipIpc works between processes on one device, which is all a 1-GPU box can offer): region export / import,
     step-stamped flags, double-buffered slots, fixed-rank-order sum, all enqueued from one C call per run.  Same losses as the
     gloo all-reduce of the same two ranks (two addends: a + b is b + a, bit for bit), no exchange time-out latched."""
     ref = _two_ranks({"VC_EXCHANGE": "torch"})
-    got = _two_ranks({"VC_EXCHANGE": "p2p", "VC_P2P_TIMEOUT_S": "20"})
+    got = _two_ranks({"VC_EXCHANGE": "p2p", "VC_P2P_TIMEOUT_S": "20", "VC_P2P_FOLD": fold})
     assert got["distributed"]["exchange"] == "p2p" and ref["distributed"]["exchange"] == "torch"
     assert got["nonfinite_loss_steps"] == 0
     for a, b in zip(ref["loss_first_last"], got["loss_first_last"]):

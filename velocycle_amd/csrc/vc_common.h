@@ -138,15 +138,6 @@ __host__ __device__ inline float vc_rec_cf_scale(int noise) { return (VC_FOLD_LO
 __host__ __device__ inline float vc_rec_omega_scale(int noise) { return (VC_FOLD_LOG2E && noise != VC_NOISE_LOGNORMAL) ? VC_LN2 : 1.f; }
 __host__ __device__ inline int vc_rec_pairs(int H, int Nb, bool full) { return 2 * H + Nb + 2 + ((full && VC_OMEGA_CS) ? 2 * H : 0); }
 
-// View of the exchange buffer of the sharded fused step (vc_svi_run_sharded; layout: include/velocycle_hip.h)
-struct VcXb {
-  float* x = nullptr;     // [0, header + n_global): gradient partials at the offsets of the gradient buffer;
-  int pw_off = 0;         //   [pw_off, pw_off + pw_cap * NW): per-cell-block partials of d loglik / d nu_omega;
-  int pw_cap = 0;         //   rows of that region (an upper bound of every rank's cell blocks: ceil(ceil(Nc / world) / 256))
-  int loss_off = 0;       //   [loss_off, loss_off + 4 * (1 + nb_post_gene)): the rank's loss terms, four floats each
-  float* sis = nullptr;   // [3][Ng_pad] snapshot {parameter, exp_avg, exp_avg_sq} of shape_inv taken by phase A (engine-owned)
-};
-
 // Peer-mapped regions of the one-shot exchange (vc_p2p_exchange.hip): region[q] = rank q's region as mapped in THIS process
 #define VC_P2P_MAX_RANKS 16
 struct VcP2p {
@@ -155,6 +146,123 @@ struct VcP2p {
   int flag_words = 0;           // 4-byte words in front of the slots (world flags, one 64-byte line each)
   long long slot_floats = 0;    // floats per slot (= the exchange buffer, padded to 64 bytes)
 };
+
+// View of the exchange buffer of the sharded fused step (vc_svi_run_sharded; layout: include/velocycle_hip.h)
+struct VcXb {
+  float* x = nullptr;     // [0, header + n_global): gradient partials at the offsets of the gradient buffer;
+  int pw_off = 0;         //   [pw_off, pw_off + pw_cap * NW): per-cell-block partials of d loglik / d nu_omega;
+  int pw_cap = 0;         //   rows of that region (an upper bound of every rank's cell blocks: ceil(ceil(Nc / world) / 256))
+  int loss_off = 0;       //   [loss_off, loss_off + 4 * (1 + nb_post_gene)): the rank's loss terms, four floats each
+  float* sis = nullptr;   // [3][Ng_pad] snapshot {parameter, exp_avg, exp_avg_sq} of shape_inv taken by phase A (engine-owned)
+  // Round 6, the peer-to-peer exchange FOLDED into phase B (no launch of its own): phase B's readers add the ranks' published
+  // buffers themselves, in rank order (vc_xget) -- nslots = 0: `x` holds the summed buffer (RCCL / torch / the separate exchange kernel)
+  int nslots = 0;
+  int dead = 0;           // the launch's verdict (vc_p2p_gate): a peer never published -> every read is NaN (the step is poisoned)
+  const float* const* slots = nullptr;    // DEVICE table [nslots]: rank q's published buffer of this step's parity, as mapped in this process
+                                           // (a table in memory, not an array in the kernel arguments: indexing those by a run-time rank
+                                           // puts the whole argument struct into scratch -- phase B ran 2x slower with it)
+};
+// what a launch needs to run the exchange's publish / wait protocol itself (vc_p2p_gate)
+struct VcGate {
+  void* const* regions = nullptr;      // DEVICE table [world]: rank q's region as mapped in this process
+  int world = 0, rank = 0;
+  long long step = 0;
+  long long* status = nullptr;
+  unsigned long long timeout_ticks = 0;
+  unsigned long long* verdict = nullptr;
+};
+#ifdef __HIPCC__
+// one float of a peer's published buffer: a system-scope load that bypasses the caches (the peer rewrote the slot two steps ago);
+// compiler-visible, so that the N loads of a sum are in flight together
+__device__ __forceinline__ float vc_xload(const float* p) {
+  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+// element i of the exchange buffer summed over the ranks: read from the summed buffer, or added up here in rank order (the order of
+// the exchange kernel: identical bits on every rank)
+__device__ __forceinline__ float vc_xget(const VcXb& xb, long long i) {
+  if (xb.nslots == 0) return xb.x[i];
+  if (xb.dead) return __builtin_nanf("");
+  float acc = 0.f;
+  for (int q0 = 0; q0 < xb.nslots; q0 += 4) {      // four ranks' loads in flight per trip
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = q0 + u < xb.nslots ? vc_xload(xb.slots[q0 + u] + i) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (q0 + u < xb.nslots) acc += v[u];
+  }
+  return acc;
+}
+
+// The publish / wait protocol of the one-shot exchange (vc_p2p_exchange.hip has the story), for every block of a launch whose
+// predecessor on the stream wrote this rank's slot: block 0 raises this rank's flag of `step` in every region (the kernel boundary
+// in front of the launch released the slot's plain stores), waits -- bounded -- for every peer's flag in its OWN region and publishes
+// the launch's ONE verdict; the other blocks wait for that verdict.  Returns 1 when the step is dead (a peer never published or had
+// given up: sticky in status[2], poison raised in every region), else 0; block-uniform.  Ends with a system-scope acquire.
+#define VC_P2P_FLAG_STRIDE 16      // 64-byte line per flag (in 4-byte words)
+#define VC_P2P_POISON 0xFFFFFFFFu  // a rank that gave up on a step publishes this instead of a step number
+__device__ __forceinline__ int vc_p2p_gate(void* const* __restrict__ regions, int world, int rank, long long step,
+                                           long long* __restrict__ status, unsigned long long timeout_ticks,
+                                           unsigned long long* __restrict__ verdict, const bool acquire = true) {
+  // acquire = false (phase B with the exchange folded in): the blocks that only wait for the verdict poll it with relaxed
+  // cache-bypassing loads and the gate ends WITHOUT the system-scope acquire -- an acquire at agent / system scope invalidates the
+  // XCD's whole L2, and ~1000 waves of a 60-block launch doing that while other blocks stream K_main's partials made the launch
+  // 150 us slower (measured); every read of a peer's slot behind this gate bypasses the caches by itself (vc_xload)
+  struct { void* const* region; int world, rank; } p = {regions, world, rank};
+  const unsigned want = (unsigned)(step + 1);
+  __shared__ int sm_dead;
+  if (threadIdx.x == 0) sm_dead = 0;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    // sticky: once this rank has poisoned a step it never sums again (the caller sees VC_ERR_STATE at its next status check)
+    const bool already = status && status[2] != 0;
+    if (threadIdx.x < (unsigned)p.world) {
+      __atomic_thread_fence(__ATOMIC_RELEASE);       // system scope
+      unsigned* f = reinterpret_cast<unsigned*>(p.region[threadIdx.x]) + (size_t)p.rank * VC_P2P_FLAG_STRIDE;
+      __hip_atomic_store(f, already ? VC_P2P_POISON : want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (already && threadIdx.x == 0) sm_dead = 1;
+    if (threadIdx.x < (unsigned)p.world && !already) {
+      const unsigned* f = reinterpret_cast<const unsigned*>(p.region[p.rank]) + (size_t)threadIdx.x * VC_P2P_FLAG_STRIDE;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        const unsigned v = __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v == VC_P2P_POISON) { sm_dead = 1; break; }              // the peer gave up on a step: so does this rank
+        if ((int)(v - want) >= 0) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { sm_dead = 1; break; }
+      }
+    }
+    __syncthreads();
+    if (sm_dead && !already) {
+      if (threadIdx.x == 0 && status && status[2] == 0) status[2] = step + 1;          // a peer never arrived / had given up
+      if (threadIdx.x < (unsigned)p.world) {
+        unsigned* f = reinterpret_cast<unsigned*>(p.region[threadIdx.x]) + (size_t)p.rank * VC_P2P_FLAG_STRIDE;
+        __hip_atomic_store(f, VC_P2P_POISON, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    if (threadIdx.x == 0) {
+      const unsigned long long vd = ((unsigned long long)want << 1) | (unsigned long long)(sm_dead ? 1 : 0);
+      if (acquire) __hip_atomic_store(verdict, vd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(verdict, vd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (write-through: the pollers bypass the caches)
+    }
+  } else {
+    // the launch's one verdict (block 0 is dispatched first and waits for nothing inside this launch)
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        const unsigned long long v = acquire ? __hip_atomic_load(verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                                             : __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(v >> 1) == want) { sm_dead = (int)(v & 1ull); break; }
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 2 * timeout_ticks + 100000000ull) { sm_dead = 1; break; }
+      }
+    }
+    __syncthreads();
+  }
+  if (acquire) __atomic_thread_fence(__ATOMIC_ACQUIRE);         // system scope: nothing of the peers' slots may come from a stale line
+  return sm_dead;
+}
+#endif
 
 struct VcBufs {
   // immutable inputs
@@ -814,7 +922,7 @@ void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad
 // phase B of the sharded step: optimiser on the summed gradient + next sample (gene blocks) and K_omega's blocks, one launch
 void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                        const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, const VcXb& xb,
-                       hipStream_t st);
+                       hipStream_t st, const VcGate* gate = nullptr);
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st);
 // tutorial flow on one rank (pw_inline, nothing per cell left to learn): K_tail's gene blocks and K_omega's blocks in one launch
@@ -825,7 +933,7 @@ void vc_launch_tail_merged(const VcDims& d, const VcBufs& b, float* params, floa
 // blocks, side by side
 void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, hipStream_t st);
-void vc_launch_p2p_xchg(const VcP2p& p, long long step, float* out, long long n, long long* status, double timeout_s,
+void vc_launch_p2p_xchg(const VcP2p& p, void* const* regions_dev, long long step, float* out, long long n, long long* status, double timeout_s,
                         unsigned long long* verdict, hipStream_t st);
 void vc_launch_adam(float* p, const float* g, float* m, float* v, long long n, const VcAdamHyper& h, long long t_host,
                     const long long* t_dev, const float* loss_hdr, double* loss_ring, long long loss_slots, hipStream_t st);

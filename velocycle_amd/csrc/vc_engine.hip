@@ -85,6 +85,7 @@ struct vc_engine {
   long long xb_total = 0;
   // one-shot peer-to-peer exchange (vc_p2p_alloc / vc_p2p_connect, vc_p2p_exchange.hip)
   VcP2p p2p{};
+  void** p2p_tab = nullptr;          // device: [3][VC_P2P_MAX_RANKS] pointers -- the regions, the parity-0 slots, the parity-1 slots
   void* p2p_own = nullptr;            // this rank's region (hipMalloc, IPC-exported)
   bool p2p_connected = false;
   int p2p_mem_kind = -1;              // 0 fine-grained, 1 uncached, 2 plain hipMalloc (vc_p2p_alloc)
@@ -425,7 +426,7 @@ extern "C" int vc_set_tuning(vc_engine* e, const vc_tuning* t) {
   if (!in(z.tail_cells, {0, 256, 512, 1024})) return e->fail(VC_ERR_ARG, "vc_set_tuning: tail_cells must be 0, 256, 512 or 1024");
   if (!in(z.count_storage, {0, 1}) || !in(z.host_hist, {0, 1}) || !in(z.hist_dense, {0, 1, 2}) || !in(z.pw_inline, {0, 1, 2}) ||
       !in(z.no_tail2, {0, 1}) || !in(z.no_tail_merged, {0, 1}) || !in(z.force_generic, {0, 1}) || !in(z.particles_layout, {0, 1, 2}) ||
-      !in(z.dense_batches, {0, 1}) || !in(z.no_tail_spec, {0, 1}) || !in(z.no_pw_lane, {0, 1}))
+      !in(z.dense_batches, {0, 1}) || !in(z.no_tail_spec, {0, 1}) || !in(z.no_pw_lane, {0, 1}) || !in(z.p2p_separate, {0, 1}))
     return e->fail(VC_ERR_ARG, "vc_set_tuning: a switch is outside its documented values");
   if (z.p2p_timeout_s < 0.f) return e->fail(VC_ERR_ARG, "vc_set_tuning: negative p2p_timeout_s");
   e->tun = z;
@@ -1743,6 +1744,17 @@ extern "C" int vc_p2p_connect(vc_engine* e, const void* all_handles) {
     TRY(e->dalloc(&e->p2p_verdict, 1));
     HIPCHK(e, hipMemset(e->p2p_verdict, 0, sizeof(unsigned long long)));
   }
+  {
+    // device tables the kernels index by rank: [0] the regions, [1] / [2] the slot of parity 0 / 1 inside every region
+    void* tab[3 * VC_P2P_MAX_RANKS] = {};
+    for (int q = 0; q < p.world; ++q) {
+      tab[q] = p.region[q];
+      for (int par = 0; par < 2; ++par)
+        tab[VC_P2P_MAX_RANKS * (1 + par) + q] = reinterpret_cast<float*>(p.region[q]) + (size_t)p.flag_words + (size_t)par * (size_t)p.slot_floats;
+    }
+    if (!e->p2p_tab) TRY(e->dalloc(&e->p2p_tab, 3 * VC_P2P_MAX_RANKS));
+    HIPCHK(e, hipMemcpy(e->p2p_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+  }
   e->p2p_connected = true;
   e->p2p_step = 0;
   return VC_OK;
@@ -1801,15 +1813,31 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
         xa.x = reinterpret_cast<float*>(e->p2p_own) + e->p2p.flag_words + (size_t)(e->p2p_step & 1) * (size_t)e->p2p.slot_floats;
       vc_launch_tail(ds, e->b, params, grad, sd, seed, a, 0, 1, xa, st);
     }
-    if (use_p2p) {
-      vc_launch_p2p_xchg(e->p2p, e->p2p_step, xbuf, (long long)e->xb_total, e->b.status, e->p2p_timeout_s, e->p2p_verdict, st);
+    VcXb xbb = xb;
+    VcGate gate;
+    if (use_p2p && !e->tun.p2p_separate) {
+      // Round 6: the exchange FOLDED into phase B -- no launch for the sum: phase B's blocks pass the exchange's gate themselves
+      // (block 0 publishes and waits; the kernel boundary behind phase A released this rank's slot) and add the ranks' slots of this
+      // step's parity where they read them, in rank order (vc_xget: the bits of the separate kernel).  K_main -> phase A -> phase B.
+      const size_t slot_off = (size_t)e->p2p.flag_words + (size_t)(e->p2p_step & 1) * (size_t)e->p2p.slot_floats;
+      (void)slot_off;
+      xbb.nslots = e->p2p.world;
+      xbb.slots = reinterpret_cast<const float* const*>(e->p2p_tab) + VC_P2P_MAX_RANKS * (1 + (int)(e->p2p_step & 1));
+      gate.regions = reinterpret_cast<void* const*>(e->p2p_tab); gate.world = e->p2p.world; gate.rank = e->p2p.rank;
+      gate.step = e->p2p_step; gate.status = e->b.status;
+      gate.timeout_ticks = (unsigned long long)(e->p2p_timeout_s * 1e8); gate.verdict = e->p2p_verdict;
+      e->p2p_step++;
+    } else if (use_p2p) {
+      vc_launch_p2p_xchg(e->p2p, reinterpret_cast<void* const*>(e->p2p_tab), e->p2p_step, xbuf, (long long)e->xb_total, e->b.status,
+                         e->p2p_timeout_s, e->p2p_verdict, st);
       e->p2p_step++;
     } else if (phase == VC_PHASE_AB && e->comm) {      // (a 1-rank communicator is summed too: the single-GPU measurement of this path)
       const int rc = g_rccl.AllReduce(xbuf, xbuf, (size_t)e->xb_total, /*ncclFloat32*/ 7, /*ncclSum*/ 0, e->comm, st);
       if (rc != 0) return e->fail(VC_ERR_STATE, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed");
     }
     if (phase != VC_PHASE_A)
-      vc_launch_phase_b(ds, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, with_hist, xb, st);
+      vc_launch_phase_b(ds, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, with_hist, xbb, st,
+                        xbb.nslots > 0 ? &gate : nullptr);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return e->fail(VC_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));

@@ -74,6 +74,10 @@ __device__ __forceinline__ void vc_loss_split(double v, float* __restrict__ out)
 __device__ __forceinline__ double vc_loss_join(const float* __restrict__ in) {
   return (((double)in[0] + (double)in[1]) + (double)in[2]) + (double)in[3];
 }
+// the same on the exchange buffer (each piece summed over the ranks: by the exchange, or here -- vc_xget)
+__device__ __forceinline__ double vc_loss_join_x(const VcXb& xb, long long i) {
+  return (((double)vc_xget(xb, i) + (double)vc_xget(xb, i + 1)) + (double)vc_xget(xb, i + 2)) + (double)vc_xget(xb, i + 3);
+}
 
 // flat offset of element `ce` of angular-speed coefficient j: mean-field {loc, log scale}; LRMN tail row i = Ng + j
 // {loc, R cov_factor entries, cov_diag}
@@ -231,7 +235,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       if (k < nown) {
         pp[k] = P[off[k]];
         if (upd) { pm[k] = Mm[off[k] - header]; pv[k] = Vv[off[k] - header]; }
-        if (upd && phase == VC_PH_B) gg[k] = xb.x[off[k]];          // the gradient summed over ranks
+        if (upd && phase == VC_PH_B) gg[k] = vc_xget(xb, off[k]);   // the gradient summed over ranks
       }
     if (r_si && !upd && samp) { pm[0] = Mm[off[0] - header]; pv[0] = Vv[off[0] - header]; }     // boot: for the snapshot below
     // phase A: the histogram blocks of phase B re-derive the shape_inv update while the gene blocks of the same launch
@@ -419,7 +423,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       float p = first ? dq_p : P[po];
       if (!boot) {
         float gq = 0.f;
-        if (phase == VC_PH_B) gq = xb.x[po];                           // the gradient summed over ranks
+        if (phase == VC_PH_B) gq = vc_xget(xb, po);                    // the gradient summed over ranks
         else if (!CND(VC_SITE_DNU)) {
           float lik;
           if (dnu_lds) {          // the partials of this batch's waves, in wave order (row 0 = the constant harmonic)
@@ -933,7 +937,7 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
   double sl = 0.0;
   if (phase == VC_PH_B) {
     // every rank's loss terms, summed piece by piece by the exchange: base + one per gene block, fixed order
-    for (int i = t; i < 1 + d.nb_post_gene; i += 256) sl += vc_loss_join(xb.x + xb.loss_off + VC_LOSS_PIECES * i);
+    for (int i = t; i < 1 + d.nb_post_gene; i += 256) sl += vc_loss_join_x(xb, xb.loss_off + VC_LOSS_PIECES * i);
   } else {
     // everything below belongs to the sample of the finished step s - 1 and was complete BEFORE this launch: prior / guide
     // terms and the r-only likelihood term (written when the sample was drawn, half (s - 1) & 1), its histogram sums (half
@@ -1136,7 +1140,7 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
         // gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
         const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
         float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
-        si = expf(vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off)));
+        si = expf(vc_adam_elem(xb.sis[g], vc_xget(xb, off), mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off)));
       }
       vc_hist_dense_block(d, b, xblk, si, half, nthr >> 6, sm_hd);
       return;
@@ -1158,7 +1162,7 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
         const int g = b.h_task[4 * task];
         const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
         float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
-        const float np = vc_adam_elem(xb.sis[g], xb.x[off], mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off));
+        const float np = vc_adam_elem(xb.sis[g], vc_xget(xb, off), mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off));
         vc_hist_wave(d, b, P, 0, task, lane, expf(np), half);
       } else {
         vc_hist_wave(d, b, P, 0, task, lane, -1.f, half);
@@ -1264,6 +1268,17 @@ __device__ __forceinline__ void vc_nuw_sums_direct(const VcDims& d, const VcBufs
   const int pw_ld = pwm ? d.pw_inline : d.NW;
   const int nw = d.NW;
   VC_WSTAMP(1, 1);
+  if (!boot && phase == VC_PH_B && xb.nslots > 0) {
+    // the exchange folded into this launch: every row is the sum of the ranks' rows, added here in rank order (vc_xget) -- the same
+    // association as below, row by row
+    for (int j = wv; j < nw; j += nwv) {
+      double r = 0.0;
+      for (int i = lane; i < n_pw; i += 64) r += (double)vc_xget(xb, xb.pw_off + (long long)i * pw_ld + j);
+      r = vc_wave_sum_d63(r);
+      if (lane == 63) sh.up[j] = (float)r;
+    }
+    return;
+  }
   if (!boot) {
     double u[2] = {0.0, 0.0};
 #pragma unroll
@@ -1540,8 +1555,14 @@ template <int MQ, int SPEC = 0>
 __global__ __launch_bounds__(1024) void vc_phase_b_kernel(const VcDims d, const VcBufs b, float* __restrict__ P,
                                                           float* __restrict__ G, const long long* __restrict__ step_dev,
                                                           uint64_t seed, const VcAdamArgs a, double* __restrict__ loss_dev,
-                                                          long long loss_slots, int nb_cell, int nb_hist, const VcXb xb) {
+                                                          long long loss_slots, int nb_cell, int nb_hist, const VcXb xb0,
+                                                          const VcGate gate) {
   vc_spec_assume<SPEC>(d);
+  // The peer-to-peer exchange folded into this launch (round 6; xb0.nslots > 0): every block passes the exchange's gate first --
+  // block 0 raises this rank's flag (the kernel boundary behind phase A released its slot), waits for the peers' and publishes the
+  // launch's verdict, the others wait for it -- and the readers below add the ranks' slots themselves (vc_xget): no launch for the sum
+  VcXb xb = xb0;
+  if (xb0.nslots > 0) xb.dead = vc_p2p_gate(gate.regions, gate.world, gate.rank, gate.step, gate.status, gate.timeout_ticks, gate.verdict, false);
   const long long s = *step_dev;
   if ((int)blockIdx.x < d.nb_post_gene) {
     VcOpt o;
@@ -1562,7 +1583,8 @@ __global__ __launch_bounds__(1024) void vc_phase_b_kernel(const VcDims d, const 
 
 void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                        const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, const VcXb& xb,
-                       hipStream_t st) {
+                       hipStream_t st, const VcGate* gate_in) {
+  const VcGate gate = gate_in ? *gate_in : VcGate{};
   const int nb_cell = d.model == VC_MODEL_VELOCITY ? (d.Nc + 255) / 256 : 0;
   const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
   const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
@@ -1570,11 +1592,11 @@ void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* g
   // (the gene blocks of phase B neither reduce nor stage rows: the smallest row bound keeps their registers free)
   if (vc_spec_launch<VC_SPECK_SHARDED, 0>(d.spec, [&](auto mq, auto sp) {
         hipLaunchKernelGGL((vc_phase_b_kernel<2, decltype(sp)::value>), grid, block, vc_hist_dyn_lds(d, with_hist, 1024), st, d, b, params, grad,
-                           step_dev, seed, a, loss_dev, loss_slots, nb_cell, nb_hist, xb);
+                           step_dev, seed, a, loss_dev, loss_slots, nb_cell, nb_hist, xb, gate);
       }))
     return;
   hipLaunchKernelGGL(vc_phase_b_kernel<2>, grid, block, vc_hist_dyn_lds(d, with_hist, 1024), st, d, b, params, grad, step_dev, seed, a,
-                     loss_dev, loss_slots, nb_cell, nb_hist, xb);
+                     loss_dev, loss_slots, nb_cell, nb_hist, xb, gate);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ class Tuning:
     p2p_timeout_s: float = 0.0                  # 0 = 2 s
     no_tail_spec: bool = False                  # True: the run-time-flag small kernels even where a compiled signature matches
     pw_lane: bool = True                        # False: the U-only kernel's wave-level reduction even where the per-lane nu_omega partials apply
+    p2p_fold: bool = True                       # False: the peer-to-peer exchange as a launch of its own between phases A and B (rounds 3-5)
     # ---- the host side (SVIRunner / fit) ---------------------------------------------------------------------------
     adam_impl: Optional[str] = None             # single-rank perf step: None = "fused3"
     adam_impl_dist: Optional[str] = None        # sharded perf step: None = "sharded"
@@ -71,6 +72,7 @@ class Tuning:
         t.p2p_timeout_s = float(self.p2p_timeout_s)
         t.no_tail_spec = int(bool(self.no_tail_spec))
         t.no_pw_lane = int(not self.pw_lane)
+        t.p2p_separate = int(not self.p2p_fold)
         return t
 
     def digest(self) -> int:
@@ -113,6 +115,7 @@ class Tuning:
         kw["dense_batches"] = e.get("VC_DENSE_BATCHES", "0") not in ("", "0")
         kw["no_tail_spec"] = e.get("VC_NO_TAIL_SPEC", "0") not in ("", "0")
         kw["pw_lane"] = e.get("VC_PW_LANE", "1") != "0"
+        kw["p2p_fold"] = e.get("VC_P2P_FOLD", "1") != "0"
         if e.get("VC_P2P_TIMEOUT_S"):
             kw["p2p_timeout_s"] = float(e["VC_P2P_TIMEOUT_S"])
         kw["adam_impl"] = e.get("VC_ADAM_IMPL") or None
