@@ -173,7 +173,10 @@ typedef struct vc_tuning {
                                 nu_omega partials applies (one condition, D == 1; A/B, tests) */
   int32_t p2p_separate;      /* 1: the peer-to-peer exchange as a launch of its own between phases A and B (rounds 3-5); 0: folded into
                                 phase B (its blocks pass the exchange's gate and add the ranks' slots where they read them) */
-  int32_t reserved[4];
+  int32_t p2p_one_launch;    /* 1 (with the peer-to-peer exchange): phases A and B of a sharded step in ONE launch, the exchange at block
+                                granularity inside it -- K_main + one launch per step; needs 256-cell cell blocks and gene + cell + loss
+                                blocks <= 240 (else the folded three-launch step).  Opt-in: it has run between processes on one device only */
+  int32_t reserved[3];
 } vc_tuning;
 
 typedef struct vc_layout {

@@ -66,12 +66,14 @@ for n_ranks, nc in ((8, 6250), (4, 12500), (2, 25000), (1, 50000)):
                      # round 6: the one-shot peer-to-peer exchange on this one rank (own region: publish, wait, sum of one slot) --
                      # folded into phase B (default) and as the launch of its own of rounds 3-5
                      ("sharded_fused_p2p_folded", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="p2p", _tun=dict(p2p_fold=True))),
-                     ("sharded_fused_p2p_separate", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="p2p", _tun=dict(p2p_fold=False)))]
+                     ("sharded_fused_p2p_separate", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="p2p", _tun=dict(p2p_fold=False))),
+                     # ... and phases A and B in ONE launch with the exchange at block granularity (K_main + one launch per step)
+                     ("sharded_p2p_one_launch", dict(adam_impl="sharded", use_graph=False, force_reduce=True, exchange="p2p", _tun=dict(p2p_one_launch=True)))]
     if quick:
         if nc == 25000:
             continue
         keep = ("fused_3_launches", "fused_3_launches_eager", "sharded_fused_engine_rccl", "sharded_fused_no_exchange",
-                "sharded_fused_p2p_folded", "sharded_fused_p2p_separate")
+                "sharded_fused_p2p_folded", "sharded_fused_p2p_separate", "sharded_p2p_one_launch")
         variants = [v for v in variants if v[0] in keep]
     for name, kw in variants:
         kw = dict(kw)

@@ -100,27 +100,30 @@ def _two_ranks(env_extra, extra_args=(), n=2):
     return _json_line(r.stdout)
 
 
-@pytest.mark.parametrize("fold", ["1", "0"])
+@pytest.mark.parametrize("fold", ["1", "0", "x"])
 def test_two_process_p2p_exchange_equals_the_collective(fold):
-    """(fold = 1, the default since round 6: phase B runs the exchange's publish / wait protocol itself and adds the ranks' slots where it
+    """(fold = x: phases A and B in ONE launch with the exchange at block granularity, vc_tail_x_kernel -- K_main + one launch per step;
+    fold = 1, the default since round 6: phase B runs the exchange's publish / wait protocol itself and adds the ranks' slots where it
     reads them -- K_main, phase A, phase B and nothing else; fold = 0: the exchange as a launch of its own.)  VC_EXCHANGE=p2p: the one-shot exchange over peer-mapped device memory (vc_p2p_exchange.hip) between two PROCESSES (both
     on cuda:0 -- hipIpc works between processes on one device, which is all a 1-GPU box can offer): region export / import,
     step-stamped flags, double-buffered slots, fixed-rank-order sum, all enqueued from one C call per run.  Same losses as the
     gloo all-reduce of the same two ranks (two addends: a + b is b + a, bit for bit), no exchange time-out latched."""
     ref = _two_ranks({"VC_EXCHANGE": "torch"})
-    got = _two_ranks({"VC_EXCHANGE": "p2p", "VC_P2P_TIMEOUT_S": "20", "VC_P2P_FOLD": fold})
+    got = _two_ranks({"VC_EXCHANGE": "p2p", "VC_P2P_TIMEOUT_S": "20", "VC_P2P_FOLD": "1" if fold == "x" else fold,
+                      "VC_P2P_ONE_LAUNCH": "1" if fold == "x" else "0"})
     assert got["distributed"]["exchange"] == "p2p" and ref["distributed"]["exchange"] == "torch"
     assert got["nonfinite_loss_steps"] == 0
     for a, b in zip(ref["loss_first_last"], got["loss_first_last"]):
         assert abs(a - b) <= 1e-9 * abs(a), (ref["loss_first_last"], got["loss_first_last"])
 
 
-def test_four_process_p2p_exchange():
+@pytest.mark.parametrize("one_launch", ["0", "1"])
+def test_four_process_p2p_exchange(one_launch):
     """The same with FOUR processes (unequal shards: 6 000 cells over 4 ranks of 1 500, tutorial-flow kernel): four regions,
     four flags per region, the sum in rank order 0..3 on every rank.  gloo adds the four buffers in another order, so the
     losses agree to float32 rounding of the re-associated sum instead of bit for bit."""
     ref = _two_ranks({"VC_EXCHANGE": "torch"}, ("--mode", "vcond"), n=4)
-    got = _two_ranks({"VC_EXCHANGE": "p2p", "VC_P2P_TIMEOUT_S": "30"}, ("--mode", "vcond"), n=4)
+    got = _two_ranks({"VC_EXCHANGE": "p2p", "VC_P2P_TIMEOUT_S": "30", "VC_P2P_ONE_LAUNCH": one_launch}, ("--mode", "vcond"), n=4)
     assert got["distributed"]["exchange"] == "p2p" and got["distributed"]["world_size"] == 4 and got["nonfinite_loss_steps"] == 0
     for (a, b), tol in zip(zip(ref["loss_first_last"], got["loss_first_last"]), (2e-6, 2e-4)):      # first step | 34 steps on
         assert abs(a - b) <= tol * abs(a), (ref["loss_first_last"], got["loss_first_last"])

@@ -56,7 +56,7 @@ class vc_tuning(C.Structure):
                 ("hist_dense", C.c_int32), ("pw_inline", C.c_int32), ("no_tail2", C.c_int32),
                 ("no_tail_merged", C.c_int32), ("force_generic", C.c_int32), ("particles_layout", C.c_int32),
                 ("dense_batches", C.c_int32), ("p2p_timeout_s", C.c_float), ("no_tail_spec", C.c_int32),
-                ("no_pw_lane", C.c_int32), ("p2p_separate", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("no_pw_lane", C.c_int32), ("p2p_separate", C.c_int32), ("p2p_one_launch", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class vc_layout(C.Structure):

@@ -140,6 +140,8 @@ __host__ __device__ inline int vc_rec_pairs(int H, int Nb, bool full) { return 2
 
 // Peer-mapped regions of the one-shot exchange (vc_p2p_exchange.hip): region[q] = rank q's region as mapped in THIS process
 #define VC_P2P_MAX_RANKS 16
+#define VC_P2P_FLAG_STRIDE 16      // 64-byte line per flag (in 4-byte words)
+#define VC_P2P_POISON 0xFFFFFFFFu  // a rank that gave up on a step publishes this instead of a step number
 struct VcP2p {
   void* region[VC_P2P_MAX_RANKS];
   int world = 0, rank = 0;
@@ -157,6 +159,8 @@ struct VcXb {
   // Round 6, the peer-to-peer exchange FOLDED into phase B (no launch of its own): phase B's readers add the ranks' published
   // buffers themselves, in rank order (vc_xget) -- nslots = 0: `x` holds the summed buffer (RCCL / torch / the separate exchange kernel)
   int nslots = 0;
+  int xmode = 0;          // 1: phases A and B run in ONE launch (vc_tail_x_kernel): what a block of the launch wrote and ANOTHER block reads
+                          // (the shape_inv snapshot `sis`) is read with cache-bypassing loads too -- no kernel boundary lies in between
   int dead = 0;           // the launch's verdict (vc_p2p_gate): a peer never published -> every read is NaN (the step is poisoned)
   const float* const* slots = nullptr;    // DEVICE table [nslots]: rank q's published buffer of this step's parity, as mapped in this process
                                            // (a table in memory, not an array in the kernel arguments: indexing those by a run-time rank
@@ -193,13 +197,77 @@ __device__ __forceinline__ float vc_xget(const VcXb& xb, long long i) {
   return acc;
 }
 
+// (xmode) a float another block of the SAME launch wrote and released (vc_x_publish): bypass the caches; else a plain load
+__device__ __forceinline__ float vc_xsis(const VcXb& xb, size_t i) { return xb.xmode ? vc_xload(xb.sis + i) : xb.sis[i]; }
+// (xmode) what phase A hands to the exchange -- slot elements, the shape_inv snapshot -- goes out as write-through system-scope stores:
+// when the wave's vmcnt has drained they have reached memory, and the block's flag may be raised WITHOUT a release fence (a release at
+// system scope writes the XCD's whole L2 back: measured + 12 us per step with one fence per block); else plain stores (the kernel
+// boundary behind phase A releases them)
+__device__ __forceinline__ void vc_xstore(float* p, float v, int xmode) {
+  if (xmode) __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else *p = v;
+}
+__device__ __forceinline__ void vc_xput(const VcXb& xb, long long i, float v) { vc_xstore(xb.x + i, v, xb.xmode); }
+
+// ---- the exchange at BLOCK granularity (round 6, vc_tail_x_kernel: phases A and B of a rank in ONE launch) -------------------------
+// Every block k of the launch (gene blocks, cell blocks, the loss block) owns ONE flag per rank: region[q].bflags[r][k] = what rank r's
+// block k has published, as seen in rank q's region.  A block writes its partials into its rank's slot (phase A), releases them,
+// raises its flag in EVERY region and waits only for the flags it depends on: a gene block for the same gene block of every rank, a
+// cell block for all cell blocks of all ranks (the nu_omega gradient), the loss block for everything.  No grid-wide barrier.
+struct VcGateX {
+  void* const* regions = nullptr;   // DEVICE table [world]
+  int world = 0, rank = 0;
+  long long step = 0;
+  long long* status = nullptr;
+  unsigned long long timeout_ticks = 0;
+  long long bflag_off = 0;          // 4-byte words from a region's base to bflags[world][nblk]
+  int nblk = 0;                     // flags per rank
+};
+// Release what this block wrote (all of its live threads call; nthr of them) and raise flags [k0, k0 + nk) of this rank in every region.
+__device__ __forceinline__ void vc_x_publish(const VcGateX& g, int k0, int nk, int nthr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                   // every store of the block has left its wave
+  const unsigned want = (g.status && g.status[2] != 0) ? VC_P2P_POISON : (unsigned)(g.step + 1);
+  if ((int)threadIdx.x < 64) {
+    // (no fence: everything the peers / the other blocks read was stored write-through -- vc_xput -- and has drained)
+    for (int i = threadIdx.x; i < g.world * nk; i += 64) {
+      const int q = i / nk, j = i % nk;
+      unsigned* f = reinterpret_cast<unsigned*>(g.regions[q]) + g.bflag_off + (size_t)g.rank * g.nblk + k0 + j;
+      __hip_atomic_store(f, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// Wait (bounded) until flags [k0, k0 + nk) of EVERY rank have reached this step in this rank's own region; 1 = dead (time-out or a
+// poisoned peer: sticky in status[2]), block-uniform.  All nthr live threads of the block call.
+__device__ __forceinline__ int vc_x_wait(const VcGateX& g, int k0, int nk, int nthr) {
+  __shared__ int sm_xdead;
+  if (threadIdx.x == 0) sm_xdead = (g.status && g.status[2] != 0) ? 1 : 0;
+  __syncthreads();
+  const unsigned want = (unsigned)(g.step + 1);
+  const unsigned* mine = reinterpret_cast<const unsigned*>(g.regions[g.rank]) + g.bflag_off;
+  for (int i = threadIdx.x; i < g.world * nk; i += nthr) {
+    const int q = i / nk, j = i % nk;
+    const unsigned* f = mine + (size_t)q * g.nblk + k0 + j;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (v == VC_P2P_POISON) { sm_xdead = 1; break; }
+      if ((int)(v - want) >= 0) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > g.timeout_ticks) { sm_xdead = 1; break; }
+    }
+  }
+  __syncthreads();
+  const int dead = sm_xdead;
+  if (dead && threadIdx.x == 0 && g.status && g.status[2] == 0) g.status[2] = g.step + 1;
+  return dead;
+}
+
 // The publish / wait protocol of the one-shot exchange (vc_p2p_exchange.hip has the story), for every block of a launch whose
 // predecessor on the stream wrote this rank's slot: block 0 raises this rank's flag of `step` in every region (the kernel boundary
 // in front of the launch released the slot's plain stores), waits -- bounded -- for every peer's flag in its OWN region and publishes
 // the launch's ONE verdict; the other blocks wait for that verdict.  Returns 1 when the step is dead (a peer never published or had
 // given up: sticky in status[2], poison raised in every region), else 0; block-uniform.  Ends with a system-scope acquire.
-#define VC_P2P_FLAG_STRIDE 16      // 64-byte line per flag (in 4-byte words)
-#define VC_P2P_POISON 0xFFFFFFFFu  // a rank that gave up on a step publishes this instead of a step number
 __device__ __forceinline__ int vc_p2p_gate(void* const* __restrict__ regions, int world, int rank, long long step,
                                            long long* __restrict__ status, unsigned long long timeout_ticks,
                                            unsigned long long* __restrict__ verdict, const bool acquire = true) {
@@ -923,6 +991,9 @@ void vc_launch_tail(const VcDims& d, const VcBufs& b, float* params, float* grad
 void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                        const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, const VcXb& xb,
                        hipStream_t st, const VcGate* gate = nullptr);
+void vc_launch_tail_x(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, const VcXb& xw, const VcXb& xr,
+                      const VcGateX& gx, int nc_cap, hipStream_t st);
 void vc_launch_omega(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int boot, int with_hist, hipStream_t st);
 // tutorial flow on one rank (pw_inline, nothing per cell left to learn): K_tail's gene blocks and K_omega's blocks in one launch

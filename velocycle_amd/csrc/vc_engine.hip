@@ -85,6 +85,8 @@ struct vc_engine {
   long long xb_total = 0;
   // one-shot peer-to-peer exchange (vc_p2p_alloc / vc_p2p_connect, vc_p2p_exchange.hip)
   VcP2p p2p{};
+  int p2p_nblk = 0;                  // flags per rank of the one-launch exchange (vc_tail_x_kernel)
+  long long p2p_bflag_off = 0;       // words from a region's base to those flags
   void** p2p_tab = nullptr;          // device: [3][VC_P2P_MAX_RANKS] pointers -- the regions, the parity-0 slots, the parity-1 slots
   void* p2p_own = nullptr;            // this rank's region (hipMalloc, IPC-exported)
   bool p2p_connected = false;
@@ -426,7 +428,7 @@ extern "C" int vc_set_tuning(vc_engine* e, const vc_tuning* t) {
   if (!in(z.tail_cells, {0, 256, 512, 1024})) return e->fail(VC_ERR_ARG, "vc_set_tuning: tail_cells must be 0, 256, 512 or 1024");
   if (!in(z.count_storage, {0, 1}) || !in(z.host_hist, {0, 1}) || !in(z.hist_dense, {0, 1, 2}) || !in(z.pw_inline, {0, 1, 2}) ||
       !in(z.no_tail2, {0, 1}) || !in(z.no_tail_merged, {0, 1}) || !in(z.force_generic, {0, 1}) || !in(z.particles_layout, {0, 1, 2}) ||
-      !in(z.dense_batches, {0, 1}) || !in(z.no_tail_spec, {0, 1}) || !in(z.no_pw_lane, {0, 1}) || !in(z.p2p_separate, {0, 1}))
+      !in(z.dense_batches, {0, 1}) || !in(z.no_tail_spec, {0, 1}) || !in(z.no_pw_lane, {0, 1}) || !in(z.p2p_separate, {0, 1}) || !in(z.p2p_one_launch, {0, 1}))
     return e->fail(VC_ERR_ARG, "vc_set_tuning: a switch is outside its documented values");
   if (z.p2p_timeout_s < 0.f) return e->fail(VC_ERR_ARG, "vc_set_tuning: negative p2p_timeout_s");
   e->tun = z;
@@ -1168,6 +1170,7 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
   // -- and with the dense histogram tables (S+U kernel) 512: its cell blocks carry the longest chain of that launch (nu_omega inside)
   if (fused_tail_kind(e) == 2 && d.Nc > 16384) d.tail_tc = d.kind == VC_KIND_VFULL ? 512 : 1024;
   if (e->tun.tail_cells) d.tail_tc = e->tun.tail_cells;
+  if (e->tun.p2p_one_launch && e->cfg.world_size >= 1 && d.Nc <= 160000) d.tail_tc = 256;      // vc_tail_x_kernel: cell block = K_omega's block
   d.nb_tail_cell = (d.Nc + d.tail_tc - 1) / d.tail_tc;
   d.nlpf = d.nb_post_gene + d.nb_tail_cell + 1;
   d.lgamma_alpha = lgammaf(d.gamma_alpha);
@@ -1696,7 +1699,10 @@ extern "C" int vc_p2p_alloc(vc_engine* e, void* ipc_handle_out) {
   p.world = e->cfg.world_size; p.rank = e->cfg.rank;
   p.flag_words = p.world * 16;                                   // one 64-byte line per flag
   p.slot_floats = (e->xb_total + 15) / 16 * 16;
-  const size_t bytes = ((size_t)p.flag_words + 2 * (size_t)p.slot_floats) * sizeof(float);
+  // (+ the per-block flags of the one-launch exchange: [world][gene blocks + cell blocks of the widest shard + the loss block] words)
+  e->p2p_nblk = e->d.nb_post_gene + e->xb_pw_cap + 1;
+  e->p2p_bflag_off = (long long)p.flag_words + 2 * (long long)p.slot_floats;
+  const size_t bytes = ((size_t)e->p2p_bflag_off + ((size_t)p.world * (size_t)e->p2p_nblk + 15) / 16 * 16) * sizeof(float);
   // Fine-grained device memory: peers raise the flags with remote stores and the owner polls them in LOCAL memory; on
   // coarse-grained memory (plain hipMalloc) the owner's L2 may keep serving the old line until a kernel boundary.
   // Tried in this order: fine-grained, uncached, plain (the last only so that a driver without IPC for the first two still
@@ -1797,7 +1803,36 @@ extern "C" int vc_svi_run_sharded(vc_engine* e, float* params, uint64_t seed, in
   VcBufs b2 = e->b;
   b2.step_ctr = (long long*)step_dev;
   b2.adam_lr0 = a.lr0; b2.adam_lrd_l = a.lrd_l; b2.adam_b1l = a.b1l; b2.adam_b2l = a.b2l; b2.adam_kind = a.kind;
+  // Round 6, opt-in (vc_tuning.p2p_one_launch with the peer-to-peer exchange): phases A and B in ONE launch, the exchange at block
+  // granularity inside it (vc_tail_x_kernel).  Admitted where every block that may spin on another is resident at one 1024-thread block
+  // per CU -- gene blocks + the cell blocks of the widest shard + the loss block <= 240 -- and the cell blocks are K_omega's (256 cells).
+  const bool one_launch = use_p2p && e->tun.p2p_one_launch && !e->tun.p2p_separate && ds.tail_tc == 256 &&
+                          ds.nb_post_gene + e->xb_pw_cap + 1 <= 240 && ds.nb_tail_cell <= e->xb_pw_cap;
   for (int64_t i = 0; i < n_steps; ++i) {
+    if (one_launch) {
+      if (e->timing) {
+        if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());
+        auto& pr = e->ev_pool[e->ev_used++];
+        HIPCHK(e, hipEventRecord(pr.first, st));
+        main_fn(ds, b2, st);
+        HIPCHK(e, hipEventRecord(pr.second, st));
+      } else {
+        main_fn(ds, b2, st);
+      }
+      const size_t slot_off = (size_t)e->p2p.flag_words + (size_t)(e->p2p_step & 1) * (size_t)e->p2p.slot_floats;
+      VcXb xw = xb, xr = xb;
+      xw.x = reinterpret_cast<float*>(e->p2p_own) + slot_off;
+      xw.xmode = 1;
+      xr.nslots = e->p2p.world; xr.xmode = 1;
+      xr.slots = reinterpret_cast<const float* const*>(e->p2p_tab) + VC_P2P_MAX_RANKS * (1 + (int)(e->p2p_step & 1));
+      VcGateX gx;
+      gx.regions = reinterpret_cast<void* const*>(e->p2p_tab); gx.world = e->p2p.world; gx.rank = e->p2p.rank;
+      gx.step = e->p2p_step; gx.status = e->b.status; gx.timeout_ticks = (unsigned long long)(e->p2p_timeout_s * 1e8);
+      gx.bflag_off = e->p2p_bflag_off; gx.nblk = e->p2p_nblk;
+      vc_launch_tail_x(ds, e->b, params, grad, sd, seed, a, loss_dev, (long long)loss_slots, with_hist, xw, xr, gx, e->xb_pw_cap, st);
+      e->p2p_step++;
+      continue;
+    }
     if (phase != VC_PHASE_B) {
       if (e->timing) {
         if (e->ev_used == e->ev_pool.size()) TRY(e->drain_events());

@@ -63,13 +63,14 @@ struct VcOpt { float step_size, b1, b2, eps, clip, c2, wd; const unsigned char* 
 // four floats on FIXED grids -- multiples of 2^20, 2^1, 2^-17 and the remainder -- with fewer than 2^19 multiples each: the
 // float32 sum of up to 16 ranks' pieces is exact piece by piece (|v| < 2^39), whatever the order of the adds.
 #define VC_LOSS_PIECES 4
-__device__ __forceinline__ void vc_loss_split(double v, float* __restrict__ out) {
+__device__ __forceinline__ void vc_loss_split(double v, float* __restrict__ out, int xmode = 0) {
   const double p0 = rint(v * (1.0 / 1048576.0)) * 1048576.0;
   const double r0 = v - p0;
   const double p1 = rint(r0 * 0.5) * 2.0;
   const double r1 = r0 - p1;
   const double p2 = rint(r1 * 131072.0) * (1.0 / 131072.0);
-  out[0] = (float)p0; out[1] = (float)p1; out[2] = (float)p2; out[3] = (float)(r1 - p2);
+  vc_xstore(out, (float)p0, xmode); vc_xstore(out + 1, (float)p1, xmode); vc_xstore(out + 2, (float)p2, xmode);
+  vc_xstore(out + 3, (float)(r1 - p2), xmode);
 }
 __device__ __forceinline__ double vc_loss_join(const float* __restrict__ in) {
   return (((double)in[0] + (double)in[1]) + (double)in[2]) + (double)in[3];
@@ -241,9 +242,9 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     // phase A: the histogram blocks of phase B re-derive the shape_inv update while the gene blocks of the same launch
     // rewrite it -- they read this snapshot {parameter, exp_avg, exp_avg_sq}
     if (phase == VC_PH_A && r_si) {
-      xb.sis[g] = pp[0];
-      xb.sis[NP + g] = Mm[off[0] - header];
-      xb.sis[2 * NP + g] = Vv[off[0] - header];
+      vc_xstore(xb.sis + g, pp[0], xb.xmode);
+      vc_xstore(xb.sis + NP + g, Mm[off[0] - header], xb.xmode);
+      vc_xstore(xb.sis + 2 * NP + g, Vv[off[0] - header], xb.xmode);
     }
   }
 
@@ -396,14 +397,14 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
       if (phase == VC_PH_A) {
 #pragma unroll
         for (int k = 0; k < VC_MAXOWN; ++k)
-          if (k < nown) xb.x[off[k]] = gg[k];
+          if (k < nown) vc_xput(xb, off[k], gg[k]);
       }
     }
     if (phase == VC_PH_A && role == 12) {
       const double tot = vc_wave_sum_d63(loss_post);
       if (lane == 63) {
         b.LPP[gblock] = tot;
-        vc_loss_split(tot, xb.x + xb.loss_off + VC_LOSS_PIECES * (1 + gblock));
+        vc_loss_split(tot, xb.x + xb.loss_off + VC_LOSS_PIECES * (1 + gblock), xb.xmode);
       }
     }
   }
@@ -436,7 +437,7 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
           }
           gq = -(lik - rw * (first ? dq_lat : b.lat[VC_SITE_DNU][jq]) / (sd * sd));
         }
-        if (phase == VC_PH_A) xb.x[po] = gq;
+        if (phase == VC_PH_A) vc_xput(xb, po, gq);
         else {
           G[po] = gq;
           float mm = first ? dq_m : Mm[po - header], vv = first ? dq_v : Vv[po - header];
@@ -781,12 +782,12 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
   // this rank writes (PW rows beyond this rank's cell blocks, the header, the nu_omega slots of the gradient region) are
   // cleared here so that they do not re-enter the next sum
   if (phase == VC_PH_A && cblock == 0) {
-    for (int tt = d.nb_tail_cell * d.NW + (int)threadIdx.x; tt < xb.pw_cap * d.NW; tt += VC_TC) xb.x[xb.pw_off + tt] = 0.f;
-    if (threadIdx.x < 4) xb.x[threadIdx.x] = 0.f;
+    for (int tt = d.nb_tail_cell * d.NW + (int)threadIdx.x; tt < xb.pw_cap * d.NW; tt += VC_TC) vc_xput(xb, xb.pw_off + tt, 0.f);
+    if (threadIdx.x < 4) vc_xput(xb, threadIdx.x, 0.f);
     if (vel) {
       const bool lrmn = d.guide == VC_GUIDE_LRMN;
       const int fin_per = lrmn ? d.R + 2 : 2;
-      for (int tt = threadIdx.x; tt < d.NW * fin_per; tt += VC_TC) xb.x[vc_nuw_elem_off(d, lrmn, tt / fin_per, tt % fin_per)] = 0.f;
+      for (int tt = threadIdx.x; tt < d.NW * fin_per; tt += VC_TC) vc_xput(xb, vc_nuw_elem_off(d, lrmn, tt / fin_per, tt % fin_per), 0.f);
     }
   }
   VC_WSTAMP(0, 4);
@@ -850,7 +851,7 @@ __device__ __forceinline__ void vc_tail_cell_block(const VcDims& d, const VcBufs
       const int j = threadIdx.x;
       float t = 0.f;
       for (int w = 0; w < VC_TC / 64; ++w) t += sm_w[w][j];
-      if (phase == VC_PH_A) xb.x[xb.pw_off + cblock * d.NW + j] = t;
+      if (phase == VC_PH_A) vc_xput(xb, xb.pw_off + cblock * d.NW + j, t);
       else b.PW[(size_t)cblock * d.NW + j] = t;
     }
     if (threadIdx.x == 0) {
@@ -878,7 +879,7 @@ __device__ __forceinline__ void vc_tail_loss_base_block(const VcDims& d, const V
   if (t == 0) {
     double tot = b.const_loss;
     for (int w = 0; w < 16; ++w) tot += sm_lb[w];
-    vc_loss_split(tot, xb.x + xb.loss_off);
+    vc_loss_split(tot, xb.x + xb.loss_off, xb.xmode);
   }
 }
 
@@ -1139,8 +1140,8 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
         // the gene blocks of this launch are rewriting shape_inv: re-derive its update from phase A's snapshot and the summed
         // gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
         const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
-        float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
-        si = expf(vc_adam_elem(xb.sis[g], vc_xget(xb, off), mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off)));
+        float mm = vc_xsis(xb, d.Ng_pad + g), vv = vc_xsis(xb, 2 * (size_t)d.Ng_pad + g);
+        si = expf(vc_adam_elem(vc_xsis(xb, g), vc_xget(xb, off), mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off)));
       }
       vc_hist_dense_block(d, b, xblk, si, half, nthr >> 6, sm_hd);
       return;
@@ -1161,8 +1162,8 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
         // summed gradient (vc_adam_elem is the arithmetic the owning thread runs: the same bits)
         const int g = b.h_task[4 * task];
         const long long off = d.poff[VC_P_SHAPE_INV_ULOCS] + g;
-        float mm = xb.sis[d.Ng_pad + g], vv = xb.sis[2 * (size_t)d.Ng_pad + g];
-        const float np = vc_adam_elem(xb.sis[g], vc_xget(xb, off), mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off));
+        float mm = vc_xsis(xb, d.Ng_pad + g), vv = vc_xsis(xb, 2 * (size_t)d.Ng_pad + g);
+        const float np = vc_adam_elem(vc_xsis(xb, g), vc_xget(xb, off), mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1], vc_wd_at(a.wd, a.frozen, off));
         vc_hist_wave(d, b, P, 0, task, lane, expf(np), half);
       } else {
         vc_hist_wave(d, b, P, 0, task, lane, -1.f, half);
@@ -1597,6 +1598,92 @@ void vc_launch_phase_b(const VcDims& d, const VcBufs& b, float* params, float* g
     return;
   hipLaunchKernelGGL(vc_phase_b_kernel<2>, grid, block, vc_hist_dyn_lds(d, with_hist, 1024), st, d, b, params, grad, step_dev, seed, a,
                      loss_dev, loss_slots, nb_cell, nb_hist, xb, gate);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phases A and B of a rank of a sharded run in ONE launch, the exchange at block granularity in between (round 6; opt-in with the
+// peer-to-peer exchange: vc_tuning.p2p_one_launch).  The step becomes K_main -> this launch.  Block kinds in dispatch order:
+//   gene block k        phase A of the block (partials into this rank's slot), publish flag k, wait for flag k of every rank, phase B of
+//                       the block on the sum of the ranks' slices (vc_xget);
+//   cell block c        256 cells: phase A (phi_xy update, next phase, basis, the block's row of d loglik / d nu_omega partials), publish
+//                       flag NG + c, wait for ALL cell blocks of all ranks, K_omega's block of the same cells (nu_omega chain, omega_c);
+//   the loss block      the rank's loss base, publish flag NG + NC (and the flags of cell blocks this rank does not have: the flag
+//                       grid is rank-invariant), wait for every flag, the loss of the step;
+//   histogram blocks    wait for the gene blocks, re-derive the shape_inv update from the snapshot those took, the next step's sums;
+//   eps blocks          depend on nothing.
+// A block that waits spins: every block it waits for must be resident or finished -- gene, cell and loss blocks come first in the
+// grid and the host admits the launch only where they fit the chip at one 1024-thread block per CU (vc_svi_run_sharded).
+// The same block code as phases A / B: the same bits as the three-launch sharded step (tests/test_hip_multiproc.py).
+// ---------------------------------------------------------------------------------------------
+template <int MQ, int SPEC = 0>
+__global__ __launch_bounds__(1024) void vc_tail_x_kernel(const VcDims d, const VcBufs b, float* __restrict__ P, float* __restrict__ G,
+                                                         const long long* __restrict__ step_dev, uint64_t seed, const VcAdamArgs a,
+                                                         double* __restrict__ loss_dev, long long loss_slots, int nb_cell, int nc_cap,
+                                                         int nb_hist, const VcXb xw, const VcXb xr0, const VcGateX gx) {
+  vc_spec_assume<SPEC>(d);
+  const long long s = *step_dev;
+  const int NG = d.nb_post_gene;
+  VcXb xr = xr0;
+  VcOpt o;
+  o.step_size = b.step_size[0];
+  o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.clip = a.clip; o.c2 = b.step_size[1]; o.wd = a.wd; o.frozen = a.frozen;
+  const int bid = blockIdx.x;
+  if (bid < NG) {
+    vc_tail_gene_block<MQ, VC_PH_A>(d, b, P, G, a.m, a.v, a.header, bid, s, seed, o, 0, xw);
+    vc_x_publish(gx, bid, 1, 1024);
+    xr.dead = vc_x_wait(gx, bid, 1, 1024);
+    vc_tail_gene_block<2, VC_PH_B>(d, b, P, G, a.m, a.v, a.header, bid, s, seed, o, 0, xr);
+    return;
+  }
+  if (bid < NG + nb_cell) {
+    if (threadIdx.x >= 256) return;        // 256 cells per block: the other waves leave before any barrier
+    const int c = bid - NG;
+    vc_tail_cell_block<VC_PH_A>(d, b, P, G, a.m, a.v, a.header, c, s, seed, o, 0, xw);
+    vc_x_publish(gx, NG + c, 1, 256);
+    if (d.model != VC_MODEL_VELOCITY) return;          // (the phase model has no nu_omega chain: nothing to wait for)
+    xr.dead = vc_x_wait(gx, NG, nc_cap, 256);
+    vc_omega_block(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_cell, nb_hist, c, VC_PH_B, xr);
+    return;
+  }
+  const int xblk = bid - NG - nb_cell;     // 0 loss, 1 .. nb_hist histogram, then eps (as vc_omega_extra_block counts them)
+  if (xblk == 0) {
+    vc_tail_loss_base_block(d, b, s, xw);
+    // this rank's loss flag + the flags of the cell blocks it does not have (a rank with fewer cells than the widest shard)
+    vc_x_publish(gx, NG + nb_cell, nc_cap - nb_cell + 1, 1024);
+    xr.dead = vc_x_wait(gx, 0, NG + nc_cap + 1, 1024);
+    vc_omega_extra_block<false>(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, 0, VC_PH_B, xr, false, 1024);
+    return;
+  }
+  if (xblk - 1 < nb_hist) {
+    xr.dead = vc_x_wait(gx, 0, NG, 1024);        // the gene blocks: their shape_inv snapshot and gradient partials
+    if (d.hist_dense) {
+      vc_omega_extra_block<false>(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, xblk, VC_PH_B, xr, false, 1024);
+      return;
+    }
+  }
+  if (threadIdx.x >= 256) return;          // list-form histogram tasks and eps pairs: K_omega's 256-thread blocks
+  vc_omega_extra_block<false>(d, b, P, G, s, seed, a, loss_dev, loss_slots, 0, nb_hist, xblk, VC_PH_B, xr, false);
+}
+
+void vc_launch_tail_x(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
+                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, const VcXb& xw, const VcXb& xr,
+                      const VcGateX& gx, int nc_cap, hipStream_t st) {
+  const int nb_cell = d.nb_tail_cell;                  // (tail_tc = 256: vc_svi_run_sharded checks) = K_omega's cell blocks
+  const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
+  const int nb_eps = (int)((d.eps_total / 2 + 255) / 256);
+  const dim3 grid(d.nb_post_gene + nb_cell + 1 + nb_hist + nb_eps), block(1024);
+  const unsigned dyn = vc_hist_dyn_lds(d, with_hist, 1024);
+  if (vc_spec_launch<VC_SPECK_SHARDED, 0>(d.spec, [&](auto mq, auto sp) {
+        hipLaunchKernelGGL((vc_tail_x_kernel<decltype(mq)::value, decltype(sp)::value>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a,
+                           loss_dev, loss_slots, nb_cell, nc_cap, nb_hist, xw, xr, gx);
+      }))
+    return;
+#define VC_TAILX_LAUNCH(MQ_) hipLaunchKernelGGL((vc_tail_x_kernel<MQ_>), grid, block, dyn, st, d, b, params, grad, step_dev, seed, a, loss_dev, loss_slots, nb_cell, nc_cap, nb_hist, xw, xr, gx)
+  if (d.nq <= 2) VC_TAILX_LAUNCH(2);
+  else if (d.nq <= 4) VC_TAILX_LAUNCH(4);
+  else if (d.nq <= 6) VC_TAILX_LAUNCH(6);
+  else VC_TAILX_LAUNCH(VC_MAXQ);
+#undef VC_TAILX_LAUNCH
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ class Tuning:
     p2p_timeout_s: float = 0.0                  # 0 = 2 s
     no_tail_spec: bool = False                  # True: the run-time-flag small kernels even where a compiled signature matches
     pw_lane: bool = True                        # False: the U-only kernel's wave-level reduction even where the per-lane nu_omega partials apply
+    p2p_one_launch: bool = False                # True (exchange="p2p"): phases A and B in ONE launch, exchange at block granularity (opt-in)
     p2p_fold: bool = True                       # False: the peer-to-peer exchange as a launch of its own between phases A and B (rounds 3-5)
     # ---- the host side (SVIRunner / fit) ---------------------------------------------------------------------------
     adam_impl: Optional[str] = None             # single-rank perf step: None = "fused3"
@@ -73,6 +74,7 @@ class Tuning:
         t.no_tail_spec = int(bool(self.no_tail_spec))
         t.no_pw_lane = int(not self.pw_lane)
         t.p2p_separate = int(not self.p2p_fold)
+        t.p2p_one_launch = int(bool(self.p2p_one_launch))
         return t
 
     def digest(self) -> int:
@@ -116,6 +118,7 @@ class Tuning:
         kw["no_tail_spec"] = e.get("VC_NO_TAIL_SPEC", "0") not in ("", "0")
         kw["pw_lane"] = e.get("VC_PW_LANE", "1") != "0"
         kw["p2p_fold"] = e.get("VC_P2P_FOLD", "1") != "0"
+        kw["p2p_one_launch"] = e.get("VC_P2P_ONE_LAUNCH", "0") not in ("", "0")
         if e.get("VC_P2P_TIMEOUT_S"):
             kw["p2p_timeout_s"] = float(e["VC_P2P_TIMEOUT_S"])
         kw["adam_impl"] = e.get("VC_ADAM_IMPL") or None
