@@ -130,6 +130,11 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
   const bool chain = !boot && phase != VC_PH_B;       // second-stage reduction + chain rule happen in this launch
   const bool upd = !boot && phase != VC_PH_A;         // ... the optimiser
   const bool samp = phase != VC_PH_A;                 // ... the next sample
+  // (one-hot batches: the batch's chunk range is a scalar load the reduction's addresses depend on -- requested first, so that it
+  // travels beside the roles' own inputs; two samples: the barrier was reached 1.1 us later without this)
+  VcChunkWalk wk;
+  wk.first = 0; wk.stride = 1; wk.end = 0;
+  if (chain) wk = vc_chunk_walk(d, b, g, wave);
 
   VC_WSTAMP(0, 0);
   // ---- LRMN: eps_W of step s - 1 (gradient) and of step s (next sample) are wave-uniform: lane k fetches, readlane
@@ -279,7 +284,6 @@ __device__ __forceinline__ void vc_tail_gene_block(const VcDims& d, const VcBufs
     float acc[MQ];
 #pragma unroll
     for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
-    const VcChunkWalk wk = vc_chunk_walk(d, b, g, wave);
     for (int ch0 = wk.first; ch0 < wk.end; ch0 += U * wk.stride) {
       float v[U][MQ];
 #pragma unroll

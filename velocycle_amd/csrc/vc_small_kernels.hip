@@ -509,6 +509,8 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
   __shared__ float sm[VC_PG_WAVES][MQ][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = gblock * 64 + lane;
+  const VcChunkWalk wk = vc_chunk_walk(d, b, g, wave);      // (one-hot batches: the waves walk their batch's chunks -- vc_common.h; a scalar
+                                                            // load the reduction's addresses depend on: requested first)
   // Chain rule to the parameter gradients: the work of one gene is split into independent ROLES and every role runs
   // on its own wave (lane = gene), so that the serial path of the block is the longest role instead of their sum:
   // role h < Nh: nu[h]; Nh + q: dnu[q]; 12: shape_inv (+ r-only loss terms); 13: log gamma / log beta (mean-field) or
@@ -576,7 +578,6 @@ __device__ __forceinline__ void vc_post_gene_block(const VcDims& d, const VcBufs
   float acc[MQ];
 #pragma unroll
   for (int q = 0; q < MQ; ++q) acc[q] = 0.f;
-  const VcChunkWalk wk = vc_chunk_walk(d, b, g, wave);      // (one-hot batches: the waves walk their batch's chunks -- vc_common.h)
   for (int ch0 = wk.first; ch0 < wk.end; ch0 += U * wk.stride) {
     float v[U][MQ];
 #pragma unroll
