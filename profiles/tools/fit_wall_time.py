@@ -66,7 +66,8 @@ with clock("handover_and_preprocess_velocity"):
     from velocycle_amd import pyro_compat as pyro
     pyro.clear_param_store()                  # as the tutorials do between the stages (a fit() continues from the store)
     mv = P.preprocess_for_velocity_estimation(ad, pf.cycle_pyro, pf.phase_pyro, spd, torch.ones(Nc, 1), torch.ones(Nc, 1),
-                                              n_harmonics=1, count_factor=mp.count_factor, ω_n_harmonics=0, condition_on=cond)
+                                              n_harmonics=1, count_factor=mp.count_factor, ω_n_harmonics=0, condition_on=cond,
+                                              with_delta_nu=False)       # as the one-sample tutorial's cell does
 with clock("velocity_fit_total"):
     vf = VelocityFitModel(mv, condition_on=cond, num_samples=nsamp, n_per_bin=50)
     vf.fit(opt(steps), num_steps=steps, verbose=False, seed=2)
