@@ -150,7 +150,16 @@ class _SelectedLayers(_Layers):
         if isinstance(v, _LazyLayer):
             v = v.fn()
         if _is_sparse(v):
-            return v.tocsr()[self._ridx][:, self._cidx]
+            # (a selection that keeps every row / every column in order costs a copy, not a fancy index: at 50 000 x 2 000
+            # scipy's column gather alone is 0.1 s per layer)
+            m = v.tocsr()
+            rows_all = len(self._ridx) == m.shape[0] and np.array_equal(self._ridx, np.arange(m.shape[0]))
+            cols_all = len(self._cidx) == m.shape[1] and np.array_equal(self._cidx, np.arange(m.shape[1]))
+            if rows_all and cols_all:
+                return m.copy()
+            if not rows_all:
+                m = m[self._ridx]
+            return m if cols_all else m[:, self._cidx]
         v = np.asarray(v)
         if len(self._ridx) == v.shape[0] and np.array_equal(self._ridx, np.arange(v.shape[0])):
             return np.take(v, self._cidx, axis=1)        # all cells: one gather along the genes

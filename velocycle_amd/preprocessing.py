@@ -50,7 +50,11 @@ def _csr_counts(layer, dense=None):
     a container whose S / U were replaced or edited afterwards never runs on stale CSR counts."""
     if not (hasattr(layer, "tocsr") and hasattr(layer, "toarray")):
         return None
-    m = layer.tocsr().astype(np.int64).astype(np.float32)
+    src = layer.tocsr()
+    # the values in one or two passes over the data array alone (scipy's astype copies the index arrays with every call), the
+    # index arrays copied once: the container's CSR never aliases the caller's matrix
+    data = src.data if src.data.dtype.kind in "iub" else src.data.astype(np.int64)
+    m = type(src)((data.astype(np.float32), src.indices.copy(), src.indptr.copy()), shape=src.shape)
     m.sum_duplicates()
     m.eliminate_zeros()
     if dense is not None:
