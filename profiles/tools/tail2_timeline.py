@@ -41,10 +41,13 @@ NGB = ((NG + 63) // 64 * 64 + 255) // 256 * 256 // 64 if False else None
 s0 = w[0]
 live = s0[:, :, 0] > 0
 # (blocks that lead the grid as histogram blocks may hold kid-0 stamps of an EARLIER launch structure of the same run: the boot launches)
-_hist_lead = 0
-while _hist_lead < w.shape[1] and (w[1][_hist_lead, :, 7] > 0).any():
-    _hist_lead += 1
+# (round 6: a histogram block of a gene block whose quarter blocks do its work leaves without a stamp -- the lead ends behind the LAST
+# stamped histogram block, plus any such unstamped block behind it)
+_h7 = np.where((w[1][:, :, 7] > 0).any(1))[0]
+_hist_lead = int(_h7.max()) + 1 if len(_h7) else 0
 live[:_hist_lead] = False
+while _hist_lead < w.shape[1] and len(_h7) and not live[_hist_lead].any():
+    _hist_lead += 1
 z = s0[:, :, 0][live].min()
 print(f"K_main last exit -> first wave of the next launch: {(z - mt3) / 100:.2f} us")
 nblk = np.where(live.any(1))[0]
@@ -62,10 +65,7 @@ def show(tag, arr, sel, ks=range(8)):
 
 u[s0 <= 0] = -1e9
 # (round 5: the histogram blocks lead the grid of the one-launch tail -- the gene blocks start behind them)
-lead = 0
-hist_blk = (w[1][:, :, 7] > 0).any(1)
-while lead < len(hist_blk) and hist_blk[lead]:
-    lead += 1
+lead = _hist_lead
 gene = np.zeros_like(live); gene[lead:lead + ngb] = True
 show("gene blocks (all waves)", u, live & gene)
 for wv, role in ((0, "nu[0]"), (12, "shape_inv"), (13, "role 14"), (15, "role 13")):
@@ -101,3 +101,14 @@ if sel.any():
     blk = np.where(sel.any(1))[0]
     print(f"   histogram blocks {blk.min()}..{blk.max()}: done by block index (every 8th): " +
           " ".join(f"{done[i]:.1f}" for i in blk[::8]))
+if os.environ.get("VC_TL_HISTDETAIL"):
+    for i in order:
+        print(f"   hist block {int(i)} waves 0..3 stamps 2 (chunks added), 4 (table rows requested, snapshot and sums read), 6 (update re-derived), 7 (done):", [[round(float((s1[i, wv, k] - z) / 100.0), 2) for k in (2, 4, 6, 7)] for wv in range(4)])
+    for i in (0, 1):
+        print(f"   hist block {int(i)} waves 0..3 stamps 2 (chunks added), 4 (table rows requested, snapshot and sums read), 6 (update re-derived), 7 (done):", [[round(float((s1[i, wv, k] - z) / 100.0), 2) for k in (2, 4, 6, 7)] for wv in range(4)])
+if os.environ.get("VC_TL_HISTDETAIL"):
+    e3 = s1[:, :, 3]
+    blk3 = np.where((e3 > 0).any(1) & ~(s1[:, :, 1] > 0).any(1))[0]      # eps blocks: stamp 3 without the chain's stamp 1
+    if len(blk3):
+        v = (e3[blk3][e3[blk3] > 0] - z) / 100.0
+        print(f"   eps blocks {blk3.min()}..{blk3.max()}: end min {v.min():.2f} med {np.median(v):.2f} max {v.max():.2f}")

@@ -347,6 +347,9 @@ struct VcBufs {
   const float* HC;                          // rows of 64 floats
   const int* hc_off;                        // [2][Ng_pad / 64] first row of a gene block (matrix S, then U)
   const int* hc_rows;                       // [2][Ng_pad / 64] rows of a gene block = its largest count (row j: cells with count > j)
+  const int* hc_rows_q;                     // [2][Ng_pad / 64][4] the same per quarter (16 genes) of a gene block
+  const int* hc_split;                      // [n_hc_split] gene blocks (matrix * Ng_pad / 64 + block) with hc_rows > VC_HIST_SPLIT_ROWS: the one-launch
+  int n_hc_split;                           // tail evaluates them in four quarter blocks each (vc_hist_dense16_finish<true>)
   const int *wg_tile;                       // [n_main_wg][4] {first cell of wave 0, cells per wave, batch, end of the workgroup's cells} of the
                                             // likelihood kernel's workgroups (cells = POSITIONS of the blocked layout: cell_pos)
   const int *bat_chunk;                     // onehot: [nGB][Nb + 1] first chunk of batch q among the chunks of a gene block (chunks of a batch are
@@ -837,55 +840,73 @@ __device__ __forceinline__ void vc_hist_dense_block(const VcDims& d, const VcBuf
 // first VC_HIST_PRE count levels (nothing is consumed: 640 levels of the table -- a second, dependent round trip for the levels
 // beyond 256 cost the blocks that have them 4.5 us at the end of the launch, round 5), `finish` -- once shape_inv of the lane's gene
 // is known -- adds them up in increasing order (+ further levels of a block whose largest count exceeds 639), one barrier, and
-// wave 0 adds the slices in slice order.  A level beyond 256 at which none of the block's 64 genes has a cell is skipped by the whole
+// wave 0 adds the slices in slice order.  A level beyond 256 at which none of the wave's genes has a cell is skipped by the whole
 // wave (its terms are 0 x finite).  Same sums as vc_hist_dense_block, bit for bit.
+// QT (round 6): a QUARTER of a gene block by four waves -- 16 genes x 16 slices = 256 threads, lane l of wave w holds gene
+// 16 * quarter + (l & 15) and slice 4 w + (l >> 4).  The evaluation is VALU-issue bound (a logarithm, a reciprocal, three float ->
+// double conversions and two double FMAs per level), so 16 waves on one CU -- four per SIMD -- take four times what a wave alone
+// takes; for the few gene blocks that hold a highly expressed gene (largest count beyond VC_HIST_SPLIT_ROWS) that was 5.6 us at the
+// very end of the launch (profiles/r06_hist_split.md).  Those blocks are evaluated by four quarter blocks on four CUs instead, one
+// wave per SIMD, each to ITS genes' largest count (hc_rows_q); every (gene, matrix, slice) sum is formed as before and a gene's 16
+// slices are added in slice order by one thread -- the same bits.  (All blocks as quarters: measured SLOWER, the launch's wave
+// dispatch is serial and 256 blocks of 1024 threads put the gene blocks 4.6 us later.)
 #define VC_HIST_PRE 40
-struct VcHistPre { float c[VC_HIST_PRE]; int rows, off, m; };
-__device__ __forceinline__ void vc_hist_dense16_rows(const VcDims& d, const VcBufs& b, int gb, VcHistPre& h, int m) {
+#define VC_HIST_SPLIT_ROWS 256
+struct VcHistPre { float c[VC_HIST_PRE]; int rows, off, m, gi, v; };
+template <bool QT>
+__device__ __forceinline__ void vc_hist_dense16_rows(const VcDims& d, const VcBufs& b, int gb, VcHistPre& h, int m, int quarter) {
   const int nblk = d.Ng_pad / 64, nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
   const bool used = m < nm && ((m == 0 && d.hist_has_S) || (m == 1 && d.hist_has_U));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   h.m = m;
-  h.rows = used ? b.hc_rows[m * nblk + gb] : 0;
+  h.gi = QT ? 16 * quarter + (lane & 15) : lane;
+  h.v = QT ? 4 * (wv & 3) + (lane >> 4) : wv;
+  h.rows = used ? (QT ? b.hc_rows_q[(m * nblk + gb) * 4 + quarter] : b.hc_rows[m * nblk + gb]) : 0;
   h.off = used ? b.hc_off[m * nblk + gb] : 0;
 }
+template <bool QT>
 __device__ __forceinline__ void vc_hist_dense16_issue(const VcDims& d, const VcBufs& b, VcHistPre& h) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float* __restrict__ tabp = b.HC + (size_t)h.off * 64 + lane;
+  const float* __restrict__ tabp = b.HC + (size_t)h.off * 64 + h.gi;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {                 // (no branch around a load: a clamped row, the value dropped afterwards)
-    const int j = wv + 16 * u, jc = j < h.rows ? j : (h.rows > 0 ? h.rows - 1 : 0);
-    const float x = tabp[(size_t)jc * 64];
-    h.c[u] = j < h.rows ? x : 0.f;
+  // (no branch around a load and no select behind it: a clamped row, and `finish` drops the value of a level that is not the thread's --
+  // with the select HERE hipcc reused one destination register in the quarter form and waited for every single load: 24 round trips,
+  // 5.8 us, found on the time stamps)
+  for (int u = 0; u < 16; ++u) {
+    const int j = h.v + 16 * u, jc = j < h.rows ? j : (h.rows > 0 ? h.rows - 1 : 0);
+    h.c[u] = tabp[(size_t)jc * 64];
   }
 #pragma unroll
   for (int u = 16; u < VC_HIST_PRE; ++u) h.c[u] = 0.f;
   if (h.rows > 256) {                            // (uniform per block: only a block with counts beyond 255 asks for more)
 #pragma unroll
     for (int u = 16; u < VC_HIST_PRE; ++u) {
-      const int j = wv + 16 * u, jc = j < h.rows ? j : h.rows - 1;
-      const float x = tabp[(size_t)jc * 64];
-      h.c[u] = j < h.rows ? x : 0.f;
+      const int j = h.v + 16 * u, jc = j < h.rows ? j : h.rows - 1;
+      h.c[u] = tabp[(size_t)jc * 64];
     }
   }
 }
+template <bool QT>
 __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const VcBufs& b, int gb, float si, int half, const VcHistPre& h,
                                                        double* sm /* 2048 doubles */) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col = QT ? (lane & 15) : lane;
   const int nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
-  const int g = gb * 64 + lane;
+  const int g = gb * 64 + h.gi;
   const float r = 1.0f / si;
   double al = 0.0, ad = 0.0;
   {
-    const float* __restrict__ tabp = b.HC + (size_t)h.off * 64 + lane;
+    const float* __restrict__ tabp = b.HC + (size_t)h.off * 64 + h.gi;
 #pragma unroll
     for (int u = 0; u < VC_HIST_PRE; ++u) {      // (the association of vc_hist_dense_block: levels in increasing order, one by one)
-      if (u >= 16 && (h.rows <= 256 || __builtin_amdgcn_ballot_w64(h.c[u] != 0.f) == 0ull)) continue;
-      const float t = r + (float)(wv + 16 * u);
-      al += (double)h.c[u] * (double)__builtin_amdgcn_logf(t);
-      ad += (double)h.c[u] * (double)__builtin_amdgcn_rcpf(t);
+      const float cu = h.v + 16 * u < h.rows ? h.c[u] : 0.f;        // (what `issue` read for a level beyond the thread's last is a clamped row)
+      if (u >= 16 && (h.rows <= 256 || __builtin_amdgcn_ballot_w64(cu != 0.f) == 0ull)) continue;
+      const float t = r + (float)(h.v + 16 * u);
+      al += (double)cu * (double)__builtin_amdgcn_logf(t);
+      ad += (double)cu * (double)__builtin_amdgcn_rcpf(t);
     }
     constexpr int UT = 32;
-    for (int j0 = wv + 16 * VC_HIST_PRE; j0 < h.rows; j0 += 16 * UT) {
+    // (QT: the lanes of a wave hold four slices -- the wave goes on while any of them has levels left; a lane that is through adds 0 x finite)
+    for (int j0 = h.v + 16 * VC_HIST_PRE; QT ? __builtin_amdgcn_ballot_w64(j0 < h.rows) != 0ull : j0 < h.rows; j0 += 16 * UT) {
       float c[UT];
 #pragma unroll
       for (int u = 0; u < UT; ++u) { const int j = j0 + 16 * u; c[u] = j < h.rows ? tabp[(size_t)j * 64] : 0.f; }
@@ -898,13 +919,13 @@ __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const Vc
       }
     }
   }
-  sm[(wv * 2 + 0) * 64 + lane] = al;
-  sm[(wv * 2 + 1) * 64 + lane] = ad;
+  sm[(h.v * 2 + 0) * 64 + col] = al;
+  sm[(h.v * 2 + 1) * 64 + col] = ad;
   __syncthreads();
-  if (wv == 0 && h.m < nm && g < d.Ng) {
+  if (wv == 0 && (!QT || lane < 16) && h.m < nm && g < d.Ng) {
     double hl = 0.0, hd = 0.0;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { hl += sm[(v * 2 + 0) * 64 + lane]; hd += sm[(v * 2 + 1) * 64 + lane]; }
+    for (int v = 0; v < 16; ++v) { hl += sm[(v * 2 + 0) * 64 + col]; hd += sm[(v * 2 + 1) * 64 + col]; }
     const size_t t = (size_t)half * b.n_tasks + (size_t)nm * g + h.m;
     b.HL[t] = hl * 0.6931471805599453094;
     b.HD[t] = hd;

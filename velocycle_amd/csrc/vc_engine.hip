@@ -1291,12 +1291,29 @@ static int finalize_impl(vc_engine* e, void* hip_stream) {
         hc_rows.resize(2 * (size_t)nblk, 0);
       }
       hc.resize(hc.size() + 64, 0.f);          // (a row of padding: the prefetch of an empty block reads row 0)
+      // gene blocks that hold a highly expressed gene: the one-launch tail gives each of them four quarter blocks (16 genes, one wave per
+      // SIMD of a CU of their own: vc_common.h, vc_hist_dense16_finish<true>), every quarter to ITS genes' largest count
+      std::vector<int> hc_rows_q(hc_rows.size() * 4, 0), hc_split;
+      for (size_t i = 0; i < hc_rows.size(); ++i) {
+        for (int qd = 0; qd < 4; ++qd) {
+          int rq = 0;
+          for (int j = hc_rows[i] - 1; j >= 0 && !rq; --j)
+            for (int l = 16 * qd; l < 16 * qd + 16; ++l)
+              if (hc[((size_t)hc_off[i] + j) * 64 + l] != 0.f) { rq = j + 1; break; }
+          hc_rows_q[i * 4 + qd] = rq;
+        }
+        if (hc_rows[i] > VC_HIST_SPLIT_ROWS) hc_split.push_back((int)i);
+      }
+      b.n_hc_split = (int)hc_split.size();
+      if (hc_split.empty()) hc_split.push_back(0);
       TRY(upload(e, hc, &b.HC));
       TRY(upload(e, hc_off, &b.hc_off));
       TRY(upload(e, hc_rows, &b.hc_rows));
+      TRY(upload(e, hc_rows_q, &b.hc_rows_q));
+      TRY(upload(e, hc_split, &b.hc_split));
     } else {
       vc_build_hist_tasks(ptr, d.Ng, task, tptr);
-      b.HC = nullptr; b.hc_off = nullptr; b.hc_rows = nullptr;
+      b.HC = nullptr; b.hc_off = nullptr; b.hc_rows = nullptr; b.hc_rows_q = nullptr; b.hc_split = nullptr; b.n_hc_split = 0;
     }
     b.n_tasks = (int)task.size() / 4;
     TRY(upload(e, task, &b.h_task));

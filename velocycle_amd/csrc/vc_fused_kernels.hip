@@ -1049,33 +1049,39 @@ __device__ __forceinline__ void vc_hist_rederive_block(const VcDims& d, const Vc
 // The same with the dense tables (d.hist_dense): ONE block per gene block -- lane = gene, wave v adds the chunks v, v + 16, ... of
 // K_main's shape_inv row exactly as wave v of the gene block does (coalesced rows), the 16 wave sums meet in the LDS, every wave
 // then holds shape_inv(s) of the block's 64 genes and takes its slices of the count axis (vc_hist_dense_block).
+// QT: a quarter block (vc_hist_dense16_finish<true>) -- four live waves, a thread = (gene of the quarter, virtual wave v of the gene
+// block that owns the gene): it adds the chunks wave v of the gene block adds, in that order; waves 4 .. 15 leave at once.
+template <bool QT>
 __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const VcBufs& b, long long s, const VcAdamArgs& a, int gb,
-                                                       double* sm_hd, int msel) {
+                                                       double* sm_hd, int msel, int quarter) {
   __shared__ float sm_a[VC_PG_WAVES][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (QT && threadIdx.x >= 256) return;
+  const int lane = threadIdx.x & 63, col = QT ? (lane & 15) : lane;
   const size_t NP = d.Ng_pad;
   const int q = d.kind == VC_KIND_PHASE ? d.Kq : d.Kq + 2;
-  const int g = gb * 64 + lane;
-  const bool live = g < d.Ng;
   VcHistPre hp;
-  vc_hist_dense16_rows(d, b, gb, hp, msel);    // (arrives with the loads below)
+  vc_hist_dense16_rows<QT>(d, b, gb, hp, msel, quarter);    // (arrives with the loads below)
+  const int g = gb * 64 + hp.gi;
+  const bool live = g < d.Ng;
   float acc = 0.f;
   if (d.kind != VC_KIND_VU) {
     constexpr int UB = 8;
-    const VcChunkWalk wk = vc_chunk_walk(d, b, gb * 64, wv);       // as wave wv of the gene block that owns these 64 genes
-    for (int ch0 = wk.first; ch0 < wk.end; ch0 += UB * wk.stride) {
+    const VcChunkWalk wk = vc_chunk_walk(d, b, gb * 64, hp.v);       // as wave hp.v of the gene block that owns these 64 genes
+    for (int ch0 = wk.first; QT ? __builtin_amdgcn_ballot_w64(ch0 < wk.end) != 0ull : ch0 < wk.end; ch0 += UB * wk.stride) {
       float v[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int ch = ch0 + u * wk.stride;
-        v[u] = b.GO[((size_t)(ch < wk.end ? ch : ch0) * d.nq + q) * NP + g];
+        // (a chunk that is not this thread's: a row that exists -- the value is dropped)
+        v[u] = b.GO[((size_t)(ch < wk.end ? ch : (QT ? 0 : ch0)) * d.nq + q) * NP + g];
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u)
         if (ch0 + u * wk.stride < wk.end) acc += v[u];
     }
   }
-  vc_hist_dense16_issue(d, b, hp);             // the table rows travel while the update is re-derived
+  VC_WSTAMP(1, 2);
+  vc_hist_dense16_issue<QT>(d, b, hp);         // the table rows travel while the update is re-derived
   const float* sis = b.SIS + (size_t)((s - 1) & 1) * 4 * NP + g;
   const float p0 = sis[0], si = live ? sis[3 * NP] : 1.f;
   float mm = sis[NP], vv = sis[2 * NP];
@@ -1091,17 +1097,18 @@ __device__ __forceinline__ void vc_hist_rederive_dense(const VcDims& d, const Vc
       for (int k = 0; k < 4; ++k) if (tb + k < t1) HDg += hd[k];
     }
   }
-  sm_a[wv][lane] = acc;
+  VC_WSTAMP(1, 4);
+  sm_a[hp.v][col] = acc;
   __syncthreads();
   float U_r = 0.f;
 #pragma unroll
-  for (int w = 0; w < VC_PG_WAVES; ++w) U_r += sm_a[w][lane];          // wave order, as the gene block's T()
+  for (int w = 0; w < VC_PG_WAVES; ++w) U_r += sm_a[w][col];          // wave order, as the gene block's T()
   if (d.kind == VC_KIND_VU) U_r = 0.f;
   const float gg = vc_si_grad(d, 1.0f / si, si, U_r, HDg, d.root_w);
   const float np = vc_adam_elem(p0, gg, mm, vv, b.step_size[0], a.b1, a.b2, a.eps, a.clip, b.step_size[1],
                                 vc_wd_at(a.wd, a.frozen, d.poff[VC_P_SHAPE_INV_ULOCS] + (live ? g : 0)));
   VC_WSTAMP(1, 6);
-  vc_hist_dense16_finish(d, b, gb, live ? expf(np) : 1.f, (int)(s & 1), hp, sm_hd);
+  vc_hist_dense16_finish<QT>(d, b, gb, live ? expf(np) : 1.f, (int)(s & 1), hp, sm_hd);
   VC_WSTAMP(1, 7);
 }
 
@@ -1128,14 +1135,29 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
     if (d.hist_dense) {                            // dense tables: one block per gene block (barriers inside)
       double* sm_hd = vc_hist_lds();
       if (TAIL2) {                                 // (compiled into the one-launch tail only: 16-wave blocks, update re-derived)
-        // one block per (matrix, gene block): vc_launch_tail2 asks for nm x Ng_pad / 64 of them
+        // vc_launch_tail2 asks for 4 x b.n_hc_split + nm x Ng_pad / 64 blocks: first the quarter blocks of the gene blocks that hold a
+        // highly expressed gene (the longest evaluations of the launch), then one block per (matrix, gene block) -- of which those leave
         const int nblk = d.Ng_pad / 64, nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
+        if (xblk < 4 * b.n_hc_split) {
+          typedef const __attribute__((address_space(4))) int* ciptr;
+          const int id = ((ciptr)(const void*)b.hc_split)[xblk >> 2], quarter = xblk & 3;
+          const int msel = id / nblk, gb = id % nblk;
+          if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense<true>(d, b, s, a, gb, sm_hd, msel, quarter); return; }
+          if (t >= 256) return;                    // (four live waves: 16 genes x 16 slices)
+          VcHistPre hp;
+          vc_hist_dense16_rows<true>(d, b, gb, hp, msel, quarter);
+          vc_hist_dense16_issue<true>(d, b, hp);
+          vc_hist_dense16_finish<true>(d, b, gb, vc_hist_si(d, b, P, 0, gb * 64 + hp.gi), half, hp, sm_hd);
+          return;
+        }
+        xblk -= 4 * b.n_hc_split;
         const int msel = nm > 1 ? xblk / nblk : 0, gb = nm > 1 ? xblk % nblk : xblk;
-        if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense(d, b, s, a, gb, sm_hd, msel); return; }
+        if (b.hc_rows[msel * nblk + gb] > VC_HIST_SPLIT_ROWS) return;       // (its quarter blocks do the work)
+        if (rederive && !CND(VC_SITE_SHAPE_INV)) { vc_hist_rederive_dense<false>(d, b, s, a, gb, sm_hd, msel, 0); return; }
         VcHistPre hp;
-        vc_hist_dense16_rows(d, b, gb, hp, msel);
-        vc_hist_dense16_issue(d, b, hp);
-        vc_hist_dense16_finish(d, b, gb, vc_hist_si(d, b, P, 0, gb * 64 + lane), half, hp, sm_hd);
+        vc_hist_dense16_rows<false>(d, b, gb, hp, msel, 0);
+        vc_hist_dense16_issue<false>(d, b, hp);
+        vc_hist_dense16_finish<false>(d, b, gb, vc_hist_si(d, b, P, 0, gb * 64 + lane), half, hp, sm_hd);
         return;
       }
       const int g = xblk * 64 + lane;
@@ -1193,6 +1215,7 @@ __device__ __forceinline__ void vc_omega_extra_block(const VcDims& d, const VcBu
       }
     }
   }
+  VC_WSTAMP(1, 3);
 }
 
 // The nu_omega chain for a block of `nthr` threads (256: K_omega's blocks; the cell-block size of the one-launch tail): per-coefficient
@@ -1786,7 +1809,7 @@ __global__ __launch_bounds__(1024) void vc_tail2_kernel(const VcDims d, const Vc
 
 void vc_launch_tail2(const VcDims& d, const VcBufs& b, float* params, float* grad, const long long* step_dev, uint64_t seed,
                      const VcAdamArgs& a, double* loss_dev, long long loss_slots, int with_hist, hipStream_t st) {
-  const int nb_hist = !with_hist ? 0 : (d.hist_dense ? (d.model == VC_MODEL_VELOCITY ? 2 : 1) * (d.Ng_pad / 64)      // a block per (matrix, gene block)
+  const int nb_hist = !with_hist ? 0 : (d.hist_dense ? (d.model == VC_MODEL_VELOCITY ? 2 : 1) * (d.Ng_pad / 64) + 4 * b.n_hc_split      // a block per (matrix, gene block) + the quarter blocks
                                                        : (b.n_tasks + 16 * VC_HIST_ROUNDS - 1) / (16 * VC_HIST_ROUNDS));
   const int nb_eps = (int)((d.eps_total / 2 + 1024 * VC_EPS_PER_THREAD - 1) / (1024 * VC_EPS_PER_THREAD));
   const dim3 grid(d.nb_post_gene + d.nb_tail_cell + 1 + nb_hist + nb_eps), block(1024);
