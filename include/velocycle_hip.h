@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-/* 2 (round 6): vc_stats ends with onehot_batches, tail_spec, tail_spec_matched, tail_spec_name[32], pw_lane, reserved3 (a consumer built against
+/* 2 (round 6): vc_stats ends with onehot_batches, tail_spec, tail_spec_matched, tail_spec_name[32], pw_lane, hist_split (a consumer built against
  * version 1 would have its smaller vc_stats overrun by vc_get_stats: vc_create refuses it); vc_tuning, vc_set_tuning / vc_get_tuning,
  * vc_dbg_signature, vc_set_optimizer / vc_adam_update exist. */
 #define VC_ABI_VERSION 2
@@ -216,7 +216,8 @@ typedef struct vc_stats {
   char tail_spec_name[32];
   int32_t pw_lane;                /* 1: the U-only likelihood kernel accumulates its d loglik / d nu_omega partials per lane from the cell
                                      record (one condition, D == 1: W_c = (1, sin k phi_c, cos k phi_c)) and stores no per-cell rows */
-  int32_t reserved3;
+  int32_t hist_split;             /* gene blocks (per count matrix) whose dense histogram sums the one-launch tail evaluates in four quarter blocks:
+                                     those whose largest count exceeds 255; 0 with the (value, multiplicity) lists (was reserved: same layout) */
 } vc_stats;
 
 /* lifecycle ------------------------------------------------------------------------------- */

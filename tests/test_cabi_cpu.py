@@ -34,7 +34,7 @@ def test_struct_sizes_match_header_layout():
     mod, _ = _lib()
     assert C.sizeof(mod.vc_config) == 12 * 4 + 4 * 8 + 8 * 4
     assert C.sizeof(mod.vc_layout) == 8 * (4 + 2 * mod.VC_P_COUNT + 2 + 2 * mod.VC_E_COUNT)
-    assert C.sizeof(mod.vc_stats) == 4 * 8 + 2 * 4 + 96 + 2 * 8 + 4 * 4 + 4 * 4 + 2 * 4 + 32 + 2 * 4      # (+ tail_spec, tail_spec_matched, tail_spec_name, pw_lane, reserved3: ABI version 2)
+    assert C.sizeof(mod.vc_stats) == 4 * 8 + 2 * 4 + 96 + 2 * 8 + 4 * 4 + 4 * 4 + 2 * 4 + 32 + 2 * 4      # (+ tail_spec, tail_spec_matched, tail_spec_name, pw_lane, hist_split: ABI version 2)
 
 
 def test_create_validates_and_reports_errors():

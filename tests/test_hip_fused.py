@@ -295,6 +295,33 @@ def test_two_launch_step_medium_sizes(mode, ncond, cw, tc):
         _same(a["g"][4:], b["g"][4:], "gradient of step 2", rtol=1e-5, atol=1e-5)
 
 
+def test_two_launch_step_with_highly_expressed_genes():
+    """Round 6 (`vc_stats.hist_split`): a gene block whose largest count exceeds 255 has its dense histogram sums evaluated by four
+    QUARTER blocks of the one-launch tail (16 genes x 16 slices of the count axis, one wave per SIMD) -- the same per-slice sums, the
+    slices of a gene added in the same order.  Genes in three gene blocks get counts beyond 255, one of them beyond the 640 levels the
+    quarter blocks prefetch (a second trip over the table), one block keeps its small counts; over 25 steps the two-launch step must
+    equal the three-launch step (K_tail / K_omega: one 4-wave block per gene block, `vc_hist_dense_block`) bit for bit, and the unfused
+    sequence to the usual rounding."""
+    from velocycle_amd.engine import HipEngine
+    from velocycle_amd.tuning import Tuning
+    from velocycle_amd.workloads import make_velocity_spec
+    spec = make_velocity_spec(3001, 300, "vjoint", n_conditions=1, Hw=1, seed=5)
+    for mat, gene, factor in ((spec.S, 3, 60.0), (spec.U, 3, 25.0), (spec.S, 70, 25.0), (spec.U, 133, 400.0), (spec.S, 299, 30.0)):
+        mat[gene] = torch.clamp(torch.floor(mat[gene] * factor), max=2000.0)           # integer counts below the tables' 2048 levels
+    assert float(spec.S.max()) > 300 and float(spec.U.max()) > 700
+    t2 = Tuning(cells_per_wave=37, pw_inline="force", hist_dense="dense")
+    e = HipEngine(spec, tuning=t2)
+    assert e.stats["launches_per_step"] == 2 and e.stats["hist_split"] >= 4, e.stats       # S: blocks 0, 1, 4; U: blocks 0, 2
+    e.close()
+    two = _run(spec, "fused3", 25, False, tuning=t2)
+    three = _run(spec, "fused3", 25, False, tuning=t2.replace(tail2=False))
+    _bits_equal(two, three, "highly expressed genes")
+    assert two["status"][0] and np.isfinite(two["l"]).all()
+    ref = _run(spec, "fused", 25, False, tuning=t2)
+    assert np.allclose(two["l"], ref["l"], rtol=2e-6, atol=0)
+    _same(two["p"], ref["p"], "params, two launches vs the unfused sequence", rtol=5e-5, atol=5e-6)
+
+
 def test_two_launch_step_resumes_and_mixes_with_step_with_loss():
     """Checkpoint / resume into a new engine and run_perf mixed with step_with_loss on the two-launch step: the same
     trajectory bit for bit (the histogram halves, the shape_inv snapshot and the nu_omega snapshot are re-primed)."""

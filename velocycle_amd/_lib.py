@@ -73,7 +73,7 @@ class vc_stats(C.Structure):
                 ("setup_transient_bytes", C.c_int64), ("count_storage_bytes", C.c_int64),
                 ("pass_cells", C.c_int32 * 4), ("launches_per_step", C.c_int32), ("pw_inline", C.c_int32),
                 ("generic", C.c_int32), ("onehot_batches", C.c_int32), ("tail_spec", C.c_int32), ("tail_spec_matched", C.c_int32),
-                ("tail_spec_name", C.c_char * 32), ("pw_lane", C.c_int32), ("reserved3", C.c_int32)]
+                ("tail_spec_name", C.c_char * 32), ("pw_lane", C.c_int32), ("hist_split", C.c_int32)]
 
 
 EXPORTS = {

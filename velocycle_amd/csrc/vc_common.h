@@ -183,14 +183,24 @@ __device__ __forceinline__ float vc_xload(const float* p) {
 }
 // element i of the exchange buffer summed over the ranks: read from the summed buffer, or added up here in rank order (the order of
 // the exchange kernel: identical bits on every rank)
+// (the table of slot pointers is read through the SCALAR cache -- it is written once, by the host, when the regions are connected: as
+// plain loads hipcc put `s_waitcnt vmcnt(0)` between every pointer and its element, which also waited for the previous rank's element:
+// 2 N dependent round trips per element instead of one; found in the ISA of phase B, round 6)
+__device__ __forceinline__ const float* vc_xslot(const void* table, int q) {
+  typedef const __attribute__((address_space(4))) unsigned long long* ctab;
+  return reinterpret_cast<const float*>(((ctab)table)[q]);
+}
 __device__ __forceinline__ float vc_xget(const VcXb& xb, long long i) {
   if (xb.nslots == 0) return xb.x[i];
   if (xb.dead) return __builtin_nanf("");
   float acc = 0.f;
   for (int q0 = 0; q0 < xb.nslots; q0 += 4) {      // four ranks' loads in flight per trip
+    const float* sl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sl[u] = vc_xslot(xb.slots, q0 + u < xb.nslots ? q0 + u : q0);
     float v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = q0 + u < xb.nslots ? vc_xload(xb.slots[q0 + u] + i) : 0.f;
+    for (int u = 0; u < 4; ++u) v[u] = vc_xload(sl[u] + i);          // (a rank beyond the last: rank q0's element again, dropped)
 #pragma unroll
     for (int u = 0; u < 4; ++u) if (q0 + u < xb.nslots) acc += v[u];
   }

@@ -2014,7 +2014,7 @@ extern "C" int vc_get_stats(const vc_engine* e, vc_stats* out) {
   else { const int tk = fused_tail_kind(e); speck = tk == 1 ? VC_SPECK_MERGED : (tk == 2 ? VC_SPECK_TAIL2 : 0); }
   const int used = (d.spec > 0 && (VC_SPECS[d.spec].kind & speck)) ? d.spec : VC_SPEC_NONE;
   out->pw_lane = d.pw_lane;
-  out->reserved3 = 0;
+  out->hist_split = d.hist_dense ? e->b.n_hc_split : 0;
   out->tail_spec = used;
   out->tail_spec_matched = d.spec;
   memset(out->tail_spec_name, 0, sizeof(out->tail_spec_name));

@@ -947,19 +947,21 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
     // everything below belongs to the sample of the finished step s - 1 and was complete BEFORE this launch: prior / guide
     // terms and the r-only likelihood term (written when the sample was drawn, half (s - 1) & 1), its histogram sums (half
     // (s - 1) & 1 when shape_inv is learned), K_main's likelihood partials -- no block of this launch writes any of it
-    const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
-#pragma unroll 4
-    for (int i = t; i < d.nlpf; i += 256) sl += lpf[i];
-    const double* lpr = b.LPR + (size_t)((s - 1) & 1) * d.nb_post_gene;
-#pragma unroll 4
-    for (int i = t; i < d.nb_post_gene; i += 256) sl += lpr[i];
-    if (d.nmat_r > 0) {
-      const double* hl = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
-#pragma unroll 4
-      for (int i = t; i < b.n_tasks; i += 256) sl -= hl[i];
-    }
-#pragma unroll 4
-    for (int i = t; i < d.n_main_wg; i += 256) sl -= (double)b.LO[i];
+    // (each list in trips of eight REQUESTS, then the eight adds in index order: written as `sl += p[i]` hipcc waited for every single
+    // load -- ~25 dependent round trips, the block ended with the gene blocks at 7 us; round 6, found next to the histogram prefetch)
+    auto add_list = [&](auto ptr, int n, double sign) {
+      for (int i0 = t; i0 < n; i0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = (double)ptr[i < n ? i : i0]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + 256 * u < n) sl += sign * v[u];
+      }
+    };
+    add_list(b.LPF + (size_t)((s - 1) & 1) * d.nlpf, d.nlpf, 1.0);
+    add_list(b.LPR + (size_t)((s - 1) & 1) * d.nb_post_gene, d.nb_post_gene, 1.0);
+    if (d.nmat_r > 0) add_list(b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks, b.n_tasks, -1.0);
+    add_list(b.LO, d.n_main_wg, -1.0);
   }
   sl = vc_wave_sum_d63(sl);
   if (lane == 63) sm_lossw[wv] = sl;
@@ -1237,11 +1239,17 @@ __device__ __forceinline__ void vc_nuw_sums_issue(const VcDims& d, const VcBufs&
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int j = wv + nwv * q, jc = j < d.NW ? j : 0;
+    // no branch around a load and no select behind it: a clamped row, and `finish` adds only the rows that exist, for coefficients that
+    // exist (with the select here hipcc waited for every single load: 11 dependent round trips on the chain wave; round 6)
+    if (on) {
 #pragma unroll
-    for (int k = 0; k < VC_NUW_RAW; ++k) {          // no branch around a load: a clamped row, the value dropped afterwards
-      const int i = lane + 64 * k, ic = i < n_pw ? i : 0;
-      const float x = on ? PWs[(size_t)ic * pw_ld + jc] : 0.f;
-      raw.r[q][k] = (j < d.NW && i < n_pw) ? x : 0.f;
+      for (int k = 0; k < VC_NUW_RAW; ++k) {
+        const int i = lane + 64 * k, ic = i < n_pw ? i : 0;
+        raw.r[q][k] = PWs[(size_t)ic * pw_ld + jc];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < VC_NUW_RAW; ++k) raw.r[q][k] = 0.f;
     }
   }
 }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void vc_p2p_xchg_kernel(VcP2p p, void* const* 
       float v[2][4];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const float* src = reinterpret_cast<const float*>(regions[q0 + u < p.world ? q0 + u : q0]) + slot_off + 4 * i;
+        const float* src = vc_xslot(regions, q0 + u < p.world ? q0 + u : q0) + slot_off + 4 * i;      // (the table through the scalar cache: vc_xget)
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[u][k] = vc_xload(src + k);
       }

@@ -180,7 +180,7 @@ class HipEngine:
                           count_storage="u16" if st.count_storage_bytes == 2 else "f32",
                           pass_cells=[int(x) for x in st.pass_cells], launches_per_step=int(st.launches_per_step),
                           pw_inline=int(st.pw_inline), generic=bool(st.generic), onehot_batches=int(st.onehot_batches),
-                          tail_spec=int(st.tail_spec), tail_spec_matched=int(st.tail_spec_matched), pw_lane=bool(st.pw_lane),
+                          tail_spec=int(st.tail_spec), tail_spec_matched=int(st.tail_spec_matched), pw_lane=bool(st.pw_lane), hist_split=int(st.hist_split),
                           tail_spec_name=bytes(st.tail_spec_name).decode() or "generic")
 
     # ------------------------------------------------------------------------------------------
