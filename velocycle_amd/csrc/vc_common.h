@@ -819,13 +819,15 @@ __device__ __forceinline__ void vc_hist_dense_block(const VcDims& d, const VcBuf
       for (int j0 = v; j0 < rows; j0 += 16 * UB) {
         float c[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) { const int j = j0 + 16 * u; c[u] = j < rows ? tabp[(size_t)j * 64] : 0.f; }
+        // (no branch around a load and no select behind it -- hipcc then waits for every single load: a clamped row, dropped below)
+        for (int u = 0; u < UB; ++u) { const int j = j0 + 16 * u; c[u] = tabp[(size_t)(j < rows ? j : j0) * 64]; }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-          if (j0 + 16 * u >= 256 && __builtin_amdgcn_ballot_w64(c[u] != 0.f) == 0ull) continue;      // (an empty level: see vc_hist_dense16_finish)
+          const float cu = j0 + 16 * u < rows ? c[u] : 0.f;
+          if (j0 + 16 * u >= 256 && __builtin_amdgcn_ballot_w64(cu != 0.f) == 0ull) continue;      // (an empty level: see vc_hist_dense16_finish)
           const float t = r + (float)(j0 + 16 * u);
-          al += (double)c[u] * (double)__builtin_amdgcn_logf(t);
-          ad += (double)c[u] * (double)__builtin_amdgcn_rcpf(t);
+          al += (double)cu * (double)__builtin_amdgcn_logf(t);
+          ad += (double)cu * (double)__builtin_amdgcn_rcpf(t);
         }
       }
       sm[(v * 2 + 0) * 64 + lane] = al;

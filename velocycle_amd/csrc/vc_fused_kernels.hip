@@ -951,11 +951,11 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
     // load -- ~25 dependent round trips, the block ended with the gene blocks at 7 us; round 6, found next to the histogram prefetch)
     auto add_list = [&](auto ptr, int n, double sign) {
       for (int i0 = t; i0 < n; i0 += 8 * 256) {
-        double v[8];
+        decltype(ptr[0] + 0) v[8];        // (the list's own type: a conversion directly behind the load is one register and one wait per load again)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = (double)ptr[i < n ? i : i0]; }
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = ptr[i < n ? i : i0]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (i0 + 256 * u < n) sl += sign * v[u];
+        for (int u = 0; u < 8; ++u) if (i0 + 256 * u < n) sl += sign * (double)v[u];
       }
     };
     add_list(b.LPF + (size_t)((s - 1) & 1) * d.nlpf, d.nlpf, 1.0);
