@@ -947,21 +947,29 @@ __device__ __forceinline__ void vc_omega_loss_block(const VcDims& d, const VcBuf
     // everything below belongs to the sample of the finished step s - 1 and was complete BEFORE this launch: prior / guide
     // terms and the r-only likelihood term (written when the sample was drawn, half (s - 1) & 1), its histogram sums (half
     // (s - 1) & 1 when shape_inv is learned), K_main's likelihood partials -- no block of this launch writes any of it
-    // (each list in trips of eight REQUESTS, then the eight adds in index order: written as `sl += p[i]` hipcc waited for every single
-    // load -- ~25 dependent round trips, the block ended with the gene blocks at 7 us; round 6, found next to the histogram prefetch)
-    auto add_list = [&](auto ptr, int n, double sign) {
+    const double* lpf = b.LPF + (size_t)((s - 1) & 1) * d.nlpf;
+#pragma unroll 4
+    for (int i = t; i < d.nlpf; i += 256) sl += lpf[i];
+    const double* lpr = b.LPR + (size_t)((s - 1) & 1) * d.nb_post_gene;
+#pragma unroll 4
+    for (int i = t; i < d.nb_post_gene; i += 256) sl += lpr[i];
+    if (d.nmat_r > 0) {
+      // the one LONG list (a term per histogram task: 16 per thread at 2 000 genes x 2 matrices) in trips of eight REQUESTS, then the
+      // eight adds in index order: as `sl -= hl[i]` hipcc waits for every single load -- 16 dependent round trips, the block ended with
+      // the gene blocks at 7 us (round 6, found next to the histogram prefetch).  The short lists stay plain loops: in trips they cost
+      // the tutorial flow's merged tail 0.75 us per step (measured, same box: 72.35 vs 71.6 us).
+      const double* hl = b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks;
+      const int n = b.n_tasks;
       for (int i0 = t; i0 < n; i0 += 8 * 256) {
-        decltype(ptr[0] + 0) v[8];        // (the list's own type: a conversion directly behind the load is one register and one wait per load again)
+        double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = ptr[i < n ? i : i0]; }
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = hl[i < n ? i : i0]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (i0 + 256 * u < n) sl += sign * (double)v[u];
+        for (int u = 0; u < 8; ++u) if (i0 + 256 * u < n) sl -= v[u];
       }
-    };
-    add_list(b.LPF + (size_t)((s - 1) & 1) * d.nlpf, d.nlpf, 1.0);
-    add_list(b.LPR + (size_t)((s - 1) & 1) * d.nb_post_gene, d.nb_post_gene, 1.0);
-    if (d.nmat_r > 0) add_list(b.HL + (size_t)(d.hist_par ? ((s - 1) & 1) : 0) * b.n_tasks, b.n_tasks, -1.0);
-    add_list(b.LO, d.n_main_wg, -1.0);
+    }
+#pragma unroll 4
+    for (int i = t; i < d.n_main_wg; i += 256) sl -= (double)b.LO[i];
   }
   sl = vc_wave_sum_d63(sl);
   if (lane == 63) sm_lossw[wv] = sl;
