@@ -944,6 +944,22 @@ __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const Vc
   }
 }
 
+// A 256-thread block of K_pre / K_hist (unfused step, K-particle step): QUARTER `quarter` of gene block `gb`, every matrix the model
+// uses, shape_inv from the parameters as they stand.  Round 6: those kernels used to give a gene block ONE 4-wave block (every wave four
+// slices of the count axis, one after the other, for both matrices: the block of a highly expressed gene took ~ 9 us -- most of the
+// 22 us of the K-particle step's first launch); a quarter block's thread has one slice of one gene.  Same sums (vc_hist_dense16_finish).
+__device__ __forceinline__ void vc_hist_dense_quarter(const VcDims& d, const VcBufs& b, int gb, int quarter, const float* __restrict__ P,
+                                                      int cond_only, int half, double* sm /* 2048 doubles */) {
+  const int nm = d.model == VC_MODEL_VELOCITY ? 2 : 1;
+  for (int m = 0; m < nm; ++m) {
+    VcHistPre hp;
+    vc_hist_dense16_rows<true>(d, b, gb, hp, m, quarter);
+    vc_hist_dense16_issue<true>(d, b, hp);
+    vc_hist_dense16_finish<true>(d, b, gb, vc_hist_si(d, b, P, cond_only, gb * 64 + hp.gi), half, hp, sm);
+    __syncthreads();           // (the next matrix reuses the slices' LDS rows)
+  }
+}
+
 #endif  // __HIPCC__
 
 // launchers implemented in the .hip translation units -----------------------------------------
@@ -951,6 +967,10 @@ __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const Vc
 struct VcAdamHyper { double lr0, lrd, b1, b2; float eps, clip, wd; int kind; const unsigned char* frozen; long long frozen_off; };
 static inline int vc_hist_blocks(const VcDims& d, const VcBufs& b, int waves) {
   return d.hist_dense ? d.Ng_pad / 64 : (b.n_tasks + waves - 1) / waves;
+}
+// ... of K_pre / K_hist: dense tables = four quarter blocks per gene block (vc_hist_dense_quarter)
+static inline int vc_hist_blocks_pre(const VcDims& d, const VcBufs& b) {
+  return d.hist_dense ? (d.Ng_pad / 64) * 4 : (b.n_tasks + 3) / 4;
 }
 typedef void (*vc_main_launch_fn)(const VcDims& d, const VcBufs& b, hipStream_t st);
 vc_main_launch_fn vc_find_main_kernel(int H, int NB, int kind, int noise, int gpl, int c16, const char** name,

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void vc_pre_generic_kernel(const VcDims d, con
   if ((int)blockIdx.x >= d.nb_pre_gene + d.nb_pre_cell) {
     const int hb = blockIdx.x - d.nb_pre_gene - d.nb_pre_cell;
     if (d.hist_dense) {          // (the histogram blocks use the launch's dynamic LDS for themselves: no s_nuw there)
-      vc_hist_dense_block(d, b, hb, vc_hist_si(d, b, P, cond_only, hb * 64 + (threadIdx.x & 63)), 0, 4, vc_hist_lds());
+      vc_hist_dense_quarter(d, b, hb >> 2, hb & 3, P, cond_only, 0, vc_hist_lds());
       return;
     }
     const int task = hb * 4 + (threadIdx.x >> 6);
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void vc_pre_generic_kernel(const VcDims d, con
 
 void vc_launch_pre_generic(const VcDims& d, const VcBufs& b, const float* params, const float* eps, uint64_t seed, long long step,
                            const long long* step_dev, int cond_only, int with_hist, hipStream_t st, int particles, int particle) {
-  const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
+  const int nb_hist = with_hist ? vc_hist_blocks_pre(d, b) : 0;
   unsigned dyn = (unsigned)(sizeof(float) * (d.NW > 0 ? d.NW : 1));
   if (vc_hist_dyn_lds(d, with_hist, 256) > dyn) dyn = vc_hist_dyn_lds(d, with_hist, 256);
   hipLaunchKernelGGL(vc_pre_generic_kernel, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), dyn, st, d, b, params, eps,

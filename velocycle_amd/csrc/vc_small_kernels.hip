@@ -142,7 +142,7 @@ void vc_launch_scatter_csr(const long long* indptr, const int* indices, const fl
 __global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBufs b,
                                                       const float* __restrict__ P, int cond_only) {
   if (d.hist_dense) {
-    vc_hist_dense_block(d, b, blockIdx.x, vc_hist_si(d, b, P, cond_only, blockIdx.x * 64 + (threadIdx.x & 63)), 0, 4, vc_hist_lds());
+    vc_hist_dense_quarter(d, b, blockIdx.x >> 2, blockIdx.x & 3, P, cond_only, 0, vc_hist_lds());
     return;
   }
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void vc_hist_kernel(const VcDims d, const VcBu
 }
 
 void vc_launch_hist(const VcDims& d, const VcBufs& b, const float* params, int cond_only, hipStream_t st) {
-  hipLaunchKernelGGL(vc_hist_kernel, dim3(vc_hist_blocks(d, b, 4)), dim3(256), vc_hist_dyn_lds(d, 1, 256), st, d, b, params, cond_only);
+  hipLaunchKernelGGL(vc_hist_kernel, dim3(vc_hist_blocks_pre(d, b)), dim3(256), vc_hist_dyn_lds(d, 1, 256), st, d, b, params, cond_only);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void vc_pre_kernel(const VcDims d, const VcBuf
   if ((int)blockIdx.x >= d.nb_pre_gene + d.nb_pre_cell) {
     // ------------------------------- histogram part (NB) -------------------------------------------
     const int hb = blockIdx.x - d.nb_pre_gene - d.nb_pre_cell;
-    if (d.hist_dense) {          // one block per gene block, the dense tail-count tables
-      vc_hist_dense_block(d, b, hb, vc_hist_si(d, b, P, cond_only, hb * 64 + (threadIdx.x & 63)), 0, 4, vc_hist_lds());
+    if (d.hist_dense) {          // four quarter blocks per gene block, the dense tail-count tables
+      vc_hist_dense_quarter(d, b, hb >> 2, hb & 3, P, cond_only, 0, vc_hist_lds());
       return;
     }
     const int task = hb * 4 + (threadIdx.x >> 6);          // one wave per task of <= 64 distinct values
@@ -438,14 +438,14 @@ void vc_launch_pre(const VcDims& d, const VcBufs& b, const float* params, const 
                    uint64_t seed, long long step, const long long* step_dev, int cond_only, int with_hist,
                    hipStream_t st, int particles, int particle) {
   if (d.generic) { vc_launch_pre_generic(d, b, params, eps, seed, step, step_dev, cond_only, with_hist, st, particles, particle); return; }
-  const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
+  const int nb_hist = with_hist ? vc_hist_blocks_pre(d, b) : 0;
   hipLaunchKernelGGL(vc_pre_kernel<false>, dim3(d.nb_pre_gene + d.nb_pre_cell + nb_hist), dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st, d, b,
                      (const VcBufs*)nullptr, params, eps, seed, step, step_dev, cond_only, particles, particle);
 }
 // the K particles of a step in one launch (fast kernel set only; b = the first particle's buffers: sizes and tables are common)
 void vc_launch_pre_particles(const VcDims& d, const VcBufs& b, const VcBufs* bs_dev, const float* params, uint64_t seed,
                              const long long* step_dev, int with_hist, int K, hipStream_t st) {
-  const int nb_hist = with_hist ? vc_hist_blocks(d, b, 4) : 0;
+  const int nb_hist = with_hist ? vc_hist_blocks_pre(d, b) : 0;
   const dim3 grid(d.nb_pre_gene + d.nb_pre_cell + nb_hist, K);
   if (vc_spec_launch<VC_SPECK_PARTICLES, 0>(d.spec, [&](auto mq, auto sp) {
         hipLaunchKernelGGL((vc_pre_kernel<true, decltype(sp)::value>), grid, dim3(256), vc_hist_dyn_lds(d, with_hist, 256), st, d, b, bs_dev, params,
