@@ -137,3 +137,29 @@ def test_valu_model_is_what_bench_reads():
         # more waves never cost more per instruction, and the floor sits between 1.9 and 2.4 ns per instruction
         assert floor["3"] <= floor["2"] * 1.01
         assert 1.9 < floor["2"] / ent["valu_per_cell_iter"] < 2.4
+
+
+def test_small_kernels_of_the_measured_configurations_wait_for_no_load_one_by_one(tmp_path):
+    """Round 6 (profiles/r06_hist_split.md): hipcc puts `s_waitcnt vmcnt(0)` behind every load of an unrolled sequence when a select, a
+    conversion or a dereference stands directly behind each load -- N dependent memory round trips instead of one (the quarter blocks'
+    table prefetch: 5.8 us; K_pre's dense histogram block: 14 us of the K-particle step).  The instantiations the bench line and the
+    shard sweep run must stay free of such clusters (profiles/tools/scan_serial_loads.py; one translation unit: ~ 1 min of hipcc)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("scan_serial_loads", os.path.join(ROOT, "profiles", "tools", "scan_serial_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    asm = str(tmp_path / "fused.s")
+    mod.compile_asm("vc_fused_kernels.hip", asm)
+    res = {mod.demangled_hint(k): v for k, v in mod.scan(asm).items()}
+    all_syms = open(asm).read()
+    # rows of vc_tail_spec_rows.inc (1-based): 1 vjoint_rank, 6 phase, 19 vjoint, 25 vjoint_2s -- the one-launch tail of the headline,
+    # of the phase model and of configs[4], and phase B of a rank of the sharded V-joint step
+    for sym, hint in (("_Z15vc_tail2_kernelILi6ELi19EE", "vc_tail2_kernel<6,19>"), ("_Z15vc_tail2_kernelILi4ELi6EE", "vc_tail2_kernel<4,6>"),
+                      ("_Z15vc_tail2_kernelILi6ELi25EE", "vc_tail2_kernel<6,25>"), ("_Z17vc_phase_b_kernelILi2ELi1EE", "vc_phase_b_kernel<2,1>")):
+        assert sym in all_syms, f"{hint} is not compiled any more: update this list"
+        assert hint not in res, (hint, res[hint])
+    # the scan itself finds a planted sequence: four loads, each waited for on its own
+    planted = tmp_path / "p.s"
+    planted.write_text("_Z4testv:\n" + "".join(f"\tglobal_load_dword v{i}, v[2:3], off\n\ts_waitcnt vmcnt(0)\n\tv_cvt_f64_f32_e32 v[4:5], v{i}\n"
+                                               for i in range(4)) + "\ts_endpgm\n")
+    assert mod.scan(str(planted)) == {"_Z4testv": [(1, 10, 4, 3)]}          # (waits BETWEEN the first and the last load)
