@@ -944,6 +944,19 @@ __device__ __forceinline__ void vc_hist_dense16_finish(const VcDims& d, const Vc
   }
 }
 
+// acc + p[i * ld + j] for i = lane, lane + 64, ... < n, added in that order in double -- eight rows REQUESTED per trip, then the eight adds
+// (written as `acc += (double)p[...]` in a loop hipcc waits for every single load: one memory round trip per row; round 6).  Same bits.
+__device__ __forceinline__ double vc_col_sum_d(const float* __restrict__ p, int n, int ld, int j, int lane, double acc) {
+  for (int i0 = lane; i0 < n; i0 += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = i0 + 64 * u; v[u] = p[(size_t)(i < n ? i : i0) * ld + j]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (i0 + 64 * u < n) acc += (double)v[u];
+  }
+  return acc;
+}
+
 // A 256-thread block of K_pre / K_hist (unfused step, K-particle step): QUARTER `quarter` of gene block `gb`, every matrix the model
 // uses, shape_inv from the parameters as they stand.  Round 6: those kernels used to give a gene block ONE 4-wave block (every wave four
 // slices of the count axis, one after the other, for both matrices: the block of a highly expressed gene took ~ 9 us -- most of the

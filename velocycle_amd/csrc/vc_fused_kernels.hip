@@ -1284,7 +1284,7 @@ __device__ __forceinline__ void vc_nuw_sums_finish(const VcDims& d, const VcBufs
       for (int q = 0; q < 2; ++q) {
         const int j = wv + nwv * q;
         if (j < nw)
-          for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
+          u[q] = vc_col_sum_d(PWs, n_pw, pw_ld, j, lane, u[q]);
       }
     }
 #pragma unroll
@@ -1294,7 +1294,7 @@ __device__ __forceinline__ void vc_nuw_sums_finish(const VcDims& d, const VcBufs
     }
     for (int j = wv + 2 * nwv; j < nw; j += nwv) {
       double r = 0.0;
-      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
+      r = vc_col_sum_d(PWs, n_pw, pw_ld, j, lane, r);
       r = vc_wave_sum_d63(r);
       if (lane == 63) sh.up[j] = (float)r;
     }
@@ -1329,7 +1329,7 @@ __device__ __forceinline__ void vc_nuw_sums_direct(const VcDims& d, const VcBufs
     for (int q = 0; q < 2; ++q) {
       const int j = wv + nwv * q;
       if (j < nw)
-        for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
+        u[q] = vc_col_sum_d(PWs, n_pw, pw_ld, j, lane, u[q]);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1338,7 +1338,7 @@ __device__ __forceinline__ void vc_nuw_sums_direct(const VcDims& d, const VcBufs
     }
     for (int j = wv + 2 * nwv; j < nw; j += nwv) {
       double r = 0.0;
-      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
+      r = vc_col_sum_d(PWs, n_pw, pw_ld, j, lane, r);
       r = vc_wave_sum_d63(r);
       if (lane == 63) sh.up[j] = (float)r;
     }

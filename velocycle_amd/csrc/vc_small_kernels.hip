@@ -862,7 +862,7 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
     for (int q = 0; q < 2; ++q) {
       const int j = wv + 4 * q;
       if (j < nw)
-        for (int i = lane; i < n_pw; i += 64) u[q] += (double)PWs[(size_t)i * pw_ld + j];
+        u[q] = vc_col_sum_d(PWs, n_pw, pw_ld, j, lane, u[q]);
     }
     s = vc_wave_sum_d(s);
     if (lane == 0) sm_lossw[wv] = s;
@@ -873,7 +873,7 @@ __device__ __forceinline__ void vc_fin_block(const VcDims& d, const VcBufs& b, c
     }
     for (int j = wv + 8; j < nw; j += 4) {          // more than 8 coefficients: the rest one after the other
       double r = 0.0;
-      for (int i = lane; i < n_pw; i += 64) r += (double)PWs[(size_t)i * pw_ld + j];
+      r = vc_col_sum_d(PWs, n_pw, pw_ld, j, lane, r);
       r = vc_wave_sum_d(r);
       if (lane == 0) sm_up[j] = (float)r;
     }
