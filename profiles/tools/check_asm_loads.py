@@ -49,7 +49,7 @@ def regs_of(text):
 
 def device_asm(tu, extra=()):
     out = os.path.join(tempfile.mkdtemp(), os.path.basename(tu).replace(".hip", ".s"))
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", *extra,
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-falign-loops=64", "--cuda-device-only", "-S", *extra,
                     "-Wno-unused-variable", "-o", out, tu], check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
     return open(out).read()
 

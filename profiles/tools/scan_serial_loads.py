@@ -24,7 +24,7 @@ CSRC = os.path.join(ROOT, "velocycle_amd", "csrc")
 
 
 def compile_asm(tu, out):
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-falign-loops=64", "--cuda-device-only", "-S",
                     "-Wno-unused-variable", "-o", out, tu], check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
 
 

@@ -59,7 +59,7 @@ def device_asm(tu, cache={}):
     if tu not in cache:
         out = os.path.join(tempfile.mkdtemp(), tu.replace(".hip", ".s"))
         extra = os.environ.get("EXTRA", "").split()
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-falign-loops=64", "--cuda-device-only", "-S",
                         *extra, os.path.join(CSRC, tu), "-o", out], check=True, stderr=subprocess.DEVNULL)
         cache[tu] = open(out).read().splitlines()
     return cache[tu]
